@@ -1,0 +1,199 @@
+/*
+ * omni_hip.h -- C ABI of the MI355X-native (gfx950 / CDNA4) swarm_loop hot path.
+ *
+ * Drop-in boundary for HKUST-Aerial-Robotics/Omni-swarm's per-keyframe CNN frontend and
+ * loop-closure matcher.  The reference has no FFI layer; the seam is four C++ call surfaces
+ * used by LoopCam / LoopDetector.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root):
+ *
+ *   omni_sp_*      SuperPointTensorRT            swarm_loop/include/swarm_loop/superpoint_tensorrt.h:12-29
+ *                                                swarm_loop/src/superpoint_tensorrt.cpp:91-230,237-310
+ *                  (+ the TensorRT engine = the graph of swarm_loop/superpoint.ipynb:135-205,
+ *                   + TensorRTInferenceGeneric   swarm_loop/src/tensorrt_generic.cpp:14-120)
+ *   omni_vlad_*    MobileNetVLADTensorRT         swarm_loop/include/swarm_loop/mobilenetvlad_tensorrt.h:6-22
+ *                                                swarm_loop/src/mobilenetvlad_tensorrt.cpp:4-14
+ *   omni_index_*   faiss::IndexFlatIP            used at swarm_loop/src/loop_detector.cpp:166,169,213,232,291,842
+ *   omni_bf_*      cv::BFMatcher(NORM_L2,true)   used at swarm_loop/src/loop_cam.cpp:147-150,
+ *                                                        swarm_loop/src/loop_detector.cpp:564-567
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch/OpenCV types cross this boundary.
+ *   - every function that can fail returns int: 0 = OMNI_OK, otherwise an OMNI_ERR_* code;
+ *     omni_last_error() gives a thread-local message.  The reference aborts on failure
+ *     (live asserts, NV_CUDA_CHECK -- SURVEY.md F13); this library never aborts.
+ *   - "_dev" variants take pointers to HBM (hipMalloc'd or omni_dev_alloc'd) and are asynchronous on the
+ *     context's stream; the plain variants take host pointers, copy, run and synchronise (the reference's
+ *     blocking batch-1 semantics, tensorrt_generic.cpp:58-75).
+ *   - handles are thread-compatible: calls on one handle are serialised internally by a mutex
+ *     (the reference's LoopDetector is entered from two threads with no lock).
+ *   - there is NO CPU fallback: if the HIP device or a kernel launch fails the call returns OMNI_ERR_HIP.
+ */
+#ifndef OMNI_HIP_H
+#define OMNI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMNI_ABI_VERSION 1
+
+enum {
+    OMNI_OK = 0,
+    OMNI_ERR_INVALID = 1,   /* bad argument / shape mismatch (the reference asserts, superpoint_tensorrt.cpp:122) */
+    OMNI_ERR_HIP = 2,       /* HIP runtime / launch failure */
+    OMNI_ERR_NOMEM = 3,
+    OMNI_ERR_CAPACITY = 4   /* batch / k / row count beyond what the handle was created for */
+};
+
+enum { OMNI_PREC_F32 = 0,   /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations: the parity mode */
+       OMNI_PREC_F16 = 1 }; /* fp16 storage + v_mfma_f32_32x32x16_f16, fp32 accumulate: the reference's engines
+                               are fp16 TensorRT (launch/realsense.launch:10-11) */
+
+enum { OMNI_STORE_F32 = 0, OMNI_STORE_F16 = 1 };   /* global-descriptor DB storage */
+
+enum { OMNI_BF_OPENCV = 0,  /* cv::batchDistance(K=1, crosscheck=true) semantics (what the reference runs) */
+       OMNI_BF_MUTUAL = 1 };/* strict mutual nearest neighbour (SURVEY.md 8c restatement) */
+
+typedef struct omni_ctx omni_ctx;
+typedef struct omni_sp omni_sp;
+typedef struct omni_vlad omni_vlad;
+typedef struct omni_index omni_index;
+
+int         omni_abi_version(void);
+const char* omni_last_error(void);
+
+/* ---- context: one per GPU/stream; owns a HIP stream, scratch and timers -------------------------------------
+ * replaces TensorRTInferenceGeneric's cudaStreamCreate / cudaMalloc plumbing (tensorrt_generic.cpp:14-36,99-120) */
+omni_ctx* omni_ctx_create(int device_id);
+void      omni_ctx_destroy(omni_ctx* ctx);
+int       omni_ctx_sync(omni_ctx* ctx);
+void*     omni_ctx_stream(omni_ctx* ctx);                 /* hipStream_t, for callers that enqueue their own work */
+int       omni_ctx_device_info(omni_ctx* ctx, char* name, int name_len, int* n_cu, int* clock_mhz, size_t* hbm_bytes);
+
+void* omni_dev_alloc(omni_ctx* ctx, size_t bytes);        /* HBM; NULL on failure */
+int   omni_dev_free(omni_ctx* ctx, void* p);
+int   omni_memcpy_h2d(omni_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);  /* blocking */
+int   omni_memcpy_d2h(omni_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);  /* blocking */
+int   omni_timer_start(omni_ctx* ctx);                    /* hipEventRecord on the ctx stream */
+int   omni_timer_stop(omni_ctx* ctx, float* ms);          /* records, synchronises, returns elapsed ms */
+
+/* ---- SuperPoint -------------------------------------------------------------------------------------------------
+ * weights: the 12 conv layers of superpoint.ipynb:143-160 in execution order
+ *   conv1a conv1b conv2a conv2b conv3a conv3b conv4a conv4b convPa convPb convDa convDb,
+ * each weight OIHW float32 and bias [O] float32 (the checkpoint's state_dict layout, superpoint.ipynb:270). */
+#define OMNI_SP_NUM_LAYERS 12
+typedef struct omni_sp_weights {
+    const float* weight[OMNI_SP_NUM_LAYERS];
+    const float* bias[OMNI_SP_NUM_LAYERS];
+} omni_sp_weights;
+
+/* SuperPointTensorRT::SuperPointTensorRT(engine, pca_comp, pca_mean, width, height, thres, max_num)
+ * (superpoint_tensorrt.cpp:91-115).  pca_comp = sklearn components_ [pca_dim x 256] row-major, pca_mean [256]
+ * (the two CSVs of :110-111); pca_comp == NULL disables PCA (#undef USE_PCA, :220-225) and desc is n x 256.
+ * width, height must be multiples of 8.  max_batch = images processed per call (reference: 1). */
+omni_sp* omni_sp_create(omni_ctx* ctx, const omni_sp_weights* w, const float* pca_comp, const float* pca_mean,
+                        int pca_dim, int width, int height, float thres, int max_num, int precision, int max_batch);
+void     omni_sp_destroy(omni_sp* sp);
+int      omni_sp_desc_dim(const omni_sp* sp);              /* pca_dim, or 256 without PCA */
+
+/* SuperPointTensorRT::inference(const cv::Mat&, std::vector<cv::Point2f>&, std::vector<float>&)
+ * (superpoint_tensorrt.cpp:117-162) for `batch` images.
+ *   gray      : batch images, u8, row stride `stride` bytes, image i at gray + i*stride*height
+ *   fisheye_mask != 0 zeroes rows [3H/4, H) first (LoopCam::extractor_img_desc_deepnet, loop_cam.cpp:536-539)
+ *   kps_xy    : [batch][max_num][2] float (x, y) integer-valued; order = (confidence desc, row-major index asc)
+ *   n_kps     : [batch]
+ *   desc      : [batch][max_num][desc_dim] float
+ *   scores    : [batch][max_num] confidences, may be NULL */
+int omni_sp_infer(omni_sp* sp, const uint8_t* gray_host, int stride, int batch, int fisheye_mask,
+                  float* kps_xy, int* n_kps, float* desc, float* scores);
+/* asynchronous, HBM-resident input; results stay in the handle's device buffers until fetched */
+int omni_sp_enqueue_dev(omni_sp* sp, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask);
+int omni_sp_fetch(omni_sp* sp, int batch, float* kps_xy, int* n_kps, float* desc, float* scores);  /* D2H + sync */
+/* device views of the last results: kps [max_batch][max_num][2] f32, n [max_batch] i32, desc [max_batch][max_num][dim] */
+int omni_sp_dev_outputs(omni_sp* sp, const float** kps_xy_dev, const int** n_kps_dev, const float** desc_dev,
+                        const float** scores_dev);
+/* the engine's raw outputs in the reference's binding layout (tensorrt_generic.cpp:62-73):
+ * semi [batch][H][W] f32 and desc [batch][256][H/8][W/8] f32 (NCHW).  For parity tests. */
+int omni_sp_get_dense(omni_sp* sp, int batch, float* semi_host, float* desc_host);
+/* run only the post-processing (getKeyPoints + NMS2 + computeDescriptors, superpoint_tensorrt.cpp:164-310) on
+ * caller-supplied engine outputs in the layout above -- isolates the detector from conv rounding in tests */
+int omni_sp_postprocess_dense(omni_sp* sp, const float* semi_host, const float* desc_host, int batch,
+                              float* kps_xy, int* n_kps, float* desc, float* scores);
+/* test hook: one intermediate activation of the last forward pass as NCHW float32 (name in {"conv1a","conv1b",...,
+ * "conv4b","heads","desc"}; post-ReLU, post-pool where the layer pools).  out may be NULL to query the shape only. */
+int omni_sp_debug_layer(omni_sp* sp, const char* name, int batch, float* out_nchw_host, int* C, int* H, int* W);
+/* per-stage device time: runs the network `reps` times on HBM-resident input with HIP events between stages.
+ * stage_ms [OMNI_SP_NUM_STAGES] average ms per call; names via omni_sp_stage_name(). */
+#define OMNI_SP_NUM_STAGES 16
+int         omni_sp_profile(omni_sp* sp, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms);
+const char* omni_sp_stage_name(int stage);
+double      omni_sp_stage_flops(const omni_sp* sp, int stage);   /* algorithmic FLOP per image for that stage */
+
+/* ---- MobileNetVLAD (ASSUMED architecture -- the reference ships only the I/O contract) --------- */
+enum { OMNI_VLAD_CONV3X3_RELU6 = 0, OMNI_VLAD_PW_RELU6 = 1, OMNI_VLAD_DW3X3_RELU6 = 2,
+       OMNI_VLAD_PW_LINEAR = 3, OMNI_VLAD_PW_LINEAR_RES = 4 };
+typedef struct omni_vlad_layer {
+    int kind, cin, cout, stride;
+    const float* weight;   /* OIHW (depthwise: [C][1][3][3]) */
+    const float* bias;
+} omni_vlad_layer;
+typedef struct omni_vlad_weights {
+    int n_layers;
+    const omni_vlad_layer* layers;
+    int n_clusters, feat_dim, out_dim;
+    const float* assign_w;   /* [K][D] */
+    const float* assign_b;   /* [K] */
+    const float* clusters;   /* [K][D] */
+    const float* fc_w;       /* [out_dim][K*D] */
+    const float* fc_b;       /* [out_dim] */
+} omni_vlad_weights;
+
+/* MobileNetVLADTensorRT(engine, width, height) (mobilenetvlad_tensorrt.h:10-19) */
+omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width, int height, int max_batch);
+void       omni_vlad_destroy(omni_vlad* v);
+/* std::vector<float> MobileNetVLADTensorRT::inference(const cv::Mat&) (mobilenetvlad_tensorrt.cpp:4-14):
+ * u8 -> f32 with NO scaling feeds the net; out [batch][out_dim] */
+int omni_vlad_infer(omni_vlad* v, const uint8_t* gray_host, int stride, int batch, int fisheye_mask, float* out);
+int omni_vlad_enqueue_dev(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask);
+int omni_vlad_fetch(omni_vlad* v, int batch, float* out);
+int omni_vlad_dev_output(omni_vlad* v, const float** out_dev);
+
+/* ---- global-descriptor index: faiss::IndexFlatIP(d) --------------------------------------------------------- */
+omni_index* omni_index_create(omni_ctx* ctx, int dim, int storage, int64_t initial_capacity_rows);
+void        omni_index_destroy(omni_index* idx);
+int         omni_index_add(omni_index* idx, int64_t n, const float* x_host);       /* IndexFlatIP::add(n, x) */
+int         omni_index_add_dev(omni_index* idx, int64_t n, const float* x_dev);
+int64_t     omni_index_ntotal(const omni_index* idx);                              /* .ntotal */
+int         omni_index_reset(omni_index* idx);
+/* IndexFlatIP::search(nq, q, k, D, I): exact inner product, k best descending, ties -> lower row id,
+ * missing results padded with I = -1, D = -FLT_MAX.  k <= 1024 (the reference caps at 1000, loop_detector.cpp:200). */
+int         omni_index_search(omni_index* idx, int nq, const float* q_host, int k, float* D, int64_t* I);
+int         omni_index_search_dev(omni_index* idx, int nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev);
+/* row sharding across GPUs: this handle holds rows g with g % world == rank at local slot g / world;
+ * search then reports GLOBAL ids (local * world + rank).  Default rank 0, world 1. */
+int         omni_index_set_shard(omni_index* idx, int rank, int world);
+/* host-side merge of per-shard top-k lists (after the all-gather): lists [n_lists][nq][k_each] -> [nq][k_out],
+ * same ordering rule (score desc, id asc), entries with I < 0 ignored */
+int         omni_topk_merge(int n_lists, int nq, int k_each, const float* D_lists, const int64_t* I_lists,
+                            int k_out, float* D, int64_t* I);
+/* device time of the dominant scan kernel for the last search on this handle (HIP events on the ctx stream) */
+int         omni_index_last_scan_ms(omni_index* idx, float* ms);
+
+/* ---- local-descriptor matcher: cv::BFMatcher(cv::NORM_L2, crossCheck=true).match(query, train, matches) -----
+ * out arrays sized >= nq; matches ordered by query index; *n_matches = count.  dim <= 256. */
+int omni_bf_match(omni_ctx* ctx, const float* q_host, int nq, const float* t_host, int nt, int dim, int mode,
+                  int* q_idx, int* t_idx, float* dist, int* n_matches);
+/* batched, HBM-resident: pair p uses q = q_dev + p*q_stride (floats), nq = nq_dev[p], likewise t.
+ * outputs (device): q_idx/t_idx/dist [n_pairs][max_n], n_matches [n_pairs]. */
+int omni_bf_match_batched_dev(omni_ctx* ctx, int n_pairs, int max_n, int dim, int mode,
+                              const float* q_dev, int64_t q_stride, const int* nq_dev,
+                              const float* t_dev, int64_t t_stride, const int* nt_dev,
+                              int* q_idx_dev, int* t_idx_dev, float* dist_dev, int* n_matches_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNI_HIP_H */

@@ -1,0 +1,437 @@
+"""ctypes binding of include/omni_hip.h plus thin numpy-friendly wrappers that mirror the reference classes.
+
+Fails loudly: a missing ``lib/libomni_hip.so`` raises ImportError-like OSError from ``lib()``, a missing GPU raises
+``OmniError`` from ``Context()``.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libomni_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = 0, 1, 2, 3, 4
+PREC_F32, PREC_F16 = 0, 1
+STORE_F32, STORE_F16 = 0, 1
+BF_OPENCV, BF_MUTUAL = 0, 1
+SP_NUM_LAYERS = 12
+SP_NUM_STAGES = 16
+SP_LAYER_NAMES = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b",
+                  "convPa", "convPb", "convDa", "convDb"]
+VLAD_KINDS = {"conv3x3": 0, "pw_relu6": 1, "dw3x3_relu6": 2, "pw_linear": 3, "pw_linear_res": 4}
+
+# every symbol include/omni_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "omni_abi_version", "omni_last_error", "omni_ctx_create", "omni_ctx_destroy", "omni_ctx_sync", "omni_ctx_stream",
+    "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
+    "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_infer", "omni_sp_enqueue_dev",
+    "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
+    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy",
+    "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
+    "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset",
+    "omni_index_search", "omni_index_search_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
+    "omni_bf_match", "omni_bf_match_batched_dev",
+]
+
+
+class OmniError(RuntimeError):
+    pass
+
+
+class _SpWeights(C.Structure):
+    _fields_ = [("weight", C.POINTER(C.c_float) * SP_NUM_LAYERS), ("bias", C.POINTER(C.c_float) * SP_NUM_LAYERS)]
+
+
+class _VladLayer(C.Structure):
+    _fields_ = [("kind", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("stride", C.c_int),
+                ("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float))]
+
+
+class _VladWeights(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("layers", C.POINTER(_VladLayer)), ("n_clusters", C.c_int), ("feat_dim", C.c_int),
+                ("out_dim", C.c_int), ("assign_w", C.POINTER(C.c_float)), ("assign_b", C.POINTER(C.c_float)),
+                ("clusters", C.POINTER(C.c_float)), ("fc_w", C.POINTER(C.c_float)), ("fc_b", C.POINTER(C.c_float))]
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"(or `make -C omni-swarm_amd`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+
+    def sig(name, res, args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+
+    sig("omni_abi_version", C.c_int, [])
+    sig("omni_last_error", C.c_char_p, [])
+    sig("omni_ctx_create", _vp, [C.c_int])
+    sig("omni_ctx_destroy", None, [_vp])
+    sig("omni_ctx_sync", C.c_int, [_vp])
+    sig("omni_ctx_stream", _vp, [_vp])
+    sig("omni_ctx_device_info", C.c_int, [_vp, C.c_char_p, C.c_int, _ip, _ip, C.POINTER(C.c_size_t)])
+    sig("omni_dev_alloc", _vp, [_vp, C.c_size_t])
+    sig("omni_dev_free", C.c_int, [_vp, _vp])
+    sig("omni_memcpy_h2d", C.c_int, [_vp, _vp, _vp, C.c_size_t])
+    sig("omni_memcpy_d2h", C.c_int, [_vp, _vp, _vp, C.c_size_t])
+    sig("omni_timer_start", C.c_int, [_vp])
+    sig("omni_timer_stop", C.c_int, [_vp, _fp])
+    sig("omni_sp_create", _vp, [_vp, C.POINTER(_SpWeights), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                C.c_int, C.c_int])
+    sig("omni_sp_destroy", None, [_vp])
+    sig("omni_sp_desc_dim", C.c_int, [_vp])
+    sig("omni_sp_infer", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _fp, _ip, _fp, _fp])
+    sig("omni_sp_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int])
+    sig("omni_sp_fetch", C.c_int, [_vp, C.c_int, _fp, _ip, _fp, _fp])
+    sig("omni_sp_dev_outputs", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)])
+    sig("omni_sp_get_dense", C.c_int, [_vp, C.c_int, _fp, _fp])
+    sig("omni_sp_postprocess_dense", C.c_int, [_vp, _fp, _fp, C.c_int, _fp, _ip, _fp, _fp])
+    sig("omni_sp_debug_layer", C.c_int, [_vp, C.c_char_p, C.c_int, _fp, _ip, _ip, _ip])
+    sig("omni_sp_profile", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _fp])
+    sig("omni_sp_stage_name", C.c_char_p, [C.c_int])
+    sig("omni_sp_stage_flops", C.c_double, [_vp, C.c_int])
+    sig("omni_vlad_create", _vp, [_vp, C.POINTER(_VladWeights), C.c_int, C.c_int, C.c_int])
+    sig("omni_vlad_destroy", None, [_vp])
+    sig("omni_vlad_infer", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _fp])
+    sig("omni_vlad_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int])
+    sig("omni_vlad_fetch", C.c_int, [_vp, C.c_int, _fp])
+    sig("omni_vlad_dev_output", C.c_int, [_vp, C.POINTER(_vp)])
+    sig("omni_index_create", _vp, [_vp, C.c_int, C.c_int, C.c_int64])
+    sig("omni_index_destroy", None, [_vp])
+    sig("omni_index_add", C.c_int, [_vp, C.c_int64, _fp])
+    sig("omni_index_add_dev", C.c_int, [_vp, C.c_int64, _vp])
+    sig("omni_index_ntotal", C.c_int64, [_vp])
+    sig("omni_index_reset", C.c_int, [_vp])
+    sig("omni_index_search", C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp, _i64p])
+    sig("omni_index_search_dev", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp])
+    sig("omni_index_set_shard", C.c_int, [_vp, C.c_int, C.c_int])
+    sig("omni_topk_merge", C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _i64p, C.c_int, _fp, _i64p])
+    sig("omni_index_last_scan_ms", C.c_int, [_vp, _fp])
+    sig("omni_bf_match", C.c_int, [_vp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _ip, _ip, _fp, _ip])
+    sig("omni_bf_match_batched_dev", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, C.c_int64,
+                                               _vp, _vp, _vp, _vp, _vp])
+    if L.omni_abi_version() != 1:
+        raise OmniError("libomni_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise OmniError(f"omni error {rc}: {lib().omni_last_error().decode()}")
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _pf(a):
+    return a.ctypes.data_as(_fp)
+
+
+class Context:
+    """One HIP stream + scratch on one GPU (omni_ctx)."""
+
+    def __init__(self, device_id: int = 0):
+        self.h = lib().omni_ctx_create(device_id)
+        if not self.h:
+            raise OmniError(f"omni_ctx_create failed: {lib().omni_last_error().decode()}")
+
+    def close(self):
+        if self.h:
+            lib().omni_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().omni_ctx_sync(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu, mhz, mem = C.c_int(), C.c_int(), C.c_size_t()
+        _check(lib().omni_ctx_device_info(self.h, name, 256, C.byref(ncu), C.byref(mhz), C.byref(mem)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "clock_mhz": mhz.value, "hbm_bytes": mem.value}
+
+    def alloc(self, nbytes: int) -> int:
+        p = lib().omni_dev_alloc(self.h, nbytes)
+        if not p:
+            raise OmniError(f"omni_dev_alloc({nbytes}) failed: {lib().omni_last_error().decode()}")
+        return p
+
+    def free(self, p):
+        _check(lib().omni_dev_free(self.h, p))
+
+    def to_device(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(max(arr.nbytes, 1))
+        _check(lib().omni_memcpy_h2d(self.h, p, arr.ctypes.data_as(_vp), arr.nbytes))
+        return p
+
+    def from_device(self, p: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        _check(lib().omni_memcpy_d2h(self.h, out.ctypes.data_as(_vp), p, out.nbytes))
+        return out
+
+    def timer_start(self):
+        _check(lib().omni_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _check(lib().omni_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+
+class SuperPoint:
+    """SuperPointTensorRT(engine, pca_comp, pca_mean, width, height, thres, max_num) -- weights replace the engine file."""
+
+    def __init__(self, ctx: Context, weights: dict, pca_comp, pca_mean, width: int, height: int, thres: float = 0.015,
+                 max_num: int = 200, precision: int = PREC_F32, max_batch: int = 1):
+        self.ctx, self.W, self.H, self.max_num, self.max_batch, self.precision = ctx, width, height, max_num, max_batch, precision
+        self._keep = []
+        w = _SpWeights()
+        for i, n in enumerate(SP_LAYER_NAMES):
+            wt, bs = _f32(weights[n + ".weight"]), _f32(weights[n + ".bias"])
+            self._keep += [wt, bs]
+            w.weight[i], w.bias[i] = _pf(wt), _pf(bs)
+        pc = pm = None
+        pca_dim = 0
+        if pca_comp is not None:
+            pc, pm = _f32(pca_comp), _f32(pca_mean)
+            pca_dim = pc.shape[0]
+        self.h = lib().omni_sp_create(ctx.h, C.byref(w), _pf(pc) if pc is not None else None,
+                                      _pf(pm) if pm is not None else None, pca_dim, width, height, thres, max_num,
+                                      precision, max_batch)
+        if not self.h:
+            raise OmniError(f"omni_sp_create failed: {lib().omni_last_error().decode()}")
+        self.desc_dim = lib().omni_sp_desc_dim(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().omni_sp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _outs(self, batch):
+        return (np.zeros((batch, self.max_num, 2), np.float32), np.zeros(batch, np.int32),
+                np.zeros((batch, self.max_num, self.desc_dim), np.float32), np.zeros((batch, self.max_num), np.float32))
+
+    @staticmethod
+    def _split(kps, n, desc, sc):
+        return [(kps[b, :n[b]].copy(), desc[b, :n[b]].copy(), sc[b, :n[b]].copy()) for b in range(len(n))]
+
+    def inference(self, gray_u8: np.ndarray, fisheye_mask: bool = False):
+        """[H,W] or [B,H,W] uint8 -> list of (kps [n,2] (x,y), desc [n,D], scores [n]) per image."""
+        g = np.ascontiguousarray(gray_u8, np.uint8)
+        if g.ndim == 2:
+            g = g[None]
+        b = g.shape[0]
+        kps, n, desc, sc = self._outs(b)
+        _check(lib().omni_sp_infer(self.h, g.ctypes.data_as(_vp), g.shape[2], b, int(fisheye_mask), _pf(kps),
+                                   n.ctypes.data_as(_ip), _pf(desc), _pf(sc)))
+        return self._split(kps, n, desc, sc)
+
+    def enqueue_dev(self, gray_dev: int, stride: int, batch: int, fisheye_mask: bool = False):
+        _check(lib().omni_sp_enqueue_dev(self.h, gray_dev, stride, batch, int(fisheye_mask)))
+
+    def fetch(self, batch: int):
+        kps, n, desc, sc = self._outs(batch)
+        _check(lib().omni_sp_fetch(self.h, batch, _pf(kps), n.ctypes.data_as(_ip), _pf(desc), _pf(sc)))
+        return self._split(kps, n, desc, sc)
+
+    def dev_outputs(self):
+        k, n, d, s = _vp(), _vp(), _vp(), _vp()
+        _check(lib().omni_sp_dev_outputs(self.h, C.byref(k), C.byref(n), C.byref(d), C.byref(s)))
+        return k.value, n.value, d.value, s.value
+
+    def get_dense(self, batch: int):
+        semi = np.empty((batch, self.H, self.W), np.float32)
+        desc = np.empty((batch, 256, self.H // 8, self.W // 8), np.float32)
+        _check(lib().omni_sp_get_dense(self.h, batch, _pf(semi), _pf(desc)))
+        return semi, desc
+
+    def postprocess_dense(self, semi: np.ndarray, desc: np.ndarray):
+        semi, desc = _f32(semi), _f32(desc)
+        if semi.ndim == 2:
+            semi, desc = semi[None], desc[None]
+        b = semi.shape[0]
+        kps, n, d, sc = self._outs(b)
+        _check(lib().omni_sp_postprocess_dense(self.h, _pf(semi), _pf(desc), b, _pf(kps), n.ctypes.data_as(_ip), _pf(d), _pf(sc)))
+        return self._split(kps, n, d, sc)
+
+    def debug_layer(self, name: str, batch: int = 1) -> np.ndarray:
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().omni_sp_debug_layer(self.h, name.encode(), batch, None, C.byref(c), C.byref(h), C.byref(w)))
+        out = np.empty((batch, c.value, h.value, w.value), np.float32)
+        _check(lib().omni_sp_debug_layer(self.h, name.encode(), batch, _pf(out), C.byref(c), C.byref(h), C.byref(w)))
+        return out
+
+    def profile(self, gray_dev: int, stride: int, batch: int, reps: int = 5):
+        ms = np.zeros(SP_NUM_STAGES, np.float32)
+        _check(lib().omni_sp_profile(self.h, gray_dev, stride, batch, reps, _pf(ms)))
+        out = []
+        for i in range(SP_NUM_STAGES):
+            name = lib().omni_sp_stage_name(i).decode()
+            if name:
+                out.append({"stage": name, "ms": float(ms[i]), "flops_per_image": lib().omni_sp_stage_flops(self.h, i)})
+        return out
+
+
+class MobileNetVLAD:
+    """MobileNetVLADTensorRT(engine, width, height); weights (ASSUMED architecture) replace the engine file."""
+
+    def __init__(self, ctx: Context, weights: dict, layer_specs, n_clusters: int, feat_dim: int, out_dim: int,
+                 width: int, height: int, max_batch: int = 1):
+        self.ctx, self.W, self.H, self.out_dim, self.max_batch = ctx, width, height, out_dim, max_batch
+        self._keep = []
+        layers = (_VladLayer * len(layer_specs))()
+        for i, (name, kind, cin, cout, stride) in enumerate(layer_specs):
+            wt, bs = _f32(weights[name + ".weight"]), _f32(weights[name + ".bias"])
+            self._keep += [wt, bs]
+            layers[i] = _VladLayer(VLAD_KINDS[kind], cin, cout, stride, _pf(wt), _pf(bs))
+        aw, ab = _f32(weights["vlad.assign.weight"]).reshape(n_clusters, feat_dim), _f32(weights["vlad.assign.bias"])
+        cl, fw, fb = _f32(weights["vlad.clusters"]), _f32(weights["fc.weight"]), _f32(weights["fc.bias"])
+        self._keep += [aw, ab, cl, fw, fb, layers]
+        vw = _VladWeights(len(layer_specs), layers, n_clusters, feat_dim, out_dim, _pf(aw), _pf(ab), _pf(cl), _pf(fw), _pf(fb))
+        self.h = lib().omni_vlad_create(ctx.h, C.byref(vw), width, height, max_batch)
+        if not self.h:
+            raise OmniError(f"omni_vlad_create failed: {lib().omni_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().omni_vlad_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inference(self, gray_u8: np.ndarray, fisheye_mask: bool = False) -> np.ndarray:
+        g = np.ascontiguousarray(gray_u8, np.uint8)
+        if g.ndim == 2:
+            g = g[None]
+        out = np.empty((g.shape[0], self.out_dim), np.float32)
+        _check(lib().omni_vlad_infer(self.h, g.ctypes.data_as(_vp), g.shape[2], g.shape[0], int(fisheye_mask), _pf(out)))
+        return out
+
+    def enqueue_dev(self, gray_dev: int, stride: int, batch: int, fisheye_mask: bool = False):
+        _check(lib().omni_vlad_enqueue_dev(self.h, gray_dev, stride, batch, int(fisheye_mask)))
+
+    def fetch(self, batch: int) -> np.ndarray:
+        out = np.empty((batch, self.out_dim), np.float32)
+        _check(lib().omni_vlad_fetch(self.h, batch, _pf(out)))
+        return out
+
+    def dev_output(self) -> int:
+        p = _vp()
+        _check(lib().omni_vlad_dev_output(self.h, C.byref(p)))
+        return p.value
+
+
+class IndexFlatIP:
+    """faiss::IndexFlatIP(d): add / search / ntotal (+ row sharding)."""
+
+    def __init__(self, ctx: Context, d: int = 4096, storage: int = STORE_F32, capacity: int = 0):
+        self.ctx, self.d = ctx, d
+        self.h = lib().omni_index_create(ctx.h, d, storage, capacity)
+        if not self.h:
+            raise OmniError(f"omni_index_create failed: {lib().omni_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().omni_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ntotal(self) -> int:
+        return lib().omni_index_ntotal(self.h)
+
+    def add(self, x: np.ndarray):
+        x = _f32(np.atleast_2d(x))
+        assert x.shape[1] == self.d
+        _check(lib().omni_index_add(self.h, x.shape[0], _pf(x)))
+
+    def add_dev(self, n: int, x_dev: int):
+        _check(lib().omni_index_add_dev(self.h, n, x_dev))
+
+    def reset(self):
+        _check(lib().omni_index_reset(self.h))
+
+    def set_shard(self, rank: int, world: int):
+        _check(lib().omni_index_set_shard(self.h, rank, world))
+
+    def search(self, q: np.ndarray, k: int):
+        q = _f32(np.atleast_2d(q))
+        D = np.empty((q.shape[0], k), np.float32)
+        I = np.empty((q.shape[0], k), np.int64)
+        _check(lib().omni_index_search(self.h, q.shape[0], _pf(q), k, _pf(D), I.ctypes.data_as(_i64p)))
+        return D, I
+
+    def search_dev(self, nq: int, q_dev: int, k: int, D_dev: int, I_dev: int):
+        _check(lib().omni_index_search_dev(self.h, nq, q_dev, k, D_dev, I_dev))
+
+    def last_scan_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().omni_index_last_scan_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+def topk_merge(D_lists: np.ndarray, I_lists: np.ndarray, k_out: int):
+    """[n_lists, nq, k_each] per-shard lists -> merged [nq, k_out] (score desc, id asc).  Host-side, no GPU needed."""
+    D_lists, I_lists = _f32(D_lists), np.ascontiguousarray(I_lists, np.int64)
+    n_lists, nq, k_each = D_lists.shape
+    D = np.empty((nq, k_out), np.float32)
+    I = np.empty((nq, k_out), np.int64)
+    _check(lib().omni_topk_merge(n_lists, nq, k_each, _pf(D_lists), I_lists.ctypes.data_as(_i64p), k_out, _pf(D),
+                                 I.ctypes.data_as(_i64p)))
+    return D, I
+
+
+def bf_match(ctx: Context, q: np.ndarray, t: np.ndarray, mode: int = BF_OPENCV):
+    """cv::BFMatcher(NORM_L2, crossCheck=true).match(q, t) -> (query_idx, train_idx, distance)."""
+    q, t = _f32(q), _f32(t)
+    nq, nt = q.shape[0], t.shape[0]
+    dim = q.shape[1] if q.ndim == 2 and nq else (t.shape[1] if t.ndim == 2 else 64)
+    qi, ti, dd = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.float32)
+    n = C.c_int(0)
+    _check(lib().omni_bf_match(ctx.h, _pf(q), nq, _pf(t), nt, dim, mode, qi.ctypes.data_as(_ip), ti.ctypes.data_as(_ip),
+                               _pf(dd), C.byref(n)))
+    return qi[:n.value].copy(), ti[:n.value].copy(), dd[:n.value].copy()
+
+
+def bf_match_batched_dev(ctx: Context, n_pairs, max_n, dim, mode, q_dev, q_stride, nq_dev, t_dev, t_stride, nt_dev,
+                         qidx_dev, tidx_dev, dist_dev, n_dev):
+    _check(lib().omni_bf_match_batched_dev(ctx.h, n_pairs, max_n, dim, mode, q_dev, q_stride, nq_dev, t_dev, t_stride,
+                                           nt_dev, qidx_dev, tidx_dev, dist_dev, n_dev))

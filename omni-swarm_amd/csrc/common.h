@@ -1,0 +1,113 @@
+// Internal helpers shared by the HIP translation units of libomni_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/omni_hip.h"
+
+namespace omni {
+
+void set_error(const char* fmt, ...);
+
+#define OMNI_HIP_TRY(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::omni::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return OMNI_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+#define OMNI_REQUIRE(cond, code, ...)                                                        \
+    do {                                                                                     \
+        if (!(cond)) { ::omni::set_error(__VA_ARGS__); return (code); }                      \
+    } while (0)
+
+#define OMNI_LAUNCH_CHECK()                                                                  \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) {                                                              \
+            ::omni::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return OMNI_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grow-only device scratch buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return OMNI_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        OMNI_HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return OMNI_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Pinned host staging buffer.
+struct HostBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return OMNI_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; bytes = 0;
+        OMNI_HIP_TRY(hipHostMalloc(&p, need, hipHostMallocDefault));
+        bytes = need;
+        return OMNI_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace omni
+
+struct omni_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop;
+    std::mutex mu;
+    omni::DevBuf scratch;     // generic per-call scratch (bf match, host-entry staging)
+    omni::DevBuf scratch2;
+    omni::HostBuf hstage;
+};
+
+// ---- 64-bit sortable keys -------------------------------------------------------------------------------------
+// key = (orderable(score) << 32) | (0xFFFFFFFF - id): descending key order == (score desc, id asc).
+__host__ __device__ static inline uint32_t omni_f32_orderable(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ static inline float omni_orderable_f32(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(u);
+#else
+    memcpy(&f, &u, 4);
+#endif
+    return f;
+}
+__host__ __device__ static inline uint64_t omni_make_key(float score, uint32_t id) {
+    return ((uint64_t)omni_f32_orderable(score) << 32) | (uint64_t)(0xFFFFFFFFu - id);
+}
+#define OMNI_KEY_EMPTY 0ull   // sorts last; decodes to id 0xFFFFFFFF -> reported as -1

@@ -1,0 +1,59 @@
+// Convolution kernels of the SuperPoint graph (swarm_loop/superpoint.ipynb:143-205) for gfx950.
+//
+// Activations are NHWC (channels innermost) so that an MFMA B-fragment -- 8 consecutive input channels of one
+// pixel at one filter tap -- is a single 16-byte LDS read.  Implicit GEMM with
+//     M = output channels (A operand = pre-packed weights), N = pixels (B operand = LDS-staged input tile),
+//     K = taps x input channels,
+// so each lane of the 32x32 accumulator fragment holds ONE pixel and 16 output channels in runs of 4: bias + ReLU
+// (+ 2x2 max-pool by two cross-lane exchanges) fuse into the epilogue and stores are 8/16-byte NHWC writes.
+//   OMNI_PREC_F16: v_mfma_f32_32x32x16_f16, fp16 activations/weights, fp32 accumulate.
+//   OMNI_PREC_F32: v_mfma_f32_32x32x2_f32 (exact f32, an fmaf chain), fp32 activations/weights: the parity mode.
+#pragma once
+#include "common.h"
+
+namespace omni {
+
+#define CONV_TH 8          // output tile rows  (4 waves x 2 rows)
+#define CONV_TW 32         // output tile cols  (2 fragments x 16)
+#define CONV_COUT_TILE 64  // output channels per workgroup (2 fragments x 32)
+#define CONV_CIN_CHUNK 64  // input channels staged per pass
+
+// Packed weight size in elements for one conv layer (ksize 1 or 3), cin % 64 == 0, cout % 64 == 0.
+static inline size_t conv_packed_elems(int cin, int cout, int ksize) { return (size_t)cin * cout * ksize * ksize; }
+
+// Host-side packing OIHW fp32 -> fragment order [cout_tile][cin_chunk][tap][k-group][m-frag][lane][elems]
+// (see conv.hip for the exact element map).  out must hold conv_packed_elems() elements of the precision's type.
+void conv_pack_weights_f16(const float* w_oihw, int cin, int cout, int ksize, __half* out);
+void conv_pack_weights_f32(const float* w_oihw, int cin, int cout, int ksize, float* out);
+
+struct ConvArgs {
+    const void* in;        // NHWC [B][H][W][cin]
+    void* out;             // NHWC [B][Ho][Wo][cout]  (Ho,Wo = H/2,W/2 when pool)
+    const void* w_packed;
+    const float* bias;     // [cout] fp32
+    int batch, H, W, cin, cout, ksize;
+    int in_cstride = 0;    // channels per pixel of the input buffer (0 = cin); > cin reads a channel slice
+    bool relu, pool;
+    bool out_f32;          // write fp32 regardless of the compute precision (final 1x1 descriptor conv)
+};
+int conv_mfma(hipStream_t stream, int precision, const ConvArgs& a);
+
+// conv1a: 1 -> 64 channels, 3x3, + ReLU, straight from the u8 image (u8 -> f32 * 1/255 via a 256-entry table that
+// reproduces cv::Mat::convertTo(CV_32F, 1/255.0), superpoint_tensorrt.cpp:127; optional fisheye row mask,
+// loop_cam.cpp:536-539).  w [64][9] fp32, out NHWC [B][H][W][64] in the precision's type.
+int conv1a_direct(hipStream_t stream, int precision, const uint8_t* gray, int stride, int batch, int H, int W,
+                  int fisheye_mask, const float* w, const float* bias, const float* u8_lut, void* out);
+
+// Detector head tail: convPb 1x1 (256 -> 65) + softmax over 65 + drop dustbin + 8x8 depth-to-space
+// (superpoint.ipynb:184,190-199).  in: NHWC [B][Hc][Wc][in_stride] (channels [in_off, in_off+256) are cPa);
+// wT [256][65] fp32 (transposed), bias [65]; semi [B][Hc*8][Wc*8] fp32.
+int detector_head(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
+                  const float* wT, const float* bias, float* semi);
+
+// desc = desc / ||desc||_2 over the 256 channels of every coarse cell (superpoint.ipynb:187-188); fp32 NHWC in place.
+int l2norm_channels(hipStream_t stream, float* desc_nhwc, int64_t n_cells);
+
+// test hook: NHWC (fp16 or fp32) -> NCHW fp32
+int nhwc_any_to_nchw_f32(hipStream_t stream, int precision_of_in, const void* in, float* out, int batch, int C, int HW);
+
+}  // namespace omni

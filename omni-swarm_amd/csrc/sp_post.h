@@ -1,0 +1,42 @@
+// SuperPoint post-processing on the GPU (the reference does all of this on the CPU after a 5.8 MB D2H copy):
+//   getKeyPoints          swarm_loop/src/superpoint_tensorrt.cpp:164-189
+//   NMS2                  swarm_loop/src/superpoint_tensorrt.cpp:237-310
+//   computeDescriptors    swarm_loop/src/superpoint_tensorrt.cpp:192-230
+#pragma once
+#include "common.h"
+
+namespace omni {
+
+struct SpPostParams {
+    int width, height;      // image size (multiples of 8)
+    float thres;            // prob > thres (strict)                      :167
+    int max_num;            // keep at most max_num key points           :305
+    int dist_thresh;        // NMS radius, 4                              :183
+    int pca_dim;            // 0 = no PCA (desc_dim 256)
+};
+
+struct SpPostBuffers {      // all device pointers, sized for max_batch images
+    unsigned char* state;   // [B][H*W]            0 none / 1 unknown / 2 alive / 3 dead
+    int* cand;              // [B][H*W]            candidate pixel indices (unordered)
+    int* counters;          // [B][4]              n_cand, n_surv, n_iter, spare
+    uint64_t* surv_keys;    // [B][H*W]            survivor keys (unordered)
+    float* raw_desc;        // [B][max_num][256]   sampled, channel-normalised descriptors
+    // results
+    float* kps_xy;          // [B][max_num][2]
+    float* scores;          // [B][max_num]
+    int* n_kps;             // [B]
+    float* desc_out;        // [B][max_num][desc_dim]
+    // constants
+    const float* pca_compT; // [256][pca_dim]  (pca_comp transposed, as superpoint_tensorrt.cpp:110)
+    const float* pca_mean;  // [256]
+};
+
+// semi: [B][H][W] f32 probability map; desc_nhwc: [B][H/8][W/8][256] f32 (channel-normalised coarse descriptors)
+int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffers& b, const float* semi,
+                   const float* desc_nhwc, int batch);
+
+// layout helpers between the reference's NCHW binding layout and the internal NHWC
+int nchw_to_nhwc(hipStream_t stream, const float* in, float* out, int batch, int C, int HW);
+int nhwc_to_nchw(hipStream_t stream, const float* in, float* out, int batch, int C, int HW);
+
+}  // namespace omni

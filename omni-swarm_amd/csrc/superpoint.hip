@@ -1,0 +1,427 @@
+// omni_sp_*: drop-in for SuperPointTensorRT (swarm_loop/include/swarm_loop/superpoint_tensorrt.h:12-29,
+// swarm_loop/src/superpoint_tensorrt.cpp:91-230) including the TensorRT engine it wraps (the graph of
+// swarm_loop/superpoint.ipynb:135-205) and the runner plumbing of tensorrt_generic.cpp:14-120.
+//
+// HBM layout per handle (sized for max_batch images, all NHWC, element type = precision):
+//   a1a [B][H][W][64]   a1b [B][H/2][W/2][64]   a2a  a2b [B][H/4][W/4][64]   a3a [..][128]  a3b [B][H/8][W/8][128]
+//   a4a a4b [..][128]   heads [B][Hc][Wc][512] (cPa | cDa, one fused N=512 conv)   draw [B][Hc][Wc][256] fp32
+//   semi [B][H][W] fp32
+#include "conv.h"
+#include "sp_post.h"
+
+namespace {
+struct LayerDef { const char* name; int cin, cout, ks; };
+const LayerDef kLayers[OMNI_SP_NUM_LAYERS] = {
+    {"conv1a", 1, 64, 3},  {"conv1b", 64, 64, 3},   {"conv2a", 64, 64, 3},   {"conv2b", 64, 64, 3},
+    {"conv3a", 64, 128, 3}, {"conv3b", 128, 128, 3}, {"conv4a", 128, 128, 3}, {"conv4b", 128, 128, 3},
+    {"convPa", 128, 256, 3}, {"convPb", 256, 65, 1}, {"convDa", 128, 256, 3}, {"convDb", 256, 256, 1}};
+enum { L1A = 0, L1B, L2A, L2B, L3A, L3B, L4A, L4B, LPA, LPB, LDA, LDB };
+// profiling stages
+enum { ST_CONV1A = 0, ST_CONV1B, ST_CONV2A, ST_CONV2B, ST_CONV3A, ST_CONV3B, ST_CONV4A, ST_CONV4B, ST_HEADS_A,
+       ST_DET_TAIL, ST_DESC_TAIL, ST_POST, ST_COUNT };
+const char* kStageNames[OMNI_SP_NUM_STAGES] = {
+    "conv1a", "conv1b+pool", "conv2a", "conv2b+pool", "conv3a", "conv3b+pool", "conv4a", "conv4b", "convPa|convDa",
+    "convPb+softmax+d2s", "convDb+l2norm", "nms+topk+describe", "", "", "", ""};
+}  // namespace
+
+struct omni_sp {
+    omni_ctx* ctx = nullptr;
+    int W = 0, H = 0, Hc = 0, Wc = 0, max_num = 0, max_batch = 0, precision = 0, pca_dim = 0, desc_dim = 256;
+    float thres = 0.f;
+    size_t esz = 4;
+    // weights
+    void* wpk[OMNI_SP_NUM_LAYERS] = {};     // packed MFMA weights (L1B..L4B, LDB) ; heads_a fused in wpk[LPA]
+    float* bias[OMNI_SP_NUM_LAYERS] = {};
+    float* w1a = nullptr;                    // [64][9]
+    float* wPbT = nullptr;                   // [256][65]
+    float* bias_heads = nullptr;             // [512]
+    float* lut = nullptr;
+    float* pca_compT = nullptr;
+    float* pca_mean = nullptr;
+    // activations
+    void *a1a = nullptr, *a1b = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
+         *a4b = nullptr, *heads = nullptr;
+    float *draw = nullptr, *semi = nullptr;
+    uint8_t* gray_stage = nullptr;           // device copy for host-pointer entry points
+    omni::SpPostBuffers pb = {};
+    omni::HostBuf hstage;
+    omni::DevBuf dense_tmp;
+    hipEvent_t ev[OMNI_SP_NUM_STAGES + 1] = {};
+    std::mutex mu;
+};
+
+namespace omni {
+
+static int dev_upload(void** dst, const void* src, size_t bytes, hipStream_t st) {
+    OMNI_HIP_TRY(hipMalloc(dst, bytes));
+    OMNI_HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+    OMNI_HIP_TRY(hipStreamSynchronize(st));
+    return OMNI_OK;
+}
+
+static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, const float* pca_mean) {
+    hipStream_t st = s->ctx->stream;
+    int rc;
+    // biases, conv1a, convPb (fp32 always)
+    for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l)
+        if ((rc = dev_upload((void**)&s->bias[l], w->bias[l], (size_t)kLayers[l].cout * 4, st))) return rc;
+    if ((rc = dev_upload((void**)&s->w1a, w->weight[L1A], 64 * 9 * 4, st))) return rc;
+    {
+        std::vector<float> t(256 * 65);
+        for (int c = 0; c < 65; ++c)
+            for (int k = 0; k < 256; ++k) t[(size_t)k * 65 + c] = w->weight[LPB][(size_t)c * 256 + k];
+        if ((rc = dev_upload((void**)&s->wPbT, t.data(), t.size() * 4, st))) return rc;
+    }
+    {
+        std::vector<float> bh(512);
+        memcpy(bh.data(), w->bias[LPA], 256 * 4);
+        memcpy(bh.data() + 256, w->bias[LDA], 256 * 4);
+        if ((rc = dev_upload((void**)&s->bias_heads, bh.data(), 512 * 4, st))) return rc;
+    }
+    {   // cv::Mat::convertTo(CV_32F, 1/255.0): float(double(u8) * (1.0/255.0))  (superpoint_tensorrt.cpp:127)
+        float lut[256];
+        for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i * (1.0 / 255.0));
+        if ((rc = dev_upload((void**)&s->lut, lut, sizeof(lut), st))) return rc;
+    }
+    // packed MFMA weights
+    auto pack_upload = [&](int l, const float* w_oihw, int cin, int cout, int ks) -> int {
+        const size_t n = conv_packed_elems(cin, cout, ks);
+        if (s->precision == OMNI_PREC_F16) {
+            std::vector<__half> p(n);
+            conv_pack_weights_f16(w_oihw, cin, cout, ks, p.data());
+            return dev_upload(&s->wpk[l], p.data(), n * 2, st);
+        }
+        std::vector<float> p(n);
+        conv_pack_weights_f32(w_oihw, cin, cout, ks, p.data());
+        return dev_upload(&s->wpk[l], p.data(), n * 4, st);
+    };
+    for (int l : {L1B, L2A, L2B, L3A, L3B, L4A, L4B, LDB})
+        if ((rc = pack_upload(l, w->weight[l], kLayers[l].cin, kLayers[l].cout, kLayers[l].ks))) return rc;
+    {   // convPa | convDa fused along the output-channel axis: one N = 512 conv over the shared conv4b activations
+        const size_t per = (size_t)256 * 128 * 9;
+        std::vector<float> wh(per * 2);
+        memcpy(wh.data(), w->weight[LPA], per * 4);
+        memcpy(wh.data() + per, w->weight[LDA], per * 4);
+        if ((rc = pack_upload(LPA, wh.data(), 128, 512, 3))) return rc;
+    }
+    if (pca_comp) {
+        std::vector<float> t((size_t)256 * s->pca_dim);
+        for (int j = 0; j < s->pca_dim; ++j)
+            for (int c = 0; c < 256; ++c) t[(size_t)c * s->pca_dim + j] = pca_comp[(size_t)j * 256 + c];
+        if ((rc = dev_upload((void**)&s->pca_compT, t.data(), t.size() * 4, st))) return rc;
+        if ((rc = dev_upload((void**)&s->pca_mean, pca_mean, 256 * 4, st))) return rc;
+    }
+    // activations
+    const size_t B = s->max_batch, H = s->H, W = s->W, e = s->esz;
+    OMNI_HIP_TRY(hipMalloc(&s->a1a, B * H * W * 64 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->a1b, B * (H / 2) * (W / 2) * 64 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->a2a, B * (H / 2) * (W / 2) * 64 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->a2b, B * (H / 4) * (W / 4) * 64 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->a3a, B * (H / 4) * (W / 4) * 128 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->a3b, B * (H / 8) * (W / 8) * 128 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->a4a, B * (H / 8) * (W / 8) * 128 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->a4b, B * (H / 8) * (W / 8) * 128 * e));
+    OMNI_HIP_TRY(hipMalloc(&s->heads, B * (H / 8) * (W / 8) * 512 * e));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->draw, B * (H / 8) * (W / 8) * 256 * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->semi, B * H * W * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->gray_stage, B * H * W));
+    // post-processing buffers
+    const size_t hw = H * W, M = s->max_num;
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.cand, B * hw * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.counters, B * 4 * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.surv_keys, B * hw * 8));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.raw_desc, B * M * 256 * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.kps_xy, B * M * 2 * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.scores, B * M * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.n_kps, B * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.desc_out, B * M * s->desc_dim * 4));
+    OMNI_HIP_TRY(hipMemsetAsync(s->pb.n_kps, 0, B * 4, st));
+    OMNI_HIP_TRY(hipMemsetAsync(s->pb.kps_xy, 0, B * M * 2 * 4, st));
+    OMNI_HIP_TRY(hipMemsetAsync(s->pb.desc_out, 0, B * M * s->desc_dim * 4, st));
+    OMNI_HIP_TRY(hipMemsetAsync(s->pb.scores, 0, B * M * 4, st));
+    s->pb.state = nullptr;
+    s->pb.pca_compT = s->pca_compT;
+    s->pb.pca_mean = s->pca_mean;
+    for (int i = 0; i <= OMNI_SP_NUM_STAGES; ++i) OMNI_HIP_TRY(hipEventCreate(&s->ev[i]));
+    OMNI_HIP_TRY(hipStreamSynchronize(st));
+    return OMNI_OK;
+}
+
+static SpPostParams post_params(const omni_sp* s) {
+    SpPostParams p;
+    p.width = s->W; p.height = s->H; p.thres = s->thres; p.max_num = s->max_num; p.dist_thresh = 4; p.pca_dim = s->pca_dim;
+    return p;
+}
+
+// Enqueue the whole network + post-processing for `batch` HBM-resident images.  ev != nullptr records an event before
+// every stage (profiling only).
+static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, bool with_events,
+                      bool run_post) {
+    hipStream_t st = s->ctx->stream;
+    const int H = s->H, W = s->W, P = s->precision;
+    int rc, stage = 0;
+    auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
+    auto conv = [&](int l, const void* in, void* out, const float* bias, int h, int w, int cin, int cout, int ks, bool relu,
+                    bool pool, bool out_f32) -> int {
+        ConvArgs a;
+        a.in = in; a.out = out; a.w_packed = s->wpk[l]; a.bias = bias; a.batch = batch; a.H = h; a.W = w; a.cin = cin;
+        a.cout = cout; a.ksize = ks; a.relu = relu; a.pool = pool; a.out_f32 = out_f32;
+        return conv_mfma(st, P, a);
+    };
+    if ((rc = mark())) return rc;
+    if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(L1B, s->a1a, s->a1b, s->bias[L1B], H, W, 64, 64, 3, true, true, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(L2A, s->a1b, s->a2a, s->bias[L2A], H / 2, W / 2, 64, 64, 3, true, false, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(L2B, s->a2a, s->a2b, s->bias[L2B], H / 2, W / 2, 64, 64, 3, true, true, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(L3A, s->a2b, s->a3a, s->bias[L3A], H / 4, W / 4, 64, 128, 3, true, false, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(L3B, s->a3a, s->a3b, s->bias[L3B], H / 4, W / 4, 128, 128, 3, true, true, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(L4A, s->a3b, s->a4a, s->bias[L4A], H / 8, W / 8, 128, 128, 3, true, false, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(L4B, s->a4a, s->a4b, s->bias[L4B], H / 8, W / 8, 128, 128, 3, true, false, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, false))) return rc;
+    if ((rc = mark())) return rc;
+    if ((rc = detector_head(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc;
+    if ((rc = mark())) return rc;
+    {   // convDb reads channels [256,512) (cDa) of the fused heads buffer: input pointer offset by 256 channels,
+        // pixel stride 512
+        ConvArgs a;
+        a.in = (const char*)s->heads + (size_t)256 * s->esz; a.out = s->draw; a.w_packed = s->wpk[LDB]; a.bias = s->bias[LDB];
+        a.batch = batch; a.H = s->Hc; a.W = s->Wc; a.cin = 256; a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false;
+        a.out_f32 = true; a.in_cstride = 512;
+        if ((rc = conv_mfma(st, P, a))) return rc;
+    }
+    if ((rc = l2norm_channels(st, s->draw, (int64_t)batch * s->Hc * s->Wc))) return rc;
+    if ((rc = mark())) return rc;
+    if (run_post) {
+        if ((rc = sp_postprocess(st, post_params(s), s->pb, s->semi, s->draw, batch))) return rc;
+    }
+    if ((rc = mark())) return rc;
+    return OMNI_OK;
+}
+
+static int sp_fetch_locked(omni_sp* s, int batch, float* kps_xy, int* n_kps, float* desc, float* scores) {
+    hipStream_t st = s->ctx->stream;
+    const size_t M = s->max_num, D = s->desc_dim;
+    const size_t b_kps = (size_t)batch * M * 2 * 4, b_n = (size_t)batch * 4, b_desc = (size_t)batch * M * D * 4, b_sc = (size_t)batch * M * 4;
+    int rc;
+    if ((rc = s->hstage.ensure(b_kps + b_n + b_desc + b_sc))) return rc;
+    char* h = s->hstage.as<char>();
+    OMNI_HIP_TRY(hipMemcpyAsync(h, s->pb.kps_xy, b_kps, hipMemcpyDeviceToHost, st));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + b_kps, s->pb.n_kps, b_n, hipMemcpyDeviceToHost, st));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + b_kps + b_n, s->pb.desc_out, b_desc, hipMemcpyDeviceToHost, st));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + b_kps + b_n + b_desc, s->pb.scores, b_sc, hipMemcpyDeviceToHost, st));
+    OMNI_HIP_TRY(hipStreamSynchronize(st));
+    if (kps_xy) memcpy(kps_xy, h, b_kps);
+    if (n_kps) memcpy(n_kps, h + b_kps, b_n);
+    if (desc) memcpy(desc, h + b_kps + b_n, b_desc);
+    if (scores) memcpy(scores, h + b_kps + b_n + b_desc, b_sc);
+    return OMNI_OK;
+}
+
+static int upload_gray(omni_sp* s, const uint8_t* gray_host, int stride, int batch) {
+    // pack rows to a dense [batch][H][W] device image (stride = W)
+    const size_t n = (size_t)batch * s->H * s->W;
+    int rc;
+    if ((rc = s->hstage.ensure(n))) return rc;
+    uint8_t* h = s->hstage.as<uint8_t>();
+    for (int b = 0; b < batch; ++b)
+        for (int y = 0; y < s->H; ++y)
+            memcpy(h + ((size_t)b * s->H + y) * s->W, gray_host + ((size_t)b * s->H + y) * stride, s->W);
+    OMNI_HIP_TRY(hipMemcpyAsync(s->gray_stage, h, n, hipMemcpyHostToDevice, s->ctx->stream));
+    OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));   // hstage is reused by fetch
+    return OMNI_OK;
+}
+
+}  // namespace omni
+
+extern "C" {
+
+omni_sp* omni_sp_create(omni_ctx* ctx, const omni_sp_weights* w, const float* pca_comp, const float* pca_mean, int pca_dim,
+                        int width, int height, float thres, int max_num, int precision, int max_batch) {
+    if (!ctx || !w) { omni::set_error("null ctx/weights"); return nullptr; }
+    for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l)
+        if (!w->weight[l] || !w->bias[l]) { omni::set_error("weights for layer %s missing", kLayers[l].name); return nullptr; }
+    if (width <= 0 || height <= 0 || width % 8 || height % 8) {
+        omni::set_error("width=%d height=%d must be positive multiples of 8 (the reference asserts the engine size, superpoint_tensorrt.cpp:122)", width, height);
+        return nullptr;
+    }
+    if (precision != OMNI_PREC_F32 && precision != OMNI_PREC_F16) { omni::set_error("bad precision %d", precision); return nullptr; }
+    if (max_num < 1 || max_num > 1024 || max_batch < 1 || max_batch > 256) { omni::set_error("max_num=%d (1..1024) / max_batch=%d (1..256) out of range", max_num, max_batch); return nullptr; }
+    if (pca_comp && (!pca_mean || pca_dim < 1 || pca_dim > 256)) { omni::set_error("bad PCA arguments"); return nullptr; }
+    if ((size_t)width * height / 16 * 4 + 16 > 160 * 1024) { omni::set_error("image %dx%d exceeds the in-LDS NMS plane", width, height); return nullptr; }
+    (void)hipSetDevice(ctx->device);
+    omni_sp* s = new omni_sp();
+    s->ctx = ctx; s->W = width; s->H = height; s->Hc = height / 8; s->Wc = width / 8; s->thres = thres; s->max_num = max_num;
+    s->max_batch = max_batch; s->precision = precision; s->esz = precision == OMNI_PREC_F16 ? 2 : 4;
+    s->pca_dim = pca_comp ? pca_dim : 0; s->desc_dim = pca_comp ? pca_dim : 256;
+    if (omni::sp_init(s, w, pca_comp, pca_mean) != OMNI_OK) { omni_sp_destroy(s); return nullptr; }
+    return s;
+}
+
+void omni_sp_destroy(omni_sp* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
+    void* ptrs[] = {s->w1a, s->wPbT, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
+                    s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.counters, s->pb.surv_keys,
+                    s->pb.raw_desc, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    s->hstage.release(); s->dense_tmp.release();
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int omni_sp_desc_dim(const omni_sp* s) { return s ? s->desc_dim : -1; }
+
+int omni_sp_enqueue_dev(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {
+    OMNI_REQUIRE(s && gray_dev, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
+    OMNI_REQUIRE(stride >= s->W, OMNI_ERR_INVALID, "stride=%d < width=%d", stride, s->W);
+    std::lock_guard<std::mutex> lk(s->mu);
+    (void)hipSetDevice(s->ctx->device);
+    return omni::sp_forward(s, gray_dev, stride, batch, fisheye_mask, false, true);
+}
+
+int omni_sp_fetch(omni_sp* s, int batch, float* kps_xy, int* n_kps, float* desc, float* scores) {
+    OMNI_REQUIRE(s, OMNI_ERR_INVALID, "null handle");
+    OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
+    std::lock_guard<std::mutex> lk(s->mu);
+    (void)hipSetDevice(s->ctx->device);
+    return omni::sp_fetch_locked(s, batch, kps_xy, n_kps, desc, scores);
+}
+
+int omni_sp_infer(omni_sp* s, const uint8_t* gray_host, int stride, int batch, int fisheye_mask, float* kps_xy, int* n_kps,
+                  float* desc, float* scores) {
+    OMNI_REQUIRE(s && gray_host && kps_xy && n_kps && desc, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
+    OMNI_REQUIRE(stride >= s->W, OMNI_ERR_INVALID, "stride=%d < width=%d", stride, s->W);
+    std::lock_guard<std::mutex> lk(s->mu);
+    (void)hipSetDevice(s->ctx->device);
+    int rc;
+    if ((rc = omni::upload_gray(s, gray_host, stride, batch))) return rc;
+    if ((rc = omni::sp_forward(s, s->gray_stage, s->W, batch, fisheye_mask, false, true))) return rc;
+    return omni::sp_fetch_locked(s, batch, kps_xy, n_kps, desc, scores);
+}
+
+int omni_sp_dev_outputs(omni_sp* s, const float** kps_xy_dev, const int** n_kps_dev, const float** desc_dev, const float** scores_dev) {
+    OMNI_REQUIRE(s, OMNI_ERR_INVALID, "null handle");
+    if (kps_xy_dev) *kps_xy_dev = s->pb.kps_xy;
+    if (n_kps_dev) *n_kps_dev = s->pb.n_kps;
+    if (desc_dev) *desc_dev = s->pb.desc_out;
+    if (scores_dev) *scores_dev = s->pb.scores;
+    return OMNI_OK;
+}
+
+int omni_sp_get_dense(omni_sp* s, int batch, float* semi_host, float* desc_host) {
+    OMNI_REQUIRE(s, OMNI_ERR_INVALID, "null handle");
+    OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
+    std::lock_guard<std::mutex> lk(s->mu);
+    (void)hipSetDevice(s->ctx->device);
+    hipStream_t st = s->ctx->stream;
+    int rc;
+    if (semi_host) OMNI_HIP_TRY(hipMemcpyAsync(semi_host, s->semi, (size_t)batch * s->H * s->W * 4, hipMemcpyDeviceToHost, st));
+    if (desc_host) {
+        const size_t n = (size_t)batch * 256 * s->Hc * s->Wc;
+        if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
+        if ((rc = omni::nhwc_to_nchw(st, s->draw, s->dense_tmp.as<float>(), batch, 256, s->Hc * s->Wc))) return rc;
+        OMNI_HIP_TRY(hipMemcpyAsync(desc_host, s->dense_tmp.p, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    OMNI_HIP_TRY(hipStreamSynchronize(st));
+    return OMNI_OK;
+}
+
+int omni_sp_postprocess_dense(omni_sp* s, const float* semi_host, const float* desc_host, int batch, float* kps_xy, int* n_kps,
+                              float* desc, float* scores) {
+    OMNI_REQUIRE(s && semi_host && desc_host, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
+    std::lock_guard<std::mutex> lk(s->mu);
+    (void)hipSetDevice(s->ctx->device);
+    hipStream_t st = s->ctx->stream;
+    int rc;
+    const size_t n = (size_t)batch * 256 * s->Hc * s->Wc;
+    if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
+    OMNI_HIP_TRY(hipMemcpyAsync(s->semi, semi_host, (size_t)batch * s->H * s->W * 4, hipMemcpyHostToDevice, st));
+    OMNI_HIP_TRY(hipMemcpyAsync(s->dense_tmp.p, desc_host, n * 4, hipMemcpyHostToDevice, st));
+    if ((rc = omni::nchw_to_nhwc(st, s->dense_tmp.as<float>(), s->draw, batch, 256, s->Hc * s->Wc))) return rc;
+    if ((rc = omni::sp_postprocess(st, omni::post_params(s), s->pb, s->semi, s->draw, batch))) return rc;
+    return omni::sp_fetch_locked(s, batch, kps_xy, n_kps, desc, scores);
+}
+
+int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw_host, int* C, int* Hl, int* Wl) {
+    OMNI_REQUIRE(s && name, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
+    struct Ent { const char* n; const void* p; int c, div, prec; };
+    const int P = s->precision;
+    const Ent tab[] = {{"conv1a", s->a1a, 64, 1, P},   {"conv1b", s->a1b, 64, 2, P},   {"conv2a", s->a2a, 64, 2, P},
+                       {"conv2b", s->a2b, 64, 4, P},   {"conv3a", s->a3a, 128, 4, P},  {"conv3b", s->a3b, 128, 8, P},
+                       {"conv4a", s->a4a, 128, 8, P},  {"conv4b", s->a4b, 128, 8, P},  {"heads", s->heads, 512, 8, P},
+                       {"desc", s->draw, 256, 8, OMNI_PREC_F32}};
+    for (const Ent& e : tab) {
+        if (strcmp(e.n, name) != 0) continue;
+        const int h = s->H / e.div, w = s->W / e.div;
+        if (C) *C = e.c;
+        if (Hl) *Hl = h;
+        if (Wl) *Wl = w;
+        if (!out_nchw_host) return OMNI_OK;
+        std::lock_guard<std::mutex> lk(s->mu);
+        (void)hipSetDevice(s->ctx->device);
+        const size_t n = (size_t)batch * e.c * h * w;
+        int rc;
+        if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
+        if ((rc = omni::nhwc_any_to_nchw_f32(s->ctx->stream, e.prec, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc;
+        OMNI_HIP_TRY(hipMemcpyAsync(out_nchw_host, s->dense_tmp.p, n * 4, hipMemcpyDeviceToHost, s->ctx->stream));
+        OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        return OMNI_OK;
+    }
+    omni::set_error("unknown layer '%s'", name);
+    return OMNI_ERR_INVALID;
+}
+
+const char* omni_sp_stage_name(int stage) { return (stage >= 0 && stage < OMNI_SP_NUM_STAGES) ? kStageNames[stage] : ""; }
+
+double omni_sp_stage_flops(const omni_sp* s, int stage) {
+    if (!s) return 0.0;
+    const double H = s->H, W = s->W;
+    auto c = [](double h, double w, double cin, double cout, double k) { return 2.0 * h * w * cin * cout * k * k; };
+    switch (stage) {
+        case ST_CONV1A: return c(H, W, 1, 64, 3);
+        case ST_CONV1B: return c(H, W, 64, 64, 3);
+        case ST_CONV2A: case ST_CONV2B: return c(H / 2, W / 2, 64, 64, 3);
+        case ST_CONV3A: return c(H / 4, W / 4, 64, 128, 3);
+        case ST_CONV3B: return c(H / 4, W / 4, 128, 128, 3);
+        case ST_CONV4A: case ST_CONV4B: return c(H / 8, W / 8, 128, 128, 3);
+        case ST_HEADS_A: return c(H / 8, W / 8, 128, 512, 3);
+        case ST_DET_TAIL: return c(H / 8, W / 8, 256, 65, 1);
+        case ST_DESC_TAIL: return c(H / 8, W / 8, 256, 256, 1);
+        default: return 0.0;
+    }
+}
+
+int omni_sp_profile(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms) {
+    OMNI_REQUIRE(s && gray_dev && stage_ms && reps >= 1, OMNI_ERR_INVALID, "bad argument");
+    OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
+    std::lock_guard<std::mutex> lk(s->mu);
+    (void)hipSetDevice(s->ctx->device);
+    for (int i = 0; i < OMNI_SP_NUM_STAGES; ++i) stage_ms[i] = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        int rc = omni::sp_forward(s, gray_dev, stride, batch, 0, true, true);
+        if (rc) return rc;
+        OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        for (int i = 0; i < ST_COUNT; ++i) {
+            float ms = 0.f;
+            OMNI_HIP_TRY(hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]));
+            stage_ms[i] += ms / reps;
+        }
+    }
+    return OMNI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""LoopDetector: keyframe database + loop-candidate decision rules on top of the HIP index (host logic mirror).
+
+Mirrors /root/reference/swarm_loop/src/loop_detector.cpp (class LoopDetector, include/swarm_loop/loop_detector.h:24-111):
+    on_image_recv                      :11-137    gating (drop / add / query / hand to compute_loop)
+    add_to_database                    :150-173   <=4 rows per keyframe into local_index / remote_index
+    query_from_database (4- and 6-arg) :176-242   top-(5+max_index) IP search + recency/threshold rule, incl. the
+                                                   fall-through return of :241 and the shared `distance` of :184-186
+    query_fisheyeframe_from_database   :245-287
+The two faiss::IndexFlatIP members are omni_index handles (exact IP, HBM-resident); geometry (compute_loop, :627-836:
+BFMatcher + findHomography + solvePnPRansac + odometry gate) stays on the host and is passed in as a callback, as the
+kernels' scope ends at the match candidate.
+
+Unlike the reference (no mutex, entered from the ROS and LCM threads) calls are serialised by a lock.
+"""
+from __future__ import annotations
+
+import threading
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+REMOTE_MAGIN_NUMBER = 1000000   # loop_detector.h:22
+SEARCH_NEAREST_NUM = 5          # loop_defines.h:32
+DEEP_DESC_SIZE = 4096           # loop_defines.h:30
+STEREO_PINHOLE, STEREO_FISHEYE, PINHOLE_DEPTH = 0, 1, 2
+
+
+@dataclass
+class ImageDescriptor:           # swarm_msgs::ImageDescriptor_t, fields used on this path (loop_cam.cpp:529-551)
+    drone_id: int = 0
+    landmark_num: int = 0
+    image_desc: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    feature_descriptor: np.ndarray = field(default_factory=lambda: np.zeros((0, 64), np.float32))
+    landmarks_2d: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
+
+
+@dataclass
+class FisheyeFrameDescriptor:    # swarm_msgs::FisheyeFrameDescriptor_t
+    msg_id: int = 0
+    drone_id: int = 0
+    landmark_num: int = 0
+    prevent_adding_db: bool = False
+    images: list = field(default_factory=list)
+
+
+class LoopDetector:
+    def __init__(self, ctx: capi.Context, self_id: int, *, inner_product_thres=0.6, init_mode_product_thres=0.3,
+                 match_index_dist=10, min_loop_num=15, min_direction_loop=3, inter_drone_init_frames=50,
+                 camera_configuration=STEREO_FISHEYE, compute_loop=None, storage=capi.STORE_F32,
+                 index_factory=None):
+        self.self_id = self_id
+        self.INNER_PRODUCT_THRES = inner_product_thres
+        self.INIT_MODE_PRODUCT_THRES = init_mode_product_thres
+        self.MATCH_INDEX_DIST = match_index_dist
+        self.MIN_LOOP_NUM = min_loop_num
+        self.MIN_DIRECTION_LOOP = min_direction_loop
+        self.inter_drone_init_frames = inter_drone_init_frames
+        self.camera_configuration = camera_configuration
+        make = index_factory or (lambda: capi.IndexFlatIP(ctx, DEEP_DESC_SIZE, storage))
+        self.local_index = make()      # LoopDetector::LoopDetector, loop_detector.cpp:842-844
+        self.remote_index = make()
+        self.imgid2fisheye: dict[int, int] = {}
+        self.imgid2dir: dict[int, int] = {}
+        self.fisheyeframe_database: dict[int, FisheyeFrameDescriptor] = {}
+        self.inter_drone_loop_count: dict[tuple[int, int], int] = {}
+        self.all_nodes: set[int] = set()
+        self.compute_loop = compute_loop or (lambda *a: False)
+        self.log: list[dict] = []
+        self._mu = threading.Lock()
+
+    def database_size(self) -> int:
+        return self.local_index.ntotal + self.remote_index.ntotal
+
+    def _add_image(self, img: ImageDescriptor) -> int:
+        if img.drone_id == self.self_id:
+            self.local_index.add(img.image_desc)
+            return self.local_index.ntotal - 1
+        self.remote_index.add(img.image_desc)
+        return self.remote_index.ntotal - 1 + REMOTE_MAGIN_NUMBER
+
+    def add_to_database(self, frame: FisheyeFrameDescriptor) -> int:
+        for i, img in enumerate(frame.images):
+            if img.landmark_num > 0:
+                index = self._add_image(img)
+                self.imgid2fisheye[index] = frame.msg_id
+                self.imgid2dir[index] = i
+        self.fisheyeframe_database[frame.msg_id] = frame
+        return frame.msg_id
+
+    def _query_index(self, img, index, remote_db: bool, thres: float, max_index: int, distance: list) -> int:
+        index_offset = REMOTE_MAGIN_NUMBER if remote_db else 0
+        search_num = SEARCH_NEAREST_NUM + max_index
+        D, I = index.search(img.image_desc, search_num)
+        return_msg_id = -1
+        ntotal = index.ntotal
+        for i in range(search_num):
+            label = int(I[0, i])
+            if label < 0:
+                continue
+            if label + index_offset not in self.imgid2fisheye:
+                continue
+            return_msg_id = label + index_offset
+            if label <= ntotal - max_index and float(D[0, i]) > thres:
+                distance[0] = float(D[0, i])
+                return return_msg_id
+        return return_msg_id
+
+    def query_from_database(self, img, init_mode: bool, nonkeyframe: bool, distance: list) -> int:
+        thres = self.INIT_MODE_PRODUCT_THRES if init_mode else self.INNER_PRODUCT_THRES
+        if img.drone_id == self.self_id:
+            _id = self._query_index(img, self.remote_index, True, thres, 1, distance)
+            if not nonkeyframe:
+                return self._query_index(img, self.local_index, False, thres, self.MATCH_INDEX_DIST, distance)
+            elif _id != -1:
+                return _id
+        else:
+            return self._query_index(img, self.local_index, False, thres, 1, distance)
+        return -1
+
+    def query_fisheyeframe_from_database(self, frame, init_mode: bool, nonkeyframe: bool):
+        direction_new = 1 if self.camera_configuration == STEREO_FISHEYE else 0
+        if frame.images[direction_new].landmark_num > 0:
+            distance = [-1.0]
+            _id = self.query_from_database(frame.images[direction_new], init_mode, nonkeyframe, distance)
+            if _id != -1 and distance[0] > -1:
+                return (self.fisheyeframe_database[self.imgid2fisheye[_id]], direction_new, self.imgid2dir[_id], _id,
+                        distance[0])
+        return None, direction_new, -1, -1, -1.0
+
+    def on_image_recv(self, frame: FisheyeFrameDescriptor) -> dict:
+        with self._mu:
+            return self._on_image_recv(frame)
+
+    def _on_image_recv(self, frame):
+        rec = {"msg_id": frame.msg_id, "drone_id": frame.drone_id, "added": False, "queried": False, "image_id": -1,
+               "old_msg_id": -1, "dir_new": -1, "dir_old": -1, "loop": False}
+        self.log.append(rec)
+        if len(frame.images) == 0:
+            return rec
+        drone_id = frame.drone_id
+        if drone_id != self.self_id and self.database_size() == 0:
+            return rec
+        new_node = frame.drone_id not in self.all_nodes
+        self.all_nodes.add(frame.drone_id)
+        if sum(1 for img in frame.images if img.landmark_num > 0) < self.MIN_DIRECTION_LOOP:
+            return rec
+        if frame.landmark_num < self.MIN_LOOP_NUM:
+            return rec
+        init_mode = False
+        if drone_id != self.self_id:
+            init_mode = self.inter_drone_loop_count.get((drone_id, self.self_id), 0) < self.inter_drone_init_frames
+        if (not frame.prevent_adding_db) or new_node:
+            self.add_to_database(frame)
+            rec["added"] = True
+        if self.database_size() > self.MATCH_INDEX_DIST or init_mode or drone_id != self.self_id:
+            rec["queried"] = True
+            old, d_new, d_old, image_id, dist = self.query_fisheyeframe_from_database(frame, init_mode, frame.prevent_adding_db)
+            if d_old >= 0:
+                rec.update(image_id=image_id, old_msg_id=old.msg_id, dir_new=d_new, dir_old=d_old, distance=dist)
+                success, pair = False, None
+                if old.drone_id == self.self_id:
+                    success = self.compute_loop(frame, old, d_new, d_old, init_mode)
+                    pair = (frame.drone_id, old.drone_id)
+                elif frame.drone_id == self.self_id:
+                    success = self.compute_loop(old, frame, d_old, d_new, init_mode)
+                    pair = (old.drone_id, frame.drone_id)
+                if success:
+                    a, b = pair
+                    self.inter_drone_loop_count[(a, b)] = self.inter_drone_loop_count.get((a, b), 0) + 1
+                    self.inter_drone_loop_count[(b, a)] = self.inter_drone_loop_count.get((b, a), 0) + 1
+                    rec["loop"] = True
+        return rec

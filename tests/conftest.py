@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import omni_loader  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def omni():
+    return omni_loader.load()
+
+
+@pytest.fixture(scope="session")
+def ctx(omni):
+    """HIP context on cuda:0.  GPU tests must FAIL (not skip) when the native library or device is missing."""
+    c = omni.capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return lambda name: np.load(os.path.join(GOLDEN, name))

@@ -1,0 +1,131 @@
+"""GPU parity: omni_index_* (HIP) vs the exact-IP oracle (faiss::IndexFlatIP semantics, loop_detector.cpp:166,213).
+Bar: ids bit-exact, scores within 1e-5 relative (fp32 dot products in a different association order)."""
+import numpy as np
+import pytest
+
+from oracle import match_ref as M
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DIM = 4096
+
+
+def _check(idx, db, q, k, rtol=1e-5):
+    D, I = idx.search(q, k)
+    Dr, Ir = M.ip_search(db, q, k)
+    assert np.array_equal(I, Ir)
+    valid = Ir >= 0
+    assert np.allclose(D[valid], Dr[valid], rtol=rtol, atol=1e-6)
+    assert (D[~valid] < -1e38).all()
+
+
+def test_golden_db(omni, ctx, golden):
+    g = golden("match.npz")
+    db = synth.global_db(3000, seed=3)
+    q, _ = synth.queries_from_db(db, 8, seed=4)
+    idx = omni.capi.IndexFlatIP(ctx, DIM)
+    idx.add(db)
+    assert idx.ntotal == 3000
+    D, I = idx.search(q, 10)
+    assert np.array_equal(I, g["ip_I"]) and np.allclose(D, g["ip_D"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 5, 2047, 2048, 2049, 6000])
+def test_sizes_and_k(omni, ctx, n):
+    rng = np.random.default_rng(n)
+    db = rng.standard_normal((n, DIM)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = db[rng.integers(0, n, 3)] + 0.01 * rng.standard_normal((3, DIM)).astype(np.float32)
+    idx = omni.capi.IndexFlatIP(ctx, DIM)
+    for s in range(0, n, 1500):                       # incremental add, like LoopDetector (1 row at a time there)
+        idx.add(db[s:s + 1500])
+    assert idx.ntotal == n
+    for k in (1, 6, 10, 15):
+        _check(idx, db, q, k)
+    _check(idx, db, q[:1], 1000)                       # the reference's hard cap (loop_detector.cpp:200)
+
+
+def test_empty_and_padding(omni, ctx):
+    idx = omni.capi.IndexFlatIP(ctx, DIM)
+    q = np.ones((2, DIM), np.float32)
+    D, I = idx.search(q, 6)
+    assert (I == -1).all() and (D < -1e38).all()
+    db = synth.global_db(3, seed=1)
+    idx.add(db)
+    _check(idx, db, q, 6)
+
+
+def test_ties_go_to_lower_row_and_row_by_row_add(omni, ctx):
+    db = synth.global_db(300, seed=2)
+    db[150] = db[20]
+    db[299] = db[20]
+    idx = omni.capi.IndexFlatIP(ctx, DIM)
+    for r in db:                                       # IndexFlatIP::add(1, x), loop_detector.cpp:166
+        idx.add(r)
+    D, I = idx.search(db[20], 5)
+    assert I[0, :3].tolist() == [20, 150, 299]
+    _check(idx, db, db[[20, 77]], 10)
+    idx.reset()
+    assert idx.ntotal == 0
+
+
+@pytest.mark.parametrize("nq", [1, 2, 7, 8, 9, 17])
+def test_query_batches(omni, ctx, nq):
+    db = synth.global_db(4500, seed=6)
+    q, _ = synth.queries_from_db(db, nq, seed=7)
+    idx = omni.capi.IndexFlatIP(ctx, DIM)
+    idx.add(db)
+    _check(idx, db, q, 10)
+
+
+def test_fp16_storage(omni, ctx):
+    db = synth.global_db(5000, seed=8)
+    q, rows = synth.queries_from_db(db, 6, seed=9)
+    idx = omni.capi.IndexFlatIP(ctx, DIM, omni.capi.STORE_F16)
+    idx.add(db)
+    db16 = db.astype(np.float16).astype(np.float32)    # the oracle sees exactly what the shard stores
+    D, I = idx.search(q, 10)
+    Dr, Ir = M.ip_search(db16, q, 10)
+    assert np.array_equal(I[:, 0], rows)
+    assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=1e-6)
+
+
+def test_shard_ids_and_merge_equals_unsharded(omni, ctx):
+    db = synth.global_db(4001, seed=10)
+    db[3000] = db[11]
+    q = np.stack([db[11], db[2500]])
+    world, k = 4, 8
+    Dl, Il = [], []
+    for r in range(world):
+        idx = omni.capi.IndexFlatIP(ctx, DIM)
+        idx.set_shard(r, world)
+        idx.add(db[r::world])
+        D, I = idx.search(q, k)
+        assert ((I % world == r) | (I < 0)).all()
+        Dl.append(D); Il.append(I)
+    D, I = omni.capi.topk_merge(np.stack(Dl), np.stack(Il), k)
+    Dr, Ir = M.ip_search(db, q, k)
+    assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_properties_100k_rows(omni, ctx):
+    """BASELINE config 4 shard size (100 000 rows, 1.6 GB fp32): too big for the scalar oracle, so check properties:
+    planted rows come back first with score ~1, results are idempotent, scores descend, ids are unique."""
+    n = 100_000
+    idx = omni.capi.IndexFlatIP(ctx, DIM, capacity=n)
+    rng = np.random.default_rng(42)
+    planted = {}
+    for s in range(0, n, 10_000):
+        blk = rng.standard_normal((10_000, DIM), dtype=np.float32)
+        blk /= np.linalg.norm(blk, axis=1, keepdims=True)
+        planted[s + 1234] = blk[1234].copy()
+        idx.add(blk)
+    assert idx.ntotal == n
+    rows = sorted(planted)
+    q = np.stack([planted[r] for r in rows])
+    D, I = idx.search(q, 10)
+    assert I[:, 0].tolist() == rows and np.allclose(D[:, 0], 1.0, atol=1e-5)
+    assert (np.diff(D, axis=1) <= 0).all() and all(len(set(r)) == 10 for r in I.tolist())
+    D2, I2 = idx.search(q, 10)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
+    assert idx.last_scan_ms() > 0

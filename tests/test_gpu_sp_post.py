@@ -1,0 +1,93 @@
+"""GPU parity: getKeyPoints + NMS2 + computeDescriptors on the GPU (omni_sp_postprocess_dense) vs the literal oracle,
+fed the SAME engine outputs.  Bar: key points and confidences bit-exact in the fixed order; descriptors 1e-5."""
+import numpy as np
+import pytest
+
+from oracle import postproc_ref as P
+from oracle import superpoint_ref as S
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _sp(omni, ctx, w, h, thr, max_num=200, pca=True):
+    comp, mean = synth.pca()
+    return omni.capi.SuperPoint(ctx, S.synth_weights(0), comp if pca else None, mean if pca else None, w, h, thr, max_num,
+                                omni.capi.PREC_F32, 1), comp, mean
+
+
+def _compare(sp, semi, desc, w, h, thr, max_num, comp, mean, atol=2e-5):
+    (kps, d, sc), = sp.postprocess_dense(semi, desc)
+    xy, conf, nc, ns = P.get_keypoints(semi, thr, max_num)
+    assert np.array_equal(kps.astype(np.int32), xy), (len(kps), len(xy))
+    assert np.array_equal(sc, conf)
+    ref, _ = P.compute_descriptors(desc, xy, w, h, comp, mean)
+    if len(xy):
+        assert np.abs(d - ref).max() < atol, np.abs(d - ref).max()
+    return len(xy)
+
+
+def test_golden_small(omni, ctx, golden):
+    g = golden("sp_small.npz")
+    sp, comp, mean = _sp(omni, ctx, 96, 64, float(g["thres"]))
+    (kps, d, sc), = sp.postprocess_dense(g["semi"], g["desc"])
+    assert np.array_equal(kps.astype(np.int32), g["kps"]) and np.array_equal(sc, g["conf"])
+    assert np.abs(d - g["desc64"]).max() < 2e-5
+
+
+def test_random_maps_with_ties_and_borders(omni, ctx):
+    rng = np.random.default_rng(0)
+    w, h = 96, 64
+    for t in range(12):
+        thr = [0.05, 0.3, 0.6][t % 3]
+        sp, comp, mean = _sp(omni, ctx, w, h, thr, max_num=[200, 16, 64][t % 3])
+        semi = rng.random((h, w)).astype(np.float32) ** 4
+        if t % 2 == 0:
+            semi = (np.round(semi * 12) / 12).astype(np.float32)      # plateaus: equal confidences never suppress
+        semi[0, :] = rng.random(w) ** 2                               # activity on the image border
+        semi[:, -1] = rng.random(h) ** 2
+        desc = rng.standard_normal((256, h // 8, w // 8)).astype(np.float32)
+        desc /= np.linalg.norm(desc, axis=0, keepdims=True)
+        _compare(sp, semi, desc, w, h, thr, sp.max_num, comp, mean)
+        sp.close()
+
+
+def test_no_candidates_and_all_candidates(omni, ctx):
+    w, h = 64, 32
+    sp, comp, mean = _sp(omni, ctx, w, h, 0.5, max_num=50)
+    desc = np.ones((256, 4, 8), np.float32) / 16
+    (kps, d, sc), = sp.postprocess_dense(np.zeros((h, w), np.float32), desc)
+    assert len(kps) == 0
+    semi = np.full((h, w), 0.9, np.float32)                          # 2048 candidates, all tied -> all survive
+    (kps, d, sc), = sp.postprocess_dense(semi, desc)
+    xy, conf, nc, ns = P.get_keypoints(semi, 0.5, 50)
+    assert nc == w * h and ns == w * h and np.array_equal(kps.astype(np.int32), xy)
+    assert kps[:3].tolist() == [[0, 0], [1, 0], [2, 0]]              # ties -> row-major order
+
+
+def test_more_survivors_than_the_lds_sort_capacity(omni, ctx):
+    w, h = 160, 96                                                    # 15360 tied candidates > 8192-key LDS batch
+    sp, comp, mean = _sp(omni, ctx, w, h, 0.1, max_num=300)
+    rng = np.random.default_rng(4)
+    semi = np.full((h, w), 0.5, np.float32)
+    hot = rng.choice(w * h, 40, replace=False)
+    semi.ravel()[hot] = 0.5 + rng.random(40).astype(np.float32) * 0.4
+    desc = rng.standard_normal((256, h // 8, w // 8)).astype(np.float32)
+    _compare(sp, semi, desc, w, h, 0.1, 300, comp, mean, atol=1e-4)
+
+
+def test_full_size_frame_from_oracle_net(omni, ctx):
+    w, h = 600, 480
+    weights = S.synth_weights(0)
+    img = synth.image_u8(0, h, w)
+    semi, desc = S.forward(weights, S.preprocess_u8(img, fisheye_mask=True))
+    for thr in (0.015, 0.2):
+        sp, comp, mean = _sp(omni, ctx, w, h, thr)
+        n = _compare(sp, semi[0], desc[0], w, h, thr, 200, comp, mean)
+        assert n == 200
+        sp.close()
+    sp, comp, mean = _sp(omni, ctx, w, h, 0.015, pca=False)          # #undef USE_PCA path: 256-d
+    (kps, d, sc), = sp.postprocess_dense(semi[0], desc[0])
+    xy, _, _, _ = P.get_keypoints(semi[0], 0.015, 200)
+    _, raw = P.compute_descriptors(desc[0], xy, w, h, comp, mean)
+    assert d.shape[1] == 256 and np.abs(d - raw).max() < 2e-5

@@ -1,0 +1,45 @@
+"""GPU parity: MobileNetVLAD (ASSUMED architecture, parity-unpinned -- oracle/mobilenetvlad_ref.py) and the LoopDetector
+host logic running on the HIP index vs the oracle's decision trace."""
+import numpy as np
+import pytest
+
+from oracle import mobilenetvlad_ref as V
+from oracle import synth
+from tests import detector_stream as DS
+
+pytestmark = pytest.mark.gpu
+
+
+def _vlad(omni, ctx, w, h, max_batch):
+    return omni.capi.MobileNetVLAD(ctx, V.synth_weights(), V.layer_specs(), V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM, w, h, max_batch)
+
+
+def test_vlad_golden_small(omni, ctx, golden):
+    g = golden("vlad_small.npz")
+    net = _vlad(omni, ctx, 128, 96, 2)
+    y = net.inference(g["images"])
+    assert np.allclose(np.linalg.norm(y, axis=1), 1, atol=1e-5)
+    rel = np.linalg.norm(y - g["out"], axis=1) / np.linalg.norm(g["out"], axis=1)
+    assert rel.max() < 1e-3, rel                                     # north_star: VLAD vectors within 1e-3 relative
+
+
+def test_vlad_full_size_batch_and_mask(omni, ctx):
+    imgs = np.stack([synth.image_u8(20 + i, 480, 600) for i in range(4)])
+    net = _vlad(omni, ctx, 600, 480, 4)
+    y = net.inference(imgs, fisheye_mask=True)
+    masked = imgs.copy()
+    masked[:, 360:] = 0                                              # loop_cam.cpp:536-539
+    ref = V.forward(V.synth_weights(), masked)
+    rel = np.linalg.norm(y - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert rel.max() < 1e-3, rel
+    y1 = net.inference(imgs[2], fisheye_mask=True)
+    assert np.array_equal(y1[0], y[2])
+
+
+def test_loop_detector_trace_equals_oracle(omni, ctx, golden):
+    from omni_swarm_amd import detector
+    frames = DS.make_stream(seed=11)
+    tr = DS.trace(DS.run_product(frames, ctx, detector))
+    assert np.array_equal(tr, golden("detector.npz")["trace"])
+    frames2 = DS.make_stream(seed=12, n_frames=60)
+    assert np.array_equal(DS.trace(DS.run_product(frames2, ctx, detector)), DS.trace(DS.run_oracle(frames2)))

@@ -1,0 +1,163 @@
+"""CPU tests of the oracle itself: restatements agree with each other and with the committed golden vectors
+(tools/gen_golden.py pinned those against the reference's own PyTorch module in the build container)."""
+import numpy as np
+import pytest
+
+from oracle import match_ref as M
+from oracle import mobilenetvlad_ref as V
+from oracle import postproc_ref as P
+from oracle import superpoint_ref as S
+from oracle import synth
+from tests import detector_stream as DS
+
+
+def test_nms2_literal_c_equals_python_equals_characterised():
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        h, w = int(rng.integers(9, 48)), int(rng.integers(9, 64))
+        prob = rng.random((h, w)).astype(np.float32) ** 5
+        if t % 3 == 0:
+            prob = (np.round(prob * 16) / 16).astype(np.float32)     # many exact ties
+        thr = [0.05, 0.2, 0.5][t % 3]
+        a = P.get_keypoints(prob, thr, 64)
+        b = P.get_keypoints_py_literal(prob, thr, 64)
+        c = P.get_keypoints_characterised(prob, thr, 64)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0])
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], c[1])
+
+
+def test_nms2_is_order_dependent():
+    # confs .3, .5, .9 spaced 3 px apart along the scan: only .9 survives one way, {.9,.3} the other
+    prob = np.zeros((9, 24), np.float32)
+    prob[4, 6], prob[4, 9], prob[4, 12] = 0.3, 0.5, 0.9
+    xy, conf, _, _ = P.get_keypoints(prob, 0.1, 10)
+    assert {tuple(p) for p in xy.tolist()} == {(12, 4)}
+    prob2 = prob[:, ::-1].copy()
+    xy2, conf2, _, _ = P.get_keypoints(prob2, 0.1, 10)
+    assert {tuple(p) for p in xy2.tolist()} == {(11, 4), (17, 4)}
+
+
+def test_nms2_equal_confidences_do_not_suppress_and_order_is_fixed():
+    prob = np.zeros((16, 16), np.float32)
+    prob[5, 5] = prob[5, 6] = prob[6, 5] = 0.7
+    xy, conf, nc, ns = P.get_keypoints(prob, 0.5, 10)
+    assert ns == 3 and xy.tolist() == [[5, 5], [6, 5], [5, 6]]      # conf ties -> row-major index ascending
+    xy1, _, _, _ = P.get_keypoints(prob, 0.5, 2)
+    assert xy1.tolist() == [[5, 5], [6, 5]]
+
+
+def test_nms2_column_wrap_quirk_only_matters_at_the_border():
+    rng = np.random.default_rng(3)
+    prob = rng.random((32, 40)).astype(np.float32) ** 4
+    interior = prob.copy()
+    interior[:, :4] = 0
+    interior[:, -4:] = 0
+    a = P.get_keypoints(interior, 0.3, 100, wrap_columns=False)
+    b = P.get_keypoints(interior, 0.3, 100, wrap_columns=True)
+    assert np.array_equal(a[0], b[0])
+
+
+def test_superpoint_oracle_matches_golden_small(golden):
+    g = golden("sp_small.npz")
+    w = S.synth_weights(0)
+    semi, desc = S.forward(w, S.preprocess_u8(g["image"]))
+    # golden came from the reference notebook module on the build container; allow cross-CPU kernel differences
+    assert np.abs(semi[0] - g["semi"]).max() < 2e-6
+    assert np.abs(desc[0] - g["desc"]).max() < 2e-5
+    xy, conf, nc, ns = P.get_keypoints(g["semi"], float(g["thres"]), 200)
+    assert np.array_equal(xy, g["kps"]) and np.array_equal(conf, g["conf"])
+    comp, mean = synth.pca()
+    d64, d256 = P.compute_descriptors(g["desc"], xy, 96, 64, comp, mean)
+    assert np.allclose(d64, g["desc64"], atol=1e-5) and np.allclose(d256, g["desc256"], atol=1e-5)
+
+
+def test_descriptor_normalisation_is_per_channel_across_keypoints(golden):
+    # superpoint_tensorrt.cpp:211-215: torch::norm(desc[256,n], 2, dim=1) -> every CHANNEL has unit norm over the key points
+    g = golden("sp_small.npz")
+    d256 = g["desc256"]
+    assert np.allclose(np.linalg.norm(d256, axis=0), 1.0, atol=1e-4)
+    assert not np.allclose(np.linalg.norm(d256, axis=1), 1.0, atol=1e-2)
+
+
+def test_preprocess_is_opencv_convert_to():
+    u = np.arange(256, dtype=np.uint8)[None]
+    x = S.preprocess_u8(u)
+    assert x.dtype == np.float32 and x[0, 255] == np.float32(1.0) and x[0, 0] == 0
+    assert np.array_equal(x[0], (u[0].astype(np.float64) * (1.0 / 255.0)).astype(np.float32))
+    img = np.full((8, 4), 9, np.uint8)
+    assert (S.preprocess_u8(img, fisheye_mask=True)[6:] == 0).all() and (S.preprocess_u8(img, True)[:6] > 0).all()
+
+
+def test_ip_search_c_equals_numpy_and_tie_rule():
+    db = synth.global_db(500, dim=512, seed=9)
+    db[77] = db[13]
+    db[400] = db[13]
+    q = db[[13, 250]] * np.float32(1.0)
+    D1, I1 = M.ip_search(db, q, 7)
+    D2, I2 = M.ip_search_numpy(db, q, 7)
+    assert np.array_equal(I1, I2) and np.allclose(D1, D2, atol=1e-6)
+    assert I1[0, :3].tolist() == [13, 77, 400]                       # ties -> lower row first
+    D3, I3 = M.ip_search(db[:3], q, 5)
+    assert (I3[:, 3:] == -1).all() and (D3[:, 3:] < -1e38).all()     # k > n padding (faiss semantics)
+
+
+def test_ip_search_matches_golden(golden):
+    g = golden("match.npz")
+    db = synth.global_db(3000, seed=3)
+    q, rows = synth.queries_from_db(db, 8, seed=4)
+    D, I = M.ip_search(db, q, 10)
+    assert np.array_equal(I, g["ip_I"]) and np.allclose(D, g["ip_D"], atol=1e-6) and np.array_equal(rows, g["ip_rows"])
+
+
+def test_bf_match_opencv_semantics_differs_from_strict_mutual():
+    # d(a1,b1)=1, d(a2,b1)=.5, d(a1,b2)=2, d(a2,b2)=3: OpenCV's crosscheck still pairs a1 with b2
+    a = np.array([[0.0, 0], [1.5, 0]], np.float32)
+    b = np.array([[1.0, 0], [-2.0, 0]], np.float32)
+    q0, t0, d0 = M.bf_match(a, b, 0)
+    q1, t1, d1 = M.bf_match(a, b, 1)
+    assert list(zip(q0, t0)) == [(0, 1), (1, 0)] and np.allclose(d0, [2.0, 0.5])
+    assert list(zip(q1, t1)) == [(1, 0)]
+
+
+def test_bf_match_golden_and_first_minimum_wins(golden):
+    g = golden("match.npz")
+    q0, t0, d0 = M.bf_match(g["bf_a"], g["bf_b"], 0)
+    assert np.array_equal(q0, g["bf0_q"]) and np.array_equal(t0, g["bf0_t"]) and np.array_equal(d0, g["bf0_d"])
+    a = np.zeros((3, 8), np.float32)
+    b = np.zeros((2, 8), np.float32)            # all distances equal -> query 0 gets train 0 only
+    q, t, d = M.bf_match(a, b, 0)
+    assert q.tolist() == [0] and t.tolist() == [0]
+    assert M.bf_match(a[:0], b, 0)[0].size == 0
+
+
+def test_detector_trace_matches_golden(golden):
+    log = DS.run_oracle(DS.make_stream(seed=11))
+    tr = DS.trace(log)
+    assert np.array_equal(tr, golden("detector.npz")["trace"])
+    assert (tr[:, 4] >= 0).sum() > 20 and tr[:, 6].sum() > 5      # the stream does exercise candidates and loops
+
+
+def test_detector_fall_through_quirk_is_restated():
+    # remote hit + local miss: the shared `distance` leaks and the LAST examined local label is returned (:184-186,241)
+    det = M.LoopDetectorRef(1, match_index_dist=1, min_loop_num=1, min_direction_loop=1)
+    rng = np.random.default_rng(0)
+    def unit():
+        v = rng.standard_normal(4096).astype(np.float32)
+        return v / np.linalg.norm(v)
+    target = unit()
+    def frame(mid, did, vec):
+        img = M.ImageDesc(drone_id=did, landmark_num=50, image_desc=vec)
+        return M.FisheyeFrameDesc(msg_id=mid, drone_id=did, landmark_num=200, images=[img, img, img, img])
+    for i in range(4):
+        det.on_image_recv(frame(10 + i, 1, unit()))
+    det.on_image_recv(frame(50, 2, target))
+    rec = det.on_image_recv(frame(60, 1, target * np.float32(0.999)))
+    assert rec["queried"] and rec["image_id"] >= 0 and rec["image_id"] < M.REMOTE_MAGIN_NUMBER
+    assert rec["distance"] > 0.9                 # the remote hit's score, attached to a local label
+
+
+def test_mobilenetvlad_oracle_golden(golden):
+    g = golden("vlad_small.npz")
+    y = V.forward(V.synth_weights(), g["images"])
+    assert np.allclose(np.linalg.norm(y, axis=1), 1, atol=1e-5)
+    assert np.abs(y - g["out"]).max() < 1e-5
