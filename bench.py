@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""bench.py -- keyframes/sec of the swarm_loop hot path on MI355X + p50 loop-match latency.
+
+A "step" is ONE fisheye key frame through the whole hot path (BASELINE.json configs[1]):
+    8 SuperPoint images (4 directions x up/down, 600x480 u8, fisheye-masked) + 4 MobileNetVLAD images
+    + 4 up<->down descriptor cross-check matches                    (LoopCam::on_flattened_images, loop_cam.cpp:178-229)
+    + <=4 row inserts into the 4096-d global index and the top-k inner-product query with the recency/threshold rule
+                                                                    (LoopDetector::on_image_recv, loop_detector.cpp:11-137)
+Inputs are resident in HBM before the timed region (a pool of distinct synthetic key frames); results (key points,
+descriptors, global descriptors, match lists, query result) are copied back to the host inside it.
+
+One process per GPU.  N > 1 (launched by torch.distributed.run): key frames are data parallel, the global index is
+row-sharded across ranks and every step has one exchange (all_gather of the new rows, all_gather of per-shard top-k).
+
+Prints ONE JSON line on rank 0 (see the task contract) with the extra objects `roofline` (dominant kernel),
+`roofline_knn`, `loop_match` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+PEAK_F32_TFLOPS = 157.3       # f32-input MFMA = vector peak
+PEAK_HBM_GBS = 8000.0         # HBM3E spec peak (6.29 TB/s measured achievable)
+SP_FLOP_PER_IMAGE = 48.85e9   # SURVEY.md 2.3 @600x480
+KF_IMAGES = 8                 # reference-faithful key frame: 8 SuperPoint + 4 MobileNetVLAD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", choices=["f16", "f32"], default="f16")
+    ap.add_argument("--db-keyframes", type=int, default=1000, help="key frames pre-loaded in the index (x4 rows) for the throughput loop")
+    ap.add_argument("--match-db-rows", type=int, default=100_000, help="index rows for the p50 loop-match measurement (node total)")
+    ap.add_argument("--pipelines", type=int, default=2, help="key frames in flight per GPU (separate HIP streams)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-keyframes", type=int, default=3, help="key frames timed on the host cores for cpu_baseline")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import omni_loader
+    omni = omni_loader.load()
+    from omni_swarm_amd import capi, detector, frontend, shard, synth, weights
+    prec = capi.PREC_F16 if args.precision == "f16" else capi.PREC_F32
+    W, H, MAXN = 600, 480, 200
+    THRES = 0.02                      # superpoint_thres of the fisheye launch files (nodelet-sfisheye.launch)
+    MATCH_INDEX_DIST, QUERY_THRES = 5, 0.3   # launch values
+    K_SEARCH = 5 + MATCH_INDEX_DIST
+
+    sp_w = weights.superpoint_synth_weights(0)
+    comp, mean = synth.pca()
+    vl_w = weights.mobilenetvlad_synth_weights()
+    vl_specs = weights.mobilenetvlad_layer_specs()
+    ctxs = [capi.Context(local_rank) for _ in range(args.pipelines)]
+    ictx = capi.Context(local_rank)
+    info = ictx.device_info()
+    cams = [frontend.LoopCam(c, sp_w, comp, mean, vl_w, vl_specs, (weights.VLAD_N_CLUSTERS, weights.VLAD_FEAT_DIM, weights.VLAD_OUT_DIM),
+                             W, H, THRES, MAXN, prec) for c in ctxs]
+
+    # ---- synthetic key-frame pool, resident in HBM ---------------------------------------------------------------
+    POOL = 4
+    pool = []
+    for p in range(POOL):
+        imgs = np.stack([synth.image_u8(1000 * rank + 8 * p + i, H, W) for i in range(KF_IMAGES)])
+        pool.append(ictx.to_device(imgs))
+
+    # ---- index: local (world 1) or row-sharded --------------------------------------------------------------------
+    rng = np.random.default_rng(7)
+
+    def random_rows(n):
+        x = rng.standard_normal((n, 4096), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return x
+
+    if world == 1:
+        det = detector.LoopDetector(ictx, self_id=1, inner_product_thres=QUERY_THRES, init_mode_product_thres=0.2,
+                                    match_index_dist=MATCH_INDEX_DIST, min_loop_num=30, min_direction_loop=3)
+        base_rows = 4 * args.db_keyframes
+        for s in range(0, base_rows, 4096):
+            det.local_index.add(random_rows(min(4096, base_rows - s)))
+        for i in range(base_rows):      # bookkeeping for pre-loaded rows: frame ids / directions
+            det.imgid2fisheye[i] = -(i // 4) - 1
+            det.imgid2dir[i] = i % 4
+        swarm = None
+    else:
+        det = None
+        swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, torch.device("cuda", local_rank))
+        per_rank = 4 * args.db_keyframes // world
+        swarm.preload_local(random_rows(per_rank), per_rank * world)
+
+    hits = [0]
+
+    def finish(cam, step):
+        out = cam.fetch()
+        if world == 1:
+            fr = detector.FisheyeFrameDescriptor(
+                msg_id=step, drone_id=1, landmark_num=out["landmark_num"], prevent_adding_db=False,
+                images=[detector.ImageDescriptor(drone_id=1, landmark_num=i["landmark_num"], image_desc=i["image_desc"],
+                                                 feature_descriptor=i["feature_descriptor"], landmarks_2d=i["landmarks_2d"])
+                        for i in out["images"]])
+            rec = det.on_image_recv(fr)
+            hits[0] += int(rec["old_msg_id"] != -1)
+        else:
+            rows = np.stack([i["image_desc"] for i in out["images"]])
+            D, I = swarm.step(rows, query_row=1, k=K_SEARCH)                # add world*4 rows, query direction 1
+            ok = (I[0] >= 0) & (I[0] <= swarm.ntotal - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
+            hits[0] += int(ok.any())
+        return out
+
+    def run(n_steps, first_step):
+        pending = None
+        for s in range(n_steps):
+            cam = cams[s % len(cams)]
+            cam.enqueue_dev(pool[(first_step + s) % POOL], W)
+            if pending is not None:
+                finish(*pending)
+            pending = (cam, first_step + s)
+        if pending is not None:
+            finish(*pending)
+
+    def barrier():
+        for c in ctxs:
+            c.sync()
+        ictx.sync()
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        if dist is not None:
+            dist.barrier()
+
+    run(args.warmup, 0)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kfps = args.steps * world / dt
+
+    # ---- roofline of the dominant kernel (conv1b + pool, 43 % of the FLOPs): HIP events on the kernel's own stream --
+    prof = cams[0].sp.profile(pool[0], W, KF_IMAGES, reps=10)
+    conv_ms = sum(p["ms"] for p in prof if p["stage"].startswith("conv"))
+    sp_ms = sum(p["ms"] for p in prof)
+    c1b = next(p for p in prof if p["stage"].startswith("conv1b"))
+    c1b_flop = c1b["flops_per_image"] * KF_IMAGES
+    peak = PEAK_F16_TFLOPS if args.precision == "f16" else PEAK_F32_TFLOPS
+    achieved = c1b_flop / (c1b["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<conv1b 3x3 64->64 +ReLU +maxpool2>", "achieved": round(achieved, 1),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4),
+                "conv_stack_tflops": round(SP_FLOP_PER_IMAGE * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
+                "stages_ms": {p["stage"]: round(p["ms"], 4) for p in prof}, "superpoint_batch8_ms": round(sp_ms, 3)}
+
+    # ---- p50 loop-match latency on a big DB (node total rows = --match-db-rows, sharded when N > 1) -----------------
+    rows_here = args.match_db_rows // world
+    midx = capi.IndexFlatIP(ictx, 4096, capi.STORE_F32, rows_here)
+    for s in range(0, rows_here, 8192):
+        midx.add(random_rows(min(8192, rows_here - s)))
+    mq = random_rows(1)
+    if world > 1:
+        big = shard.ShardedIndex(midx, rank, world, dist, torch.device("cuda", local_rank))
+        search = lambda: big.search(mq, K_SEARCH)
+    else:
+        search = lambda: midx.search(mq, K_SEARCH)
+    lat, scan = [], []
+    for i in range(60):
+        if dist is not None:
+            dist.barrier()
+        t = time.perf_counter()
+        search()
+        lat.append((time.perf_counter() - t) * 1e3)
+        scan.append(midx.last_scan_ms())
+    lat, scan = lat[10:], scan[10:]
+    if dist is not None:
+        t = torch.tensor([float(np.median(lat))], device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        p50 = float(t.item())
+    else:
+        p50 = float(np.median(lat))
+    scan_ms = float(np.median(scan))
+    gbs = rows_here * 4096 * 4 / (scan_ms * 1e-3) / 1e9
+    roofline_knn = {"bound": "hbm", "kernel": "ip_scan_kernel<float,1>", "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": rows_here * 16384,
+                    "launch_ms": round(scan_ms, 4), "rows_per_gpu": rows_here}
+    loop_match = {"p50_ms": round(p50, 4), "db_rows_node": args.match_db_rows, "db_rows_per_gpu": rows_here, "k": K_SEARCH,
+                  "includes": "H2D query, scan, top-k, D2H result" + (", all_gather + merge" if world > 1 else "")}
+    midx.close()
+
+    # ---- CPU baseline: the reference's PyTorch-CPU SuperPoint path + oracle post-processing, same host ---------------
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_keyframes, W, H, THRES, MAXN, comp, mean, sp_w, vl_w)
+
+    if rank == 0:
+        line = {
+            "metric": "keyframes/sec (4x fisheye 600x480) + p50 loop-match ms @ 100k-frame DB",
+            "value": round(kfps, 2), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: reference-faithful fisheye key frame = 8 SuperPoint + 4 MobileNetVLAD(assumed arch) "
+                                   "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query; "
+                                   f"{args.db_keyframes}-keyframe DB ({4 * args.db_keyframes} rows); seeded synthetic weights",
+                       "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": args.pipelines,
+                       "parallelism": f"dp{world} keyframes + {world}-way row-sharded index" if world > 1 else "single GPU",
+                       "device": info["name"], "n_cu": info["n_cu"]},
+            "loop_candidates_found": hits[0],
+            "gflop_per_keyframe_superpoint": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
+            "achieved_tflops_end_to_end": round(kfps * SP_FLOP_PER_IMAGE * KF_IMAGES / 1e12 / world, 1),
+            "roofline": roofline, "roofline_knn": roofline_knn, "loop_match": loop_match, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(n_kf, W, H, thres, max_num, comp, mean, sp_w, vl_w):
+    """The reference's CPU path restated (oracle): PyTorch SuperPointNet fp32 on all host cores + C post-processing +
+    MobileNetVLAD(assumed) + BF match + flat IP search, timed on a bounded sample of the same workload."""
+    import torch
+    from oracle import match_ref, mobilenetvlad_ref, postproc_ref, superpoint_ref
+    from omni_swarm_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    db = synth.global_db(4000, seed=3)
+    imgs = np.stack([synth.image_u8(i, H, W) for i in range(8)])
+
+    def keyframe():
+        x = superpoint_ref.preprocess_u8(imgs, fisheye_mask=True)
+        feats = []
+        for b in range(8):
+            semi, desc = superpoint_ref.forward(sp_w, x[b])
+            xy, conf, _, _ = postproc_ref.get_keypoints(semi[0], thres, max_num)
+            d64, _ = postproc_ref.compute_descriptors(desc[0], xy, W, H, comp, mean)
+            feats.append(d64)
+        masked = imgs[:4].copy()
+        masked[:, H * 3 // 4:] = 0
+        g = mobilenetvlad_ref.forward(vl_w, masked)
+        for d in range(4):
+            match_ref.bf_match(feats[d], feats[4 + d], 0)
+        match_ref.ip_search_numpy(db, g[1], 10)
+
+    keyframe()                                  # warm-up
+    t = time.perf_counter()
+    for _ in range(n_kf):
+        keyframe()
+    dt = (time.perf_counter() - t) / n_kf
+    return {"value": round(1.0 / dt, 4), "unit": "keyframes/s", "cores": cores, "kind": "port",
+            "sample": f"{n_kf} key frames (8 SuperPoint + 4 MobileNetVLAD 600x480, post-processing, 4 BF matches, 1 search over 4000 rows) "
+                      f"after 1 warm-up; torch {torch.__version__} fp32, {cores} threads",
+            "ms_per_keyframe": round(dt * 1e3, 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,10 @@
 // scalar C oracle (oracle/csrc/oracle.c:l2_dist).
 #include "common.h"
 
+// The distance arithmetic below must not be contracted into FMAs (HIP's __fmul_rn/__fadd_rn are plain operators after
+// inlining): the sum of squares has to round exactly like the scalar reference loop.
+#pragma clang fp contract(off)
+
 namespace omni {
 
 #define BF_THREADS 256
@@ -97,7 +101,7 @@ bf_match_kernel(int max_n, int dim, int mode,
                 for (int c = 0; c < 4; ++c) {
                     const int j = j0 + tx * 4 + c;
                     if (i < nq && j < nt) {
-                        const float d = sqrtf(acc[r][c]);
+                        const float d = (float)sqrt((double)acc[r][c]);   // correctly rounded fp32 sqrt (53 >= 2*24+2: double rounding is innocuous)
                         atomicMin(&rowbest[i], bf_key(d, j));
                         atomicMin(&colbest[j], bf_key(d, i));
                     }

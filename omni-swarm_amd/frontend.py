@@ -1,0 +1,86 @@
+"""LoopCam: the per-keyframe CNN frontend (host-side mirror over the C ABI).
+
+Mirrors /root/reference/swarm_loop/src/loop_cam.cpp:
+    on_flattened_images                :178-229   loop over the camera directions of one fisheye key frame
+    generate_stereo_image_descriptor   :341-523   SuperPoint(up), SuperPoint(down), MobileNetVLAD(up), BF up<->down
+    extractor_img_desc_deepnet         :525-585   fisheye mask (rows [3H/4,H) zeroed), the two CNN calls
+    match_HFNet_local_features         :141-174   cv::BFMatcher(NORM_L2, crossCheck) on the 64-d descriptors
+The reference runs these 8 + 4 engine calls and 4 matches strictly one after another, each with its own H2D/D2H and
+stream sync; here one key frame is three batched enqueues on one HIP stream (8 SuperPoint images, 4
+MobileNetVLAD images, 4 descriptor-set pairs) with every intermediate resident in HBM and one small D2H at the end.
+Camera geometry (camodocal liftProjective, SVD triangulation, loop_cam.cpp:73-106,405-454,558-576) is host-side f64
+work outside the kernel scope and is left to the caller: the 2-D key points, descriptors, global
+descriptors and the up/down match lists are everything those steps consume.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+
+
+class LoopCam:
+    def __init__(self, ctx: capi.Context, sp_weights: dict, pca_comp, pca_mean, vlad_weights: dict, vlad_specs,
+                 vlad_shape=(32, 112, 4096), width: int = 600, height: int = 480, thres: float = 0.015,
+                 max_num: int = 200, precision: int = capi.PREC_F16, n_dirs: int = 4, fisheye: bool = True,
+                 accept_min_3d_pts: int = 0):
+        self.ctx, self.W, self.H, self.n_dirs, self.max_num, self.fisheye = ctx, width, height, n_dirs, max_num, fisheye
+        self.accept_min_3d_pts = accept_min_3d_pts
+        self.sp = capi.SuperPoint(ctx, sp_weights, pca_comp, pca_mean, width, height, thres, max_num, precision, 2 * n_dirs)
+        k, d, o = vlad_shape
+        self.vlad = capi.MobileNetVLAD(ctx, vlad_weights, vlad_specs, k, d, o, width, height, n_dirs)
+        self.out_dim = o
+        self.dim = self.sp.desc_dim
+        m = max_num
+        self._d_qidx = ctx.alloc(n_dirs * m * 4)
+        self._d_tidx = ctx.alloc(n_dirs * m * 4)
+        self._d_dist = ctx.alloc(n_dirs * m * 4)
+        self._d_nm = ctx.alloc(n_dirs * 4)
+        self._kps_dev, self._n_dev, self._desc_dev, _ = self.sp.dev_outputs()
+
+    def close(self):
+        for p in (self._d_qidx, self._d_tidx, self._d_dist, self._d_nm):
+            self.ctx.free(p)
+        self.sp.close()
+        self.vlad.close()
+
+    def enqueue_dev(self, gray_dev: int, stride: int):
+        """gray_dev: [2*n_dirs][H][W] u8 in HBM -- images 0..n_dirs-1 are the 'up' (main) camera of each direction,
+        n_dirs..2*n_dirs-1 the 'down' camera.  Asynchronous on the context's stream."""
+        n, m, dim = self.n_dirs, self.max_num, self.dim
+        self.sp.enqueue_dev(gray_dev, stride, 2 * n, self.fisheye)              # loop_cam.cpp:350-351
+        self.vlad.enqueue_dev(gray_dev, stride, n, self.fisheye)                # :553-556 (main camera only)
+        # match_HFNet_local_features: up = query, down = train (:147-150); pair p = direction p
+        capi.bf_match_batched_dev(self.ctx, n, m, dim, capi.BF_OPENCV,
+                                  self._desc_dev, m * dim, self._n_dev,
+                                  self._desc_dev + n * m * dim * 4, m * dim, self._n_dev + n * 4,
+                                  self._d_qidx, self._d_tidx, self._d_dist, self._d_nm)
+
+    def fetch(self) -> dict:
+        """Synchronises and returns one FisheyeFrameDescriptor_t's worth of CNN outputs."""
+        n, m = self.n_dirs, self.max_num
+        feats = self.sp.fetch(2 * n)
+        gdesc = self.vlad.fetch(n)
+        nm = self.ctx.from_device(self._d_nm, (n,), np.int32)
+        qi = self.ctx.from_device(self._d_qidx, (n, m), np.int32)
+        ti = self.ctx.from_device(self._d_tidx, (n, m), np.int32)
+        images = []
+        for d in range(n):
+            kps_up, desc_up, sc_up = feats[d]
+            kps_dn, desc_dn, _ = feats[n + d]
+            k = int(nm[d]) if len(kps_up) > self.accept_min_3d_pts else 0       # :388 `if (pts_up.size() > ACCEPT_MIN_3D_PTS)`
+            images.append({"landmarks_2d": kps_up, "feature_descriptor": desc_up, "scores": sc_up,
+                           "landmark_num": len(kps_up), "image_desc": gdesc[d],
+                           "landmarks_2d_down": kps_dn, "feature_descriptor_down": desc_dn,
+                           "ids_up": qi[d, :k].copy(), "ids_down": ti[d, :k].copy(), "direction": d})
+        return {"images": images, "landmark_num": int(sum(i["landmark_num"] for i in images))}
+
+    def on_flattened_images(self, up: np.ndarray, down: np.ndarray) -> dict:
+        """Host-pointer convenience (the reference's blocking call): up/down [n_dirs][H][W] uint8."""
+        g = np.ascontiguousarray(np.concatenate([up, down]), np.uint8)
+        p = self.ctx.to_device(g)
+        try:
+            self.enqueue_dev(p, self.W)
+            return self.fetch()
+        finally:
+            self.ctx.free(p)

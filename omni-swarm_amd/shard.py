@@ -58,3 +58,57 @@ class ShardedIndex:
         Dl = np.ascontiguousarray(allp[..., 0].astype(np.int32)).view(np.float32)
         Il = np.ascontiguousarray(allp[..., 1])
         return capi.topk_merge(Dl, Il, k)
+
+
+class SwarmIndex:
+    """Data-parallel key frames + one row-sharded index: the per-step exchange of bench.py at N > 1.
+
+    Every rank produces m new rows per step (the <=4 direction descriptors of its own key frame).  One step is
+        all_gather(rows)                       -> every rank sees the world*m new rows in rank order = global id order
+        local add of the rows it owns          (g % world == rank, slot g // world; no further traffic)
+        local batched search of the `world` queries (one per rank) over its shard
+        all_gather(per-shard top-k)            -> each rank merges the lists for ITS query
+    i.e. two small collectives per step (world*m*16 KB and world*k*16 B per rank), both latency-bound on xGMI.
+    "add before query" is kept (loop_detector.cpp:89-104): all of the step's rows are visible to all of its queries.
+    """
+
+    def __init__(self, local_index, rank: int, world: int, dist, device=None):
+        self.local, self.rank, self.world, self.dist, self.device = local_index, rank, world, dist, device or "cpu"
+        self.local.set_shard(rank, world)
+        self._ntotal = 0
+
+    @property
+    def ntotal(self) -> int:
+        return self._ntotal
+
+    def preload_local(self, rows_local: np.ndarray, ntotal_global: int):
+        """Bulk load: this rank's rows of an index holding ntotal_global rows (ntotal_global % world == 0)."""
+        assert ntotal_global % self.world == 0 and rows_local.shape[0] * self.world == ntotal_global
+        self.local.add(rows_local)
+        self._ntotal = ntotal_global
+
+    def _all_gather(self, arr: np.ndarray) -> np.ndarray:
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return torch.stack(out).cpu().numpy()
+
+    def step(self, rows: np.ndarray, query_row: int, k: int):
+        rows = np.ascontiguousarray(rows, np.float32)
+        m = rows.shape[0]
+        assert self._ntotal % self.world == 0
+        allrows = self._all_gather(rows).reshape(self.world * m, -1)       # global ids base .. base + world*m - 1
+        g = self._ntotal + np.arange(self.world * m)
+        mine = allrows[(g % self.world) == self.rank]
+        self.local.add(mine)
+        self._ntotal += self.world * m
+        queries = allrows.reshape(self.world, m, -1)[:, query_row]         # one query per rank
+        D, I = self.local.search(queries, k)                               # [world, k], global ids
+        packed = np.empty((self.world, k, 2), np.int64)
+        packed[..., 0] = D.view(np.int32).astype(np.int64)
+        packed[..., 1] = I
+        allp = self._all_gather(packed)                                    # [shard, query, k, 2]
+        Dl = np.ascontiguousarray(allp[:, self.rank, :, 0].astype(np.int32)).view(np.float32)[:, None, :]
+        Il = np.ascontiguousarray(allp[:, self.rank, :, 1])[:, None, :]
+        return capi.topk_merge(Dl, Il, k)

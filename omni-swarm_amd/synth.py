@@ -1,0 +1,87 @@
+"""Seeded synthetic inputs for bench.py and the parity tests.  No reference algorithm lives here.
+
+No dataset, checkpoint or bag exists offline: every generator here is deterministic in its seed so the
+GPU box, the build container and the committed golden fixtures all see the same bytes.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.ndimage import gaussian_filter
+
+BASE_SEED = 20260925
+
+
+def image_u8(index: int, height: int = 480, width: int = 600, n_shapes: int = 200,
+             fisheye_mask: bool = False) -> np.ndarray:
+    """Image-like u8 frame: random rectangles/ellipses, blur sigma=1.5, N(0,4) noise (8d)."""
+    rng = np.random.default_rng(BASE_SEED + index)
+    img = np.full((height, width), 96.0, np.float32)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(n_shapes):
+        cx, cy = rng.uniform(0, width), rng.uniform(0, height)
+        rx, ry = rng.uniform(4, width / 8), rng.uniform(4, height / 8)
+        val = rng.uniform(-90, 110)
+        if rng.random() < 0.5:
+            m = (np.abs(xx - cx) < rx) & (np.abs(yy - cy) < ry)
+        else:
+            m = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 < 1.0
+        img[m] += val
+    img = gaussian_filter(img, 1.5)
+    img += rng.normal(0, 4.0, img.shape).astype(np.float32)
+    out = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if fisheye_mask:                       # loop_cam.cpp:536-539
+        out[height * 3 // 4: height * 3 // 4 + height // 4] = 0
+    return out
+
+
+def pca(seed: int = 1, d_out: int = 64, d_in: int = 256):
+    """Orthonormal components (QR of a Gaussian) + small mean, shaped like sklearn PCA (pca.ipynb:28-31)."""
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.normal(size=(d_in, d_out)))
+    comp = np.ascontiguousarray(q.T.astype(np.float32))          # [64, 256]
+    mean = (np.random.default_rng(seed + 1).normal(size=d_in) * 0.01).astype(np.float32)
+    return comp, mean
+
+
+def global_db(n_rows: int, dim: int = 4096, seed: int = 3, dup_frac: float = 0.01, dup_cos: float = 0.8,
+              chunk: int = 8192) -> np.ndarray:
+    """L2-normalised Gaussian rows; ``dup_frac`` of rows are near-duplicates (cos ~ dup_cos) of an earlier row."""
+    rng = np.random.default_rng(seed)
+    db = np.empty((n_rows, dim), np.float32)
+    for s in range(0, n_rows, chunk):
+        e = min(n_rows, s + chunk)
+        x = rng.standard_normal((e - s, dim), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        db[s:e] = x
+    n_dup = int(n_rows * dup_frac)
+    if n_dup and n_rows > 16:
+        rng2 = np.random.default_rng(seed + 100)
+        dst = rng2.choice(np.arange(n_rows // 2, n_rows), size=min(n_dup, n_rows - n_rows // 2), replace=False)
+        src = rng2.integers(0, n_rows // 2, size=len(dst))
+        noise = rng2.standard_normal((len(dst), dim), dtype=np.float32)
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        v = dup_cos * db[src] + np.sqrt(1 - dup_cos ** 2) * noise
+        db[dst] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    return db
+
+
+def queries_from_db(db: np.ndarray, n_q: int, seed: int = 4, sigma: float = 0.02):
+    """Rows perturbed with N(0, sigma) per element, renormalised (8d)."""
+    rng = np.random.default_rng(seed)
+    rows = rng.integers(0, db.shape[0], size=n_q)
+    q = db[rows] + rng.normal(0, sigma, size=(n_q, db.shape[1])).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32), rows
+
+
+def local_descriptors(n: int, dim: int = 64, seed: int = 5, pair_noise: float | None = None):
+    """n x dim float descriptors (unit vectors); with pair_noise returns a second, permuted+noised set."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, dim)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    if pair_noise is None:
+        return a
+    perm = rng.permutation(n)
+    b = a[perm] + rng.normal(0, pair_noise, (n, dim)).astype(np.float32)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    return a, b.astype(np.float32), perm

@@ -25,58 +25,20 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-N_CLUSTERS = 32
-OUT_DIM = 4096
-STEM_OUT = 16
-# (expand t, cout, stride) per inverted-residual block; MobileNetV2 (t,c,n,s) table at alpha=0.35, make_divisible 8
-BLOCKS = (
-    [(1, 8, 1)] +
-    [(6, 8, 2), (6, 8, 1)] +
-    [(6, 16, 2), (6, 16, 1), (6, 16, 1)] +
-    [(6, 24, 2), (6, 24, 1), (6, 24, 1), (6, 24, 1)] +
-    [(6, 32, 1), (6, 32, 1), (6, 32, 1)] +
-    [(6, 56, 2), (6, 56, 1), (6, 56, 1)] +
-    [(6, 112, 1)]
-)
-FEAT_DIM = BLOCKS[-1][1]          # 112
-VLAD_DIM = N_CLUSTERS * FEAT_DIM  # 3584
+import os as _os
+import sys as _sys
 
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import omni_loader as _omni_loader  # noqa: E402
 
-def layer_specs():
-    """Flat list of (name, kind, cin, cout, stride) -- the same table the HIP side walks."""
-    specs = [("stem", "conv3x3", 3, STEM_OUT, 2)]
-    cin = STEM_OUT
-    for i, (t, c, s) in enumerate(BLOCKS):
-        hid = cin * t
-        if t != 1:
-            specs.append((f"b{i}.expand", "pw_relu6", cin, hid, 1))
-        specs.append((f"b{i}.dw", "dw3x3_relu6", hid, hid, s))
-        specs.append((f"b{i}.project", "pw_linear_res" if (s == 1 and cin == c) else "pw_linear", hid, c, 1))
-        cin = c
-    return specs
+_omni_loader.load()
+from omni_swarm_amd import weights as _W  # noqa: E402
 
-
-def synth_weights(seed: int = 10) -> dict[str, np.ndarray]:
-    g = torch.Generator().manual_seed(seed)
-    w = {}
-
-    def u(shape, bound):
-        return ((torch.rand(*shape, generator=g) * 2 - 1) * bound).numpy().astype(np.float32)
-
-    for name, kind, cin, cout, stride in layer_specs():
-        if kind == "conv3x3":
-            w[name + ".weight"] = u((cout, cin, 3, 3), np.sqrt(6.0 / (cin * 9)))
-        elif kind == "dw3x3_relu6":
-            w[name + ".weight"] = u((cout, 1, 3, 3), np.sqrt(6.0 / 9))
-        else:
-            w[name + ".weight"] = u((cout, cin, 1, 1), np.sqrt(6.0 / cin) * (0.7 if "linear" in kind else 1.0))
-        w[name + ".bias"] = u((cout,), 0.1)
-    w["vlad.assign.weight"] = u((N_CLUSTERS, FEAT_DIM, 1, 1), 1.0)
-    w["vlad.assign.bias"] = u((N_CLUSTERS,), 0.5)
-    w["vlad.clusters"] = u((N_CLUSTERS, FEAT_DIM), 1.0)
-    w["fc.weight"] = u((OUT_DIM, VLAD_DIM), np.sqrt(3.0 / VLAD_DIM) * 4)
-    w["fc.bias"] = u((OUT_DIM,), 0.01)
-    return w
+# the assumed layer table and the seeded weights are shared with the HIP side (omni-swarm_amd/weights.py)
+N_CLUSTERS, OUT_DIM, STEM_OUT, BLOCKS = _W.VLAD_N_CLUSTERS, _W.VLAD_OUT_DIM, _W.VLAD_STEM_OUT, _W.VLAD_BLOCKS
+FEAT_DIM, VLAD_DIM = _W.VLAD_FEAT_DIM, _W.VLAD_DIM
+layer_specs = _W.mobilenetvlad_layer_specs
+synth_weights = _W.mobilenetvlad_synth_weights
 
 
 @torch.no_grad()

@@ -21,41 +21,17 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-# (name, cin, cout, ksize) in execution order -- superpoint.ipynb:143-160
-LAYERS = [
-    ("conv1a", 1, 64, 3), ("conv1b", 64, 64, 3),
-    ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
-    ("conv3a", 64, 128, 3), ("conv3b", 128, 128, 3),
-    ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
-    ("convPa", 128, 256, 3), ("convPb", 256, 65, 1),
-    ("convDa", 128, 256, 3), ("convDb", 256, 256, 1),
-]
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import omni_loader as _omni_loader  # noqa: E402
+
+_omni_loader.load()
+from omni_swarm_amd.weights import SUPERPOINT_LAYERS as LAYERS  # noqa: E402  (layer table: superpoint.ipynb:143-160)
+from omni_swarm_amd.weights import superpoint_synth_weights as synth_weights  # noqa: E402,F401
+
 SP_DESC_RAW_LEN = 256  # superpoint_tensorrt.h:10
-
-
-def synth_weights(seed: int = 0, convPb_gain: float = 4.0, dustbin_bias: float = 12.0) -> dict[str, np.ndarray]:
-    """Seeded synthetic weights (the real checkpoint superpoint_v1.pth is not in the reference tree).
-
-    torch's default Conv2d init shrinks the signal ~sqrt(1/6) per layer, so after ten layers every image
-    gives the same (bias-driven) heat map.  Use He-uniform weights (bound sqrt(6/fan_in)) with small biases
-    so activations stay O(1) and image dependent, scale ``convPb`` by ``convPb_gain`` and lift the dustbin
-    logit by ``dustbin_bias`` so thresholds 0.012-0.02 select ~5e3-1e4 candidates per 600x480 frame and NMS
-    leaves ~2000 survivors ("No weights for SuperPoint either").
-    """
-    g = torch.Generator().manual_seed(seed)
-    w = {}
-    for name, cin, cout, k in LAYERS:
-        fan_in = cin * k * k
-        bound_w = np.sqrt(6.0 / fan_in)
-        wt = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * bound_w
-        bs = (torch.rand(cout, generator=g) * 2 - 1) * 0.05
-        if name == "convPb":
-            wt = wt * convPb_gain
-            bs = bs * convPb_gain
-            bs[64] += dustbin_bias
-        w[name + ".weight"] = wt.numpy().astype(np.float32)
-        w[name + ".bias"] = bs.numpy().astype(np.float32)
-    return w
 
 
 def _t(w, name):

@@ -56,6 +56,19 @@ def _worker(rank, world, port, out):
     D, I = idx.search(q, 9)
     Dr, Ir = M.ip_search(db, q, 9)
     ok = bool(np.array_equal(I, Ir) and np.array_equal(D, Dr) and I[0, 0] == 3 and I[0, 1] == 200)
+    # SwarmIndex: data-parallel key frames, two collectives per step
+    sw = shard.SwarmIndex(_CpuShard(128), rank, world, dist)
+    pre = rng.standard_normal((40, 128)).astype(np.float32)             # same stream on both ranks -> same global DB
+    sw.preload_local(pre[rank::world], 40)
+    ref_db = [r for r in pre]
+    for step in range(3):
+        new = np.random.default_rng(100 + step).standard_normal((world, 4, 128)).astype(np.float32)
+        new[1, 1] = pre[6] * 1.01 if step == 1 else new[1, 1]           # rank 1's query hits a preloaded row
+        D, I = sw.step(new[rank], query_row=1, k=7)
+        ref_db += [r for r in new.reshape(world * 4, 128)]
+        Dr, Ir = M.ip_search(np.stack(ref_db), new[rank, 1], 7)
+        ok = ok and bool(np.array_equal(I, Ir) and np.array_equal(D, Dr)) and sw.ntotal == len(ref_db)
+        ok = ok and sw.local.ntotal == len(ref_db) // world
     out[rank] = ok
     dist.destroy_process_group()
 
