@@ -11,8 +11,9 @@
 // scalar C oracle (oracle/csrc/oracle.c:l2_dist).
 #include "common.h"
 
-// The distance arithmetic below must not be contracted into FMAs (HIP's __fmul_rn/__fadd_rn are plain operators after
-// inlining): the sum of squares has to round exactly like the scalar reference loop.
+// The distance arithmetic below must not be contracted into FMAs: the sum of squares has to round exactly like the
+// scalar reference loop.  Plain operators under this pragma carry no 'contract' flag (HIP's __fmul_rn/__fadd_rn are
+// header inlines parsed under the default -ffp-contract=fast and DO get fused).
 #pragma clang fp contract(off)
 
 namespace omni {
@@ -84,13 +85,12 @@ bf_match_kernel(int max_n, int dim, int mode,
                     for (int c = 0; c < 4; ++c) {
                         // (a-b)^2 accumulated sequentially in k, no fma contraction (matches the C oracle bit for bit;
                         // a-b == -(b-a) exactly, so both match directions see the same value)
-                        float d0 = __fsub_rn(a[r].x, b[c].x), d1 = __fsub_rn(a[r].y, b[c].y);
-                        float d2 = __fsub_rn(a[r].z, b[c].z), d3 = __fsub_rn(a[r].w, b[c].w);
+                        const float d0 = a[r].x - b[c].x, d1 = a[r].y - b[c].y, d2 = a[r].z - b[c].z, d3 = a[r].w - b[c].w;
                         float s = acc[r][c];
-                        s = __fadd_rn(s, __fmul_rn(d0, d0));
-                        s = __fadd_rn(s, __fmul_rn(d1, d1));
-                        s = __fadd_rn(s, __fmul_rn(d2, d2));
-                        s = __fadd_rn(s, __fmul_rn(d3, d3));
+                        s = s + d0 * d0;
+                        s = s + d1 * d1;
+                        s = s + d2 * d2;
+                        s = s + d3 * d3;
                         acc[r][c] = s;
                     }
             }
