@@ -1,0 +1,409 @@
+// omni_swarm.hpp -- header-only C++17 host adapters over the C ABI (include/omni_hip.h) with the call surfaces of the
+// reference classes, so LoopCam / LoopDetector change only in #include and type names:
+//
+//   Swarm::SuperPointHIP       <-> Swarm::SuperPointTensorRT      swarm_loop/include/swarm_loop/superpoint_tensorrt.h:12-29
+//   Swarm::MobileNetVLADHIP    <-> Swarm::MobileNetVLADTensorRT   swarm_loop/include/swarm_loop/mobilenetvlad_tensorrt.h:6-22
+//   omni::IndexFlatIP          <-> faiss::IndexFlatIP             (add / search / ntotal; loop_detector.cpp:166-170,213,232,291)
+//   omni::BFMatcherL2X         <-> cv::BFMatcher(NORM_L2, true)   (match; loop_cam.cpp:147-150, loop_detector.cpp:564-567)
+//   omni::LoopDetectorCore     <-> LoopDetector's DB + decision rules (loop_detector.cpp:11-287), geometry via callback
+//
+// Compiles with plain g++ (no HIP, ROS, OpenCV or faiss headers); link with -lomni_hip.  Define OMNI_WITH_OPENCV to get
+// the cv::Mat / cv::Point2f / cv::DMatch overloads the reference call sites use verbatim.
+// Errors: the reference aborts (assert / NV_CUDA_CHECK); these adapters throw std::runtime_error carrying
+// omni_last_error() from constructors and return empty results + set last_status from inference calls.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/omni_hip.h"
+#ifdef OMNI_WITH_OPENCV
+#include <opencv2/opencv.hpp>
+#endif
+
+namespace omni {
+
+struct Point2f { float x, y; };
+struct DMatch { int queryIdx, trainIdx; float distance; };   // cv::DMatch fields used by the reference
+
+inline void check(int rc, const char* what) {
+    if (rc != OMNI_OK) throw std::runtime_error(std::string(what) + ": " + omni_last_error());
+}
+
+// ---- shared context (one HIP stream); the reference creates one cudaStream per runner (tensorrt_generic.cpp:103) ----
+class Context {
+public:
+    explicit Context(int device_id = 0) : h_(omni_ctx_create(device_id)) {
+        if (!h_) throw std::runtime_error(std::string("omni_ctx_create: ") + omni_last_error());
+    }
+    ~Context() { omni_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    omni_ctx* get() const { return h_; }
+private:
+    omni_ctx* h_;
+};
+
+// ---- weight container: "OMNW1" file = named float32 tensors (written by tools/export_weights.py from a state_dict) ----
+struct Tensor { std::vector<uint32_t> shape; std::vector<float> data; };
+using WeightMap = std::map<std::string, Tensor>;
+
+inline WeightMap load_omnw(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open weight file " + path);
+    char magic[8];
+    f.read(magic, 8);
+    if (std::memcmp(magic, "OMNW1\0\0\0", 8) != 0) throw std::runtime_error(path + ": not an OMNW1 file");
+    uint32_t n = 0;
+    f.read(reinterpret_cast<char*>(&n), 4);
+    WeightMap m;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t len = 0, nd = 0;
+        f.read(reinterpret_cast<char*>(&len), 4);
+        std::string name(len, '\0');
+        f.read(&name[0], len);
+        f.read(reinterpret_cast<char*>(&nd), 4);
+        Tensor t;
+        t.shape.resize(nd);
+        size_t cnt = 1;
+        for (uint32_t d = 0; d < nd; ++d) { f.read(reinterpret_cast<char*>(&t.shape[d]), 4); cnt *= t.shape[d]; }
+        t.data.resize(cnt);
+        f.read(reinterpret_cast<char*>(t.data.data()), cnt * 4);
+        if (!f) throw std::runtime_error(path + ": truncated");
+        m.emplace(std::move(name), std::move(t));
+    }
+    return m;
+}
+
+// components_.csv: one row per component, comma separated; mean_.csv: one value per line
+// (load_csv_mat_eigen / load_csv_vec_eigen, superpoint_tensorrt.cpp:14-89)
+inline std::vector<float> load_csv_floats(const std::string& path, int* rows = nullptr, int* cols = nullptr) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<float> v;
+    std::string line;
+    int r = 0, c = 0;
+    while (std::getline(f, line)) {
+        if (line.empty()) continue;
+        std::stringstream ss(line);
+        std::string cell;
+        int cc = 0;
+        while (std::getline(ss, cell, ',')) { if (!cell.empty()) { v.push_back(std::stof(cell)); ++cc; } }
+        if (cc) { ++r; c = cc; }
+    }
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    return v;
+}
+
+}  // namespace omni
+
+namespace Swarm {
+
+// SuperPointTensorRT(engine_path, pca_comp, pca_mean, width, height, thres, max_num, enable_perf)
+class SuperPointHIP {
+public:
+    SuperPointHIP(omni::Context& ctx, const std::string& weights_path, const std::string& pca_comp_csv, const std::string& pca_mean_csv,
+                  int width, int height, float thres = 0.015f, int max_num = 200, bool enable_perf = false,
+                  int precision = OMNI_PREC_F16, int max_batch = 1)
+        : width_(width), height_(height), max_num_(max_num), max_batch_(max_batch), enable_perf_(enable_perf) {
+        static const char* names[OMNI_SP_NUM_LAYERS] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b",
+                                                        "convPa", "convPb", "convDa", "convDb"};
+        omni::WeightMap w = omni::load_omnw(weights_path);
+        omni_sp_weights sw{};
+        for (int i = 0; i < OMNI_SP_NUM_LAYERS; ++i) {
+            auto wi = w.find(std::string(names[i]) + ".weight"), bi = w.find(std::string(names[i]) + ".bias");
+            if (wi == w.end() || bi == w.end()) throw std::runtime_error(std::string("weights missing for ") + names[i]);
+            sw.weight[i] = wi->second.data.data();
+            sw.bias[i] = bi->second.data.data();
+        }
+        std::vector<float> comp, mean;
+        int rows = 0, cols = 0;
+        if (!pca_comp_csv.empty()) {
+            comp = omni::load_csv_floats(pca_comp_csv, &rows, &cols);
+            mean = omni::load_csv_floats(pca_mean_csv);
+            if (cols != 256 || mean.size() != 256) throw std::runtime_error("PCA files must be [pca_dim x 256] and [256]");
+        }
+        h_ = omni_sp_create(ctx.get(), &sw, comp.empty() ? nullptr : comp.data(), mean.empty() ? nullptr : mean.data(), rows, width, height,
+                            thres, max_num, precision, max_batch);
+        if (!h_) throw std::runtime_error(std::string("omni_sp_create: ") + omni_last_error());
+        dim_ = omni_sp_desc_dim(h_);
+    }
+    ~SuperPointHIP() { omni_sp_destroy(h_); }
+    SuperPointHIP(const SuperPointHIP&) = delete;
+    SuperPointHIP& operator=(const SuperPointHIP&) = delete;
+
+    // void inference(const cv::Mat& input, std::vector<cv::Point2f>& keypoints, std::vector<float>& local_descriptors)
+    // (superpoint_tensorrt.cpp:117-162): keypoints/local_descriptors are cleared first (:120-121); descriptors are n x dim.
+    void inference(const uint8_t* gray, int stride, std::vector<omni::Point2f>& keypoints, std::vector<float>& local_descriptors,
+                   bool fisheye_mask = false) {
+        keypoints.clear();
+        local_descriptors.clear();
+        kps_.resize((size_t)max_num_ * 2);
+        desc_.resize((size_t)max_num_ * dim_);
+        int n = 0;
+        last_status = omni_sp_infer(h_, gray, stride, 1, fisheye_mask ? 1 : 0, kps_.data(), &n, desc_.data(), nullptr);
+        if (last_status != OMNI_OK) { std::fprintf(stderr, "[SuperPointHIP] %s\n", omni_last_error()); return; }
+        keypoints.reserve(n);
+        for (int i = 0; i < n; ++i) keypoints.push_back({kps_[2 * i], kps_[2 * i + 1]});
+        local_descriptors.assign(desc_.begin(), desc_.begin() + (size_t)n * dim_);
+        if (enable_perf_) std::printf(" SuperPointHIP features %d desc size %zu\n", n, local_descriptors.size());
+    }
+#ifdef OMNI_WITH_OPENCV
+    void inference(const cv::Mat& input, std::vector<cv::Point2f>& keypoints, std::vector<float>& local_descriptors) {
+        std::vector<omni::Point2f> k;
+        if (input.rows != height_ || input.cols != width_ || input.type() != CV_8UC1) { keypoints.clear(); local_descriptors.clear(); last_status = OMNI_ERR_INVALID; return; }
+        inference(input.data, (int)input.step, k, local_descriptors);
+        keypoints.clear();
+        for (auto& p : k) keypoints.emplace_back(p.x, p.y);
+    }
+#endif
+    int desc_dim() const { return dim_; }
+    omni_sp* handle() const { return h_; }
+    int last_status = OMNI_OK;
+private:
+    omni_sp* h_ = nullptr;
+    int width_, height_, max_num_, max_batch_, dim_ = 0;
+    bool enable_perf_;
+    std::vector<float> kps_, desc_;
+};
+
+// MobileNetVLADTensorRT(engine_path, width, height, enable_perf); std::vector<float> inference(const cv::Mat&)
+// ASSUMED architecture: the OMNW1 file carries the layer table as "<layer>.weight/.bias" tensors plus a
+// "layers" index tensor [n][4] = (kind, cin, cout, stride) in execution order (tools/export_weights.py).
+class MobileNetVLADHIP {
+public:
+    MobileNetVLADHIP(omni::Context& ctx, const std::string& weights_path, int width, int height, bool enable_perf = false, int max_batch = 1)
+        : width_(width), height_(height) {
+        (void)enable_perf;
+        omni::WeightMap w = omni::load_omnw(weights_path);
+        auto need = [&](const std::string& n) -> omni::Tensor& {
+            auto it = w.find(n);
+            if (it == w.end()) throw std::runtime_error("weights missing: " + n);
+            return it->second;
+        };
+        omni::Tensor& tab = need("layers");
+        const int n_layers = (int)tab.shape.at(0);
+        std::vector<omni_vlad_layer> layers(n_layers);
+        for (int i = 0; i < n_layers; ++i) {
+            const std::string base = "layer" + std::to_string(i);
+            layers[i].kind = (int)tab.data[i * 4 + 0]; layers[i].cin = (int)tab.data[i * 4 + 1];
+            layers[i].cout = (int)tab.data[i * 4 + 2]; layers[i].stride = (int)tab.data[i * 4 + 3];
+            layers[i].weight = need(base + ".weight").data.data();
+            layers[i].bias = need(base + ".bias").data.data();
+        }
+        omni_vlad_weights vw{};
+        vw.n_layers = n_layers; vw.layers = layers.data();
+        vw.n_clusters = (int)need("vlad.clusters").shape.at(0); vw.feat_dim = (int)need("vlad.clusters").shape.at(1);
+        vw.out_dim = (int)need("fc.bias").shape.at(0);
+        vw.assign_w = need("vlad.assign.weight").data.data(); vw.assign_b = need("vlad.assign.bias").data.data();
+        vw.clusters = need("vlad.clusters").data.data(); vw.fc_w = need("fc.weight").data.data(); vw.fc_b = need("fc.bias").data.data();
+        out_dim_ = vw.out_dim;
+        h_ = omni_vlad_create(ctx.get(), &vw, width, height, max_batch);
+        if (!h_) throw std::runtime_error(std::string("omni_vlad_create: ") + omni_last_error());
+    }
+    ~MobileNetVLADHIP() { omni_vlad_destroy(h_); }
+    MobileNetVLADHIP(const MobileNetVLADHIP&) = delete;
+    MobileNetVLADHIP& operator=(const MobileNetVLADHIP&) = delete;
+
+    std::vector<float> inference(const uint8_t* gray, int stride, bool fisheye_mask = false) {
+        std::vector<float> out(out_dim_);
+        last_status = omni_vlad_infer(h_, gray, stride, 1, fisheye_mask ? 1 : 0, out.data());
+        if (last_status != OMNI_OK) { std::fprintf(stderr, "[MobileNetVLADHIP] %s\n", omni_last_error()); out.clear(); }
+        return out;
+    }
+#ifdef OMNI_WITH_OPENCV
+    std::vector<float> inference(const cv::Mat& input) { return inference(input.data, (int)input.step); }
+#endif
+    int last_status = OMNI_OK;
+private:
+    omni_vlad* h_ = nullptr;
+    int width_, height_, out_dim_ = 0;
+};
+
+}  // namespace Swarm
+
+namespace omni {
+
+// faiss::IndexFlatIP(d): the members LoopDetector touches
+class IndexFlatIP {
+public:
+    using idx_t = int64_t;                       // faiss::Index::idx_t
+    IndexFlatIP(Context& ctx, int d, int storage = OMNI_STORE_F32) : d(d), h_(omni_index_create(ctx.get(), d, storage, 0)) {
+        if (!h_) throw std::runtime_error(std::string("omni_index_create: ") + omni_last_error());
+    }
+    ~IndexFlatIP() { omni_index_destroy(h_); }
+    IndexFlatIP(const IndexFlatIP&) = delete;
+    IndexFlatIP& operator=(const IndexFlatIP&) = delete;
+    void add(idx_t n, const float* x) { check(omni_index_add(h_, n, x), "IndexFlatIP::add"); ntotal = omni_index_ntotal(h_); }
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+        check(omni_index_search(h_, (int)n, x, (int)k, distances, labels), "IndexFlatIP::search");
+    }
+    void reset() { check(omni_index_reset(h_), "IndexFlatIP::reset"); ntotal = 0; }
+    int d;
+    idx_t ntotal = 0;                            // public data member, as in faiss
+    omni_index* handle() const { return h_; }
+private:
+    omni_index* h_;
+};
+
+// cv::BFMatcher(cv::NORM_L2, /*crossCheck=*/true).match(query, train, matches)
+class BFMatcherL2X {
+public:
+    explicit BFMatcherL2X(Context& ctx, int mode = OMNI_BF_OPENCV) : ctx_(ctx), mode_(mode) {}
+    void match(const float* query, int nq, const float* train, int nt, int dim, std::vector<DMatch>& matches) {
+        matches.clear();
+        std::vector<int> qi(nq > 0 ? nq : 1), ti(nq > 0 ? nq : 1);
+        std::vector<float> dd(nq > 0 ? nq : 1);
+        int n = 0;
+        check(omni_bf_match(ctx_.get(), query, nq, train, nt, dim, mode_, qi.data(), ti.data(), dd.data(), &n), "BFMatcherL2X::match");
+        for (int i = 0; i < n; ++i) matches.push_back({qi[i], ti[i], dd[i]});
+    }
+#ifdef OMNI_WITH_OPENCV
+    void match(const cv::Mat& query, const cv::Mat& train, std::vector<cv::DMatch>& matches) {
+        std::vector<DMatch> m;
+        match(query.ptr<float>(), query.rows, train.ptr<float>(), train.rows, query.cols, m);
+        matches.clear();
+        for (auto& x : m) matches.emplace_back(x.queryIdx, x.trainIdx, x.distance);
+    }
+#endif
+private:
+    Context& ctx_;
+    int mode_;
+};
+
+// ---- LoopDetector's database and decision rules (loop_detector.cpp:11-287), POD messages instead of swarm_msgs -------
+struct ImageDescriptor {                         // ImageDescriptor_t, fields used on this path
+    int drone_id = 0, landmark_num = 0;
+    std::vector<float> image_desc;               // 4096
+    std::vector<float> feature_descriptor;       // n x 64
+    std::vector<Point2f> landmarks_2d;
+};
+struct FisheyeFrameDescriptor {                  // FisheyeFrameDescriptor_t
+    int64_t msg_id = 0;
+    int drone_id = 0, landmark_num = 0;
+    bool prevent_adding_db = false;
+    std::vector<ImageDescriptor> images;
+};
+struct LoopCandidate { bool found = false; int64_t old_msg_id = -1; int image_id = -1, direction_new = -1, direction_old = -1; double distance = -1; bool added = false, queried = false, loop = false; };
+
+class LoopDetectorCore {
+public:
+    static constexpr int REMOTE_MAGIN_NUMBER = 1000000;   // loop_detector.h:22
+    static constexpr int SEARCH_NEAREST_NUM = 5;          // loop_defines.h:32
+    // tunables (swarm_loop.cpp:221-237)
+    double INNER_PRODUCT_THRES = 0.6, INIT_MODE_PRODUCT_THRES = 0.3;
+    int MATCH_INDEX_DIST = 10, MIN_LOOP_NUM = 15, MIN_DIRECTION_LOOP = 3, inter_drone_init_frames = 50;
+    bool stereo_fisheye = true;
+    // geometry stage (compute_loop, :627-836) stays on the host: (new, old, dir_new, dir_old, init_mode) -> success
+    std::function<bool(const FisheyeFrameDescriptor&, const FisheyeFrameDescriptor&, int, int, bool)> compute_loop;
+
+    LoopDetectorCore(Context& ctx, int self_id, int storage = OMNI_STORE_F32)
+        : self_id(self_id), local_index(ctx, 4096, storage), remote_index(ctx, 4096, storage) {}
+
+    int database_size() const { return (int)(local_index.ntotal + remote_index.ntotal); }
+
+    LoopCandidate on_image_recv(const FisheyeFrameDescriptor& f) {               // :11-137
+        LoopCandidate r;
+        if (f.images.empty()) return r;
+        const int drone_id = f.drone_id;
+        if (drone_id != self_id && database_size() == 0) return r;                // :36-38
+        const bool new_node = all_nodes.find(drone_id) == all_nodes.end();
+        all_nodes.insert(drone_id);
+        int dir_count = 0;
+        for (auto& img : f.images) if (img.landmark_num > 0) ++dir_count;
+        if (dir_count < MIN_DIRECTION_LOOP) return r;                             // :60-63
+        if (f.landmark_num < MIN_LOOP_NUM) return r;                              // :65
+        bool init_mode = false;
+        if (drone_id != self_id) init_mode = inter_drone_loop_count[{drone_id, self_id}] < inter_drone_init_frames;   // :67-72
+        if (!f.prevent_adding_db || new_node) { add_to_database(f); r.added = true; }                               // :89-94
+        if (database_size() > MATCH_INDEX_DIST || init_mode || drone_id != self_id) {                               // :98
+            r.queried = true;
+            int direction_new = stereo_fisheye ? 1 : 0, direction_old = -1, image_id = -1;
+            double distance = -1;
+            const FisheyeFrameDescriptor* old = query_fisheyeframe_from_database(f, init_mode, f.prevent_adding_db, direction_new, direction_old, image_id, distance);
+            if (direction_old >= 0 && old) {
+                r.found = true; r.old_msg_id = old->msg_id; r.image_id = image_id; r.direction_new = direction_new; r.direction_old = direction_old; r.distance = distance;
+                bool success = false;
+                if (old->drone_id == self_id) success = compute_loop && compute_loop(f, *old, direction_new, direction_old, init_mode);       // :110-111
+                else if (f.drone_id == self_id) success = compute_loop && compute_loop(*old, f, direction_old, direction_new, init_mode);    // :114-115
+                if (success) {                                                                                                                // :826-827
+                    ++inter_drone_loop_count[{f.drone_id, old->drone_id}];
+                    ++inter_drone_loop_count[{old->drone_id, f.drone_id}];
+                    r.loop = true;
+                }
+            }
+        }
+        return r;
+    }
+
+    int self_id;
+    IndexFlatIP local_index, remote_index;
+    std::map<int, int64_t> imgid2fisheye;
+    std::map<int, int> imgid2dir;
+    std::map<int64_t, FisheyeFrameDescriptor> fisheyeframe_database;
+    std::map<std::pair<int, int>, int> inter_drone_loop_count;
+    std::set<int> all_nodes;
+
+private:
+    int add_image(const ImageDescriptor& img) {                                   // :164-173
+        if (img.drone_id == self_id) { local_index.add(1, img.image_desc.data()); return (int)local_index.ntotal - 1; }
+        remote_index.add(1, img.image_desc.data());
+        return (int)remote_index.ntotal - 1 + REMOTE_MAGIN_NUMBER;
+    }
+    void add_to_database(const FisheyeFrameDescriptor& f) {                       // :150-162
+        for (size_t i = 0; i < f.images.size(); ++i)
+            if (f.images[i].landmark_num > 0) { int index = add_image(f.images[i]); imgid2fisheye[index] = f.msg_id; imgid2dir[index] = (int)i; }
+        fisheyeframe_database[f.msg_id] = f;
+    }
+    int query_index(const ImageDescriptor& img, IndexFlatIP& index, bool remote_db, double thres, int max_index, double& distance) {   // :199-242
+        float distances[1000] = {0};
+        IndexFlatIP::idx_t labels[1000];
+        const int index_offset = remote_db ? REMOTE_MAGIN_NUMBER : 0;
+        for (auto& l : labels) l = -1;
+        const int search_num = SEARCH_NEAREST_NUM + max_index;
+        index.search(1, img.image_desc.data(), search_num, distances, labels);
+        int return_msg_id = -1;
+        for (int i = 0; i < search_num; ++i) {
+            if (labels[i] < 0) continue;
+            if (imgid2fisheye.find((int)labels[i] + index_offset) == imgid2fisheye.end()) continue;
+            return_msg_id = (int)labels[i] + index_offset;
+            if (labels[i] <= index.ntotal - max_index && distances[i] > thres) { distance = distances[i]; return return_msg_id; }
+        }
+        return return_msg_id;                                                     // :241 fall-through (sic)
+    }
+    int query_from_database(const ImageDescriptor& img, bool init_mode, bool nonkeyframe, double& distance) {    // :176-197
+        const double thres = init_mode ? INIT_MODE_PRODUCT_THRES : INNER_PRODUCT_THRES;
+        if (img.drone_id == self_id) {
+            int _id = query_index(img, remote_index, true, thres, 1, distance);
+            if (!nonkeyframe) return query_index(img, local_index, false, thres, MATCH_INDEX_DIST, distance);
+            else if (_id != -1) return _id;
+        } else {
+            return query_index(img, local_index, false, thres, 1, distance);
+        }
+        return -1;
+    }
+    const FisheyeFrameDescriptor* query_fisheyeframe_from_database(const FisheyeFrameDescriptor& f, bool init_mode, bool nonkeyframe, int direction_new,
+                                                                   int& direction_old, int& image_id, double& distance) {   // :245-287
+        direction_old = -1;
+        if ((int)f.images.size() <= direction_new || f.images[direction_new].landmark_num <= 0) return nullptr;
+        distance = -1;
+        int id = query_from_database(f.images[direction_new], init_mode, nonkeyframe, distance);
+        if (id != -1 && distance > -1) {
+            image_id = id;
+            direction_old = imgid2dir[id];
+            return &fisheyeframe_database[imgid2fisheye[id]];
+        }
+        return nullptr;
+    }
+};
+
+}  // namespace omni
