@@ -148,6 +148,7 @@ class Context:
     """One HIP stream + scratch on one GPU (omni_ctx)."""
 
     def __init__(self, device_id: int = 0):
+        self.device_id = device_id
         self.h = lib().omni_ctx_create(device_id)
         if not self.h:
             raise OmniError(f"omni_ctx_create failed: {lib().omni_last_error().decode()}")

@@ -90,15 +90,29 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
             for (int i = 0; i < 16; ++i) acc[m][f][i] = 0.f;
 
     for (int ch = 0; ch < n_ch; ++ch) {
-        // ---- stage the input halo tile for this channel chunk (previous chunk's last barrier protects the buffer)
-        for (int idx = tid; idx < ITH * ITW * PPP; idx += 256) {
-            const int pix = idx / PPP, piece = idx - pix * PPP;
-            const int iy = pix / ITW, ixx = pix - iy * ITW;
-            const int gy = tile_y0 - HALO + iy, gx = tile_x0 - HALO + ixx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const uint4*>(in_b + ((int64_t)gy * W + gx) * in_cstride + ch * CONV_CIN_CHUNK + piece * PIECE);
-            *reinterpret_cast<uint4*>(in_tile + pix * PS + piece * PIECE) = v;
+        // ---- stage the input halo tile for this channel chunk (previous chunk's last barrier protects the buffer).
+        // All global loads are issued before the first LDS store so their latencies overlap (a load-store-per-iteration
+        // loop serialises ~11 HBM round trips per tile).
+        {
+            constexpr int NPIECES = ITH * ITW * PPP;
+            constexpr int NIT = (NPIECES + 255) / 256;
+            uint4 stage[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                const int pix = idx / PPP, piece = idx - pix * PPP;
+                const int iy = pix / ITW, ixx = pix - iy * ITW;
+                const int gy = tile_y0 - HALO + iy, gx = tile_x0 - HALO + ixx;
+                stage[it] = make_uint4(0u, 0u, 0u, 0u);
+                if (idx < NPIECES && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    stage[it] = *reinterpret_cast<const uint4*>(in_b + ((int64_t)gy * W + gx) * in_cstride + ch * CONV_CIN_CHUNK + piece * PIECE);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                const int pix = idx / PPP, piece = idx - pix * PPP;
+                if (idx < NPIECES) *reinterpret_cast<uint4*>(in_tile + pix * PS + piece * PIECE) = stage[it];
+            }
         }
         const T* wp_ch = wp_ct + (int64_t)ch * TAPS * 4096;
 #pragma unroll
@@ -306,20 +320,22 @@ __device__ __forceinline__ float wave_max_f(float v) {
     return v;
 }
 
+#define DET_THREADS 512
+#define DET_WAVES (DET_THREADS / 64)
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(DET_THREADS)
 detector_head_kernel(const T* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
                      const float* __restrict__ wT, const float* __restrict__ bias, float* __restrict__ semi) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* wTs = reinterpret_cast<float*>(smem_raw);      // [256][65]
-    float* xs = wTs + 256 * 65;                            // [4][256]
+    float* xs = wTs + 256 * 65;                            // [DET_WAVES][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 256 * 65; i += 256) wTs[i] = wT[i];
+    for (int i = tid; i < 256 * 65; i += DET_THREADS) wTs[i] = wT[i];
     const float my_bias = bias[lane];
     const float dust_bias = bias[64];
     __syncthreads();
     float* x = xs + wave * 256;
-    for (int base = blockIdx.x * 4; base < n_cells; base += gridDim.x * 4) {
+    for (int base = blockIdx.x * DET_WAVES; base < n_cells; base += gridDim.x * DET_WAVES) {
         const int cell = base + wave;
         const bool valid = cell < n_cells;
         if (valid) {
@@ -362,16 +378,16 @@ detector_head_kernel(const T* __restrict__ in, int in_stride, int in_off, int n_
 int detector_head(hipStream_t st, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                   const float* wT, const float* bias, float* semi) {
     const int n_cells = batch * Hc * Wc;
-    const size_t smem = (size_t)(256 * 65 + 4 * 256) * 4;
-    int grid = cdiv(n_cells, 4);
-    if (grid > 1024) grid = 1024;
+    const size_t smem = (size_t)(256 * 65 + DET_WAVES * 256) * 4;
+    int grid = cdiv(n_cells, DET_WAVES);
+    if (grid > 512) grid = 512;                            // 2 workgroups/CU (75 KB LDS each): weights staged once per workgroup
     if (precision == OMNI_PREC_F16) {
         OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(detector_head_kernel<_Float16>, dim3(grid), dim3(256), smem, st, (const _Float16*)in, in_stride, in_off,
+        hipLaunchKernelGGL(detector_head_kernel<_Float16>, dim3(grid), dim3(DET_THREADS), smem, st, (const _Float16*)in, in_stride, in_off,
                            n_cells, Hc, Wc, wT, bias, semi);
     } else {
         OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(detector_head_kernel<float>, dim3(grid), dim3(256), smem, st, (const float*)in, in_stride, in_off, n_cells,
+        hipLaunchKernelGGL(detector_head_kernel<float>, dim3(grid), dim3(DET_THREADS), smem, st, (const float*)in, in_stride, in_off, n_cells,
                            Hc, Wc, wT, bias, semi);
     }
     OMNI_LAUNCH_CHECK();

@@ -295,6 +295,10 @@ int omni_index_search(omni_index* ix, int nq, const float* q_host, int k, float*
     OMNI_REQUIRE(nq >= 1 && nq <= 4096, OMNI_ERR_CAPACITY, "nq=%d outside [1,4096]", nq);
     OMNI_REQUIRE(k >= 1 && k <= TOPK_MAX_K, OMNI_ERR_CAPACITY, "k=%d outside [1,%d]", k, TOPK_MAX_K);
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->ntotal == 0) {      // faiss pads an empty index's result with -1 labels; nothing to launch
+        for (size_t i = 0; i < (size_t)nq * k; ++i) { D[i] = -3.402823466e+38f; I[i] = -1; }
+        return OMNI_OK;
+    }
     (void)hipSetDevice(ix->ctx->device);
     hipStream_t st = ix->ctx->stream;
     int rc;

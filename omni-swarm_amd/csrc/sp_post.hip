@@ -23,26 +23,51 @@ namespace omni {
 #define ST_DEAD 3u
 
 // ---- getKeyPoints: mask = prob > thres; findNonZero  (:167-173) -------------------------------------------------
+// 2048 pixels per workgroup, ONE global atomic per workgroup (per-wave atomics on a single counter serialise in L2).
+// The list order is irrelevant: NMS2's scan order is the row-major PIXEL order, which the state plane encodes.
+#define CAND_PX_PER_BLOCK 2048
 __global__ void __launch_bounds__(256)
 sp_cand_kernel(const float* __restrict__ semi, int hw, float thres, int* __restrict__ cand, int* __restrict__ counters) {
+    __shared__ int s_wave_cnt[4];
+    __shared__ int s_base;
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const bool c = (p < hw) && (semi[(int64_t)b * hw + p] > thres);
-    const unsigned long long m = __ballot(c);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&counters[b * 4 + 0], __popcll(m));
-    base = __shfl(base, leader, 64);
-    if (c) cand[(int64_t)b * hw + base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p0 = blockIdx.x * CAND_PX_PER_BLOCK + tid * 8;          // 8 consecutive pixels per thread
+    const float* sm = semi + (int64_t)b * hw;
+    float v[8];
+    if (p0 + 8 <= hw) {
+        const float4 a = *reinterpret_cast<const float4*>(sm + p0), c = *reinterpret_cast<const float4*>(sm + p0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (p0 + j < hw) ? sm[p0 + j] : -3.0e38f;
+    }
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mask |= (v[j] > thres) ? (1u << j) : 0u;
+    const int mine = __popc(mask);
+    int incl = mine;                                                   // inclusive prefix over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    if (lane == 63) s_wave_cnt[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        const int total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        s_base = total ? atomicAdd(&counters[b * 4 + 0], total) : 0;
+    }
+    __syncthreads();
+    int pos = s_base + incl - mine;
+    for (int w = 0; w < wave; ++w) pos += s_wave_cnt[w];
+    int* out = cand + (int64_t)b * hw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (mask & (1u << j)) out[pos++] = p0 + j;
 }
 
 __device__ __forceinline__ unsigned st_get(const unsigned* st, int p) { return (st[p >> 4] >> ((p & 15) * 2)) & 3u; }
 
 // ---- NMS2 (:237-310) ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NMS_THREADS)
-sp_nms_kernel(const float* __restrict__ semi, int W, int H, int r, int max_num, const int* __restrict__ cand,
+sp_nms_kernel(const float* __restrict__ semi, int W, int H, int /*r: fixed at 4*/, int max_num, const int* __restrict__ cand,
               int* __restrict__ counters, uint64_t* __restrict__ surv_keys, float* __restrict__ kps_xy,
               float* __restrict__ scores, int* __restrict__ n_kps, int state_words, int smem_main_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // all LDS is dynamic: keeps the base 16-B aligned
@@ -64,7 +89,9 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int r, int max_num, 
     }
     __syncthreads();
 
-    // relaxation of alive()
+    // relaxation of alive().  The neighbour scan is branch-free and fully unrolled (R = 4): all LDS state reads and all
+    // (predicated) heat-map loads of a candidate are independent, so their latencies overlap instead of chaining.
+    constexpr int R = 4;
     int iters = 0;
     for (;;) {
         int changed = 0;
@@ -74,17 +101,20 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int r, int max_num, 
             const int y = p / W, x = p - y * W;
             const float c0 = sm[p];
             bool any_alive = false, any_unknown = false;
-            for (int k = -r; k <= 0; ++k) {
-                const int v = y + k;
-                if (v < 0) continue;
-                const int jmax = (k == 0) ? -1 : r;               // earlier in row-major order only
-                for (int j = -r; j <= jmax; ++j) {
-                    const int u = x + j;
-                    if (u < 0 || u >= W) continue;                // fixed spec: out-of-image neighbours ignored
-                    const int q = v * W + u;
-                    const unsigned s = st_get(st, q);
-                    if (s == ST_NONE || s == ST_DEAD) continue;
-                    if (sm[q] > c0) { if (s == ST_ALIVE) any_alive = true; else any_unknown = true; }
+#pragma unroll
+            for (int k = -R; k <= 0; ++k) {
+#pragma unroll
+                for (int j = -R; j <= R; ++j) {
+                    if (k == 0 && j >= 0) continue;                   // earlier in row-major order only (compile time)
+                    const int v = y + k, u = x + j;
+                    const bool inb = (v >= 0) && (u >= 0) && (u < W); // fixed spec: out-of-image neighbours ignored
+                    const int q = inb ? v * W + u : p;
+                    const unsigned sq = inb ? st_get(st, q) : ST_NONE;
+                    const bool live = (sq == ST_UNKNOWN) || (sq == ST_ALIVE);
+                    const float cq = live ? sm[q] : 0.f;
+                    const bool higher = live && (cq > c0);
+                    any_alive |= higher && (sq == ST_ALIVE);
+                    any_unknown |= higher && (sq == ST_UNKNOWN);
                 }
             }
             if (any_alive) { atomicOr(&st[p >> 4], 2u << ((p & 15) * 2)); changed = 1; }            // 01 -> 11 dead
@@ -105,14 +135,17 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int r, int max_num, 
         const int y = p / W, x = p - y * W;
         const float c0 = sm[p];
         bool beaten = false;
-        for (int k = -r; k <= r && !beaten; ++k) {
-            const int v = y + k;
-            if (v < 0 || v >= H) continue;
-            for (int j = -r; j <= r; ++j) {
-                const int u = x + j;
-                if (u < 0 || u >= W || (k == 0 && j == 0)) continue;
-                const int q = v * W + u;
-                if (st_get(st, q) == ST_ALIVE && sm[q] > c0) { beaten = true; break; }
+#pragma unroll
+        for (int k = 0; k <= R; ++k) {                                 // only LATER neighbours can beat an alive point
+#pragma unroll
+            for (int j = -R; j <= R; ++j) {
+                if (k == 0 && j <= 0) continue;
+                const int v = y + k, u = x + j;
+                const bool inb = (v < H) && (u >= 0) && (u < W);
+                const int q = inb ? v * W + u : p;
+                const bool al = inb && (st_get(st, q) == ST_ALIVE);
+                const float cq = al ? sm[q] : 0.f;
+                beaten |= al && (cq > c0);
             }
         }
         if (!beaten) sk[atomicAdd(&s_nsurv, 1)] = omni_make_key(c0, (uint32_t)p);
@@ -156,21 +189,25 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int r, int max_num, 
 }
 
 // ---- computeDescriptors (:192-230) --------------------------------------------------------------------------------
-// thread = channel.  Pass 1 samples every key point (torch::grid_sampler, bilinear, zeros, align_corners=false) and
-// accumulates the per-CHANNEL sum of squares ACROSS the image's key points -- torch::norm(desc, 2, /*dim=*/1) on the
-// [256, n] tensor (:214): the reference normalises channels across key points, not descriptors across channels.
+// Pass 1: torch::grid_sampler (bilinear, zeros, align_corners=false) of every key point; 8 key points per workgroup,
+// thread = channel (NHWC: the 4 taps are coalesced 1 KiB rows).
+#define SAMPLE_KPB 8
 __global__ void __launch_bounds__(256)
 sp_sample_kernel(const float* __restrict__ desc_nhwc, int W, int H, int max_num, const float* __restrict__ kps_xy,
                  const int* __restrict__ n_kps, float* __restrict__ raw_desc) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const int c = threadIdx.x;
     const int Wc = W >> 3, Hc = H >> 3;
     const int n = n_kps[b];
+    const int i0 = blockIdx.x * SAMPLE_KPB;
+    if (i0 >= n) return;
     const float* dm = desc_nhwc + (int64_t)b * Hc * Wc * 256;
     float* raw = raw_desc + (int64_t)b * max_num * 256;
     const float fW = (float)W, fH = (float)H, fWc = (float)Wc, fHc = (float)Hc;
-    float ss = 0.f;
-    for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int kk = 0; kk < SAMPLE_KPB; ++kk) {
+        const int i = i0 + kk;
+        if (i >= n) break;
         const float kx = kps_xy[((int64_t)b * max_num + i) * 2 + 0];
         const float ky = kps_xy[((int64_t)b * max_num + i) * 2 + 1];
         // grid = 2*k/size - 1 (:204-205); unnormalise with align_corners=false: ((g+1)*size_c - 1)/2
@@ -191,9 +228,22 @@ sp_sample_kernel(const float* __restrict__ desc_nhwc, int W, int H, int max_num,
             if (x1 >= 0 && x1 < Wc) v += dm[((int64_t)y1 * Wc + x1) * 256 + c] * (wx1 * wy1);
         }
         raw[(int64_t)i * 256 + c] = v;
-        ss = fmaf(v, v, ss);
     }
+}
+
+// Pass 1b: divide every CHANNEL by its L2 norm ACROSS the image's key points -- torch::norm(desc, 2, /*dim=*/1) on the
+// [256, n] tensor (:214): the reference normalises channels across key points, not descriptors across channels.
+// One workgroup per image, thread = channel, sequential (deterministic) sum over the key points.
+__global__ void __launch_bounds__(256)
+sp_chan_norm_kernel(int max_num, const int* __restrict__ n_kps, float* __restrict__ raw_desc) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const int n = n_kps[b];
+    float* raw = raw_desc + (int64_t)b * max_num * 256;
+    float ss = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) { const float v = raw[(int64_t)i * 256 + c]; ss = fmaf(v, v, ss); }
     const float dn = sqrtf(ss);
+#pragma unroll 8
     for (int i = 0; i < n; ++i) raw[(int64_t)i * 256 + c] = raw[(int64_t)i * 256 + c] / dn;   // 0/0 -> NaN as in the reference
 }
 
@@ -289,14 +339,16 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
     OMNI_REQUIRE(smem <= 160 * 1024, OMNI_ERR_CAPACITY, "image %dx%d too large for the in-LDS NMS state plane", p.width, p.height);
     OMNI_REQUIRE(p.max_num >= 1 && p.max_num <= 1024, OMNI_ERR_CAPACITY, "max_num=%d outside [1,1024]", p.max_num);
     OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
-    hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(hw, 256), batch), dim3(256), 0, stream, semi, hw, p.thres, b.cand, b.counters);
+    hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(hw, CAND_PX_PER_BLOCK), batch), dim3(256), 0, stream, semi, hw, p.thres, b.cand, b.counters);
     OMNI_LAUNCH_CHECK();
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(sp_nms_kernel, dim3(batch), dim3(NMS_THREADS), smem, stream, semi, p.width, p.height, p.dist_thresh,
                        p.max_num, b.cand, b.counters, b.surv_keys, b.kps_xy, b.scores, b.n_kps, state_words, smem_main);
     OMNI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sp_sample_kernel, dim3(batch), dim3(256), 0, stream, desc_nhwc, p.width, p.height, p.max_num, b.kps_xy,
-                       b.n_kps, b.raw_desc);
+    hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(p.max_num, SAMPLE_KPB), batch), dim3(256), 0, stream, desc_nhwc, p.width, p.height,
+                       p.max_num, b.kps_xy, b.n_kps, b.raw_desc);
+    OMNI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sp_chan_norm_kernel, dim3(batch), dim3(256), 0, stream, p.max_num, b.n_kps, b.raw_desc);
     OMNI_LAUNCH_CHECK();
     if (p.pca_dim > 0) {
         hipLaunchKernelGGL(sp_pca_kernel, dim3(cdiv(p.max_num, 4), batch), dim3(256), 0, stream, b.raw_desc, p.max_num, b.n_kps,

@@ -8,7 +8,7 @@
 #include "common.h"
 
 #define TOPK_CHUNK 2048
-#define TOPK_THREADS 256
+#define TOPK_THREADS 1024
 #define TOPK_MAX_K 1024
 
 namespace omni {

@@ -7,7 +7,8 @@ Mirrors /root/reference/swarm_loop/src/loop_cam.cpp:
     match_HFNet_local_features         :141-174   cv::BFMatcher(NORM_L2, crossCheck) on the 64-d descriptors
 The reference runs these 8 + 4 engine calls and 4 matches strictly one after another, each with its own H2D/D2H and
 stream sync; here one key frame is three batched enqueues on one HIP stream (8 SuperPoint images, 4
-MobileNetVLAD images, 4 descriptor-set pairs) with every intermediate resident in HBM and one small D2H at the end.
+MobileNetVLAD images on a second stream, 4 descriptor-set pairs) with every intermediate resident in HBM and one small
+D2H at the end.
 Camera geometry (camodocal liftProjective, SVD triangulation, loop_cam.cpp:73-106,405-454,558-576) is host-side f64
 work outside the kernel scope and is left to the caller: the 2-D key points, descriptors, global
 descriptors and the up/down match lists are everything those steps consume.
@@ -28,7 +29,9 @@ class LoopCam:
         self.accept_min_3d_pts = accept_min_3d_pts
         self.sp = capi.SuperPoint(ctx, sp_weights, pca_comp, pca_mean, width, height, thres, max_num, precision, 2 * n_dirs)
         k, d, o = vlad_shape
-        self.vlad = capi.MobileNetVLAD(ctx, vlad_weights, vlad_specs, k, d, o, width, height, n_dirs)
+        # MobileNetVLAD is ~50 small launches: on its own HIP stream they overlap SuperPoint's large convolutions
+        self.vctx = capi.Context(ctx.device_id)
+        self.vlad = capi.MobileNetVLAD(self.vctx, vlad_weights, vlad_specs, k, d, o, width, height, n_dirs)
         self.out_dim = o
         self.dim = self.sp.desc_dim
         m = max_num
@@ -43,6 +46,7 @@ class LoopCam:
             self.ctx.free(p)
         self.sp.close()
         self.vlad.close()
+        self.vctx.close()
 
     def enqueue_dev(self, gray_dev: int, stride: int):
         """gray_dev: [2*n_dirs][H][W] u8 in HBM -- images 0..n_dirs-1 are the 'up' (main) camera of each direction,
