@@ -35,6 +35,8 @@ struct ConvArgs {
     int in_cstride = 0;    // channels per pixel of the input buffer (0 = cin); > cin reads a channel slice
     bool relu, pool;
     bool out_f32;          // write fp32 regardless of the compute precision (final 1x1 descriptor conv)
+    int n_cu = 0;          // CUs on the device (> 0 enables the persistent cin=64 fp16 kernel)
+    bool force_v1 = false; // test hook: always use the generic kernel
 };
 int conv_mfma(hipStream_t stream, int precision, const ConvArgs& a);
 

@@ -208,6 +208,201 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2 kernel for the fp16 3x3 layers with 64 INPUT channels (conv1b, conv2a, conv2b, conv3a: 65 % of the FLOPs).
+//   * persistent workgroups (one per CU, 4 waves = one per SIMD): all 9 taps of the 64x64 weight block (73.7 KB) are
+//     staged into LDS ONCE per workgroup -- no per-tap staging, no per-tap barriers;
+//   * the 10x34-pixel input halo tile (43.5 KB) is double buffered and filled by LDS-DMA (global_load_lds_dwordx4,
+//     1 KiB per wave instruction, no VGPR round trip) for tile t+1 while the MFMAs of tile t run: ONE barrier per tile;
+//   * LDS image is lane-linear as DMA requires; bank conflicts are removed by an XOR swizzle applied to the per-lane
+//     SOURCE address and to the fragment reads (16-byte chunk c of pixel p lives at chunk c ^ ((p >> 1) & 7)), so 16
+//     consecutive pixels hit 16 distinct 16-byte slots of the 256-byte bank row;
+//   * out-of-image halo pixels are DMA'd from a clamped (valid) address and then overwritten with zeros.
+// LDS: 73 728 + 2 x 44 032 = 161 792 B of the CU's 163 840.
+// ---------------------------------------------------------------------------------------------------------------
+#define C64_ITW 34
+#define C64_ITH 10
+#define C64_PIX (C64_ITW * C64_ITH)            // 340 pixels
+#define C64_CHUNKS (C64_PIX * 8)               // 2720 16-byte chunks
+#define C64_BUF_BYTES (43 * 1024)              // 43 wave-instructions of 1 KiB
+#define C64_W_BYTES (9 * 4096 * 2)
+#define C64_SMEM (C64_W_BYTES + 2 * C64_BUF_BYTES)
+
+template <bool POOL>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_c64_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
+                       const float* __restrict__ bias, int H, int W, int cout, int n_ct, int tiles_x, int tiles_y, int batch, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    _Float16* wts = reinterpret_cast<_Float16*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hh = lane >> 5, dy = n >> 4, xx = n & 15;
+    const int ct = blockIdx.x % n_ct, wg = blockIdx.x / n_ct, nwg = gridDim.x / n_ct;
+    const int tiles_per_img = tiles_x * tiles_y;
+    const int total = batch * tiles_per_img;
+
+    {   // weights for this cout tile: 9 taps x 8 KB, fragment order (see pack_weights)
+        const uint4* src = reinterpret_cast<const uint4*>(wp + (int64_t)ct * 9 * 4096);
+        uint4* dst = reinterpret_cast<uint4*>(wts);
+        for (int i = tid; i < C64_W_BYTES / 16; i += 256) dst[i] = src[i];
+    }
+    float4 bias_r[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_r[m][g] = *reinterpret_cast<const float4*>(bias + ct * 64 + m * 32 + 8 * g + 4 * hh);
+
+    auto buf_ptr = [&](int which) -> char* { return smem_raw + C64_W_BYTES + which * C64_BUF_BYTES; };
+
+    // issue the LDS-DMA of tile t into buffer `which` (async; completion = vmcnt)
+    auto issue = [&](int t, int which) {
+        const int b = t / tiles_per_img, r = t - b * tiles_per_img;
+        const int y0 = (r / tiles_x) * CONV_TH - 1, x0 = (r % tiles_x) * CONV_TW - 1;
+        const _Float16* img = in + (int64_t)b * H * W * 64;
+        char* base = buf_ptr(which);
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int wi = wave * 11 + j;                       // wave-uniform instruction index, 1 KiB each
+            if (wi < 43) {
+                int idx = wi * 64 + lane;
+                idx = idx < C64_CHUNKS ? idx : C64_CHUNKS - 1;   // tail lanes of instruction 42: harmless duplicate
+                const int pix = idx >> 3, phys = idx & 7;
+                const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
+                int gy = y0 + iy, gx = x0 + ix;
+                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);        // clamped: zero-fixed below
+                gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+                const int logical = phys ^ ((pix >> 1) & 7);
+                const _Float16* g = img + ((int64_t)gy * W + gx) * 64 + logical * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(base + wi * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto zero_fix = [&](int t, int which) {
+        const int b = t / tiles_per_img, r = t - b * tiles_per_img;
+        const int y0 = (r / tiles_x) * CONV_TH - 1, x0 = (r % tiles_x) * CONV_TW - 1;
+        if (y0 >= 0 && y0 + C64_ITH <= H && x0 >= 0 && x0 + C64_ITW <= W) return;     // interior tile (workgroup-uniform)
+        char* base = buf_ptr(which);
+        for (int pix = tid; pix < C64_PIX; pix += 256) {
+            const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
+            const int gy = y0 + iy, gx = x0 + ix;
+            if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
+                uint4* p = reinterpret_cast<uint4*>(base + pix * 128);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) p[c] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+
+    int t = wg;
+    if (t < total) issue(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t < total) zero_fix(t, 0);
+    __syncthreads();
+
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    int cur = 0;
+    for (; t < total; t += nwg, cur ^= 1) {
+        const int tn = t + nwg;
+        if (tn < total) issue(tn, cur ^ 1);
+
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][f][i] = 0.f;
+        const _Float16* tile = reinterpret_cast<const _Float16*>(buf_ptr(cur));
+        // 36 k-steps (9 taps x 4 groups of 16 channels), software pipelined by hand: the four fragment reads of step s+1
+        // are issued before the four MFMAs of step s (one wave per SIMD has no other wave to hide LDS latency behind).
+        half8_t fa0[2], fa1[2], fb0[2], fb1[2];
+        auto load_step = [&](int step, int slot) {
+            const int tap = step >> 2, kg = step & 3;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int p0 = (2 * wave + dy + ky) * C64_ITW + xx + kx;
+            const int p1 = p0 + 16;
+            const int c = kg * 2 + hh;
+            // issue order = order of first use by the next step's MFMAs: (a0,b0) (a1,b0) (a0,b1) (a1,b1)
+            fb0[slot] = *reinterpret_cast<const half8_t*>(tile + p0 * 64 + ((c ^ ((p0 >> 1) & 7)) << 3));
+            fa0[slot] = *reinterpret_cast<const half8_t*>(wts + (step * 2 + 0) * 512 + lane * 8);
+            fa1[slot] = *reinterpret_cast<const half8_t*>(wts + (step * 2 + 1) * 512 + lane * 8);
+            fb1[slot] = *reinterpret_cast<const half8_t*>(tile + p1 * 64 + ((c ^ ((p1 >> 1) & 7)) << 3));
+        };
+        load_step(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int step = 0; step < 36; ++step) {
+            const int sl = step & 1;
+            if (step + 1 < 36) load_step(step + 1, sl ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[sl], fb0[sl], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[sl], fb0[sl], acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[sl], fb1[sl], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[sl], fb1[sl], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep "reads of step s+1, then MFMAs of step s" exactly as written
+        }
+
+        // epilogue (same mapping as conv_mfma_kernel)
+        const int b = t / tiles_per_img, r = t - b * tiles_per_img;
+        const int tile_y0 = (r / tiles_x) * CONV_TH, tile_x0 = (r % tiles_x) * CONV_TW;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int oy = tile_y0 + 2 * wave + dy, ox = tile_x0 + 16 * f + xx;
+            bool writer = (oy < H) && (ox < W);
+            int py = oy, px = ox;
+            if constexpr (POOL) { writer = writer && ((n & 1) == 0) && ((n & 16) == 0); py = oy >> 1; px = ox >> 1; }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                floatx16 v = acc[m][f];
+                if constexpr (POOL) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float q = v[i];
+                        q = fmaxf(q, __shfl_xor(q, 1, 64));
+                        q = fmaxf(q, __shfl_xor(q, 16, 64));
+                        v[i] = q;
+                    }
+                }
+                if (writer) {
+                    _Float16* o = out + (((int64_t)b * Ho + py) * Wo + px) * cout + ct * 64 + m * 32 + 4 * hh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bs = bias_r[m][g];
+                        float r0 = v[4 * g + 0] + bs.x, r1 = v[4 * g + 1] + bs.y, r2 = v[4 * g + 2] + bs.z, r3 = v[4 * g + 3] + bs.w;
+                        if (relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+                        half4_t h4;
+                        h4[0] = (_Float16)r0; h4[1] = (_Float16)r1; h4[2] = (_Float16)r2; h4[3] = (_Float16)r3;
+                        *reinterpret_cast<half4_t*>(o + 8 * g) = h4;
+                    }
+                }
+            }
+        }
+        // next tile's DMA must have landed before anyone reads it; everyone must be done with `cur` before it is refilled
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tn < total) zero_fix(tn, cur ^ 1);
+        __syncthreads();
+    }
+}
+
+template <bool POOL>
+static int launch_conv_c64(hipStream_t st, const ConvArgs& a, int n_cu) {
+    auto kfn = conv3x3_c64_f16_kernel<POOL>;
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM));
+    const int tiles_x = cdiv(a.W, CONV_TW), tiles_y = cdiv(a.H, CONV_TH), n_ct = a.cout / 64;
+    const int total = a.batch * tiles_x * tiles_y;
+    int per_ct = n_cu / n_ct;
+    if (per_ct < 1) per_ct = 1;
+    if (per_ct > total) per_ct = total;
+    hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(256), C64_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
+                       reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 template <typename T, int KS, bool POOL>
 static int launch_conv(hipStream_t st, const ConvArgs& a) {
     const size_t smem = conv_smem_bytes<T, KS>();
@@ -225,6 +420,9 @@ int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {
     OMNI_REQUIRE(a.ksize == 1 || a.ksize == 3, OMNI_ERR_INVALID, "conv_mfma: ksize=%d", a.ksize);
     OMNI_REQUIRE(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), OMNI_ERR_INVALID, "pooling needs even H, W");
     OMNI_REQUIRE(!(a.pool && a.ksize == 1), OMNI_ERR_INVALID, "1x1 + pool not instantiated");
+    if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 64 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 64) && a.n_cu > 0 &&
+        !a.force_v1)
+        return a.pool ? launch_conv_c64<true>(st, a, a.n_cu) : launch_conv_c64<false>(st, a, a.n_cu);
     if (precision == OMNI_PREC_F16) {
         if (a.ksize == 3) return a.pool ? launch_conv<_Float16, 3, true>(st, a) : launch_conv<_Float16, 3, false>(st, a);
         return launch_conv<_Float16, 1, false>(st, a);
@@ -322,54 +520,74 @@ __device__ __forceinline__ float wave_max_f(float v) {
 
 #define DET_THREADS 512
 #define DET_WAVES (DET_THREADS / 64)
+#define DET_CPW 4                                            // cells per wave per pass: each weight read feeds 4 FMAs
 template <typename T>
 __global__ void __launch_bounds__(DET_THREADS)
 detector_head_kernel(const T* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
                      const float* __restrict__ wT, const float* __restrict__ bias, float* __restrict__ semi) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* wTs = reinterpret_cast<float*>(smem_raw);      // [256][65]
-    float* xs = wTs + 256 * 65;                            // [DET_WAVES][256]
+    float* xs = wTs + 256 * 65;                            // [DET_WAVES][DET_CPW][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 256 * 65; i += DET_THREADS) wTs[i] = wT[i];
     const float my_bias = bias[lane];
     const float dust_bias = bias[64];
     __syncthreads();
-    float* x = xs + wave * 256;
-    for (int base = blockIdx.x * DET_WAVES; base < n_cells; base += gridDim.x * DET_WAVES) {
-        const int cell = base + wave;
-        const bool valid = cell < n_cells;
-        if (valid) {
-            const T* ip = in + (int64_t)cell * in_stride + in_off + lane * 4;
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<float4*>(x + lane * 4) = *reinterpret_cast<const float4*>(ip);
-            } else {
-                const half4_t h = *reinterpret_cast<const half4_t*>(ip);
-                *reinterpret_cast<float4*>(x + lane * 4) = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    float* x = xs + wave * DET_CPW * 256;
+    for (int base = blockIdx.x * DET_WAVES * DET_CPW; base < n_cells; base += gridDim.x * DET_WAVES * DET_CPW) {
+        const int cell0 = base + wave * DET_CPW;
+#pragma unroll
+        for (int c = 0; c < DET_CPW; ++c) {
+            const int cell = cell0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cell < n_cells) {
+                const T* ip = in + (int64_t)cell * in_stride + in_off + lane * 4;
+                if constexpr (sizeof(T) == 4) {
+                    v = *reinterpret_cast<const float4*>(ip);
+                } else {
+                    const half4_t h = *reinterpret_cast<const half4_t*>(ip);
+                    v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                }
             }
+            *reinterpret_cast<float4*>(x + c * 256 + lane * 4) = v;
         }
         __syncthreads();
-        if (valid) {
-            float acc = my_bias;
-            for (int k = 0; k < 256; k += 4) {
-                const float4 xv = *reinterpret_cast<const float4*>(x + k);
-                acc = fmaf(xv.x, wTs[(k + 0) * 65 + lane], acc);
-                acc = fmaf(xv.y, wTs[(k + 1) * 65 + lane], acc);
-                acc = fmaf(xv.z, wTs[(k + 2) * 65 + lane], acc);
-                acc = fmaf(xv.w, wTs[(k + 3) * 65 + lane], acc);
-            }
-            float dpart = 0.f;
+        float acc[DET_CPW], dpart[DET_CPW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dpart = fmaf(x[lane * 4 + j], wTs[(lane * 4 + j) * 65 + 64], dpart);
-            const float dust = wave_sum_f(dpart) + dust_bias;
-            const float mx = fmaxf(wave_max_f(acc), dust);
-            const float e = expf(acc - mx);
+        for (int c = 0; c < DET_CPW; ++c) { acc[c] = my_bias; dpart[c] = 0.f; }
+        for (int k = 0; k < 256; k += 4) {
+            const float w0 = wTs[(k + 0) * 65 + lane], w1 = wTs[(k + 1) * 65 + lane];
+            const float w2 = wTs[(k + 2) * 65 + lane], w3 = wTs[(k + 3) * 65 + lane];
+#pragma unroll
+            for (int c = 0; c < DET_CPW; ++c) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + c * 256 + k);
+                acc[c] = fmaf(xv.x, w0, acc[c]);
+                acc[c] = fmaf(xv.y, w1, acc[c]);
+                acc[c] = fmaf(xv.z, w2, acc[c]);
+                acc[c] = fmaf(xv.w, w3, acc[c]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float wd = wTs[(lane * 4 + j) * 65 + 64];
+#pragma unroll
+            for (int c = 0; c < DET_CPW; ++c) dpart[c] = fmaf(x[c * 256 + lane * 4 + j], wd, dpart[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < DET_CPW; ++c) {
+            const int cell = cell0 + c;
+            const float dust = wave_sum_f(dpart[c]) + dust_bias;
+            const float mx = fmaxf(wave_max_f(acc[c]), dust);
+            const float e = expf(acc[c] - mx);
             const float ed = expf(dust - mx);
-            const float s = wave_sum_f(e) + ed;
-            const float p = e / s;
-            const int wx = cell % Wc;
-            const int hy = (cell / Wc) % Hc;
-            const int b = cell / (Wc * Hc);
-            semi[((int64_t)b * Hc * 8 + hy * 8 + (lane >> 3)) * (Wc * 8) + wx * 8 + (lane & 7)] = p;
+            const float sum = wave_sum_f(e) + ed;
+            const float p = e / sum;
+            if (cell < n_cells) {
+                const int wx = cell % Wc;
+                const int hy = (cell / Wc) % Hc;
+                const int b = cell / (Wc * Hc);
+                semi[((int64_t)b * Hc * 8 + hy * 8 + (lane >> 3)) * (Wc * 8) + wx * 8 + (lane & 7)] = p;
+            }
         }
         __syncthreads();
     }
@@ -378,9 +596,9 @@ detector_head_kernel(const T* __restrict__ in, int in_stride, int in_off, int n_
 int detector_head(hipStream_t st, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                   const float* wT, const float* bias, float* semi) {
     const int n_cells = batch * Hc * Wc;
-    const size_t smem = (size_t)(256 * 65 + DET_WAVES * 256) * 4;
-    int grid = cdiv(n_cells, DET_WAVES);
-    if (grid > 512) grid = 512;                            // 2 workgroups/CU (75 KB LDS each): weights staged once per workgroup
+    const size_t smem = (size_t)(256 * 65 + DET_WAVES * DET_CPW * 256) * 4;
+    int grid = cdiv(n_cells, DET_WAVES * DET_CPW);
+    if (grid > 256) grid = 256;                            // one 98.5 KB workgroup per CU: weights staged once per workgroup
     if (precision == OMNI_PREC_F16) {
         OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(detector_head_kernel<_Float16>, dim3(grid), dim3(DET_THREADS), smem, st, (const _Float16*)in, in_stride, in_off,

@@ -111,8 +111,9 @@ vlad_pw_kernel(const float* __restrict__ in, int64_t P, int cin, int cout, const
             *reinterpret_cast<float4*>(&ws[r][q * 4]) = v;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) {
+        const int kend = (kc + 3) & ~3;                    // cin of the early layers is 8..48: do not run the padded tail
+#pragma unroll 4
+        for (int k = 0; k < kend; ++k) {
             const float4 wv = *reinterpret_cast<const float4*>(&ws[k][tc * 4]);
             const float x0 = xs[tp * 2][k], x1 = xs[tp * 2 + 1][k];
             acc[0][0] = fmaf(x0, wv.x, acc[0][0]); acc[0][1] = fmaf(x0, wv.y, acc[0][1]);
