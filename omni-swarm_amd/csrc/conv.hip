@@ -50,6 +50,70 @@ static constexpr size_t conv_smem_bytes() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Shared epilogue.  Fragment geometry (both conv kernels): wave w owns output rows 2w and 2w+1 of the 8x32 tile; N-fragment
+// f is ROW 2w+f, its 32 lanes-columns are the 32 consecutive pixels of that row (a single-row fragment keeps every
+// ds_read_b128 of the B operand bank-conflict free: 16 consecutive pixels -> 16 distinct 16-byte slots).  Lane holds pixel
+// n = lane & 31 and output channels (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32-channel M-fragment.
+// 2x2 max-pool = elementwise max of the two row accumulators (in registers) + one cross-lane exchange with lane^1.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename OutT, bool POOL, typename BiasFn>
+__device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[2][2], OutT* __restrict__ out, int b, int H, int W, int cout, int ct,
+                                              int tile_y0, int tile_x0, int wave, int lane, int relu, BiasFn bias_of) {
+    const int n = lane & 31, hh = lane >> 5;
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const int ox = tile_x0 + n;
+    auto store4 = [&](OutT* o, float r0, float r1, float r2, float r3) {
+        if (relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+        if constexpr (sizeof(OutT) == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(r0, r1, r2, r3);
+        } else {
+            half4_t h4;
+            h4[0] = (_Float16)r0; h4[1] = (_Float16)r1; h4[2] = (_Float16)r2; h4[3] = (_Float16)r3;
+            *reinterpret_cast<half4_t*>(o) = h4;
+        }
+    };
+    if constexpr (POOL) {
+        const int oy = tile_y0 + 2 * wave;
+        const bool writer = (oy < H) && (ox < W) && ((n & 1) == 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            floatx16 v;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float q = fmaxf(acc[m][0][i], acc[m][1][i]);
+                q = fmaxf(q, __shfl_xor(q, 1, 64));
+                v[i] = q;
+            }
+            if (writer) {
+                OutT* o = out + (((int64_t)b * Ho + (oy >> 1)) * Wo + (ox >> 1)) * cout + ct * 64 + m * 32 + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bs = bias_of(m, g);
+                    store4(o + 8 * g, v[4 * g + 0] + bs.x, v[4 * g + 1] + bs.y, v[4 * g + 2] + bs.z, v[4 * g + 3] + bs.w);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int oy = tile_y0 + 2 * wave + f;
+            if ((oy < H) && (ox < W)) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    OutT* o = out + (((int64_t)b * Ho + oy) * Wo + ox) * cout + ct * 64 + m * 32 + 4 * hh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bs = bias_of(m, g);
+                        store4(o + 8 * g, acc[m][f][4 * g + 0] + bs.x, acc[m][f][4 * g + 1] + bs.y, acc[m][f][4 * g + 2] + bs.z,
+                               acc[m][f][4 * g + 3] + bs.w);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM conv (KS = 1 or 3, stride 1, pad KS/2), fused bias + ReLU (+ 2x2 max-pool).
 // grid = (tiles, cout/64, batch), 256 threads = 4 waves; wave w owns output rows 2w, 2w+1 of the 8x32 tile as two
 // N-fragments of (2 rows x 16 cols) and all 64 output channels as two M-fragments: 4 accumulators (64 VGPRs).
@@ -73,7 +137,6 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, hh = lane >> 5;
-    const int dy = n >> 4, xx = n & 15;
     const int tiles_x = (W + CONV_TW - 1) / CONV_TW;
     const int tile_y0 = (blockIdx.x / tiles_x) * CONV_TH, tile_x0 = (blockIdx.x % tiles_x) * CONV_TW;
     const int ct = blockIdx.y, b = blockIdx.z;
@@ -130,9 +193,8 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
             const T* wcur = wbuf + (tap & 1) * 4096;
             const int ky = tap / KS, kx = tap - ky * KS;
             // LDS pixel index of this lane's pixel for fragment f at this tap (tile origin = -HALO)
-            const int prow = 2 * wave + dy + ky;
-            const T* bp0 = in_tile + (prow * ITW + xx + kx) * PS + hh * TR::EPL;
-            const T* bp1 = bp0 + 16 * PS;
+            const T* bp0 = in_tile + ((2 * wave + ky) * ITW + n + kx) * PS + hh * TR::EPL;   // fragment 0 = row 2w
+            const T* bp1 = bp0 + ITW * PS;                                                  // fragment 1 = row 2w+1
 #pragma unroll
             for (int kg = 0; kg < TR::KG; ++kg) {
                 if constexpr (sizeof(T) == 2) {
@@ -168,44 +230,11 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
     }
 
     // ---- epilogue: (2x2 max-pool) + bias + ReLU, NHWC stores of 4 consecutive channels per register quad
-    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int oy = tile_y0 + 2 * wave + dy, ox = tile_x0 + 16 * f + xx;
-        bool writer = (oy < H) && (ox < W);
-        int py = oy, px = ox;
-        if constexpr (POOL) { writer = writer && ((n & 1) == 0) && ((n & 16) == 0); py = oy >> 1; px = ox >> 1; }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            floatx16 v = acc[m][f];
-            if constexpr (POOL) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float t = v[i];
-                    t = fmaxf(t, __shfl_xor(t, 1, 64));
-                    t = fmaxf(t, __shfl_xor(t, 16, 64));
-                    v[i] = t;
-                }
-            }
-            if (writer) {
-                const int64_t obase = (((int64_t)b * Ho + py) * Wo + px) * cout + ct * 64 + m * 32 + 4 * hh;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = ct * 64 + m * 32 + 8 * g + 4 * hh;
-                    const float4 bs = *reinterpret_cast<const float4*>(bias + c);
-                    float r0 = v[4 * g + 0] + bs.x, r1 = v[4 * g + 1] + bs.y, r2 = v[4 * g + 2] + bs.z, r3 = v[4 * g + 3] + bs.w;
-                    if (relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-                    if (sizeof(T) == 4 || out_f32) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_v) + obase + 8 * g) = make_float4(r0, r1, r2, r3);
-                    } else {
-                        half4_t h4;
-                        h4[0] = (_Float16)r0; h4[1] = (_Float16)r1; h4[2] = (_Float16)r2; h4[3] = (_Float16)r3;
-                        *reinterpret_cast<half4_t*>(reinterpret_cast<_Float16*>(out_v) + obase + 8 * g) = h4;
-                    }
-                }
-            }
-        }
-    }
+    auto bias_of = [&](int m, int g) { return *reinterpret_cast<const float4*>(bias + ct * 64 + m * 32 + 8 * g + 4 * hh); };
+    if (sizeof(T) == 4 || out_f32)
+        conv_epilogue<float, POOL>(acc, reinterpret_cast<float*>(out_v), b, H, W, cout, ct, tile_y0, tile_x0, wave, lane, relu, bias_of);
+    else
+        conv_epilogue<_Float16, POOL>(acc, reinterpret_cast<_Float16*>(out_v), b, H, W, cout, ct, tile_y0, tile_x0, wave, lane, relu, bias_of);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -236,7 +265,7 @@ conv3x3_c64_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
     _Float16* wts = reinterpret_cast<_Float16*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, hh = lane >> 5, dy = n >> 4, xx = n & 15;
+    const int n = lane & 31, hh = lane >> 5;
     const int ct = blockIdx.x % n_ct, wg = blockIdx.x / n_ct, nwg = gridDim.x / n_ct;
     const int tiles_per_img = tiles_x * tiles_y;
     const int total = batch * tiles_per_img;
@@ -301,7 +330,6 @@ conv3x3_c64_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
     if (t < total) zero_fix(t, 0);
     __syncthreads();
 
-    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     int cur = 0;
     for (; t < total; t += nwg, cur ^= 1) {
         const int tn = t + nwg;
@@ -321,8 +349,8 @@ conv3x3_c64_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
         auto load_step = [&](int step, int slot) {
             const int tap = step >> 2, kg = step & 3;
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int p0 = (2 * wave + dy + ky) * C64_ITW + xx + kx;
-            const int p1 = p0 + 16;
+            const int p0 = (2 * wave + ky) * C64_ITW + n + kx;     // fragment 0 = row 2w, 32 consecutive pixels
+            const int p1 = p0 + C64_ITW;                            // fragment 1 = row 2w+1
             const int c = kg * 2 + hh;
             // issue order = order of first use by the next step's MFMAs: (a0,b0) (a1,b0) (a0,b1) (a1,b1)
             fb0[slot] = *reinterpret_cast<const half8_t*>(tile + p0 * 64 + ((c ^ ((p0 >> 1) & 7)) << 3));
@@ -344,40 +372,10 @@ conv3x3_c64_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
             __builtin_amdgcn_sched_barrier(0);   // keep "reads of step s+1, then MFMAs of step s" exactly as written
         }
 
-        // epilogue (same mapping as conv_mfma_kernel)
-        const int b = t / tiles_per_img, r = t - b * tiles_per_img;
-        const int tile_y0 = (r / tiles_x) * CONV_TH, tile_x0 = (r % tiles_x) * CONV_TW;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int oy = tile_y0 + 2 * wave + dy, ox = tile_x0 + 16 * f + xx;
-            bool writer = (oy < H) && (ox < W);
-            int py = oy, px = ox;
-            if constexpr (POOL) { writer = writer && ((n & 1) == 0) && ((n & 16) == 0); py = oy >> 1; px = ox >> 1; }
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                floatx16 v = acc[m][f];
-                if constexpr (POOL) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float q = v[i];
-                        q = fmaxf(q, __shfl_xor(q, 1, 64));
-                        q = fmaxf(q, __shfl_xor(q, 16, 64));
-                        v[i] = q;
-                    }
-                }
-                if (writer) {
-                    _Float16* o = out + (((int64_t)b * Ho + py) * Wo + px) * cout + ct * 64 + m * 32 + 4 * hh;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 bs = bias_r[m][g];
-                        float r0 = v[4 * g + 0] + bs.x, r1 = v[4 * g + 1] + bs.y, r2 = v[4 * g + 2] + bs.z, r3 = v[4 * g + 3] + bs.w;
-                        if (relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-                        half4_t h4;
-                        h4[0] = (_Float16)r0; h4[1] = (_Float16)r1; h4[2] = (_Float16)r2; h4[3] = (_Float16)r3;
-                        *reinterpret_cast<half4_t*>(o + 8 * g) = h4;
-                    }
-                }
-            }
+        {   // epilogue
+            const int b = t / tiles_per_img, r = t - b * tiles_per_img;
+            auto bias_of = [&](int m, int g) { return bias_r[m][g]; };
+            conv_epilogue<_Float16, POOL>(acc, out, b, H, W, cout, ct, (r / tiles_x) * CONV_TH, (r % tiles_x) * CONV_TW, wave, lane, relu, bias_of);
         }
         // next tile's DMA must have landed before anyone reads it; everyone must be done with `cur` before it is refilled
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
