@@ -36,7 +36,7 @@ struct ConvArgs {
     bool relu, pool;
     bool out_f32;          // write fp32 regardless of the compute precision (final 1x1 descriptor conv)
     int n_cu = 0;          // CUs on the device (> 0 enables the persistent cin=64 fp16 kernel)
-    bool force_v1 = false; // test hook: always use the generic kernel
+    int variant = 0;       // test hook (OMNI_CONV_V1): 0 = best kernel per layer, 1 = generic kernel everywhere, 2 = v2 persistent kernel
 };
 int conv_mfma(hipStream_t stream, int precision, const ConvArgs& a);
 

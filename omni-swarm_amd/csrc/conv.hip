@@ -401,6 +401,215 @@ static int launch_conv_c64(hipStream_t st, const ConvArgs& a, int n_cu) {
     return OMNI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v3 "ping-pong" kernel for the same layers (fp16, 3x3, 64 input channels).  Why: in v2 one wave per SIMD does everything
+// in sequence -- DMA issue, 144 MFMAs, max-pool/bias/ReLU/stores, barriers -- so the matrix pipe idles ~60 % of a tile.
+//   * 8 waves = two GROUPS of four (waves 0-3 / 4-7; wave i and i+4 share a SIMD).  Phases are separated by ONE workgroup
+//     barrier; in every phase one group runs the 144-MFMA loop of its tile while the other group SERVICES: issues the
+//     LDS-DMA of its next tile into its own buffer (free since its MFMA phase ended), runs the epilogue of the tile it
+//     just computed (accumulators stay in registers across the barrier), waits for its DMA and zero-fixes the halo.  Next
+//     phase the roles swap, so each SIMD's matrix pipe always has a wave feeding it.
+//   * LDS: 73 728 B resident weights (shared by both groups) + one 44 032 B halo buffer per group = 161 792 B.
+//   * fragment reads are inline-asm ds_read_b128 prefetched TWO k-steps ahead behind counted s_waitcnt lgkmcnt(8/4/0):
+//     hipcc's own schedule of this loop waited lgkmcnt(0) every other step, exposing a full LDS round trip each time.
+//   * B-fragment addresses: 12 per-lane bases (4 halo rows x 3 kx) computed once per kernel; the 16-channel group kg is
+//     one XOR with kg << 5 (the swizzle touches bits 4-6 only), A-fragment addresses are immediates on two bases.
+// K order (tap-major, 16-channel groups inner) is that of the other two kernels: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+#define PP_THREADS 512
+
+template <int STEP>
+__device__ __forceinline__ void pp_load_step(uint32_t a_base0, uint32_t a_base1, const uint32_t (&bb)[4][3], half8_t& fa0, half8_t& fa1,
+                                             half8_t& fb0, half8_t& fb1) {
+    constexpr int tap = STEP >> 2, kg = STEP & 3, ky = tap / 3, kx = tap - ky * 3;
+    constexpr int aoff = (STEP % 18) * 2048;
+    const uint32_t ab = STEP < 18 ? a_base0 : a_base1;
+    const uint32_t b0 = bb[ky][kx] ^ (kg << 5), b1 = bb[ky + 1][kx] ^ (kg << 5);
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5 offset:%7\n\tds_read_b128 %2, %5 offset:%8\n\tds_read_b128 %3, %6"
+                 : "=&v"(fb0), "=&v"(fa0), "=&v"(fa1), "=&v"(fb1)
+                 : "v"(b0), "v"(ab), "v"(b1), "i"(aoff), "i"(aoff + 1024));
+}
+
+template <int N>
+__device__ __forceinline__ void pp_wait(half8_t& fa0, half8_t& fa1, half8_t& fb0, half8_t& fb1) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0), "+v"(fa1), "+v"(fb0), "+v"(fb1) : "i"(N));
+}
+
+template <int STEP>
+__device__ __forceinline__ void pp_mfma_steps(uint32_t a_base0, uint32_t a_base1, const uint32_t (&bb)[4][3], floatx16 (&acc)[2][2],
+                                              half8_t (&fa0)[3], half8_t (&fa1)[3], half8_t (&fb0)[3], half8_t (&fb1)[3]) {
+    if constexpr (STEP < 36) {
+        constexpr int sl = STEP % 3;
+        if constexpr (STEP + 2 < 36) pp_load_step<STEP + 2>(a_base0, a_base1, bb, fa0[(STEP + 2) % 3], fa1[(STEP + 2) % 3], fb0[(STEP + 2) % 3], fb1[(STEP + 2) % 3]);
+        pp_wait<(STEP + 2 < 36) ? 8 : (STEP + 1 < 36 ? 4 : 0)>(fa0[sl], fa1[sl], fb0[sl], fb1[sl]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[sl], fb0[sl], acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[sl], fb0[sl], acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[sl], fb1[sl], acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[sl], fb1[sl], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_mfma_steps<STEP + 1>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
+    }
+}
+
+template <bool POOL>
+__global__ void __launch_bounds__(PP_THREADS)
+conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
+                      const float* __restrict__ bias, int H, int W, int cout, int n_ct, int tiles_x, int tiles_y, int batch, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wl = wave & 3;
+    const int n = lane & 31, hh = lane >> 5;
+    const int ct = blockIdx.x % n_ct, wg = blockIdx.x / n_ct, nwg = gridDim.x / n_ct;
+    const int tiles_per_img = tiles_x * tiles_y;
+    const int total = batch * tiles_per_img;
+    const int n_mine = wg < total ? (total - wg + nwg - 1) / nwg : 0;      // tiles of this workgroup: t_k = wg + k * nwg
+
+    {   // weights for this cout tile: 9 taps x 8 KB, fragment order (see pack_weights)
+        const uint4* src = reinterpret_cast<const uint4*>(wp + (int64_t)ct * 9 * 4096);
+        uint4* dst = reinterpret_cast<uint4*>(smem_raw);
+        for (int i = tid; i < C64_W_BYTES / 16; i += PP_THREADS) dst[i] = src[i];
+    }
+    char* const buf = smem_raw + C64_W_BYTES + grp * C64_BUF_BYTES;        // this group's halo buffer
+    const uint32_t buf_lds = lds0 + C64_W_BYTES + grp * C64_BUF_BYTES;
+    uint32_t bb[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int p = (2 * wl + r) * C64_ITW + n + kx;
+            bb[r][kx] = buf_lds + p * 128 + ((hh ^ ((p >> 1) & 7)) << 4);
+        }
+    const uint32_t a_base0 = lds0 + lane * 16, a_base1 = a_base0 + 18 * 2048;
+
+    auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
+        b = t / tiles_per_img;
+        const int r = t - b * tiles_per_img;
+        ty0 = (r / tiles_x) * CONV_TH; tx0 = (r % tiles_x) * CONV_TW;
+    };
+    // LDS-DMA of tile t into this group's buffer: 43 wave-instructions of 1 KiB, 11 per wave (10 for the last)
+    auto issue = [&](int t) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int y0 = ty0 - 1, x0 = tx0 - 1;
+        const _Float16* img = in + (int64_t)b * H * W * 64;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int wi = wl * 11 + j;
+            if (wi < 43) {
+                int idx = wi * 64 + lane;
+                idx = idx < C64_CHUNKS ? idx : C64_CHUNKS - 1;
+                const int pix = idx >> 3, phys = idx & 7;
+                const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
+                int gy = y0 + iy, gx = x0 + ix;
+                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+                const int logical = phys ^ ((pix >> 1) & 7);
+                const _Float16* g = img + ((int64_t)gy * W + gx) * 64 + logical * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(buf + wi * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // zero the out-of-image halo pixels of tile t: every wave fixes exactly the chunks its OWN DMA instructions wrote, after
+    // its own vmcnt(0) -- no cross-wave dependency, so no barrier between DMA and fix
+    auto zero_fix = [&](int t) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int y0 = ty0 - 1, x0 = tx0 - 1;
+        if (y0 >= 0 && y0 + C64_ITH <= H && x0 >= 0 && x0 + C64_ITW <= W) return;      // interior tile (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int wi = wl * 11 + j;
+            if (wi < 43) {
+                const int idx = wi * 64 + lane;
+                const int pix = idx >> 3;
+                const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
+                const int gy = y0 + iy, gx = x0 + ix;
+                if (idx < C64_CHUNKS && (gy < 0 || gy >= H || gx < 0 || gx >= W))
+                    *reinterpret_cast<uint4*>(buf + idx * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+
+    float4 bias_r[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_r[m][g] = *reinterpret_cast<const float4*>(bias + ct * 64 + m * 32 + 8 * g + 4 * hh);
+
+    // group g computes tiles k = g, g+2, ... in phases p = k; services (epilogue of k, DMA of k+2) in phase k+1.
+    // group 0 loads its first tile here, group 1 during phase 0.
+    int k_load = grp;                       // next tile index this group will DMA
+    if (grp == 0 && k_load < n_mine) {
+        issue(wg + k_load * nwg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        zero_fix(wg + k_load * nwg);
+        k_load += 2;
+    }
+    __syncthreads();
+
+    floatx16 acc[2][2];
+    int t_pending = -1;
+    for (int p = 0; p <= n_mine; ++p) {
+        if ((p & 1) == grp) {
+            if (p < n_mine) {                // compute role: tile k = p
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[m][f][i] = 0.f;
+                // keep the 54 XOR-ed B addresses out of loop-invariant hoisting (they would pin 54 VGPRs and spill)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) asm volatile("" : "+v"(bb[r][kx]));
+                half8_t fa0[3], fa1[3], fb0[3], fb1[3];
+                pp_load_step<0>(a_base0, a_base1, bb, fa0[0], fa1[0], fb0[0], fb1[0]);
+                pp_load_step<1>(a_base0, a_base1, bb, fa0[1], fa1[1], fb0[1], fb1[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                pp_mfma_steps<0>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
+                t_pending = wg + p * nwg;
+            }
+        } else {                             // service role
+            const bool load = k_load < n_mine;
+            if (load) issue(wg + k_load * nwg);
+            if (t_pending >= 0) {
+                int b, ty0, tx0;
+                tile_origin(t_pending, b, ty0, tx0);
+                auto bias_of = [&](int m, int g) { return bias_r[m][g]; };
+                conv_epilogue<_Float16, POOL>(acc, out, b, H, W, cout, ct, ty0, tx0, wl, lane, relu, bias_of);
+                t_pending = -1;
+            }
+            if (load) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                zero_fix(wg + k_load * nwg);
+                k_load += 2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool POOL>
+static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
+    auto kfn = conv3x3_c64_pp_kernel<POOL>;
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM));
+    const int tiles_x = cdiv(a.W, CONV_TW), tiles_y = cdiv(a.H, CONV_TH), n_ct = a.cout / 64;
+    const int total = a.batch * tiles_x * tiles_y;
+    int per_ct = n_cu / n_ct;
+    if (per_ct < 1) per_ct = 1;
+    if (per_ct > cdiv(total, 2)) per_ct = cdiv(total, 2);      // at least two tiles per workgroup: one per wave group
+    hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), C64_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
+                       reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 template <typename T, int KS, bool POOL>
 static int launch_conv(hipStream_t st, const ConvArgs& a) {
     const size_t smem = conv_smem_bytes<T, KS>();
@@ -419,8 +628,10 @@ int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {
     OMNI_REQUIRE(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), OMNI_ERR_INVALID, "pooling needs even H, W");
     OMNI_REQUIRE(!(a.pool && a.ksize == 1), OMNI_ERR_INVALID, "1x1 + pool not instantiated");
     if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 64 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 64) && a.n_cu > 0 &&
-        !a.force_v1)
-        return a.pool ? launch_conv_c64<true>(st, a, a.n_cu) : launch_conv_c64<false>(st, a, a.n_cu);
+        a.variant != 1) {
+        if (a.variant == 2) return a.pool ? launch_conv_c64<true>(st, a, a.n_cu) : launch_conv_c64<false>(st, a, a.n_cu);
+        return a.pool ? launch_conv_pp<true>(st, a, a.n_cu) : launch_conv_pp<false>(st, a, a.n_cu);
+    }
     if (precision == OMNI_PREC_F16) {
         if (a.ksize == 3) return a.pool ? launch_conv<_Float16, 3, true>(st, a) : launch_conv<_Float16, 3, false>(st, a);
         return launch_conv<_Float16, 1, false>(st, a);

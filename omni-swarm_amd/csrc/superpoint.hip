@@ -47,7 +47,7 @@ struct omni_sp {
     omni::HostBuf hstage;
     omni::DevBuf dense_tmp;
     hipEvent_t ev[OMNI_SP_NUM_STAGES + 1] = {};
-    bool force_v1 = false;                   // OMNI_CONV_V1=1: generic conv kernel everywhere (A/B and debugging)
+    int conv_variant = 0;                    // OMNI_CONV_V1=1: generic conv kernel everywhere, 2: v2 persistent kernel (A/B and debugging)
     std::mutex mu;
 };
 
@@ -167,7 +167,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         ConvArgs a;
         a.in = in; a.out = out; a.w_packed = s->wpk[l]; a.bias = bias; a.batch = batch; a.H = h; a.W = w; a.cin = cin;
         a.cout = cout; a.ksize = ks; a.relu = relu; a.pool = pool; a.out_f32 = out_f32;
-        a.n_cu = s->ctx->prop.multiProcessorCount; a.force_v1 = s->force_v1;
+        a.n_cu = s->ctx->prop.multiProcessorCount; a.variant = s->conv_variant;
         return conv_mfma(st, P, a);
     };
     if ((rc = mark())) return rc;
@@ -263,7 +263,7 @@ omni_sp* omni_sp_create(omni_ctx* ctx, const omni_sp_weights* w, const float* pc
     s->ctx = ctx; s->W = width; s->H = height; s->Hc = height / 8; s->Wc = width / 8; s->thres = thres; s->max_num = max_num;
     s->max_batch = max_batch; s->precision = precision; s->esz = precision == OMNI_PREC_F16 ? 2 : 4;
     s->pca_dim = pca_comp ? pca_dim : 0; s->desc_dim = pca_comp ? pca_dim : 256;
-    { const char* e = getenv("OMNI_CONV_V1"); s->force_v1 = e && e[0] == '1'; }
+    { const char* e = getenv("OMNI_CONV_V1"); s->conv_variant = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0; }
     if (omni::sp_init(s, w, pca_comp, pca_mean) != OMNI_OK) { omni_sp_destroy(s); return nullptr; }
     return s;
 }

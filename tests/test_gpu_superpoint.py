@@ -127,19 +127,22 @@ def test_f16_path_tolerances(omni, ctx):
     assert np.array_equal(kps.astype(np.int32), xy16) and np.array_equal(sc, conf16)
 
 
-def test_f16_persistent_kernel_is_bit_identical_to_generic_kernel(omni, ctx, monkeypatch):
-    """The cin=64 persistent LDS-DMA kernel and the generic kernel accumulate K in the same order: same bits."""
+def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, monkeypatch):
+    """The cin=64 kernels (v3 8-wave ping-pong = default, v2 persistent LDS-DMA) and the generic kernel accumulate K in the
+    same order: same bits.  Odd sizes exercise border tiles, partial tiles and workgroups with a single tile."""
     weights = S.synth_weights(0)
-    imgs = np.stack([synth.image_u8(30 + i, 480, 600) for i in range(2)])
-    outs = []
-    for v1 in ("0", "1"):
-        monkeypatch.setenv("OMNI_CONV_V1", v1)
-        sp = omni.capi.SuperPoint(ctx, weights, None, None, 600, 480, 0.015, 200, omni.capi.PREC_F16, 2)
-        sp.inference(imgs, fisheye_mask=True)
-        outs.append([sp.debug_layer(n, 2) for n in ("conv1b", "conv2a", "conv2b", "conv3a")] + list(sp.get_dense(2)))
-        sp.close()
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    for (h, w, nb) in ((480, 600, 2), (72, 104, 1), (208, 400, 3)):
+        imgs = np.stack([synth.image_u8(30 + i, h, w) for i in range(nb)])
+        outs = []
+        for v in ("0", "1", "2"):
+            monkeypatch.setenv("OMNI_CONV_V1", v)
+            sp = omni.capi.SuperPoint(ctx, weights, None, None, w, h, 0.015, 200, omni.capi.PREC_F16, nb)
+            sp.inference(imgs, fisheye_mask=True)
+            outs.append([sp.debug_layer(n, nb) for n in ("conv1b", "conv2a", "conv2b", "conv3a")] + list(sp.get_dense(nb)))
+            sp.close()
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert np.array_equal(a, b)
 
 
 def test_bad_arguments_return_errors_not_aborts(omni, ctx):
