@@ -256,6 +256,7 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
 #define C64_BUF_BYTES (43 * 1024)              // 43 wave-instructions of 1 KiB
 #define C64_W_BYTES (9 * 4096 * 2)
 #define C64_SMEM (C64_W_BYTES + 2 * C64_BUF_BYTES)
+#define PP_SMEM (C64_SMEM + 256)               // + the cout tile's bias
 
 template <bool POOL>
 __global__ void __launch_bounds__(256, 1)
@@ -418,16 +419,61 @@ static int launch_conv_c64(hipStream_t st, const ConvArgs& a, int n_cu) {
 // ---------------------------------------------------------------------------------------------------------------
 #define PP_THREADS 512
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dpp_swap_pairs(float v) {      // value of lane ^ 1 (quad_perm [1,0,3,2]): a VALU modifier, no LDS
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t pack_relu_f16(float a, float b, int relu) {
+    if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+    float2_t f; f[0] = a; f[1] = b;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2_t));
+}
+// 16 accumulator values of one 32-channel M-fragment (+ bias) -> two 16-byte NHWC stores per lane: the lower half-wave
+// (hh = 0) ends up with channels [16 gp, 16 gp + 8) and the upper one with [16 gp + 8, 16 gp + 16) of pair gp after one
+// v_permlane32_swap per dword (the half-waves hold interleaved 4-channel runs of the same pixel).
+__device__ __forceinline__ void store_frag16(const float (&v)[16], const float4 (&bs)[4], _Float16* __restrict__ pix_base /* + m*32 */, int hh,
+                                             int relu, bool pred) {
+    uint32_t d[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        d[g][0] = pack_relu_f16(v[4 * g + 0] + bs[g].x, v[4 * g + 1] + bs[g].y, relu);
+        d[g][1] = pack_relu_f16(v[4 * g + 2] + bs[g].z, v[4 * g + 3] + bs[g].w, relu);
+    }
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+        uint32_t x[2], y[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            auto r = __builtin_amdgcn_permlane32_swap(d[2 * gp][w], d[2 * gp + 1][w], false, false);
+            x[w] = r[0]; y[w] = r[1];
+        }
+        if (pred) *reinterpret_cast<uint4*>(pix_base + 16 * gp + 8 * hh) = make_uint4(x[0], x[1], y[0], y[1]);
+    }
+}
+
+
+// one fragment read of k-step STEP: WHICH = 0: B row f=0, 1: A m=0, 2: A m=1, 3: B row f=1 (= order of first use)
+template <int STEP, int WHICH>
+__device__ __forceinline__ void pp_read(uint32_t a_base0, uint32_t a_base1, const uint32_t (&bb)[4][3], half8_t& dst) {
+    constexpr int tap = STEP >> 2, kg = STEP & 3, ky = tap / 3, kx = tap - ky * 3;
+    if constexpr (WHICH == 0 || WHICH == 3) {
+        const uint32_t addr = bb[ky + (WHICH == 3 ? 1 : 0)][kx] ^ (kg << 5);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+    } else {
+        constexpr int aoff = (STEP % 18) * 2048 + (WHICH == 2 ? 1024 : 0);
+        const uint32_t ab = STEP < 18 ? a_base0 : a_base1;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ab), "i"(aoff));
+    }
+}
 template <int STEP>
 __device__ __forceinline__ void pp_load_step(uint32_t a_base0, uint32_t a_base1, const uint32_t (&bb)[4][3], half8_t& fa0, half8_t& fa1,
                                              half8_t& fb0, half8_t& fb1) {
-    constexpr int tap = STEP >> 2, kg = STEP & 3, ky = tap / 3, kx = tap - ky * 3;
-    constexpr int aoff = (STEP % 18) * 2048;
-    const uint32_t ab = STEP < 18 ? a_base0 : a_base1;
-    const uint32_t b0 = bb[ky][kx] ^ (kg << 5), b1 = bb[ky + 1][kx] ^ (kg << 5);
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5 offset:%7\n\tds_read_b128 %2, %5 offset:%8\n\tds_read_b128 %3, %6"
-                 : "=&v"(fb0), "=&v"(fa0), "=&v"(fa1), "=&v"(fb1)
-                 : "v"(b0), "v"(ab), "v"(b1), "i"(aoff), "i"(aoff + 1024));
+    pp_read<STEP, 0>(a_base0, a_base1, bb, fb0);
+    pp_read<STEP, 1>(a_base0, a_base1, bb, fa0);
+    pp_read<STEP, 2>(a_base0, a_base1, bb, fa1);
+    pp_read<STEP, 3>(a_base0, a_base1, bb, fb1);
 }
 
 template <int N>
@@ -435,27 +481,42 @@ __device__ __forceinline__ void pp_wait(half8_t& fa0, half8_t& fa1, half8_t& fb0
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0), "+v"(fa1), "+v"(fb0), "+v"(fb1) : "i"(N));
 }
 
-template <int STEP>
+// k-step STEP: its four MFMAs with the four fragment reads of step STEP + 2 interleaved one per MFMA shadow (an in-order
+// wave issues ~8 instructions per 32-cycle MFMA; bunching the reads behind the fourth MFMA overflows that gap and leaves
+// the other three empty).  On entry the reads of STEP and STEP + 1 are in flight: lgkmcnt(4) retires those of STEP.
+template <int STEP, int ABL>
 __device__ __forceinline__ void pp_mfma_steps(uint32_t a_base0, uint32_t a_base1, const uint32_t (&bb)[4][3], floatx16 (&acc)[2][2],
                                               half8_t (&fa0)[3], half8_t (&fa1)[3], half8_t (&fb0)[3], half8_t (&fb1)[3]) {
     if constexpr (STEP < 36) {
-        constexpr int sl = STEP % 3;
-        if constexpr (STEP + 2 < 36) pp_load_step<STEP + 2>(a_base0, a_base1, bb, fa0[(STEP + 2) % 3], fa1[(STEP + 2) % 3], fb0[(STEP + 2) % 3], fb1[(STEP + 2) % 3]);
-        pp_wait<(STEP + 2 < 36) ? 8 : (STEP + 1 < 36 ? 4 : 0)>(fa0[sl], fa1[sl], fb0[sl], fb1[sl]);
+        constexpr int sl = STEP % 3, nx = (STEP + 2) % 3;
+        constexpr bool pre = STEP + 2 < 36;
+        constexpr bool rdB = pre && ABL != 1 && ABL != 2, rdA = pre && ABL != 1 && ABL != 3;
+        pp_wait<ABL ? 0 : ((STEP + 1 < 36) ? 4 : 0)>(fa0[sl], fa1[sl], fb0[sl], fb1[sl]);
         __builtin_amdgcn_sched_barrier(0);
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[sl], fb0[sl], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (rdB) pp_read<STEP + 2, 0>(a_base0, a_base1, bb, fb0[nx]);
+        __builtin_amdgcn_sched_barrier(0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[sl], fb0[sl], acc[1][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (rdA) pp_read<STEP + 2, 1>(a_base0, a_base1, bb, fa0[nx]);
+        __builtin_amdgcn_sched_barrier(0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[sl], fb1[sl], acc[0][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (rdA) pp_read<STEP + 2, 2>(a_base0, a_base1, bb, fa1[nx]);
+        __builtin_amdgcn_sched_barrier(0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[sl], fb1[sl], acc[1][1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        pp_mfma_steps<STEP + 1>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
+        if constexpr (rdB) pp_read<STEP + 2, 3>(a_base0, a_base1, bb, fb1[nx]);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_mfma_steps<STEP + 1, ABL>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
     }
 }
 
-template <bool POOL>
+template <bool POOL, int ABL>
 __global__ void __launch_bounds__(PP_THREADS)
 conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
-                      const float* __restrict__ bias, int H, int W, int cout, int n_ct, int tiles_x, int tiles_y, int batch, int relu) {
+                      const float* __restrict__ bias, int H, int W, int cout, int n_ct, int tiles_x, int tiles_y, int batch, int relu, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -489,12 +550,31 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         const int r = t - b * tiles_per_img;
         ty0 = (r / tiles_x) * CONV_TH; tx0 = (r % tiles_x) * CONV_TW;
     };
+    // per-lane source offsets (bytes, relative to the halo origin) of this wave's 11 DMA instructions, valid for interior tiles
+    uint32_t goff[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+        int idx = (wl * 11 + j) * 64 + lane;
+        idx = idx < C64_CHUNKS ? idx : C64_CHUNKS - 1;        // tail lanes of instruction 42: harmless duplicate
+        const int pix = idx >> 3, phys = idx & 7;
+        const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
+        goff[j] = (uint32_t)((iy * W + ix) * 128 + ((phys ^ ((pix >> 1) & 7)) << 4));
+    }
     // LDS-DMA of tile t into this group's buffer: 43 wave-instructions of 1 KiB, 11 per wave (10 for the last)
     auto issue = [&](int t) {
         int b, ty0, tx0;
         tile_origin(t, b, ty0, tx0);
         const int y0 = ty0 - 1, x0 = tx0 - 1;
         const _Float16* img = in + (int64_t)b * H * W * 64;
+        if (y0 >= 0 && y0 + C64_ITH <= H && x0 >= 0 && x0 + C64_ITW <= W) {       // interior (wave-uniform): base + 32-bit lane offset
+            const char* org = reinterpret_cast<const char*>(img + ((int64_t)y0 * W + x0) * 64);
+#pragma unroll
+            for (int j = 0; j < 11; ++j)
+                if (wl * 11 + j < 43)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(org + goff[j]),
+                                                     (__attribute__((address_space(3))) void*)(buf + (wl * 11 + j) * 1024), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 11; ++j) {
             const int wi = wl * 11 + j;
@@ -504,7 +584,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 const int pix = idx >> 3, phys = idx & 7;
                 const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
                 int gy = y0 + iy, gx = x0 + ix;
-                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);     // clamped to a valid address, zero-fixed after landing
                 gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
                 const int logical = phys ^ ((pix >> 1) & 7);
                 const _Float16* g = img + ((int64_t)gy * W + gx) * 64 + logical * 8;
@@ -534,11 +614,14 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         }
     };
 
-    float4 bias_r[2][4];
+    // bias lives in LDS behind the halo buffers (256 B): holding it in registers (32 VGPRs) spills next to 64 accumulators,
+    // 48 fragment registers and the DMA / fragment address tables
+    float* const bias_lds = reinterpret_cast<float*>(smem_raw + C64_SMEM);
+    if (tid < 64) bias_lds[tid] = bias[ct * 64 + tid];
+    auto bias4 = [&](int m, float4 (&bs)[4]) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias_r[m][g] = *reinterpret_cast<const float4*>(bias + ct * 64 + m * 32 + 8 * g + 4 * hh);
+        for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const float4*>(bias_lds + m * 32 + 8 * g + 4 * hh);
+    };
 
     // group g computes tiles k = g, g+2, ... in phases p = k; services (epilogue of k, DMA of k+2) in phase k+1.
     // group 0 loads its first tile here, group 1 during phase 0.
@@ -571,43 +654,101 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 pp_load_step<0>(a_base0, a_base1, bb, fa0[0], fa1[0], fb0[0], fb1[0]);
                 pp_load_step<1>(a_base0, a_base1, bb, fa0[1], fa1[1], fb0[1], fb1[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                pp_mfma_steps<0>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
+                __builtin_amdgcn_s_setprio(2);       // the matrix-pipe wave outranks its SIMD partner's service work
+                pp_mfma_steps<0, ABL>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
+                __builtin_amdgcn_s_setprio(0);
                 t_pending = wg + p * nwg;
             }
         } else {                             // service role
-            const bool load = k_load < n_mine;
+            // bias BEFORE the DMA is issued: hipcc orders any ds_read behind an in-flight LDS-DMA with s_waitcnt vmcnt(0), which
+            // would expose the whole DMA latency in front of the epilogue
+            float4 bs[POOL ? 1 : 2][4];
+            if constexpr (POOL) bias4(n & 1, bs[0]);
+            else { bias4(0, bs[0]); bias4(1, bs[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool load = k_load < n_mine && !(dbg & 1);
             if (load) issue(wg + k_load * nwg);
-            if (t_pending >= 0) {
+            bool full = false;               // every lane of every store instruction of the epilogue is active
+            if (t_pending >= 0 && !(dbg & 2)) {
                 int b, ty0, tx0;
                 tile_origin(t_pending, b, ty0, tx0);
-                auto bias_of = [&](int m, int g) { return bias_r[m][g]; };
-                conv_epilogue<_Float16, POOL>(acc, out, b, H, W, cout, ct, ty0, tx0, wl, lane, relu, bias_of);
+                full = (ty0 + CONV_TH <= H) && (tx0 + CONV_TW <= W);
+                const int ox = tx0 + n;
+                if constexpr (POOL) {
+                    // 2x2 max-pool: rows 2wl / 2wl+1 are the two accumulators of a lane, columns n / n^1 one DPP exchange.
+                    // Even lanes then store M-fragment 0 and odd lanes M-fragment 1 of pooled pixel n >> 1.
+                    const int oy = ty0 + 2 * wl;
+                    const bool odd = n & 1;
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float q0 = fmaxf(acc[0][0][i], acc[0][1][i]), q1 = fmaxf(acc[1][0][i], acc[1][1][i]);
+                        q0 = fmaxf(q0, dpp_swap_pairs(q0));
+                        q1 = fmaxf(q1, dpp_swap_pairs(q1));
+                        v[i] = odd ? q1 : q0;
+                    }
+                    _Float16* o = out + (((int64_t)b * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * cout + ct * 64 + (odd ? 32 : 0);
+                    store_frag16(v, bs[0], o, hh, relu, (oy < H) && (ox < W));
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int oy = ty0 + 2 * wl + f;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            float v[16];
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) v[i] = acc[m][f][i];
+                            _Float16* o = out + (((int64_t)b * H + oy) * W + ox) * cout + ct * 64 + m * 32;
+                            store_frag16(v, bs[m], o, hh, relu, (oy < H) && (ox < W));
+                        }
+                    }
+                }
                 t_pending = -1;
             }
             if (load) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // vmcnt retires in issue order: the DMA loads were issued before the epilogue's stores, so waiting down to
+                // the number of store instructions leaves the stores in flight across the barrier (only when every store
+                // instruction was certainly issued, i.e. the output tile is interior; otherwise wait for everything)
+                if (full) {
+                    if constexpr (POOL) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 zero_fix(wg + k_load * nwg);
                 k_load += 2;
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes (zero-fix) done; global stores may stay in flight
+        __builtin_amdgcn_s_barrier();
     }
 }
 
-template <bool POOL>
-static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
-    auto kfn = conv3x3_c64_pp_kernel<POOL>;
-    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM));
+template <bool POOL, int ABL>
+static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int dbg) {
+    auto kfn = conv3x3_c64_pp_kernel<POOL, ABL>;
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM));
     const int tiles_x = cdiv(a.W, CONV_TW), tiles_y = cdiv(a.H, CONV_TH), n_ct = a.cout / 64;
     const int total = a.batch * tiles_x * tiles_y;
     int per_ct = n_cu / n_ct;
     if (per_ct < 1) per_ct = 1;
     if (per_ct > cdiv(total, 2)) per_ct = cdiv(total, 2);      // at least two tiles per workgroup: one per wave group
-    hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), C64_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
+    hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), PP_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
-                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0);
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
+}
+template <bool POOL>
+static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
+    // OMNI_PP_DBG: timing ablations only (WRONG results): bit 0 no DMA, bit 1 no epilogue, bits 2-3: 1 no fragment reads, 2 no B reads, 3 no A reads
+    static const int dbg = [] { const char* e = getenv("OMNI_PP_DBG"); return e ? atoi(e) : 0; }();
+    switch (dbg >> 2) {
+        case 1: return launch_conv_pp_abl<POOL, 1>(st, a, n_cu, dbg & 3);
+        case 2: return launch_conv_pp_abl<POOL, 2>(st, a, n_cu, dbg & 3);
+        case 3: return launch_conv_pp_abl<POOL, 3>(st, a, n_cu, dbg & 3);
+        default: return launch_conv_pp_abl<POOL, 0>(st, a, n_cu, dbg & 3);
+    }
 }
 
 template <typename T, int KS, bool POOL>
