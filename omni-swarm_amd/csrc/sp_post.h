@@ -18,9 +18,11 @@ struct SpPostParams {
 struct SpPostBuffers {      // all device pointers, sized for max_batch images
     unsigned char* state;   // [B][H*W]            0 none / 1 unknown / 2 alive / 3 dead
     int* cand;              // [B][H*W]            candidate pixel indices (unordered)
+    uint64_t* cand_masks;   // [B][H*W][2]         per candidate: earlier / later higher-confidence window masks
     int* counters;          // [B][4]              n_cand, n_surv, n_iter, spare
     uint64_t* surv_keys;    // [B][H*W]            survivor keys (unordered)
-    float* raw_desc;        // [B][max_num][256]   sampled, channel-normalised descriptors
+    float* raw_desc;        // [B][max_num][256]   sampled descriptors (before the channel normalisation)
+    float* norm_partial;    // [B][8][256]         per-channel sums of squares over key-point segments
     // results
     float* kps_xy;          // [B][max_num][2]
     float* scores;          // [B][max_num]

@@ -6,10 +6,12 @@
 //     survive(p) <=> alive(p) and no alive q anywhere in the window with conf(q) > conf(p)
 // alive() only depends on strictly-higher-confidence earlier neighbours, so it is a DAG and a chaotic relaxation
 // (unknown -> alive/dead as soon as all relevant neighbours are decided) converges to the unique serial answer.
-// One 1024-thread workgroup per image runs the relaxation with the 2-bit pixel state plane held in LDS
-// (600x480 -> 72 KB of the CU's 160 KB), then selects the top max_num survivors with an in-LDS bitonic sort on
-// 64-bit (confidence, row-major index) keys: final order = confidence desc, index asc (the fixed spec; the
-// reference's std::sort leaves ties unspecified).
+// Split in two: (1) sp_cand_kernel, parallel over image tiles, thresholds the map and records for every candidate WHICH window
+// positions hold a higher-confidence candidate (two 40-bit masks); (2) sp_nms_kernel, one 1024-thread workgroup per image,
+// runs the relaxation over those masks with the 2-bit pixel state plane held in LDS (600x480 -> 72 KB of the CU's 160 KB,
+// no heat-map reads inside the sweeps), then selects the top max_num survivors on 64-bit (confidence, row-major index) keys
+// by radix-selecting the cut-off confidence and ranking the few keys above it: final order = confidence desc, index asc
+// (the fixed spec; the reference's std::sort leaves ties unspecified).
 #include "sp_post.h"
 #include "topk.h"
 
@@ -22,100 +24,134 @@ namespace omni {
 #define ST_ALIVE 2u
 #define ST_DEAD 3u
 
-// ---- getKeyPoints: mask = prob > thres; findNonZero  (:167-173) -------------------------------------------------
-// 2048 pixels per workgroup, ONE global atomic per workgroup (per-wave atomics on a single counter serialise in L2).
-// The list order is irrelevant: NMS2's scan order is the row-major PIXEL order, which the state plane encodes.
-#define CAND_PX_PER_BLOCK 2048
+// ---- getKeyPoints: mask = prob > thres; findNonZero  (:167-173) + the static part of NMS2 --------------------------
+// One workgroup per 64x16-pixel tile (4-pixel halo in LDS, non-candidates and out-of-image pixels stored as -inf).  Every
+// candidate gets two 40-bit masks of the 9x9 window positions that hold a HIGHER-confidence candidate:
+//     earlier mask: rows above + same row to the left  (what can kill it during the serial scan, :265-283)
+//     later mask:   same row to the right + rows below (what can still beat an alive point, survive())
+// bit (k+4)*9 + (j+4) for window row k in [-4,-1], column j in [-4,4]; bit 36 + (j+4) for k = 0, j in [-4,-1]; the later
+// mask uses the same numbering for the NEGATED offset.  These masks are pure functions of the heat map, so this part is
+// embarrassingly parallel over the whole chip; only the alive/dead recursion over them stays per image (sp_nms_kernel).
+// The candidate list is unordered: NMS2's scan order is the row-major PIXEL order, which the masks encode.
+#define CT_W 64
+#define CT_H 16
+#define NEG_SENTINEL (-3.0e38f)
 __global__ void __launch_bounds__(256)
-sp_cand_kernel(const float* __restrict__ semi, int hw, float thres, int* __restrict__ cand, int* __restrict__ counters) {
+sp_cand_kernel(const float* __restrict__ semi, int W, int H, float thres, int* __restrict__ cand, uint64_t* __restrict__ masks,
+               int* __restrict__ counters) {
+    __shared__ float tile[CT_H + 8][CT_W + 8 + 1];
     __shared__ int s_wave_cnt[4];
     __shared__ int s_base;
+    __shared__ unsigned short s_list[CT_W * CT_H];
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p0 = blockIdx.x * CAND_PX_PER_BLOCK + tid * 8;          // 8 consecutive pixels per thread
+    const int tiles_x = (W + CT_W - 1) / CT_W;
+    const int ty0 = (blockIdx.x / tiles_x) * CT_H, tx0 = (blockIdx.x % tiles_x) * CT_W;
+    const int hw = W * H;
     const float* sm = semi + (int64_t)b * hw;
-    float v[8];
-    if (p0 + 8 <= hw) {
-        const float4 a = *reinterpret_cast<const float4*>(sm + p0), c = *reinterpret_cast<const float4*>(sm + p0 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (p0 + j < hw) ? sm[p0 + j] : -3.0e38f;
+    for (int i = tid; i < (CT_H + 8) * (CT_W + 8); i += 256) {
+        const int iy = i / (CT_W + 8), ix = i - iy * (CT_W + 8);
+        const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
+        float v = NEG_SENTINEL;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) { const float t = sm[gy * W + gx]; v = (t > thres) ? t : NEG_SENTINEL; }
+        tile[iy][ix] = v;
     }
-    unsigned mask = 0;
+    __syncthreads();
+    // 1. local candidate list (tile coordinates), unordered: 4 consecutive pixels of one row per thread
+    const int py = tid >> 4, px0 = (tid & 15) * 4;
+    unsigned cmask = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) mask |= (v[j] > thres) ? (1u << j) : 0u;
-    const int mine = __popc(mask);
+    for (int e = 0; e < 4; ++e) cmask |= (tile[py + 4][px0 + e + 4] > -1.0e38f) ? (1u << e) : 0u;
+    const int mine = __popc(cmask);
     int incl = mine;                                                   // inclusive prefix over the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
     if (lane == 63) s_wave_cnt[wave] = incl;
     __syncthreads();
-    if (tid == 0) {
-        const int total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
-        s_base = total ? atomicAdd(&counters[b * 4 + 0], total) : 0;
+    const int total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    if (total == 0) return;
+    if (tid == 0) s_base = atomicAdd(&counters[b * 4 + 0], total);     // ONE global atomic per workgroup
+    {
+        int pos = incl - mine;
+        for (int w = 0; w < wave; ++w) pos += s_wave_cnt[w];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (cmask & (1u << e)) s_list[pos++] = (unsigned short)(((py + 4) << 8) | (px0 + e + 4));
     }
     __syncthreads();
-    int pos = s_base + incl - mine;
-    for (int w = 0; w < wave; ++w) pos += s_wave_cnt[w];
+    // 2. masks: one wave per candidate, lane = window position (lanes 0-39 carry a mask bit), two ballots per candidate
     int* out = cand + (int64_t)b * hw;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (mask & (1u << j)) out[pos++] = p0 + j;
+    uint64_t* mo = masks + (int64_t)b * hw * 2;
+    const int bit_k = (lane < 36) ? (lane / 9 - 4) : 0;
+    const int bit_j = (lane < 36) ? (lane - (bit_k + 4) * 9 - 4) : (lane - 40);
+    const bool bit_on = lane < 40;
+    for (int ci = wave; ci < total; ci += 4) {
+        const int cy = s_list[ci] >> 8, cx = s_list[ci] & 255;
+        const float c0 = tile[cy][cx];
+        const float ve = bit_on ? tile[cy + bit_k][cx + bit_j] : NEG_SENTINEL;
+        const float vl = bit_on ? tile[cy - bit_k][cx - bit_j] : NEG_SENTINEL;
+        const uint64_t m0 = __ballot(ve > c0), m1 = __ballot(vl > c0);
+        if (lane == 0) {
+            const int pos = s_base + ci;
+            out[pos] = (ty0 + cy - 4) * W + tx0 + cx - 4;
+            mo[2 * (int64_t)pos] = m0;
+            mo[2 * (int64_t)pos + 1] = m1;
+        }
+    }
 }
 
 __device__ __forceinline__ unsigned st_get(const unsigned* st, int p) { return (st[p >> 4] >> ((p & 15) * 2)) & 3u; }
+// pixel offset of mask bit i (earlier-mask numbering)
+__device__ __forceinline__ int mask_bit_offset(int i, int W) {
+    const int k = (i < 36) ? (i / 9 - 4) : 0;
+    const int j = (i < 36) ? (i - (k + 4) * 9 - 4) : (i - 40);
+    return k * W + j;
+}
 
-// ---- NMS2 (:237-310) ----------------------------------------------------------------------------------------------
+// ---- NMS2 (:237-310): the alive/dead recursion over the masks + top max_num ------------------------------------------
+#define NMS_RANK_CAP 1024          // keys ranked by counting (beyond that: bitonic fallback)
 __global__ void __launch_bounds__(NMS_THREADS)
-sp_nms_kernel(const float* __restrict__ semi, int W, int H, int /*r: fixed at 4*/, int max_num, const int* __restrict__ cand,
+sp_nms_kernel(const float* __restrict__ semi, int W, int H, int max_num, const int* __restrict__ cand, const uint64_t* __restrict__ masks,
               int* __restrict__ counters, uint64_t* __restrict__ surv_keys, float* __restrict__ kps_xy,
               float* __restrict__ scores, int* __restrict__ n_kps, int state_words, int smem_main_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // all LDS is dynamic: keeps the base 16-B aligned
     unsigned* st = reinterpret_cast<unsigned*>(smem_raw);
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);     // reused after the relaxation
+    int* sv = reinterpret_cast<int*>(smem_raw + smem_main_bytes);     // [0] n_surv  [1] gathered  [2] bucket  [3] need
+    int* hist = sv + 4;                                               // [256]
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int hw = W * H;
     const float* sm = semi + (int64_t)b * hw;
     const int* cd = cand + (int64_t)b * hw;
+    const uint64_t* mk = masks + (int64_t)b * hw * 2;
     uint64_t* sk = surv_keys + (int64_t)b * hw;
     const int n_cand = counters[b * 4 + 0];
 
     for (int i = tid; i < state_words; i += NMS_THREADS) st[i] = 0u;
+    if (tid < 4) sv[tid] = 0;
     __syncthreads();
-    for (int ci = tid; ci < n_cand; ci += NMS_THREADS) {
+    for (int ci = tid; ci < n_cand; ci += NMS_THREADS) {              // grid(vv,uu) = 1 (:259); nothing earlier can kill it -> alive
         const int p = cd[ci];
-        atomicOr(&st[p >> 4], ST_UNKNOWN << ((p & 15) * 2));      // grid(vv,uu) = 1  (:259)
+        atomicOr(&st[p >> 4], (mk[2 * (int64_t)ci] ? ST_UNKNOWN : ST_ALIVE) << ((p & 15) * 2));
     }
     __syncthreads();
 
-    // relaxation of alive().  The neighbour scan is branch-free and fully unrolled (R = 4): all LDS state reads and all
-    // (predicated) heat-map loads of a candidate are independent, so their latencies overlap instead of chaining.
-    constexpr int R = 4;
+    // chaotic relaxation of alive(): LDS state plane + the per-candidate mask only (no heat-map reads)
     int iters = 0;
     for (;;) {
         int changed = 0;
         for (int ci = tid; ci < n_cand; ci += NMS_THREADS) {
             const int p = cd[ci];
             if (st_get(st, p) != ST_UNKNOWN) continue;
-            const int y = p / W, x = p - y * W;
-            const float c0 = sm[p];
+            uint64_t m = mk[2 * (int64_t)ci];
             bool any_alive = false, any_unknown = false;
-#pragma unroll
-            for (int k = -R; k <= 0; ++k) {
-#pragma unroll
-                for (int j = -R; j <= R; ++j) {
-                    if (k == 0 && j >= 0) continue;                   // earlier in row-major order only (compile time)
-                    const int v = y + k, u = x + j;
-                    const bool inb = (v >= 0) && (u >= 0) && (u < W); // fixed spec: out-of-image neighbours ignored
-                    const int q = inb ? v * W + u : p;
-                    const unsigned sq = inb ? st_get(st, q) : ST_NONE;
-                    const bool live = (sq == ST_UNKNOWN) || (sq == ST_ALIVE);
-                    const float cq = live ? sm[q] : 0.f;
-                    const bool higher = live && (cq > c0);
-                    any_alive |= higher && (sq == ST_ALIVE);
-                    any_unknown |= higher && (sq == ST_UNKNOWN);
-                }
+            while (m) {
+                const int i = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const unsigned sq = st_get(st, p + mask_bit_offset(i, W));
+                any_alive |= (sq == ST_ALIVE);
+                any_unknown |= (sq == ST_UNKNOWN);
             }
             if (any_alive) { atomicOr(&st[p >> 4], 2u << ((p & 15) * 2)); changed = 1; }            // 01 -> 11 dead
             else if (!any_unknown) { atomicXor(&st[p >> 4], 3u << ((p & 15) * 2)); changed = 1; }   // 01 -> 10 alive
@@ -126,56 +162,103 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int /*r: fixed at 4*
     }
 
     // survive(): alive and not beaten by any alive neighbour (an earlier one cannot exist; a later one can)
-    int& s_nsurv = *reinterpret_cast<int*>(smem_raw + smem_main_bytes);
-    if (tid == 0) s_nsurv = 0;
-    __syncthreads();
     for (int ci = tid; ci < n_cand; ci += NMS_THREADS) {
         const int p = cd[ci];
         if (st_get(st, p) != ST_ALIVE) continue;
-        const int y = p / W, x = p - y * W;
-        const float c0 = sm[p];
+        uint64_t m = mk[2 * (int64_t)ci + 1];
         bool beaten = false;
-#pragma unroll
-        for (int k = 0; k <= R; ++k) {                                 // only LATER neighbours can beat an alive point
-#pragma unroll
-            for (int j = -R; j <= R; ++j) {
-                if (k == 0 && j <= 0) continue;
-                const int v = y + k, u = x + j;
-                const bool inb = (v < H) && (u >= 0) && (u < W);
-                const int q = inb ? v * W + u : p;
-                const bool al = inb && (st_get(st, q) == ST_ALIVE);
-                const float cq = al ? sm[q] : 0.f;
-                beaten |= al && (cq > c0);
-            }
+        while (m) {
+            const int i = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            beaten |= (st_get(st, p - mask_bit_offset(i, W)) == ST_ALIVE);
         }
-        if (!beaten) sk[atomicAdd(&s_nsurv, 1)] = omni_make_key(c0, (uint32_t)p);
+        if (!beaten) sk[atomicAdd(&sv[0], 1)] = omni_make_key(sm[p], (uint32_t)p);
     }
     __syncthreads();
-    const int n_surv = s_nsurv;
-    __syncthreads();   // everyone has read the state plane; LDS is reused for sorting from here on
+    const int n_surv = sv[0];
+    __syncthreads();   // everyone has read the state plane; LDS is reused for selection / sorting from here on
 
-    // top max_num by (conf desc, index asc): running best in keys[0, max_num), batches appended behind it
+    // ---- top max_num by (conf desc, index asc) ----------------------------------------------------------------
     const int M = max_num;
-    for (int i = tid; i < M; i += NMS_THREADS) keys[i] = OMNI_KEY_EMPTY;
-    const int batch_cap = NMS_SORT_CAP - M;
-    int off = 0;
-    do {
-        const int cnt = (n_surv - off) < batch_cap ? (n_surv - off) : batch_cap;
-        int n_pow2 = 2;
-        while (n_pow2 < M + cnt) n_pow2 <<= 1;
-        __syncthreads();
-        for (int i = tid; i < n_pow2 - M; i += NMS_THREADS) keys[M + i] = (i < cnt) ? sk[off + i] : OMNI_KEY_EMPTY;
-        __syncthreads();
-        bitonic_sort_desc(keys, n_pow2, tid, NMS_THREADS);
-        off += cnt;
-    } while (off < n_surv);
-    __syncthreads();
-
     const int n_out = n_surv < M ? n_surv : M;
+    uint64_t* res = keys;                                             // where the n_out sorted keys end up
+    // 1. cut-off: the 32-bit confidence pattern c* of the M-th largest key (radix select, 4 passes of 8 bits)
+    uint32_t cutoff = 0;
+    if (n_surv > M) {
+        int need = M;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n_surv; i += NMS_THREADS) {
+                const uint32_t h = (uint32_t)(sk[i] >> 32);
+                if (pass == 0 || (h >> (shift + 8)) == (cutoff >> (shift + 8))) atomicAdd(&hist[(h >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {                                            // one wave: lane l owns the 4 buckets 255-4l .. 252-4l
+                int c[4], tot = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { c[e] = hist[255 - 4 * tid - e]; tot += c[e]; }
+                int incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (tid >= off) incl += t; }
+                int above = incl - tot;                               // keys in strictly higher buckets than this lane's first
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (above < need && need <= above + c[e]) { sv[2] = 255 - 4 * tid - e; sv[3] = need - above; }
+                    above += c[e];
+                }
+            }
+            __syncthreads();
+            cutoff |= (uint32_t)sv[2] << shift;
+            need = sv[3];
+            __syncthreads();
+        }
+    }
+    // 2. gather every key with confidence >= c* (= the top M plus the ties at the cut-off) into LDS
+    for (int i = tid; i < n_surv; i += NMS_THREADS) {
+        const uint64_t k = sk[i];
+        if ((uint32_t)(k >> 32) >= cutoff) {
+            const int slot = atomicAdd(&sv[1], 1);
+            if (slot < NMS_RANK_CAP) keys[slot] = k;
+        }
+    }
+    __syncthreads();
+    const int T = sv[1];
+    if (T <= NMS_RANK_CAP) {
+        // 3a. rank by counting (keys are distinct: they contain the pixel index) -- no barriers, LDS broadcast reads
+        uint64_t* sorted = keys + NMS_RANK_CAP;
+        for (int i = tid; i < T; i += NMS_THREADS) {
+            const uint64_t k = keys[i];
+            int rank = 0;
+            for (int j = 0; j < T; ++j) rank += (keys[j] > k);
+            if (rank < M) sorted[rank] = k;
+        }
+        res = sorted;
+        __syncthreads();
+    } else {
+        // 3b. massive ties at the cut-off (e.g. saturated maps): running best in keys[0, M), batches appended behind it
+        __syncthreads();
+        for (int i = tid; i < M; i += NMS_THREADS) keys[i] = OMNI_KEY_EMPTY;
+        const int batch_cap = NMS_SORT_CAP - M;
+        int off = 0;
+        do {
+            const int cnt = (n_surv - off) < batch_cap ? (n_surv - off) : batch_cap;
+            int n_pow2 = 2;
+            while (n_pow2 < M + cnt) n_pow2 <<= 1;
+            __syncthreads();
+            for (int i = tid; i < n_pow2 - M; i += NMS_THREADS) keys[M + i] = (i < cnt) ? sk[off + i] : OMNI_KEY_EMPTY;
+            __syncthreads();
+            bitonic_sort_desc(keys, n_pow2, tid, NMS_THREADS);
+            off += cnt;
+        } while (off < n_surv);
+        __syncthreads();
+    }
+
     for (int i = tid; i < M; i += NMS_THREADS) {
         float x = 0.f, y = 0.f, c = 0.f;
         if (i < n_out) {
-            const uint64_t key = keys[i];
+            const uint64_t key = res[i];
             const uint32_t p = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
             c = omni_orderable_f32((uint32_t)(key >> 32));
             y = (float)(p / (uint32_t)W);
@@ -231,25 +314,33 @@ sp_sample_kernel(const float* __restrict__ desc_nhwc, int W, int H, int max_num,
     }
 }
 
-// Pass 1b: divide every CHANNEL by its L2 norm ACROSS the image's key points -- torch::norm(desc, 2, /*dim=*/1) on the
+// Pass 1b: every CHANNEL is divided by its L2 norm ACROSS the image's key points -- torch::norm(desc, 2, /*dim=*/1) on the
 // [256, n] tensor (:214): the reference normalises channels across key points, not descriptors across channels.
-// One workgroup per image, thread = channel, sequential (deterministic) sum over the key points.
+// Sum of squares in NORM_SEGS fixed segments of key points (grid = segments x images, thread = channel); the consumers add
+// the segment sums in a fixed order (deterministic) and divide on the fly, so the normalised tensor is never materialised.
+#define NORM_SEGS 8
 __global__ void __launch_bounds__(256)
-sp_chan_norm_kernel(int max_num, const int* __restrict__ n_kps, float* __restrict__ raw_desc) {
-    const int b = blockIdx.x, c = threadIdx.x;
+sp_chan_sumsq_kernel(int max_num, const int* __restrict__ n_kps, const float* __restrict__ raw_desc, float* __restrict__ partial) {
+    const int b = blockIdx.y, seg = blockIdx.x, c = threadIdx.x;
     const int n = n_kps[b];
-    float* raw = raw_desc + (int64_t)b * max_num * 256;
+    const int per = (n + NORM_SEGS - 1) / NORM_SEGS;
+    const int i0 = seg * per, i1 = (i0 + per < n) ? i0 + per : n;
+    const float* raw = raw_desc + (int64_t)b * max_num * 256;
     float ss = 0.f;
 #pragma unroll 8
-    for (int i = 0; i < n; ++i) { const float v = raw[(int64_t)i * 256 + c]; ss = fmaf(v, v, ss); }
-    const float dn = sqrtf(ss);
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) raw[(int64_t)i * 256 + c] = raw[(int64_t)i * 256 + c] / dn;   // 0/0 -> NaN as in the reference
+    for (int i = i0; i < i1; ++i) { const float v = raw[(int64_t)i * 256 + c]; ss = fmaf(v, v, ss); }
+    partial[((int64_t)b * NORM_SEGS + seg) * 256 + c] = ss;
+}
+__device__ __forceinline__ float chan_norm_of(const float* __restrict__ partial, int b, int c) {
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < NORM_SEGS; ++s) ss += partial[((int64_t)b * NORM_SEGS + s) * 256 + c];
+    return sqrtf(ss);
 }
 
-// Pass 2: (d - mean) * comp^T  (:221) -- 4 key points per workgroup, thread = (64-channel part, output dim)
+// Pass 2: (d / norm - mean) * comp^T  (:214-221) -- 4 key points per workgroup, thread = (64-channel part, output dim)
 __global__ void __launch_bounds__(256)
-sp_pca_kernel(const float* __restrict__ raw_desc, int max_num, const int* __restrict__ n_kps, int pca_dim,
+sp_pca_kernel(const float* __restrict__ raw_desc, const float* __restrict__ partial, int max_num, const int* __restrict__ n_kps, int pca_dim,
               const float* __restrict__ compT, const float* __restrict__ mean, float* __restrict__ out) {
     __shared__ float sx[4][256];
     __shared__ float sp[4][4][64];
@@ -258,9 +349,10 @@ sp_pca_kernel(const float* __restrict__ raw_desc, int max_num, const int* __rest
     const int i0 = blockIdx.x * 4;
     if (i0 >= n) return;
     const int tid = threadIdx.x;
+    const float dn = chan_norm_of(partial, b, tid);
     for (int kp = 0; kp < 4; ++kp) {
         const int i = i0 + kp;
-        sx[kp][tid] = (i < n) ? (raw_desc[((int64_t)b * max_num + i) * 256 + tid] - mean[tid]) : 0.f;
+        sx[kp][tid] = (i < n) ? (raw_desc[((int64_t)b * max_num + i) * 256 + tid] / dn - mean[tid]) : 0.f;   // 0/0 -> NaN as in the reference
     }
     __syncthreads();
     const int part = tid >> 6;
@@ -290,12 +382,12 @@ sp_pca_kernel(const float* __restrict__ raw_desc, int max_num, const int* __rest
     }
 }
 
-__global__ void copy_raw_desc_kernel(const float* __restrict__ raw, int max_num, const int* __restrict__ n_kps,
-                                     float* __restrict__ out) {
+__global__ void copy_raw_desc_kernel(const float* __restrict__ raw, const float* __restrict__ partial, int max_num,
+                                     const int* __restrict__ n_kps, float* __restrict__ out) {
     const int b = blockIdx.y;
     const int i = blockIdx.x;
     if (i >= n_kps[b]) return;
-    out[((int64_t)b * max_num + i) * 256 + threadIdx.x] = raw[((int64_t)b * max_num + i) * 256 + threadIdx.x];
+    out[((int64_t)b * max_num + i) * 256 + threadIdx.x] = raw[((int64_t)b * max_num + i) * 256 + threadIdx.x] / chan_norm_of(partial, b, threadIdx.x);
 }
 
 // ---- layout helpers -----------------------------------------------------------------------------------------------
@@ -335,26 +427,28 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
     size_t smem = (size_t)state_words * 4;
     if (smem < (size_t)NMS_SORT_CAP * 8) smem = (size_t)NMS_SORT_CAP * 8;
     const int smem_main = (int)smem;
-    smem += 16;
+    smem += 16 + 256 * 4;                                             // selection scalars + radix histogram
     OMNI_REQUIRE(smem <= 160 * 1024, OMNI_ERR_CAPACITY, "image %dx%d too large for the in-LDS NMS state plane", p.width, p.height);
     OMNI_REQUIRE(p.max_num >= 1 && p.max_num <= 1024, OMNI_ERR_CAPACITY, "max_num=%d outside [1,1024]", p.max_num);
+    OMNI_REQUIRE(p.dist_thresh == 4, OMNI_ERR_INVALID, "NMS radius %d: the window masks are built for 4 (superpoint_tensorrt.cpp:183)", p.dist_thresh);
     OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
-    hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(hw, CAND_PX_PER_BLOCK), batch), dim3(256), 0, stream, semi, hw, p.thres, b.cand, b.counters);
+    hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(p.width, CT_W) * cdiv(p.height, CT_H), batch), dim3(256), 0, stream, semi, p.width, p.height,
+                       p.thres, b.cand, b.cand_masks, b.counters);
     OMNI_LAUNCH_CHECK();
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(sp_nms_kernel, dim3(batch), dim3(NMS_THREADS), smem, stream, semi, p.width, p.height, p.dist_thresh,
-                       p.max_num, b.cand, b.counters, b.surv_keys, b.kps_xy, b.scores, b.n_kps, state_words, smem_main);
+    hipLaunchKernelGGL(sp_nms_kernel, dim3(batch), dim3(NMS_THREADS), smem, stream, semi, p.width, p.height, p.max_num, b.cand,
+                       b.cand_masks, b.counters, b.surv_keys, b.kps_xy, b.scores, b.n_kps, state_words, smem_main);
     OMNI_LAUNCH_CHECK();
     hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(p.max_num, SAMPLE_KPB), batch), dim3(256), 0, stream, desc_nhwc, p.width, p.height,
                        p.max_num, b.kps_xy, b.n_kps, b.raw_desc);
     OMNI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sp_chan_norm_kernel, dim3(batch), dim3(256), 0, stream, p.max_num, b.n_kps, b.raw_desc);
+    hipLaunchKernelGGL(sp_chan_sumsq_kernel, dim3(NORM_SEGS, batch), dim3(256), 0, stream, p.max_num, b.n_kps, b.raw_desc, b.norm_partial);
     OMNI_LAUNCH_CHECK();
     if (p.pca_dim > 0) {
-        hipLaunchKernelGGL(sp_pca_kernel, dim3(cdiv(p.max_num, 4), batch), dim3(256), 0, stream, b.raw_desc, p.max_num, b.n_kps,
+        hipLaunchKernelGGL(sp_pca_kernel, dim3(cdiv(p.max_num, 4), batch), dim3(256), 0, stream, b.raw_desc, b.norm_partial, p.max_num, b.n_kps,
                            p.pca_dim, b.pca_compT, b.pca_mean, b.desc_out);
     } else {
-        hipLaunchKernelGGL(copy_raw_desc_kernel, dim3(p.max_num, batch), dim3(256), 0, stream, b.raw_desc, p.max_num, b.n_kps,
+        hipLaunchKernelGGL(copy_raw_desc_kernel, dim3(p.max_num, batch), dim3(256), 0, stream, b.raw_desc, b.norm_partial, p.max_num, b.n_kps,
                            b.desc_out);
     }
     OMNI_LAUNCH_CHECK();

@@ -129,9 +129,11 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     // post-processing buffers
     const size_t hw = H * W, M = s->max_num;
     OMNI_HIP_TRY(hipMalloc((void**)&s->pb.cand, B * hw * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.cand_masks, B * hw * 16));
     OMNI_HIP_TRY(hipMalloc((void**)&s->pb.counters, B * 4 * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->pb.surv_keys, B * hw * 8));
     OMNI_HIP_TRY(hipMalloc((void**)&s->pb.raw_desc, B * M * 256 * 4));
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.norm_partial, B * 8 * 256 * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->pb.kps_xy, B * M * 2 * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->pb.scores, B * M * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->pb.n_kps, B * 4));
@@ -274,8 +276,8 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
     void* ptrs[] = {s->w1a, s->wPbT, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
-                    s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.counters, s->pb.surv_keys,
-                    s->pb.raw_desc, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
+                    s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
+                    s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     s->hstage.release(); s->dense_tmp.release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
