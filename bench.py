@@ -130,15 +130,18 @@ def main():
         return out
 
     def run(n_steps, first_step):
-        pending = None
+        """`pipelines` key frames in flight: key frame s is enqueued (kernels + D2H copies, no host sync) before the host
+        waits for key frame s - pipelines + 1, so the GPU always has queued work while the host runs the detector."""
+        from collections import deque
+        pending = deque()
         for s in range(n_steps):
             cam = cams[s % len(cams)]
             cam.enqueue_dev(pool[(first_step + s) % POOL], W)
-            if pending is not None:
-                finish(*pending)
-            pending = (cam, first_step + s)
-        if pending is not None:
-            finish(*pending)
+            pending.append((cam, first_step + s))
+            if len(pending) >= len(cams):
+                finish(*pending.popleft())
+        while pending:
+            finish(*pending.popleft())
 
     def barrier():
         for c in ctxs:

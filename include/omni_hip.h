@@ -61,6 +61,7 @@ typedef struct omni_ctx omni_ctx;
 typedef struct omni_sp omni_sp;
 typedef struct omni_vlad omni_vlad;
 typedef struct omni_index omni_index;
+typedef struct omni_cam omni_cam;
 
 int         omni_abi_version(void);
 const char* omni_last_error(void);
@@ -192,6 +193,30 @@ int omni_bf_match_batched_dev(omni_ctx* ctx, int n_pairs, int max_n, int dim, in
                               const float* q_dev, int64_t q_stride, const int* nq_dev,
                               const float* t_dev, int64_t t_stride, const int* nt_dev,
                               int* q_idx_dev, int* t_idx_dev, float* dist_dev, int* n_matches_dev);
+
+/* ---- key-frame frontend: the device work of LoopCam::on_flattened_images (swarm_loop/src/loop_cam.cpp:178-229;
+ * generate_stereo_image_descriptor :341-523, extractor_img_desc_deepnet :525-585, match_HFNet_local_features :141-174)
+ * as one asynchronous unit: SuperPoint on the 2*n_dirs images (up cameras first, then down), MobileNetVLAD on the n_dirs
+ * up images, BFMatcher(L2, crossCheck) up <-> down per direction, and the D2H copy of every result into one pinned block.
+ * The handles are borrowed (sp created with max_batch >= 2*n_dirs on sp_ctx, vlad with max_batch >= n_dirs on vlad_ctx,
+ * both contexts on the same device).  Camera lifting / triangulation (:73-106, 405-454, 558-576) stay with the caller. */
+typedef struct omni_cam_result {      /* pointers into the handle's pinned host block; valid until its next enqueue */
+    int n_dirs, max_num, desc_dim, global_dim;
+    const float* kps_xy;      /* [2*n_dirs][max_num][2] */
+    const int*   n_kps;       /* [2*n_dirs] */
+    const float* desc;        /* [2*n_dirs][max_num][desc_dim] */
+    const float* scores;      /* [2*n_dirs][max_num] */
+    const float* global_desc; /* [n_dirs][global_dim] */
+    const int*   match_up;    /* [n_dirs][max_num]  key-point index in the up image   (cv::DMatch::queryIdx) */
+    const int*   match_down;  /* [n_dirs][max_num]  key-point index in the down image (cv::DMatch::trainIdx) */
+    const float* match_dist;  /* [n_dirs][max_num] */
+    const int*   n_matches;   /* [n_dirs] */
+} omni_cam_result;
+omni_cam* omni_cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_dirs, int max_num,
+                          int global_dim, int bf_mode);
+void      omni_cam_destroy(omni_cam* cam);
+int       omni_cam_enqueue_dev(omni_cam* cam, const uint8_t* gray_dev, int stride, int fisheye_mask);   /* no host sync */
+int       omni_cam_wait(omni_cam* cam, omni_cam_result* out);                                          /* two event waits */
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ SYMBOLS = [
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset",
     "omni_index_search", "omni_index_search_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
-    "omni_bf_match", "omni_bf_match_batched_dev",
+    "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_wait",
 ]
 
 
@@ -48,6 +48,13 @@ class _SpWeights(C.Structure):
 class _VladLayer(C.Structure):
     _fields_ = [("kind", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("stride", C.c_int),
                 ("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float))]
+
+
+class _CamResult(C.Structure):
+    _fields_ = [("n_dirs", C.c_int), ("max_num", C.c_int), ("desc_dim", C.c_int), ("global_dim", C.c_int),
+                ("kps_xy", C.POINTER(C.c_float)), ("n_kps", C.POINTER(C.c_int)), ("desc", C.POINTER(C.c_float)),
+                ("scores", C.POINTER(C.c_float)), ("global_desc", C.POINTER(C.c_float)), ("match_up", C.POINTER(C.c_int)),
+                ("match_down", C.POINTER(C.c_int)), ("match_dist", C.POINTER(C.c_float)), ("n_matches", C.POINTER(C.c_int))]
 
 
 class _VladWeights(C.Structure):
@@ -125,6 +132,10 @@ def lib():
     sig("omni_bf_match", C.c_int, [_vp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _ip, _ip, _fp, _ip])
     sig("omni_bf_match_batched_dev", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, C.c_int64,
                                                _vp, _vp, _vp, _vp, _vp])
+    sig("omni_cam_create", _vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
+    sig("omni_cam_destroy", None, [_vp])
+    sig("omni_cam_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int])
+    sig("omni_cam_wait", C.c_int, [_vp, C.POINTER(_CamResult)])
     if L.omni_abi_version() != 1:
         raise OmniError("libomni_hip.so ABI version mismatch")
     _lib = L
@@ -436,3 +447,38 @@ def bf_match_batched_dev(ctx: Context, n_pairs, max_n, dim, mode, q_dev, q_strid
                          qidx_dev, tidx_dev, dist_dev, n_dev):
     _check(lib().omni_bf_match_batched_dev(ctx.h, n_pairs, max_n, dim, mode, q_dev, q_stride, nq_dev, t_dev, t_stride,
                                            nt_dev, qidx_dev, tidx_dev, dist_dev, n_dev))
+
+
+class Cam:
+    """omni_cam: one key frame's CNN + matching work as a single asynchronous unit (LoopCam::on_flattened_images,
+    loop_cam.cpp:178-229).  wait() returns numpy VIEWS of the handle's pinned host block (valid until the next enqueue)."""
+
+    def __init__(self, sp: SuperPoint, vlad, n_dirs: int, global_dim: int, bf_mode: int = BF_OPENCV):
+        self.sp, self.vlad, self.n = sp, vlad, n_dirs
+        self.h = lib().omni_cam_create(sp.ctx.h, sp.h, vlad.ctx.h, vlad.h, n_dirs, sp.max_num, global_dim, bf_mode)
+        if not self.h:
+            raise OmniError(f"omni_cam_create failed: {lib().omni_last_error().decode()}")
+        self._res = _CamResult()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().omni_cam_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enqueue_dev(self, gray_dev: int, stride: int, fisheye_mask: bool = True):
+        _check(lib().omni_cam_enqueue_dev(self.h, gray_dev, stride, int(fisheye_mask)))
+
+    def wait(self) -> dict:
+        r = self._res
+        _check(lib().omni_cam_wait(self.h, C.byref(r)))
+        n, m, d, g = r.n_dirs, r.max_num, r.desc_dim, r.global_dim
+        A = np.ctypeslib.as_array
+        return {"kps_xy": A(r.kps_xy, (2 * n, m, 2)), "n_kps": A(r.n_kps, (2 * n,)), "desc": A(r.desc, (2 * n, m, d)),
+                "scores": A(r.scores, (2 * n, m)), "global_desc": A(r.global_desc, (n, g)), "match_up": A(r.match_up, (n, m)),
+                "match_down": A(r.match_down, (n, m)), "match_dist": A(r.match_dist, (n, m)), "n_matches": A(r.n_matches, (n,))}

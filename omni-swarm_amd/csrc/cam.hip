@@ -1,0 +1,130 @@
+// omni_cam_*: the CNN + matching part of one fisheye key frame as ONE asynchronous unit -- the device-side work of
+//   LoopCam::on_flattened_images / generate_stereo_image_descriptor / extractor_img_desc_deepnet / match_HFNet_local_features
+//   (swarm_loop/src/loop_cam.cpp:178-229, 341-523, 525-585, 141-174).
+// The reference runs 8 SuperPoint + 4 MobileNetVLAD engine calls and 4 BFMatcher calls strictly one after another, each
+// with its own H2D / D2H and a blocking stream sync.  Here enqueue() puts on the GPU, without any host
+// synchronisation:  SuperPoint(2n images) -> BF cross-check of the n up/down descriptor sets   on the SuperPoint stream,
+//                   MobileNetVLAD(n images)                                                    on the MobileNetVLAD stream,
+// plus the D2H copies of every result into ONE pinned host block, and records one event per stream.  wait() blocks on the
+// two events and hands out pointers into the pinned block (valid until the next enqueue on this handle).  Several handles
+// (each with its own SuperPoint / MobileNetVLAD instance) keep several key frames in flight.
+#include "common.h"
+
+struct omni_cam {
+    omni_sp* sp = nullptr;
+    omni_vlad* vlad = nullptr;
+    omni_ctx *c1 = nullptr, *c2 = nullptr;
+    int n = 0, M = 0, D = 0, out_dim = 0, bf_mode = 0;
+    int *d_qidx = nullptr, *d_tidx = nullptr, *d_nm = nullptr;
+    float* d_dist = nullptr;
+    const float *kps_dev = nullptr, *desc_dev = nullptr, *sc_dev = nullptr, *g_dev = nullptr;
+    const int* n_dev = nullptr;
+    char* host = nullptr;
+    size_t off_kps = 0, off_n = 0, off_desc = 0, off_sc = 0, off_g = 0, off_q = 0, off_t = 0, off_d = 0, off_nm = 0, host_bytes = 0;
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    bool pending = false;
+    std::mutex mu;
+};
+
+extern "C" {
+
+omni_cam* omni_cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_dirs, int max_num, int global_dim,
+                          int bf_mode) {
+    if (!sp_ctx || !sp || !vlad_ctx || !vlad) { omni::set_error("null handle"); return nullptr; }
+    if (n_dirs < 1 || n_dirs > 64 || max_num < 1 || max_num > 1024 || global_dim < 1) { omni::set_error("bad n_dirs/max_num/global_dim"); return nullptr; }
+    if (sp_ctx->device != vlad_ctx->device) { omni::set_error("SuperPoint and MobileNetVLAD contexts are on different devices"); return nullptr; }
+    (void)hipSetDevice(sp_ctx->device);
+    omni_cam* c = new omni_cam();
+    c->sp = sp; c->vlad = vlad; c->c1 = sp_ctx; c->c2 = vlad_ctx; c->n = n_dirs; c->M = max_num; c->D = omni_sp_desc_dim(sp);
+    c->out_dim = global_dim; c->bf_mode = bf_mode;
+    const size_t n = n_dirs, M = max_num, D = c->D;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    c->off_kps = o; o += al(2 * n * M * 2 * 4);
+    c->off_n = o;   o += al(2 * n * 4);
+    c->off_desc = o; o += al(2 * n * M * D * 4);
+    c->off_sc = o;  o += al(2 * n * M * 4);
+    c->off_g = o;   o += al(n * (size_t)global_dim * 4);
+    c->off_q = o;   o += al(n * M * 4);
+    c->off_t = o;   o += al(n * M * 4);
+    c->off_d = o;   o += al(n * M * 4);
+    c->off_nm = o;  o += al(n * 4);
+    c->host_bytes = o;
+    bool ok = hipHostMalloc((void**)&c->host, o, hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void**)&c->d_qidx, n * M * 4) == hipSuccess && hipMalloc((void**)&c->d_tidx, n * M * 4) == hipSuccess &&
+              hipMalloc((void**)&c->d_dist, n * M * 4) == hipSuccess && hipMalloc((void**)&c->d_nm, n * 4) == hipSuccess &&
+              hipEventCreateWithFlags(&c->e1, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->e2, hipEventDisableTiming) == hipSuccess &&
+              omni_sp_dev_outputs(sp, &c->kps_dev, &c->n_dev, &c->desc_dev, &c->sc_dev) == OMNI_OK &&
+              omni_vlad_dev_output(vlad, &c->g_dev) == OMNI_OK;
+    if (!ok) { omni::set_error("omni_cam_create: allocation failed"); omni_cam_destroy(c); return nullptr; }
+    memset(c->host, 0, o);
+    return c;
+}
+
+void omni_cam_destroy(omni_cam* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->c1->device);
+    (void)hipStreamSynchronize(c->c1->stream);
+    (void)hipStreamSynchronize(c->c2->stream);
+    void* ptrs[] = {c->d_qidx, c->d_tidx, c->d_dist, c->d_nm};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->host) (void)hipHostFree(c->host);
+    if (c->e1) (void)hipEventDestroy(c->e1);
+    if (c->e2) (void)hipEventDestroy(c->e2);
+    delete c;
+}
+
+int omni_cam_enqueue_dev(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask) {
+    OMNI_REQUIRE(c && gray_dev, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->c1->device);
+    const int n = c->n, M = c->M, D = c->D;
+    int rc;
+    // images 0..n-1 = "up" (main) camera of each direction, n..2n-1 = "down" camera (loop_cam.cpp:350-351)
+    if ((rc = omni_sp_enqueue_dev(c->sp, gray_dev, stride, 2 * n, fisheye_mask))) return rc;
+    if ((rc = omni_vlad_enqueue_dev(c->vlad, gray_dev, stride, n, fisheye_mask))) return rc;       // main camera only (:553-556)
+    // match_HFNet_local_features: up = query, down = train (:147-150); pair p = direction p
+    if ((rc = omni_bf_match_batched_dev(c->c1, n, M, D, c->bf_mode, c->desc_dev, (int64_t)M * D, c->n_dev,
+                                        c->desc_dev + (size_t)n * M * D, (int64_t)M * D, c->n_dev + n, c->d_qidx, c->d_tidx, c->d_dist, c->d_nm)))
+        return rc;
+    hipStream_t s1 = c->c1->stream, s2 = c->c2->stream;
+    char* h = c->host;
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_kps, c->kps_dev, (size_t)2 * n * M * 2 * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_n, c->n_dev, (size_t)2 * n * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_desc, c->desc_dev, (size_t)2 * n * M * D * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_sc, c->sc_dev, (size_t)2 * n * M * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_q, c->d_qidx, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_t, c->d_tidx, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_d, c->d_dist, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_nm, c->d_nm, (size_t)n * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipEventRecord(c->e1, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_g, c->g_dev, (size_t)n * c->out_dim * 4, hipMemcpyDeviceToHost, s2));
+    OMNI_HIP_TRY(hipEventRecord(c->e2, s2));
+    c->pending = true;
+    return OMNI_OK;
+}
+
+int omni_cam_wait(omni_cam* c, omni_cam_result* out) {
+    OMNI_REQUIRE(c && out, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    OMNI_REQUIRE(c->pending, OMNI_ERR_INVALID, "omni_cam_wait without a pending omni_cam_enqueue_dev");
+    (void)hipSetDevice(c->c1->device);
+    OMNI_HIP_TRY(hipEventSynchronize(c->e1));
+    OMNI_HIP_TRY(hipEventSynchronize(c->e2));
+    c->pending = false;
+    const char* h = c->host;
+    out->n_dirs = c->n; out->max_num = c->M; out->desc_dim = c->D; out->global_dim = c->out_dim;
+    out->kps_xy = reinterpret_cast<const float*>(h + c->off_kps);
+    out->n_kps = reinterpret_cast<const int*>(h + c->off_n);
+    out->desc = reinterpret_cast<const float*>(h + c->off_desc);
+    out->scores = reinterpret_cast<const float*>(h + c->off_sc);
+    out->global_desc = reinterpret_cast<const float*>(h + c->off_g);
+    out->match_up = reinterpret_cast<const int*>(h + c->off_q);
+    out->match_down = reinterpret_cast<const int*>(h + c->off_t);
+    out->match_dist = reinterpret_cast<const float*>(h + c->off_d);
+    out->n_matches = reinterpret_cast<const int*>(h + c->off_nm);
+    return OMNI_OK;
+}
+
+}  // extern "C"

@@ -13,8 +13,16 @@
 
 struct VladLayerDev { int kind, cin, cout, stride, hin, win, hout, wout; float* w; float* b; };
 
+struct VladFusedBlock {      // one inverted-residual block = [expand] + depthwise + project, weights point into `layers`
+    int cin, hid, cout, stride, expand, res, hin, win, hout, wout;
+    const float* bp;
+    float* blob;             // device: packed per-chunk weights (see VladBlockArgs)
+};
+
 struct omni_vlad {
     omni_ctx* ctx = nullptr;
+    bool fused = false;                       // every block has a fused kernel (OMNI_VLAD_UNFUSED=1 forces the layer-by-layer path)
+    std::vector<VladFusedBlock> blocks;
     int W = 0, H = 0, max_batch = 0, K = 0, Dm = 0, out_dim = 0, hf = 0, wf = 0;
     std::vector<VladLayerDev> layers;
     float *assign_wT = nullptr, *assign_b = nullptr, *clusters = nullptr, *fc_w = nullptr, *fc_b = nullptr;
@@ -234,6 +242,327 @@ vlad_fc_kernel(const float* __restrict__ v, int nb, int n_in, const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused inverted-residual block: expand 1x1 + ReLU6 -> depthwise 3x3 (stride 1|2) + ReLU6 -> project 1x1 (+ residual)
+// in ONE kernel per block.  The 6x-expanded tensor never leaves the CU: per output tile of TILE pixels the expanded halo
+// region lives in LDS, processed in chunks of 32 hidden channels:
+//     xin [R][CIN]   input region (R = (TH*s+2) x (TW*s+2) pixels), loaded once, also the residual source
+//     h   [R][32]    expanded chunk (0 outside the image: the depthwise conv pads the EXPANDED tensor with zeros)
+//     d   [TILE][32] depthwise output chunk
+// and the projection accumulates over chunks in registers.  Lane = hidden channel in the first two steps (weights of the
+// lane's channel sit in registers, LDS reads are broadcasts or unit-stride), lane = output channel in the third.
+// 57 launches per inference become 23, and the 55 MB expanded tensors of the 300x240 layers are never written.
+// ---------------------------------------------------------------------------------------------------------------
+struct VladBlockArgs {
+    const float* in; float* out;
+    const float* blob;         // per 32-channel chunk of the hidden layer: [We cin x 32 | be 32 | Wd 9 x 32 | bd 32 | Wp 32 x cout], zero padded
+    const float* bp;           // [cout]
+    int Hi, Wi, Ho, Wo, hid, cout, stride, expand, res, batch;
+};
+
+// Weights reach the lanes through LDS: the next chunk's blob is fetched into registers while the current chunk computes and
+// written to the alternate LDS buffer afterwards, so only the first chunk pays a global-memory round trip (a workgroup per
+// CU with nothing else resident cannot hide one per weight matrix per chunk).
+template <int CIN, int CP, int TILE>
+__global__ void __launch_bounds__(256)
+vlad_block_kernel(VladBlockArgs a) {
+    constexpr int TW = 8, TH = TILE / TW;
+    constexpr int NACC = TILE * CP / 256;
+    constexpr int NLD = (32 * (CIN + 11 + CP) / 4 + 255) / 256;      // float4 per thread that cover the largest blob
+    static_assert(NACC >= 1, "tile too small for this cout");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int s = a.stride;
+    const int RW = TW * s + 2, RH = TH * s + 2, R = RW * RH;
+    const int blob = 32 * (CIN + 11 + a.cout), blob4 = blob / 4;     // cout % 4 == 0
+    float* xin = reinterpret_cast<float*>(smem_raw);       // [R][CIN]
+    float* h = xin + R * CIN;                               // [R][32]
+    float* d = h + R * 32;                                  // [TILE][32]
+    float* wbuf = d + TILE * 32;                            // [2][blob]
+    const int tid = threadIdx.x;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int iy0 = oy0 * s - 1, ix0 = ox0 * s - 1;        // region origin in the input
+    const float* inb = a.in + (int64_t)b * a.Hi * a.Wi * CIN;
+    const int n_chunks = (a.hid + 31) / 32;
+
+    for (int i = tid; i < blob4; i += 256) reinterpret_cast<float4*>(wbuf)[i] = reinterpret_cast<const float4*>(a.blob)[i];
+    for (int i = tid; i < R * (CIN / 4); i += 256) {
+        const int r = i / (CIN / 4), q = i - r * (CIN / 4);
+        const int gy = iy0 + r / RW, gx = ix0 + r % RW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) v = *reinterpret_cast<const float4*>(inb + ((int64_t)gy * a.Wi + gx) * CIN + q * 4);
+        *reinterpret_cast<float4*>(xin + r * CIN + q * 4) = v;
+    }
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    const int c = tid & 31, rg = tid >> 5;                  // steps 1-2: lane = hidden channel of the chunk
+    const int co = tid & (CP - 1), og = tid / CP;           // step 3: lane = output channel
+    __syncthreads();
+
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        const float* wb = wbuf + (ci & 1) * blob;
+        const float* w_we = wb;
+        const float* w_be = wb + CIN * 32;
+        const float* w_wd = w_be + 32;
+        const float* w_bd = w_wd + 9 * 32;
+        const float* w_wp = w_bd + 32;
+        float4 st[NLD];
+        const bool more = ci + 1 < n_chunks;
+        if (more) {
+            const float4* src = reinterpret_cast<const float4*>(a.blob + (int64_t)(ci + 1) * blob);
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) { const int i = tid + j * 256; if (i < blob4) st[j] = src[i]; }
+        }
+        // 1. expand (or copy, for the t = 1 block)
+        if (a.expand) {
+            float we[CIN];
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) we[k] = w_we[k * 32 + c];
+            const float be = w_be[c];
+            for (int r = rg; r < R; r += 8) {
+                const int gy = iy0 + r / RW, gx = ix0 + r % RW;
+                float v = 0.f;
+                if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
+                    float t = be;
+#pragma unroll
+                    for (int k4 = 0; k4 < CIN / 4; ++k4) {
+                        const float4 x = *reinterpret_cast<const float4*>(xin + r * CIN + k4 * 4);
+                        t = fmaf(x.x, we[k4 * 4 + 0], t); t = fmaf(x.y, we[k4 * 4 + 1], t);
+                        t = fmaf(x.z, we[k4 * 4 + 2], t); t = fmaf(x.w, we[k4 * 4 + 3], t);
+                    }
+                    v = relu6f(t);
+                }
+                h[r * 32 + c] = v;
+            }
+        } else {
+            const int cc = ci * 32 + c;
+            for (int r = rg; r < R; r += 8) h[r * 32 + c] = (cc < CIN) ? xin[r * CIN + cc] : 0.f;
+        }
+        __syncthreads();
+        // 2. depthwise 3x3 + ReLU6
+        {
+            float wd[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wd[t] = w_wd[t * 32 + c];
+            const float bd = w_bd[c];
+#pragma unroll
+            for (int i = 0; i < TILE / 8; ++i) {
+                const int o = rg + 8 * i;
+                const int oy = o / TW, ox = o - oy * TW;
+                const float* hp = h + ((oy * s) * RW + ox * s) * 32 + c;
+                float t = bd;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) t = fmaf(hp[(dy * RW + dx) * 32], wd[dy * 3 + dx], t);
+                d[o * 32 + c] = relu6f(t);
+            }
+        }
+        __syncthreads();
+        // 3. projection, accumulated over the chunks (padded hidden channels carry zero weights)
+        if (co < a.cout) {
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const float w = w_wp[k * a.cout + co];
+#pragma unroll
+                for (int i = 0; i < NACC; ++i) acc[i] = fmaf(d[(og + (256 / CP) * i) * 32 + k], w, acc[i]);
+            }
+        }
+        if (more) {
+            float4* dst = reinterpret_cast<float4*>(wbuf + ((ci + 1) & 1) * blob);
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) { const int i = tid + j * 256; if (i < blob4) dst[i] = st[j]; }
+        }
+        __syncthreads();
+    }
+    if (co < a.cout) {
+        const float bp = a.bp[co];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            const int o = og + (256 / CP) * i;
+            const int oy = o / TW, ox = o - oy * TW;
+            if (oy0 + oy < a.Ho && ox0 + ox < a.Wo) {
+                float v = acc[i] + bp;
+                if (a.res) v += xin[((oy + 1) * RW + ox + 1) * CIN + co];       // stride 1, cin == cout
+                a.out[(((int64_t)b * a.Ho + oy0 + oy) * a.Wo + ox0 + ox) * a.cout + co] = v;
+            }
+        }
+    }
+}
+
+template <int CIN, int CP, int TILE>
+static int launch_vlad_block(hipStream_t st, const VladBlockArgs& a) {
+    constexpr int TW = 8, TH = TILE / TW;
+    const int RW = TW * a.stride + 2, RH = TH * a.stride + 2;
+    const size_t smem = ((size_t)RW * RH * (CIN + 32) + TILE * 32 + 2 * 32 * (CIN + 11 + a.cout)) * 4;
+    auto kfn = vlad_block_kernel<CIN, CP, TILE>;
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int tiles = cdiv(a.Wo, TW) * cdiv(a.Ho, TH);
+    hipLaunchKernelGGL(kfn, dim3(tiles * a.batch), dim3(256), smem, st, a);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+// returns OMNI_ERR_INVALID (without setting an error) when no instantiation covers the block's shape
+static bool vlad_block_supported(int cin, int cout) {
+    const int cp = cout <= 8 ? 8 : cout <= 16 ? 16 : cout <= 32 ? 32 : cout <= 64 ? 64 : cout <= 128 ? 128 : 0;
+    if (!cp) return false;
+    return (cin == 8 && (cp == 8 || cp == 16)) || (cin == 16 && (cp == 8 || cp == 16 || cp == 32)) || (cin == 24 && cp == 32) ||
+           (cin == 32 && (cp == 32 || cp == 64)) || (cin == 56 && (cp == 64 || cp == 128));
+}
+static int vlad_block(hipStream_t st, int cin, const VladBlockArgs& a) {
+    const int cp = a.cout <= 8 ? 8 : a.cout <= 16 ? 16 : a.cout <= 32 ? 32 : a.cout <= 64 ? 64 : 128;
+#define VB(CI, CPV, T) if (cin == CI && cp == CPV) return launch_vlad_block<CI, CPV, T>(st, a)
+    VB(8, 8, 32); VB(8, 16, 32); VB(16, 8, 32); VB(16, 16, 32); VB(16, 32, 32); VB(24, 32, 16); VB(32, 32, 16); VB(32, 64, 16);
+    VB(56, 64, 16); VB(56, 128, 16);
+#undef VB
+    set_error("vlad_block: no kernel for cin=%d cout=%d", cin, a.cout);
+    return OMNI_ERR_INVALID;
+}
+
+// stem, coalesced: thread = (pixel, 4 output channels), float4 NHWC stores
+__global__ void __launch_bounds__(256)
+vlad_stem4_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, int mask0, int mask1, int Ho, int Wo, int cout,
+                  int cstride, const float* __restrict__ w /*[cout][9]*/, const float* __restrict__ bias, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int cq = cout >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Ho * Wo * cq) return;
+    const int p = i / cq, c4 = (i - p * cq) * 4;
+    const int oy = p / Wo, ox = p - oy * Wo;
+    const uint8_t* g = gray + (int64_t)b * stride * H;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int y = oy * cstride - 1 + t / 3, x = ox * cstride - 1 + t % 3;
+        float px = 0.f;                                    // zero padding is applied AFTER normalisation
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float raw = (y >= mask0 && y < mask1) ? 0.f : (float)g[(int64_t)y * stride + x];
+            px = (raw - 128.0f) / 128.0f;
+        }
+        v[t] = px;
+    }
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = bias[c4 + j];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc = fmaf(v[t], w[(c4 + j) * 9 + t], acc);
+        r[j] = relu6f(acc);
+    }
+    *reinterpret_cast<float4*>(out + ((int64_t)b * Ho * Wo + p) * cout + c4) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// NetVLAD aggregation, parallel over positions: workgroup = (cluster k, image), thread = (d, part) with 8 position parts;
+// partial sums are combined in a fixed order (deterministic), then the intra-normalisation over d.
+#define AGG_PARTS 8
+__global__ void __launch_bounds__(1024)
+vlad_aggregate8_kernel(const float* __restrict__ feat, const float* __restrict__ assign, int n_pos, int Dm, int K,
+                       const float* __restrict__ clusters, float* __restrict__ vlad) {
+    __shared__ float part[AGG_PARTS][128];
+    __shared__ float red[128];
+    const int b = blockIdx.y, k = blockIdx.x;
+    const int dd = threadIdx.x & 127, pt = threadIdx.x >> 7;
+    const float* f = feat + (int64_t)b * n_pos * Dm;
+    const float* a = assign + (int64_t)b * n_pos * K;
+    float v = 0.f;
+    if (dd < Dm) {
+        const float c = clusters[k * Dm + dd];
+        for (int p = pt; p < n_pos; p += AGG_PARTS) v = fmaf(a[p * K + k], c - f[(int64_t)p * Dm + dd], v);
+    }
+    part[pt][dd] = v;
+    __syncthreads();
+    if (pt == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < AGG_PARTS; ++q) t += part[q][dd];
+        part[0][dd] = t;
+        red[dd] = (dd < Dm) ? t * t : 0.f;
+    }
+    __syncthreads();
+    for (int s2 = 64; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2]; __syncthreads(); }
+    const float nrm = sqrtf(red[0]);
+    if (pt == 0 && dd < Dm) vlad[((int64_t)b * K + k) * Dm + dd] = part[0][dd] / nrm;
+}
+
+// NetVLAD soft-assignment with the assignment matrix staged in LDS: workgroup = 8 positions, wave = 2 positions x 32 clusters
+__global__ void __launch_bounds__(256)
+vlad_assign2_kernel(const float* __restrict__ feat, int64_t n_pos, int Dm, int K, const float* __restrict__ awT /*[Dm][K]*/,
+                    const float* __restrict__ ab, float* __restrict__ assign) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* aw = reinterpret_cast<float*>(smem_raw);            // [Dm][K]
+    float* fs = aw + Dm * K;                                    // [8][Dm]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 8;
+    for (int i = tid; i < Dm * K; i += 256) aw[i] = awT[i];
+    for (int i = tid; i < 8 * Dm; i += 256) { const int64_t p = p0 + i / Dm; fs[i] = (p < n_pos) ? feat[p * Dm + i % Dm] : 0.f; }
+    __syncthreads();
+    const int k = lane & 31, sub = lane >> 5;                  // K <= 32 on this path
+    const int pl = wave * 2 + sub;
+    const int64_t p = p0 + pl;
+    float logit = -3.0e38f;
+    if (k < K) {
+        float acc = ab[k];
+        for (int dd = 0; dd < Dm; ++dd) acc = fmaf(fs[pl * Dm + dd], aw[dd * K + k], acc);
+        logit = acc;
+    }
+    float mx = logit;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float e = (k < K) ? expf(logit - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (k < K && p < n_pos) assign[p * K + k] = e / sum;
+}
+
+// FC, 4 output rows per wave: every LDS read of the batch vectors feeds 4 weight rows (the single-row version is LDS-bound)
+__global__ void __launch_bounds__(256)
+vlad_fc4_kernel(const float* __restrict__ v, int nb, int n_in, const float* __restrict__ W, const float* __restrict__ bias,
+                int n_out, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* vs = reinterpret_cast<float*>(smem_raw);        // [nb][n_in]
+    for (int i = threadIdx.x * 4; i < nb * n_in; i += 256 * 4) *reinterpret_cast<float4*>(vs + i) = *reinterpret_cast<const float4*>(v + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (j0 >= n_out) return;
+    float acc[4][FC_MAXB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < FC_MAXB; ++b) acc[r][b] = 0.f;
+    for (int i = lane * 4; i < n_in; i += 256) {
+        float4 w4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w4[r] = (j0 + r < n_out) ? *reinterpret_cast<const float4*>(W + (int64_t)(j0 + r) * n_in + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < FC_MAXB; ++b) {
+            if (b < nb) {
+                const float4 x = *reinterpret_cast<const float4*>(vs + b * n_in + i);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[r][b] = fmaf(w4[r].x, x.x, acc[r][b]); acc[r][b] = fmaf(w4[r].y, x.y, acc[r][b]);
+                    acc[r][b] = fmaf(w4[r].z, x.z, acc[r][b]); acc[r][b] = fmaf(w4[r].w, x.w, acc[r][b]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < FC_MAXB; ++b) {
+            if (b < nb && j0 + r < n_out) {
+                float sacc = acc[r][b];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+                if (lane == 0) out[(int64_t)b * n_out + j0 + r] = sacc + bias[j0 + r];
+            }
+        }
+}
+
 static int upload(float** dst, const float* src, size_t n, hipStream_t st) {
     OMNI_HIP_TRY(hipMalloc((void**)dst, n * 4));
     OMNI_HIP_TRY(hipMemcpyAsync(*dst, src, n * 4, hipMemcpyHostToDevice, st));
@@ -241,7 +570,7 @@ static int upload(float** dst, const float* src, size_t n, hipStream_t st) {
     return OMNI_OK;
 }
 
-static int vlad_forward(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {
+static int vlad_backbone_unfused(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, int* cur_out) {
     hipStream_t st = v->ctx->stream;
     const int H = v->H, W = v->W;
     const int m0 = fisheye_mask ? H * 3 / 4 : H, m1 = fisheye_mask ? H * 3 / 4 + H / 4 : H;
@@ -274,13 +603,54 @@ static int vlad_forward(omni_vlad* v, const uint8_t* gray_dev, int stride, int b
         }
         OMNI_LAUNCH_CHECK();
     }
+    *cur_out = cur;
+    return OMNI_OK;
+}
+
+// stem + one fused kernel per inverted-residual block (v->blocks, built at create time)
+static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, int* cur_out) {
+    hipStream_t st = v->ctx->stream;
+    const int H = v->H, W = v->W;
+    const int m0 = fisheye_mask ? H * 3 / 4 : H, m1 = fisheye_mask ? H * 3 / 4 + H / 4 : H;
+    const VladLayerDev& S = v->layers[0];
+    hipLaunchKernelGGL(vlad_stem4_kernel, dim3(cdiv(S.hout * S.wout * (S.cout / 4), 256), batch), dim3(256), 0, st, gray_dev, stride, H, W, m0, m1,
+                       S.hout, S.wout, S.cout, S.stride, S.w, S.b, v->buf[0]);
+    OMNI_LAUNCH_CHECK();
+    int cur = 0, rc;
+    for (const VladFusedBlock& B : v->blocks) {
+        VladBlockArgs a;
+        a.in = v->buf[cur]; a.out = v->buf[cur ^ 1];
+        a.blob = B.blob; a.bp = B.bp;
+        a.Hi = B.hin; a.Wi = B.win; a.Ho = B.hout; a.Wo = B.wout; a.hid = B.hid; a.cout = B.cout; a.stride = B.stride;
+        a.expand = B.expand; a.res = B.res; a.batch = batch;
+        if ((rc = vlad_block(st, B.cin, a))) return rc;
+        cur ^= 1;
+    }
+    *cur_out = cur;
+    return OMNI_OK;
+}
+
+static int vlad_forward(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {
+    hipStream_t st = v->ctx->stream;
+    int cur = 0, rc;
+    if (v->fused) { if ((rc = vlad_backbone_fused(v, gray_dev, stride, batch, fisheye_mask, &cur))) return rc; }
+    else if ((rc = vlad_backbone_unfused(v, gray_dev, stride, batch, fisheye_mask, &cur))) return rc;
     const int n_pos = v->hf * v->wf;
     const int64_t n_all = (int64_t)batch * n_pos;
-    hipLaunchKernelGGL(vlad_assign_kernel, dim3((unsigned)cdiv64(n_all, 4)), dim3(256), 0, st, v->buf[cur], n_all, v->Dm, v->K, v->assign_wT,
-                       v->assign_b, v->assign);
-    OMNI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(v->K, batch), dim3(128), 0, st, v->buf[cur], v->assign, n_pos, v->Dm, v->K, v->clusters,
-                       v->vlad);
+    if (v->fused && v->K <= 32) {
+        const size_t smem = ((size_t)v->Dm * v->K + 8 * v->Dm) * 4;
+        hipLaunchKernelGGL(vlad_assign2_kernel, dim3((unsigned)cdiv64(n_all, 8)), dim3(256), smem, st, v->buf[cur], n_all, v->Dm, v->K,
+                           v->assign_wT, v->assign_b, v->assign);
+        OMNI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(vlad_aggregate8_kernel, dim3(v->K, batch), dim3(1024), 0, st, v->buf[cur], v->assign, n_pos, v->Dm, v->K,
+                           v->clusters, v->vlad);
+    } else {
+        hipLaunchKernelGGL(vlad_assign_kernel, dim3((unsigned)cdiv64(n_all, 4)), dim3(256), 0, st, v->buf[cur], n_all, v->Dm, v->K, v->assign_wT,
+                           v->assign_b, v->assign);
+        OMNI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(v->K, batch), dim3(128), 0, st, v->buf[cur], v->assign, n_pos, v->Dm, v->K, v->clusters,
+                           v->vlad);
+    }
     OMNI_LAUNCH_CHECK();
     const int n_in = v->K * v->Dm;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(batch), dim3(256), 0, st, v->vlad, n_in);
@@ -288,9 +658,15 @@ static int vlad_forward(omni_vlad* v, const uint8_t* gray_dev, int stride, int b
     for (int b0 = 0; b0 < batch; b0 += FC_MAXB) {
         const int nb = batch - b0 < FC_MAXB ? batch - b0 : FC_MAXB;
         const size_t smem = (size_t)nb * n_in * 4;
-        OMNI_HIP_TRY(hipFuncSetAttribute((const void*)vlad_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(vlad_fc_kernel, dim3(cdiv(v->out_dim, 4)), dim3(256), smem, st, v->vlad + (int64_t)b0 * n_in, nb, n_in, v->fc_w,
-                           v->fc_b, v->out_dim, v->out + (int64_t)b0 * v->out_dim);
+        if (v->fused) {
+            OMNI_HIP_TRY(hipFuncSetAttribute((const void*)vlad_fc4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(vlad_fc4_kernel, dim3(cdiv(v->out_dim, 16)), dim3(256), smem, st, v->vlad + (int64_t)b0 * n_in, nb, n_in, v->fc_w,
+                               v->fc_b, v->out_dim, v->out + (int64_t)b0 * v->out_dim);
+        } else {
+            OMNI_HIP_TRY(hipFuncSetAttribute((const void*)vlad_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(vlad_fc_kernel, dim3(cdiv(v->out_dim, 4)), dim3(256), smem, st, v->vlad + (int64_t)b0 * n_in, nb, n_in, v->fc_w,
+                               v->fc_b, v->out_dim, v->out + (int64_t)b0 * v->out_dim);
+        }
         OMNI_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(batch), dim3(256), 0, st, v->out, v->out_dim);
@@ -345,6 +721,44 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
         if (e > max_elems) max_elems = e;
     }
     if (ok && c != w->feat_dim) { omni::set_error("backbone ends with %d channels, NetVLAD expects %d", c, w->feat_dim); ok = false; }
+    if (ok) {   // group the layer table into inverted-residual blocks for the fused kernels
+        bool fusable = v->layers.size() > 1 && v->layers[0].cout % 4 == 0;
+        size_t i = 1;
+        while (fusable && i < v->layers.size()) {
+            VladFusedBlock B{};
+            const VladLayerDev* e = nullptr;
+            if (v->layers[i].kind == OMNI_VLAD_PW_RELU6) { e = &v->layers[i]; ++i; }
+            if (i + 1 >= v->layers.size()) { fusable = false; break; }
+            const VladLayerDev& dwl = v->layers[i];
+            const VladLayerDev& pl = v->layers[i + 1];
+            if (dwl.kind != OMNI_VLAD_DW3X3_RELU6 || (pl.kind != OMNI_VLAD_PW_LINEAR && pl.kind != OMNI_VLAD_PW_LINEAR_RES) ||
+                (dwl.stride != 1 && dwl.stride != 2)) { fusable = false; break; }
+            B.cin = e ? e->cin : dwl.cin; B.hid = dwl.cin; B.cout = pl.cout; B.stride = dwl.stride; B.expand = e ? 1 : 0;
+            B.res = pl.kind == OMNI_VLAD_PW_LINEAR_RES; B.hin = dwl.hin; B.win = dwl.win; B.hout = dwl.hout; B.wout = dwl.wout;
+            B.bp = pl.b; B.blob = nullptr;
+            if (!omni::vlad_block_supported(B.cin, B.cout) || B.cout % 4 || (B.res && (B.stride != 1 || B.cin != B.cout)) || (!e && B.hid > 32)) { fusable = false; break; }
+            {   // pack the block's weights per 32-channel chunk of the hidden layer (host copies of the layer weights, OIHW)
+                const omni_vlad_layer* Le = e ? &w->layers[i - 1] : nullptr;
+                const omni_vlad_layer& Ld = w->layers[i];
+                const omni_vlad_layer& Lp = w->layers[i + 1];
+                const int n_chunks = (B.hid + 31) / 32, blob = 32 * (B.cin + 11 + B.cout);
+                std::vector<float> pk((size_t)n_chunks * blob, 0.f);
+                for (int ch = 0; ch < B.hid; ++ch) {
+                    float* q = pk.data() + (size_t)(ch / 32) * blob;
+                    const int c = ch % 32;
+                    if (Le) { for (int k = 0; k < B.cin; ++k) q[k * 32 + c] = Le->weight[(size_t)ch * B.cin + k]; q[B.cin * 32 + c] = Le->bias[ch]; }
+                    for (int t = 0; t < 9; ++t) q[(B.cin + 1) * 32 + t * 32 + c] = Ld.weight[(size_t)ch * 9 + t];
+                    q[(B.cin + 10) * 32 + c] = Ld.bias[ch];
+                    for (int co = 0; co < B.cout; ++co) q[(B.cin + 11) * 32 + c * B.cout + co] = Lp.weight[(size_t)co * B.hid + ch];
+                }
+                if (omni::upload(&B.blob, pk.data(), pk.size(), st)) { fusable = false; ok = false; break; }
+            }
+            v->blocks.push_back(B);
+            i += 2;
+        }
+        const char* env = getenv("OMNI_VLAD_UNFUSED");
+        v->fused = fusable && !(env && env[0] == '1');
+    }
     if (ok) {
         v->hf = h; v->wf = wd; v->buf_elems = max_elems * max_batch;
         std::vector<float> awT((size_t)v->Dm * v->K);
@@ -369,6 +783,7 @@ void omni_vlad_destroy(omni_vlad* v) {
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
     for (auto& L : v->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
+    for (auto& B : v->blocks) if (B.blob) (void)hipFree(B.blob);
     void* ptrs[] = {v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     v->hstage.release();

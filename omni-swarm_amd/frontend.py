@@ -30,53 +30,42 @@ class LoopCam:
         self.sp = capi.SuperPoint(ctx, sp_weights, pca_comp, pca_mean, width, height, thres, max_num, precision, 2 * n_dirs)
         k, d, o = vlad_shape
         # MobileNetVLAD is ~50 small launches: on its own HIP stream they overlap SuperPoint's large convolutions
-        self.vctx = capi.Context(ctx.device_id)
+        import os
+        self._own_vctx = os.environ.get("OMNI_VLAD_SAME_STREAM", "0") != "1"
+        self.vctx = capi.Context(ctx.device_id) if self._own_vctx else ctx
         self.vlad = capi.MobileNetVLAD(self.vctx, vlad_weights, vlad_specs, k, d, o, width, height, n_dirs)
         self.out_dim = o
         self.dim = self.sp.desc_dim
-        m = max_num
-        self._d_qidx = ctx.alloc(n_dirs * m * 4)
-        self._d_tidx = ctx.alloc(n_dirs * m * 4)
-        self._d_dist = ctx.alloc(n_dirs * m * 4)
-        self._d_nm = ctx.alloc(n_dirs * 4)
-        self._kps_dev, self._n_dev, self._desc_dev, _ = self.sp.dev_outputs()
+        # the whole key frame as one asynchronous unit with a single pinned result block (csrc/cam.hip)
+        self.cam = capi.Cam(self.sp, self.vlad, n_dirs, o, capi.BF_OPENCV)
 
     def close(self):
-        for p in (self._d_qidx, self._d_tidx, self._d_dist, self._d_nm):
-            self.ctx.free(p)
+        self.cam.close()
         self.sp.close()
         self.vlad.close()
-        self.vctx.close()
+        if self._own_vctx:
+            self.vctx.close()
 
     def enqueue_dev(self, gray_dev: int, stride: int):
         """gray_dev: [2*n_dirs][H][W] u8 in HBM -- images 0..n_dirs-1 are the 'up' (main) camera of each direction,
-        n_dirs..2*n_dirs-1 the 'down' camera.  Asynchronous on the context's stream."""
-        n, m, dim = self.n_dirs, self.max_num, self.dim
-        self.sp.enqueue_dev(gray_dev, stride, 2 * n, self.fisheye)              # loop_cam.cpp:350-351
-        self.vlad.enqueue_dev(gray_dev, stride, n, self.fisheye)                # :553-556 (main camera only)
-        # match_HFNet_local_features: up = query, down = train (:147-150); pair p = direction p
-        capi.bf_match_batched_dev(self.ctx, n, m, dim, capi.BF_OPENCV,
-                                  self._desc_dev, m * dim, self._n_dev,
-                                  self._desc_dev + n * m * dim * 4, m * dim, self._n_dev + n * 4,
-                                  self._d_qidx, self._d_tidx, self._d_dist, self._d_nm)
+        n_dirs..2*n_dirs-1 the 'down' camera.  Asynchronous: SuperPoint + BF matching on the context's stream,
+        MobileNetVLAD on a second stream, all D2H copies included (loop_cam.cpp:350-351, 553-556, 147-150)."""
+        self.cam.enqueue_dev(gray_dev, stride, self.fisheye)
 
     def fetch(self) -> dict:
-        """Synchronises and returns one FisheyeFrameDescriptor_t's worth of CNN outputs."""
-        n, m = self.n_dirs, self.max_num
-        feats = self.sp.fetch(2 * n)
-        gdesc = self.vlad.fetch(n)
-        nm = self.ctx.from_device(self._d_nm, (n,), np.int32)
-        qi = self.ctx.from_device(self._d_qidx, (n, m), np.int32)
-        ti = self.ctx.from_device(self._d_tidx, (n, m), np.int32)
+        """Waits for the key frame and returns one FisheyeFrameDescriptor_t's worth of CNN outputs (copies: the pinned
+        block is reused by the next enqueue)."""
+        n = self.n_dirs
+        r = self.cam.wait()
+        nk = r["n_kps"]
         images = []
         for d in range(n):
-            kps_up, desc_up, sc_up = feats[d]
-            kps_dn, desc_dn, _ = feats[n + d]
-            k = int(nm[d]) if len(kps_up) > self.accept_min_3d_pts else 0       # :388 `if (pts_up.size() > ACCEPT_MIN_3D_PTS)`
-            images.append({"landmarks_2d": kps_up, "feature_descriptor": desc_up, "scores": sc_up,
-                           "landmark_num": len(kps_up), "image_desc": gdesc[d],
-                           "landmarks_2d_down": kps_dn, "feature_descriptor_down": desc_dn,
-                           "ids_up": qi[d, :k].copy(), "ids_down": ti[d, :k].copy(), "direction": d})
+            nu, nd = int(nk[d]), int(nk[n + d])
+            k = int(r["n_matches"][d]) if nu > self.accept_min_3d_pts else 0    # :388 `if (pts_up.size() > ACCEPT_MIN_3D_PTS)`
+            images.append({"landmarks_2d": r["kps_xy"][d, :nu].copy(), "feature_descriptor": r["desc"][d, :nu].copy(),
+                           "scores": r["scores"][d, :nu].copy(), "landmark_num": nu, "image_desc": r["global_desc"][d].copy(),
+                           "landmarks_2d_down": r["kps_xy"][n + d, :nd].copy(), "feature_descriptor_down": r["desc"][n + d, :nd].copy(),
+                           "ids_up": r["match_up"][d, :k].copy(), "ids_down": r["match_down"][d, :k].copy(), "direction": d})
         return {"images": images, "landmark_num": int(sum(i["landmark_num"] for i in images))}
 
     def on_flattened_images(self, up: np.ndarray, down: np.ndarray) -> dict:
