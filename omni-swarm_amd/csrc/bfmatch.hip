@@ -5,8 +5,9 @@
 // (first minimum wins); every query keeps, among the train rows that picked it, the nearest (lowest train index on
 // ties); matches are emitted in ascending query order.  OMNI_BF_MUTUAL gives the strict mutual-NN variant.
 //
-// One workgroup per descriptor pair-set; the distance matrix is produced in 64x64 LDS tiles with a 4x4 register
-// tile per thread; "first minimum wins" is a 64-bit LDS atomicMin on (distance bits << 32 | index).
+// One workgroup per 64x64 tile of every pair's distance matrix (4x4 register tile per thread); "first minimum wins" is a
+// 64-bit atomicMin on (distance bits << 32 | index) into the pair's row / column best arrays; a second small kernel per
+// pair does the cross-check and the ordered compaction.
 // Distances: d = sqrtf(sum_k (a_k-b_k)^2), sequential in k, mul and add NOT contracted -- bit-identical to the
 // scalar C oracle (oracle/csrc/oracle.c:l2_dist).
 #include "common.h"
@@ -27,108 +28,124 @@ __device__ __forceinline__ unsigned long long bf_key(float d, int idx) {
     return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)idx;
 }
 
+// Kernel 1: one workgroup per (pair, 64-query tile, 64-train tile): the 64x64 distance tile with a 4x4 register tile per
+// thread; row / column minima go to the pair's global best arrays with 64-bit atomicMin on (distance bits << 32 | index)
+// -- order independent, so "first minimum wins" holds however the tiles are scheduled.
 __global__ void __launch_bounds__(BF_THREADS)
-bf_match_kernel(int max_n, int dim, int mode,
-                const float* __restrict__ q_base, int64_t q_stride, const int* __restrict__ nq_arr,
-                const float* __restrict__ t_base, int64_t t_stride, const int* __restrict__ nt_arr,
-                int* __restrict__ out_qidx, int* __restrict__ out_tidx, float* __restrict__ out_dist,
-                int* __restrict__ out_n) {
+bf_tile_kernel(int max_n, int dim, const float* __restrict__ q_base, int64_t q_stride, const int* __restrict__ nq_arr,
+               const float* __restrict__ t_base, int64_t t_stride, const int* __restrict__ nt_arr,
+               unsigned long long* __restrict__ best /*[pairs][2][max_n]*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int p = blockIdx.z;
+    const int tid = threadIdx.x;
+    int nq = nq_arr[p], nt = nt_arr[p];
+    nq = nq < 0 ? 0 : (nq > max_n ? max_n : nq);
+    nt = nt < 0 ? 0 : (nt > max_n ? max_n : nt);
+    const int i0 = blockIdx.y * BF_TILE, j0 = blockIdx.x * BF_TILE;
+    if (i0 >= nq || j0 >= nt) return;
+    const float* q = q_base + (int64_t)p * q_stride;
+    const float* t = t_base + (int64_t)p * t_stride;
+    const int ld = dim + 4;
+    float* as = reinterpret_cast<float*>(smem_raw);                                    // [64][ld] query tile
+    float* bs = as + BF_TILE * ld;                                                     // [64][ld] train tile
+    unsigned long long* rowbest = best + (int64_t)p * 2 * max_n;
+    unsigned long long* colbest = rowbest + max_n;
+    for (int idx = tid; idx < BF_TILE * (dim >> 2); idx += BF_THREADS) {
+        const int r = idx / (dim >> 2), c4 = idx % (dim >> 2);
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (i0 + r < nq) va = *reinterpret_cast<const float4*>(q + (int64_t)(i0 + r) * dim + c4 * 4);
+        if (j0 + r < nt) vb = *reinterpret_cast<const float4*>(t + (int64_t)(j0 + r) * dim + c4 * 4);
+        *reinterpret_cast<float4*>(as + r * ld + c4 * 4) = va;
+        *reinterpret_cast<float4*>(bs + r * ld + c4 * 4) = vb;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+    for (int k = 0; k < dim; k += 4) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(as + (ty * 4 + r) * ld + k);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(bs + (tx * 4 + c) * ld + k);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // (a-b)^2 accumulated sequentially in k, no fma contraction (matches the C oracle bit for bit;
+                // a-b == -(b-a) exactly, so both match directions see the same value)
+                const float d0 = a[r].x - b[c].x, d1 = a[r].y - b[c].y, d2 = a[r].z - b[c].z, d3 = a[r].w - b[c].w;
+                float sacc = acc[r][c];
+                sacc = sacc + d0 * d0;
+                sacc = sacc + d1 * d1;
+                sacc = sacc + d2 * d2;
+                sacc = sacc + d3 * d3;
+                acc[r][c] = sacc;
+            }
+    }
+    // tile-local minima first (LDS-free: per-thread over its 4x4, then one atomic per row / column per thread)
+    unsigned long long rmin[4], cmin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rmin[r] = ~0ull;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cmin[c] = ~0ull;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty * 4 + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = j0 + tx * 4 + c;
+            if (i < nq && j < nt) {
+                const float d = (float)sqrt((double)acc[r][c]);   // correctly rounded fp32 sqrt (53 >= 2*24+2: double rounding is innocuous)
+                const unsigned long long kr = bf_key(d, j), kc = bf_key(d, i);
+                rmin[r] = kr < rmin[r] ? kr : rmin[r];
+                cmin[c] = kc < cmin[c] ? kc : cmin[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (rmin[r] != ~0ull) atomicMin(&rowbest[i0 + ty * 4 + r], rmin[r]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (cmin[c] != ~0ull) atomicMin(&colbest[j0 + tx * 4 + c], cmin[c]);
+}
+
+// Kernel 2: one workgroup per pair: cross-check + ordered compaction
+__global__ void __launch_bounds__(BF_THREADS)
+bf_cross_kernel(int max_n, int mode, const int* __restrict__ nq_arr, const int* __restrict__ nt_arr,
+                const unsigned long long* __restrict__ best, int* __restrict__ out_qidx, int* __restrict__ out_tidx,
+                float* __restrict__ out_dist, int* __restrict__ out_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long* qbest = reinterpret_cast<unsigned long long*>(smem_raw);      // [max_n] cross-check result
     const int p = blockIdx.x;
     const int tid = threadIdx.x;
     int nq = nq_arr[p], nt = nt_arr[p];
     nq = nq < 0 ? 0 : (nq > max_n ? max_n : nq);
     nt = nt < 0 ? 0 : (nt > max_n ? max_n : nt);
-    const float* q = q_base + (int64_t)p * q_stride;
-    const float* t = t_base + (int64_t)p * t_stride;
-    const int ld = dim + 4;
-    unsigned long long* rowbest = reinterpret_cast<unsigned long long*>(smem_raw);   // [max_n] query -> (d, train)
-    unsigned long long* colbest = rowbest + max_n;                                     // [max_n] train -> (d, query)
-    unsigned long long* qbest = colbest + max_n;                                       // [max_n] cross-check result
-    float* as = reinterpret_cast<float*>(qbest + max_n);                               // [64][ld] query tile
-    float* bs = as + BF_TILE * ld;                                                     // [64][ld] train tile
-
-    for (int i = tid; i < max_n; i += BF_THREADS) { rowbest[i] = ~0ull; colbest[i] = ~0ull; qbest[i] = ~0ull; }
+    const unsigned long long* rowbest = best + (int64_t)p * 2 * max_n;
+    const unsigned long long* colbest = rowbest + max_n;
+    for (int i = tid; i < max_n; i += BF_THREADS) qbest[i] = ~0ull;
     __syncthreads();
-
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int i0 = 0; i0 < nq; i0 += BF_TILE) {
-        for (int idx = tid; idx < BF_TILE * (dim >> 2); idx += BF_THREADS) {
-            int r = idx / (dim >> 2), c4 = idx % (dim >> 2);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 + r < nq) v = *reinterpret_cast<const float4*>(q + (int64_t)(i0 + r) * dim + c4 * 4);
-            *reinterpret_cast<float4*>(as + r * ld + c4 * 4) = v;
-        }
-        for (int j0 = 0; j0 < nt; j0 += BF_TILE) {
-            __syncthreads();   // previous bs consumers done (and as staged on first pass)
-            for (int idx = tid; idx < BF_TILE * (dim >> 2); idx += BF_THREADS) {
-                int r = idx / (dim >> 2), c4 = idx % (dim >> 2);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j0 + r < nt) v = *reinterpret_cast<const float4*>(t + (int64_t)(j0 + r) * dim + c4 * 4);
-                *reinterpret_cast<float4*>(bs + r * ld + c4 * 4) = v;
-            }
-            __syncthreads();
-            float acc[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
-            for (int k = 0; k < dim; k += 4) {
-                float4 a[4], b[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(as + (ty * 4 + r) * ld + k);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(bs + (tx * 4 + c) * ld + k);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        // (a-b)^2 accumulated sequentially in k, no fma contraction (matches the C oracle bit for bit;
-                        // a-b == -(b-a) exactly, so both match directions see the same value)
-                        const float d0 = a[r].x - b[c].x, d1 = a[r].y - b[c].y, d2 = a[r].z - b[c].z, d3 = a[r].w - b[c].w;
-                        float s = acc[r][c];
-                        s = s + d0 * d0;
-                        s = s + d1 * d1;
-                        s = s + d2 * d2;
-                        s = s + d3 * d3;
-                        acc[r][c] = s;
-                    }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + ty * 4 + r;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int j = j0 + tx * 4 + c;
-                    if (i < nq && j < nt) {
-                        const float d = (float)sqrt((double)acc[r][c]);   // correctly rounded fp32 sqrt (53 >= 2*24+2: double rounding is innocuous)
-                        atomicMin(&rowbest[i], bf_key(d, j));
-                        atomicMin(&colbest[j], bf_key(d, i));
-                    }
-                }
-            }
-        }
-        __syncthreads();   // as consumers done before restaging
-    }
-    __syncthreads();
-
     if (mode == OMNI_BF_OPENCV) {
         // for train j ascending: idx = tidx[j]; if (tdist[j] < dist[idx]) {dist[idx] = tdist[j]; nidx[idx] = j;}
         // == per query, min over (d, j) of the trains that picked it
         for (int j = tid; j < nt; j += BF_THREADS) {
-            unsigned long long cb = colbest[j];
-            int i = (int)(cb & 0xFFFFFFFFull);
+            const unsigned long long cb = colbest[j];
+            if (cb == ~0ull) continue;                       // nq == 0
+            const int i = (int)(cb & 0xFFFFFFFFull);
             atomicMin(&qbest[i], (cb & 0xFFFFFFFF00000000ull) | (unsigned)j);
         }
     } else {
         for (int i = tid; i < nq; i += BF_THREADS) {
-            unsigned long long rb = rowbest[i];
-            int j = (int)(rb & 0xFFFFFFFFull);
+            const unsigned long long rb = rowbest[i];
+            if (rb == ~0ull) continue;                       // nt == 0
+            const int j = (int)(rb & 0xFFFFFFFFull);
             if ((int)(colbest[j] & 0xFFFFFFFFull) == i) qbest[i] = rb;
         }
     }
     __syncthreads();
-
     // ordered compaction by query index: wave 0 walks the queries 64 at a time
     if (tid < 64) {
         int base = 0;
@@ -137,14 +154,14 @@ bf_match_kernel(int max_n, int dim, int mode,
         float* od = out_dist + (int64_t)p * max_n;
         for (int i0 = 0; i0 < nq; i0 += 64) {
             const int i = i0 + tid;
-            const unsigned long long b = (i < nq) ? qbest[i] : ~0ull;
-            const bool has = (b != ~0ull);
+            const unsigned long long bq = (i < nq) ? qbest[i] : ~0ull;
+            const bool has = (bq != ~0ull);
             const unsigned long long m = __ballot(has);
             if (has) {
                 const int pos = base + __popcll(m & ((1ull << tid) - 1ull));
                 oq[pos] = i;
-                ot[pos] = (int)(b & 0xFFFFFFFFull);
-                od[pos] = __uint_as_float((unsigned)(b >> 32));
+                ot[pos] = (int)(bq & 0xFFFFFFFFull);
+                od[pos] = __uint_as_float((unsigned)(bq >> 32));
             }
             base += __popcll(m);
         }
@@ -152,17 +169,23 @@ bf_match_kernel(int max_n, int dim, int mode,
     }
 }
 
-static size_t bf_smem(int max_n, int dim) { return (size_t)max_n * 8 * 3 + (size_t)2 * BF_TILE * (dim + 4) * 4; }
-
 static int bf_launch(omni_ctx* ctx, int n_pairs, int max_n, int dim, int mode, const float* q, int64_t qs, const int* nq,
                      const float* t, int64_t ts, const int* nt, int* oq, int* ot, float* od, int* on) {
     OMNI_REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= BF_MAX_DIM, OMNI_ERR_INVALID, "dim=%d must be a multiple of 4 in [4,%d]", dim, BF_MAX_DIM);
     OMNI_REQUIRE(max_n >= 1 && max_n <= BF_MAX_N, OMNI_ERR_CAPACITY, "max_n=%d outside [1,%d]", max_n, BF_MAX_N);
     OMNI_REQUIRE(mode == OMNI_BF_OPENCV || mode == OMNI_BF_MUTUAL, OMNI_ERR_INVALID, "bad mode %d", mode);
-    size_t smem = bf_smem(max_n, dim);
-    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)bf_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(bf_match_kernel, dim3(n_pairs), dim3(BF_THREADS), smem, ctx->stream, max_n, dim, mode, q, qs, nq, t,
-                       ts, nt, oq, ot, od, on);
+    int rc;
+    const size_t best_bytes = (size_t)n_pairs * 2 * max_n * 8;
+    if ((rc = ctx->scratch2.ensure(best_bytes))) return rc;          // stream-ordered reuse: every user of scratch2 runs on ctx->stream
+    unsigned long long* best = ctx->scratch2.as<unsigned long long>();
+    OMNI_HIP_TRY(hipMemsetAsync(best, 0xFF, best_bytes, ctx->stream));
+    const size_t smem1 = (size_t)2 * BF_TILE * (dim + 4) * 4;
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)bf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1));
+    const int tiles = cdiv(max_n, BF_TILE);
+    hipLaunchKernelGGL(bf_tile_kernel, dim3(tiles, tiles, n_pairs), dim3(BF_THREADS), smem1, ctx->stream, max_n, dim, q, qs, nq, t, ts, nt, best);
+    OMNI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bf_cross_kernel, dim3(n_pairs), dim3(BF_THREADS), (size_t)max_n * 8, ctx->stream, max_n, mode, nq, nt, best, oq, ot,
+                       od, on);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }

@@ -52,6 +52,11 @@ int conv1a_direct(hipStream_t stream, int precision, const uint8_t* gray, int st
 int detector_head(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                   const float* wT, const float* bias, float* semi);
 
+// Same on the matrix cores (v_mfma_f32_32x32x2_f32 for the 64 kept channels, VALU for the dustbin); weights packed on the host.
+void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*[16384]*/, float* wdust /*[256]*/);
+int detector_head_mfma(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
+                       const float* wA, const float* wdust, const float* bias, float* semi, int n_cu);
+
 // desc = desc / ||desc||_2 over the 256 channels of every coarse cell (superpoint.ipynb:187-188); fp32 NHWC in place.
 int l2norm_channels(hipStream_t stream, float* desc_nhwc, int64_t n_cells);
 

@@ -962,6 +962,137 @@ int detector_head(hipStream_t st, int precision, const void* in, int in_stride, 
     return OMNI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Detector head tail on the matrix cores: the 256 -> 64 part of convPb as v_mfma_f32_32x32x2_f32 (exact f32, an fmaf chain),
+// M = output channels (A = weights from LDS), N = 32 coarse cells per wave (B = the cell's 256 activations straight from
+// HBM, converted to f32), K permuted so that half-wave kk owns input channels [128 kk, 128 kk + 128); the dustbin logit
+// (channel 64) is a VALU dot product over the same registers.  A lane then holds 32 of its cell's 64 logits (the other
+// half-wave the other 32): softmax needs one cross-half exchange, and the 8x8 depth-to-space turns each accumulator quad
+// into one 16-byte store (channel c = 8 ry + rx: 4 consecutive rx).
+// ---------------------------------------------------------------------------------------------------------------
+#define DETM_THREADS 256
+template <typename T>
+__global__ void __launch_bounds__(DETM_THREADS)
+detector_head_mfma_kernel(const T* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
+                          const float* __restrict__ wA /*[2][32][2][32][4] fragment order*/, const float* __restrict__ wdust /*[256]*/,
+                          const float* __restrict__ bias /*[65]*/, float* __restrict__ semi) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wl = reinterpret_cast<float*>(smem_raw);           // [2][32][2][32][4] = 16384 floats
+    float* wd = wl + 16384;                                    // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < 16384 / 4; i += DETM_THREADS) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wA)[i];
+    wd[tid] = wdust[tid];
+    float* bl = wd + 256;                                      // [65] bias (LDS: 32 registers otherwise)
+    if (tid < 65) bl[tid] = bias[tid];
+    __syncthreads();
+    const float dust_bias = bl[64];
+    const int n_frag = (n_cells + 31) >> 5;
+    constexpr int EPV = 16 / sizeof(T);                       // elements per 16-byte load: 8 halfs or 4 floats
+    constexpr int XPC = 32 / EPV;                             // 16-byte loads per 32-channel chunk
+    for (int f = blockIdx.x * 4 + wave; f < n_frag; f += gridDim.x * 4) {
+        const int cell = f * 32 + n;
+        const bool valid = cell < n_cells;
+        const T* ip = in + (int64_t)(valid ? cell : n_cells - 1) * in_stride + in_off + hh * 128;
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        float dust = 0.f;
+        uint4 xr[XPC], xn[XPC];
+#pragma unroll
+        for (int i = 0; i < XPC; ++i) xr[i] = *reinterpret_cast<const uint4*>(ip + i * EPV);
+#pragma unroll 1
+        for (int ch = 0; ch < 4; ++ch) {                      // 4 chunks of 32 input channels per half-wave; next chunk prefetched
+            if (ch + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < XPC; ++i) xn[i] = *reinterpret_cast<const uint4*>(ip + (ch + 1) * 32 + i * EPV);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int t4 = ch * 8 + t;
+                float x4[4];
+                if constexpr (sizeof(T) == 2) {
+                    const uint4 u = xr[t >> 1];
+                    const uint32_t lo = (t & 1) ? u.z : u.x, hi = (t & 1) ? u.w : u.y;
+                    const half2_t a = __builtin_bit_cast(half2_t, lo), b = __builtin_bit_cast(half2_t, hi);
+                    x4[0] = (float)a[0]; x4[1] = (float)a[1]; x4[2] = (float)b[0]; x4[3] = (float)b[1];
+                } else {
+                    const uint4 u = xr[t];
+                    x4[0] = __uint_as_float(u.x); x4[1] = __uint_as_float(u.y); x4[2] = __uint_as_float(u.z); x4[3] = __uint_as_float(u.w);
+                }
+                const floatx4 a0 = *reinterpret_cast<const floatx4*>(wl + (((0 * 32 + t4) * 2 + hh) * 32 + n) * 4);
+                const floatx4 a1 = *reinterpret_cast<const floatx4*>(wl + (((1 * 32 + t4) * 2 + hh) * 32 + n) * 4);
+                const floatx4 d4 = *reinterpret_cast<const floatx4*>(wd + hh * 128 + t4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], x4[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], x4[e], acc1, 0, 0, 0);
+                    dust = fmaf(x4[e], d4[e], dust);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < XPC; ++i) xr[i] = xn[i];
+        }
+        dust = dust + __shfl_xor(dust, 32, 64) + dust_bias;
+        float l0[16], l1[16], mx = dust;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            l0[r] = acc0[r] + bl[c]; l1[r] = acc1[r] + bl[32 + c];
+            mx = fmaxf(mx, fmaxf(l0[r], l1[r]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { l0[r] = expf(l0[r] - mx); l1[r] = expf(l1[r] - mx); sum += l0[r] + l1[r]; }
+        sum = sum + __shfl_xor(sum, 32, 64) + expf(dust - mx);
+        if (valid) {
+            const int wx = cell % Wc;
+            const int hy = (cell / Wc) % Hc;
+            const int b = cell / (Wc * Hc);
+            float* o = semi + ((int64_t)b * Hc * 8 + hy * 8) * (Wc * 8) + wx * 8 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // channel c = 32 m + 8 g + 4 hh + (r & 3)  ->  row ry = 4 m + g, columns rx = 4 hh + (r & 3)
+                *reinterpret_cast<float4*>(o + (int64_t)g * (Wc * 8)) =
+                    make_float4(l0[4 * g + 0] / sum, l0[4 * g + 1] / sum, l0[4 * g + 2] / sum, l0[4 * g + 3] / sum);
+                *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) =
+                    make_float4(l1[4 * g + 0] / sum, l1[4 * g + 1] / sum, l1[4 * g + 2] / sum, l1[4 * g + 3] / sum);
+            }
+        }
+    }
+}
+
+// host: [256][65] transposed weights -> MFMA A-fragment order [m][t4][kk][i][e] = W[32 m + i][128 kk + 4 t4 + e], plus the dustbin row
+void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*16384*/, float* wdust /*256*/) {
+    for (int m = 0; m < 2; ++m)
+        for (int t4 = 0; t4 < 32; ++t4)
+            for (int kk = 0; kk < 2; ++kk)
+                for (int i = 0; i < 32; ++i)
+                    for (int e = 0; e < 4; ++e)
+                        wA[((((size_t)m * 32 + t4) * 2 + kk) * 32 + i) * 4 + e] = wT[(size_t)(128 * kk + 4 * t4 + e) * 65 + 32 * m + i];
+    for (int k = 0; k < 256; ++k) wdust[k] = wT[(size_t)k * 65 + 64];
+}
+
+int detector_head_mfma(hipStream_t st, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
+                       const float* wA, const float* wdust, const float* bias, float* semi, int n_cu) {
+    const int n_cells = batch * Hc * Wc;
+    const size_t smem = (size_t)(16384 + 256 + 80) * 4;
+    int grid = cdiv(cdiv(n_cells, 32), 4);
+    if (n_cu > 0 && grid > n_cu) grid = n_cu;
+    if (precision == OMNI_PREC_F16) {
+        OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(detector_head_mfma_kernel<_Float16>, dim3(grid), dim3(DETM_THREADS), smem, st, (const _Float16*)in, in_stride, in_off,
+                           n_cells, Hc, Wc, wA, wdust, bias, semi);
+    } else {
+        OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(detector_head_mfma_kernel<float>, dim3(grid), dim3(DETM_THREADS), smem, st, (const float*)in, in_stride, in_off,
+                           n_cells, Hc, Wc, wA, wdust, bias, semi);
+    }
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 // desc / ||desc||_2 per coarse cell: one wave per cell, lane holds 4 channels
 __global__ void __launch_bounds__(256)
 l2norm_kernel(float* __restrict__ d, int64_t n_cells) {

@@ -34,6 +34,7 @@ struct omni_sp {
     float* bias[OMNI_SP_NUM_LAYERS] = {};
     float* w1a = nullptr;                    // [64][9]
     float* wPbT = nullptr;                   // [256][65]
+    float *wPbA = nullptr, *wPbDust = nullptr; // convPb in MFMA A-fragment order + the dustbin row
     float* bias_heads = nullptr;             // [512]
     float* lut = nullptr;
     float* pca_compT = nullptr;
@@ -72,6 +73,10 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         for (int c = 0; c < 65; ++c)
             for (int k = 0; k < 256; ++k) t[(size_t)k * 65 + c] = w->weight[LPB][(size_t)c * 256 + k];
         if ((rc = dev_upload((void**)&s->wPbT, t.data(), t.size() * 4, st))) return rc;
+        std::vector<float> wa(16384), wdst(256);
+        detector_pack_weights(t.data(), wa.data(), wdst.data());
+        if ((rc = dev_upload((void**)&s->wPbA, wa.data(), wa.size() * 4, st))) return rc;
+        if ((rc = dev_upload((void**)&s->wPbDust, wdst.data(), wdst.size() * 4, st))) return rc;
     }
     {
         std::vector<float> bh(512);
@@ -191,7 +196,9 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if ((rc = mark())) return rc;
     if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
-    if ((rc = detector_head(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc;
+    if (s->conv_variant == 1) { if ((rc = detector_head(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
+    else if ((rc = detector_head_mfma(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
+                                      s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
     {   // convDb reads channels [256,512) (cDa) of the fused heads buffer: input pointer offset by 256 channels,
         // pixel stride 512
@@ -275,7 +282,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
-    void* ptrs[] = {s->w1a, s->wPbT, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
+    void* ptrs[] = {s->w1a, s->wPbT, s->wPbA, s->wPbDust, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
                     s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -141,8 +141,10 @@ def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, m
             outs.append([sp.debug_layer(n, nb) for n in ("conv1b", "conv2a", "conv2b", "conv3a")] + list(sp.get_dense(nb)))
             sp.close()
         for other in outs[1:]:
-            for a, b in zip(outs[0], other):
+            for a, b in zip(outs[0][:4], other[:4]):                 # conv1b .. conv3a: same bits
                 assert np.array_equal(a, b)
+            # variant 1 also swaps the MFMA detector head for the VALU one (another fp32 summation order)
+            assert np.abs(outs[0][4] - other[4]).max() < 1e-5 and np.array_equal(outs[0][5], other[5])
 
 
 def test_bad_arguments_return_errors_not_aborts(omni, ctx):
