@@ -36,9 +36,17 @@ struct ConvArgs {
     bool relu, pool;
     bool out_f32;          // write fp32 regardless of the compute precision (final 1x1 descriptor conv)
     int n_cu = 0;          // CUs on the device (> 0 enables the persistent cin=64 fp16 kernel)
-    int variant = 0;       // test hook (OMNI_CONV_V1): 0 = best kernel per layer, 1 = generic kernel everywhere, 2 = v2 persistent kernel
+    int variant = 0;       // test hook (OMNI_CONV_V1): 0 = best kernel per layer, 1 = generic kernel everywhere, 2 = v2 persistent kernel,
+                           // 3 = v3 ping-pong kernel without the conv1a fusion
 };
 int conv_mfma(hipStream_t stream, int precision, const ConvArgs& a);
+
+// conv1a + conv1b + ReLU + 2x2 max-pool fused (fp16 path): conv1a runs on the matrix cores inside conv1b's ping-pong kernel
+// with split fp16 operands (conv.hip); a = the conv1b layer (a.in unused).  Host-side packers for its constant inputs.
+int conv1ab_fused(hipStream_t stream, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const _Float16* w1a_frag,
+                  const float* bias1a, const uint32_t* lut_hl);
+void conv1a_pack_split_weights(const float* w /*[64][9]*/, const float* bias /*[64]*/, uint16_t* frag /*[2048]*/);
+void conv1a_make_split_lut(uint32_t* lut /*[256]*/);
 
 // conv1a: 1 -> 64 channels, 3x3, + ReLU, straight from the u8 image (u8 -> f32 * 1/255 via a 256-entry table that
 // reproduces cv::Mat::convertTo(CV_32F, 1/255.0), superpoint_tensorrt.cpp:127; optional fisheye row mask,

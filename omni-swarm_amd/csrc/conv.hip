@@ -256,7 +256,9 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
 #define C64_BUF_BYTES (43 * 1024)              // 43 wave-instructions of 1 KiB
 #define C64_W_BYTES (9 * 4096 * 2)
 #define C64_SMEM (C64_W_BYTES + 2 * C64_BUF_BYTES)
-#define PP_SMEM (C64_SMEM + 256)               // + the cout tile's bias
+#define PP_SMEM (C64_SMEM + 256)                // + the cout tile's bias
+// FUSE1A: halo buffers without the DMA tail padding, + conv1a's bias, the u8 -> (hi, lo) half table and four 240-byte image patches
+#define PP_SMEM_FUSED (C64_W_BYTES + 2 * C64_PIX * 128 + 256 + 256 + 1024 + 960)
 
 template <bool POOL>
 __global__ void __launch_bounds__(256, 1)
@@ -422,11 +424,18 @@ static int launch_conv_c64(hipStream_t st, const ConvArgs& a, int n_cu) {
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+// fmaxf() on MFMA results costs three instructions under plain -O3 (hipcc canonicalises both inputs with a v_max x, x first);
+// the epilogues below are instruction-count bound next to the partner wave's MFMA stream, so they use the bare instruction
+// (only on accumulators that were written a whole phase earlier: hipcc pads no MFMA hazard in front of inline asm)
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// ReLU as an integer max on the bit pattern (negative floats and -0 are negative integers): one compiler-visible instruction,
+// so the MFMA -> VALU wait states in front of it are still inserted by hipcc (they are NOT for an inline-asm reader)
+__device__ __forceinline__ float vrelu(float a) { const int b = __builtin_bit_cast(int, a); return __builtin_bit_cast(float, b > 0 ? b : 0); }
 __device__ __forceinline__ float dpp_swap_pairs(float v) {      // value of lane ^ 1 (quad_perm [1,0,3,2]): a VALU modifier, no LDS
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
 __device__ __forceinline__ uint32_t pack_relu_f16(float a, float b, int relu) {
-    if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+    if (relu) { a = vrelu(a); b = vrelu(b); }
     float2_t f; f[0] = a; f[1] = b;
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2_t));
 }
@@ -513,10 +522,26 @@ __device__ __forceinline__ void pp_mfma_steps(uint32_t a_base0, uint32_t a_base1
     }
 }
 
-template <bool POOL, int ABL>
+// conv1a fused into conv1b (FUSE1A): the service phase BUILDS the group's next 10x34x64 halo tile from the u8 image instead of
+// DMA-ing it from HBM -- conv1a (1 -> 64 channels, 3x3, K = 9) as two v_mfma_f32_32x32x16_f16 per 32 pixels with split
+// operands, x = xh + xl (the 256-entry u8 -> f32 table pre-split into two halfs) and w = wh + wl:
+//     K slots 0-8: xh*wh, 9-17: xl*wh, 18-26: xh*wl (xl*wl ~ 2^-24 relative is dropped): fp32-class accuracy on the matrix cores,
+// bias + ReLU + the zero padding of conv1b in the epilogue, written straight into the swizzled LDS image.  The 36.9 MB/image
+// conv1a activation tensor never exists: conv1b's input traffic drops from 397 MB to 2.3 MB per 8 images, which was what
+// held the kernel at ~3 TB/s of DMA next to its MFMA work.
+struct Fuse1aArgs {
+    const uint8_t* gray; int gstride; int mask_r0, mask_r1;
+    const _Float16* w1a_frag;     // [2 k-halves][2 m][64 lanes][8 halfs] A fragments of the split conv1a weights
+    const float* bias1a;          // [64]
+    const uint32_t* lut_hl;       // [256] half(x) | half(x - half(x)) << 16,  x = float(double(i) * (1.0 / 255.0))
+    unsigned long long* trace;    // OMNI_PP_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
+};
+
+template <bool POOL, int ABL, bool FUSE1A>
 __global__ void __launch_bounds__(PP_THREADS)
 conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
-                      const float* __restrict__ bias, int H, int W, int cout, int n_ct, int tiles_x, int tiles_y, int batch, int relu, int dbg) {
+                      const float* __restrict__ bias, int H, int W, int cout, int n_ct, int tiles_x, int tiles_y, int batch, int relu, int dbg,
+                      Fuse1aArgs fz) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -533,8 +558,9 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         uint4* dst = reinterpret_cast<uint4*>(smem_raw);
         for (int i = tid; i < C64_W_BYTES / 16; i += PP_THREADS) dst[i] = src[i];
     }
-    char* const buf = smem_raw + C64_W_BYTES + grp * C64_BUF_BYTES;        // this group's halo buffer
-    const uint32_t buf_lds = lds0 + C64_W_BYTES + grp * C64_BUF_BYTES;
+    constexpr int BUFB = FUSE1A ? C64_PIX * 128 : C64_BUF_BYTES;           // no DMA tail padding when the tile is built in place
+    char* const buf = smem_raw + C64_W_BYTES + grp * BUFB;                 // this group's halo buffer
+    const uint32_t buf_lds = lds0 + C64_W_BYTES + grp * BUFB;
     uint32_t bb[4][3];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -616,20 +642,136 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
 
     // bias lives in LDS behind the halo buffers (256 B): holding it in registers (32 VGPRs) spills next to 64 accumulators,
     // 48 fragment registers and the DMA / fragment address tables
-    float* const bias_lds = reinterpret_cast<float*>(smem_raw + C64_SMEM);
+    float* const bias_lds = reinterpret_cast<float*>(smem_raw + C64_W_BYTES + 2 * BUFB);
     if (tid < 64) bias_lds[tid] = bias[ct * 64 + tid];
+    float* const bias1a_lds = bias_lds + 64;                              // FUSE1A only
+    uint32_t* const lut_lds = reinterpret_cast<uint32_t*>(bias_lds + 128);
+    if constexpr (FUSE1A) {
+        if (tid < 64) bias1a_lds[tid] = fz.bias1a[tid];
+        if (tid < 256) lut_lds[tid] = fz.lut_hl[tid];
+    }
     auto bias4 = [&](int m, float4 (&bs)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const float4*>(bias_lds + m * 32 + 8 * g + 4 * hh);
     };
 
+    // ---- FUSE1A: wave wl builds halo pixels [96 wl, 96 wl + 96) = fragments 3 wl + fi (p = 32 (3 wl + fi) + n, row-major over the
+    // 10 x 34 tile): at most 4 halo rows, i.e. a 6-row x 40-byte patch of the u8 image (4-byte aligned columns).  ONE
+    // buffer_load_dword per wave fetches the patch (the descriptor's bounds check makes every address safe; rows/columns
+    // outside the image are clamped and masked later), it is parked in a wave-private 240-byte LDS slot (shared by the two
+    // groups, which never service at the same time) and the 27 taps of a lane are ds_read_u8 at immediate offsets.
+    const int fr_r0 = (96 * wl) / C64_ITW;
+    int fr_iy[3], fr_ix[3];                  // tile-invariant halo coordinates of this lane's pixel in its three fragments
+#pragma unroll
+    for (int fi = 0; fi < 3; ++fi) {
+        const int p = (3 * wl + fi) * 32 + n;
+        fr_iy[fi] = p / C64_ITW; fr_ix[fi] = p - fr_iy[fi] * C64_ITW;
+    }
+    unsigned char* const patch = reinterpret_cast<unsigned char*>(lut_lds + 256) + wl * 240;
+    auto build_issue = [&](int t, uint32_t& pv) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int j = lane / 10, d = lane - j * 10;
+        int yy = ty0 - 2 + fr_r0 + j, xo = ((tx0 - 2) & ~3) + 4 * d;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+        xo = xo < 0 ? 0 : (xo > fz.gstride - 4 ? fz.gstride - 4 : xo);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(fz.gray), 0, batch * H * fz.gstride, 0x00020000);
+        pv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (b * H + yy) * fz.gstride + xo, 0, 0);
+    };
+    // table reads and operand packing of all three fragments first (their latencies overlap), then MFMAs + stores per fragment
+    auto build_finish = [&](int t, uint32_t pv) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int cx0 = (tx0 - 2) & ~3, xsh = (tx0 - 2) - cx0;
+        {   // park the patch in LDS with everything that must read as x = 0 already zeroed: rows outside the image or inside the
+            // fisheye mask, columns outside the image (the loads were clamped to valid addresses) -- no per-tap checks later
+            const int j = lane / 10, d = lane - j * 10;
+            const int yy = ty0 - 2 + fr_r0 + j, x0c = cx0 + 4 * d;
+            const bool rok = yy >= 0 && yy < H && !(yy >= fz.mask_r0 && yy < fz.mask_r1);
+            uint32_t bm = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bm |= (x0c + k >= 0 && x0c + k < W) ? (0xFFu << (8 * k)) : 0u;
+            if (lane < 60) reinterpret_cast<uint32_t*>(patch)[lane] = rok ? (pv & bm) : 0u;
+        }
+        half8_t wa[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) wa[j][m] = *reinterpret_cast<const half8_t*>(fz.w1a_frag + ((j * 2 + m) * 64 + lane) * 8);
+        const int nf = (3 * wl + 2) * 32 < C64_PIX ? 3 : 2;                   // wave-uniform: fragments 0..10 over 4 waves
+        uint32_t T[3][9], pinm[3];
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) {
+            const int gy = ty0 - 1 + fr_iy[fi], gx = tx0 - 1 + fr_ix[fi];
+            // halo pixels outside the image are conv1b's zero padding: every tap and the bias slot read as 0
+            pinm[fi] = (fr_iy[fi] < C64_ITH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xFFFFFFFFu : 0u;
+            int iyc = fr_iy[fi] - fr_r0;                                      // tail lanes of fragment 10 (p >= 340): stay inside the patch
+            iyc = iyc > 3 ? 3 : iyc;
+            const unsigned char* pb = patch + iyc * 40 + fr_ix[fi] + xsh;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) T[fi][tp] = lut_lds[pb[(tp / 3) * 40 + tp % 3]] & pinm[fi];
+        }
+        half8_t B0[3], B1[3];
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) {
+            const uint32_t one = 0x3C00u & pinm[fi];                          // K slots 27/28 carry the bias (hi, lo) times 1.0
+            auto Hh = [&](int x, int y) { return (T[fi][x] & 0xFFFFu) | (T[fi][y] << 16); };
+            auto Ll = [&](int x, int y) { return (T[fi][x] >> 16) | (T[fi][y] & 0xFFFF0000u); };
+            uint32_t b0[4], b1[4];
+            if (hh == 0) {
+                b0[0] = Hh(0, 1); b0[1] = Hh(2, 3); b0[2] = Hh(4, 5); b0[3] = Hh(6, 7);
+                b1[0] = Ll(7, 8); b1[1] = Hh(0, 1); b1[2] = Hh(2, 3); b1[3] = Hh(4, 5);
+            } else {
+                b0[0] = (T[fi][8] & 0xFFFFu) | (T[fi][0] & 0xFFFF0000u); b0[1] = Ll(1, 2); b0[2] = Ll(3, 4); b0[3] = Ll(5, 6);
+                b1[0] = Hh(6, 7); b1[1] = (T[fi][8] & 0xFFFFu) | (one << 16); b1[2] = one; b1[3] = 0u;
+            }
+            B0[fi] = __builtin_bit_cast(half8_t, make_uint4(b0[0], b0[1], b0[2], b0[3]));
+            B1[fi] = __builtin_bit_cast(half8_t, make_uint4(b1[0], b1[1], b1[2], b1[3]));
+        }
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) {
+            if (fi >= nf) continue;
+            const int p = (3 * wl + fi) * 32 + n;
+            const uint32_t sw = (uint32_t)((p >> 1) & 7);
+            char* const prow = buf + p * 128 + 8 * hh;
+            floatx16 a1[2];
+            // the partner wave streams MFMAs back to back at priority 2: without outranking it for these four, each of them
+            // waits for a gap in a matrix pipe that has none
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a1[m][i] = 0.f;
+                a1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][m], B0[fi], a1[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][m], B1[fi], a1[m], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (p < C64_PIX) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<uint2*>(prow + (((uint32_t)(m * 4 + gq) ^ sw) << 4)) =
+                            make_uint2(pack_relu_f16(a1[m][4 * gq + 0], a1[m][4 * gq + 1], 1), pack_relu_f16(a1[m][4 * gq + 2], a1[m][4 * gq + 3], 1));
+            }
+        }
+    };
+
     // group g computes tiles k = g, g+2, ... in phases p = k; services (epilogue of k, DMA of k+2) in phase k+1.
     // group 0 loads its first tile here, group 1 during phase 0.
     int k_load = grp;                       // next tile index this group will DMA
+    __syncthreads();                         // weights / bias / table staged (FUSE1A reads them in the prologue already)
     if (grp == 0 && k_load < n_mine) {
-        issue(wg + k_load * nwg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        zero_fix(wg + k_load * nwg);
+        if constexpr (FUSE1A) {
+            uint32_t pv;
+            build_issue(wg + k_load * nwg, pv);
+            build_finish(wg + k_load * nwg, pv);
+        } else {
+            issue(wg + k_load * nwg);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            zero_fix(wg + k_load * nwg);
+        }
         k_load += 2;
     }
     __syncthreads();
@@ -654,8 +796,11 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 pp_load_step<0>(a_base0, a_base1, bb, fa0[0], fa1[0], fb0[0], fb1[0]);
                 pp_load_step<1>(a_base0, a_base1, bb, fa0[1], fa1[1], fb0[1], fb1[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(2);       // the matrix-pipe wave outranks its SIMD partner's service work
+                if (!(dbg & 16)) __builtin_amdgcn_s_setprio(2);       // the matrix-pipe wave outranks its SIMD partner's service work
+                const bool trc = FUSE1A && fz.trace && blockIdx.x == 0 && wl == 0 && lane == 0 && p >= 2 && p < 6;
+                if (trc) fz.trace[p * 8 + 4] = __builtin_amdgcn_s_memtime();
                 pp_mfma_steps<0, ABL>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
+                if (trc) fz.trace[p * 8 + 5] = __builtin_amdgcn_s_memtime();
                 __builtin_amdgcn_s_setprio(0);
                 t_pending = wg + p * nwg;
             }
@@ -667,7 +812,15 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
             else { bias4(0, bs[0]); bias4(1, bs[1]); }
             __builtin_amdgcn_sched_barrier(0);
             const bool load = k_load < n_mine && !(dbg & 1);
-            if (load) issue(wg + k_load * nwg);
+            if (dbg & 32) __builtin_amdgcn_s_setprio(3);
+            uint32_t pv = 0;
+            const bool tr = FUSE1A && fz.trace && blockIdx.x == 0 && wl == 0 && lane == 0 && p >= 2 && p < 6;
+            if (tr) fz.trace[p * 8 + 0] = __builtin_amdgcn_s_memtime();
+            if (load) {
+                if constexpr (FUSE1A) build_issue(wg + k_load * nwg, pv);   // the patch load flies under the epilogue
+                else issue(wg + k_load * nwg);
+            }
+            if (tr) fz.trace[p * 8 + 1] = __builtin_amdgcn_s_memtime();
             bool full = false;               // every lane of every store instruction of the epilogue is active
             if (t_pending >= 0 && !(dbg & 2)) {
                 int b, ty0, tx0;
@@ -682,9 +835,9 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                     float v[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float q0 = fmaxf(acc[0][0][i], acc[0][1][i]), q1 = fmaxf(acc[1][0][i], acc[1][1][i]);
-                        q0 = fmaxf(q0, dpp_swap_pairs(q0));
-                        q1 = fmaxf(q1, dpp_swap_pairs(q1));
+                        float q0 = vmax(acc[0][0][i], acc[0][1][i]), q1 = vmax(acc[1][0][i], acc[1][1][i]);
+                        q0 = vmax(q0, dpp_swap_pairs(q0));
+                        q1 = vmax(q1, dpp_swap_pairs(q1));
                         v[i] = odd ? q1 : q0;
                     }
                     _Float16* o = out + (((int64_t)b * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * cout + ct * 64 + (odd ? 32 : 0);
@@ -705,7 +858,12 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 }
                 t_pending = -1;
             }
-            if (load) {
+            if (tr) fz.trace[p * 8 + 2] = __builtin_amdgcn_s_memtime();
+            if (load && FUSE1A) {
+                if constexpr (FUSE1A) build_finish(wg + k_load * nwg, pv);
+                if (tr) fz.trace[p * 8 + 3] = __builtin_amdgcn_s_memtime();
+                k_load += 2;
+            } else if (load) {
                 // vmcnt retires in issue order: the DMA loads were issued before the epilogue's stores, so waiting down to
                 // the number of store instructions leaves the stores in flight across the barrier (only when every store
                 // instruction was certainly issued, i.e. the output tile is interior; otherwise wait for everything)
@@ -719,23 +877,26 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 k_load += 2;
             }
         }
+        if (dbg & 32) __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes (zero-fix) done; global stores may stay in flight
         __builtin_amdgcn_s_barrier();
     }
 }
 
-template <bool POOL, int ABL>
-static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int dbg) {
-    auto kfn = conv3x3_c64_pp_kernel<POOL, ABL>;
-    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM));
+template <bool POOL, int ABL, bool FUSE1A = false>
+static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int dbg, const Fuse1aArgs& fz = Fuse1aArgs{}) {
+    auto kfn = conv3x3_c64_pp_kernel<POOL, ABL, FUSE1A>;
+    constexpr int smem_bytes = FUSE1A ? PP_SMEM_FUSED : PP_SMEM;
+    static_assert(smem_bytes <= 160 * 1024, "LDS budget");
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes));
     const int tiles_x = cdiv(a.W, CONV_TW), tiles_y = cdiv(a.H, CONV_TH), n_ct = a.cout / 64;
     const int total = a.batch * tiles_x * tiles_y;
     int per_ct = n_cu / n_ct;
     if (per_ct < 1) per_ct = 1;
     if (per_ct > cdiv(total, 2)) per_ct = cdiv(total, 2);      // at least two tiles per workgroup: one per wave group
-    hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), PP_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
+    hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), smem_bytes, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
-                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg);
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg, fz);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
@@ -761,6 +922,69 @@ static int launch_conv(hipStream_t st, const ConvArgs& a) {
                        a.bias, a.H, a.W, a.cin, a.cout, a.relu ? 1 : 0, a.out_f32 ? 1 : 0, a.in_cstride > 0 ? a.in_cstride : a.cin);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
+}
+
+// conv1a (from the u8 image) + conv1b + ReLU + 2x2 max-pool in one launch (fp16 path); a.in is unused
+int conv1ab_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const _Float16* w1a_frag,
+                  const float* bias1a, const uint32_t* lut_hl) {
+    OMNI_REQUIRE(a.cin == 64 && a.cout % 64 == 0 && a.ksize == 3 && a.pool && a.n_cu > 0, OMNI_ERR_INVALID, "conv1ab_fused: bad layer shape");
+    OMNI_REQUIRE(gstride % 4 == 0 && ((uintptr_t)gray & 3) == 0 && (int64_t)a.batch * a.H * gstride < (1ll << 31), OMNI_ERR_INVALID,
+                 "conv1ab_fused: image rows must be 4-byte aligned (stride %d)", gstride);
+    Fuse1aArgs fz;
+    fz.gray = gray; fz.gstride = gstride;
+    fz.mask_r0 = fisheye_mask ? a.H * 3 / 4 : a.H; fz.mask_r1 = fisheye_mask ? a.H * 3 / 4 + a.H / 4 : a.H;   // cv::Rect(0, rows*3/4, cols, rows/4)
+    fz.w1a_frag = w1a_frag; fz.bias1a = bias1a; fz.lut_hl = lut_hl; fz.trace = nullptr;
+    static const bool want_trace = [] { const char* e = getenv("OMNI_PP_TRACE"); return e && e[0] == '1'; }();
+    static unsigned long long* trace_dev = nullptr;
+    if (want_trace) {
+        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
+        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * 8, st));
+        fz.trace = trace_dev;
+    }
+    static const int dbg = [] { const char* e = getenv("OMNI_PP_DBG"); return e ? atoi(e) : 0; }();   // timing ablations only
+    const int rc = launch_conv_pp_abl<true, 0, true>(st, a, a.n_cu, dbg, fz);
+    if (want_trace && rc == OMNI_OK) {
+        unsigned long long h[64];
+        OMNI_HIP_TRY(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, st));
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
+        static int printed = 0;
+        if (printed++ == 20)
+            for (int p = 2; p < 6; ++p)
+                fprintf(stderr, "pp trace phase %d: service start %llu issue +%llu epilogue +%llu build +%llu | mfma loop %llu cycles (start +%lld vs service start)\n", p,
+                        h[p * 8], h[p * 8 + 1] - h[p * 8], h[p * 8 + 2] - h[p * 8 + 1], h[p * 8 + 3] - h[p * 8 + 2], h[p * 8 + 5] - h[p * 8 + 4],
+                        (long long)(h[p * 8 + 4] - h[p * 8]));
+    }
+    return rc;
+}
+
+static inline uint16_t f2h_bits(float v) { const __half h = __float2half_rn(v); uint16_t u; memcpy(&u, &h, 2); return u; }
+static inline float h2f(uint16_t u) { __half h; memcpy(&h, &u, 2); return __half2float(h); }
+// w [64][9] fp32 -> A fragments [j][m][lane = hh*32 + i][e] of the split weights over K slots kk = 16 j + 8 hh + e:
+// kk 0-8: wh[kk], 9-17: wh[kk-9], 18-26: wl[kk-18], 27: bias hi, 28: bias lo, 29-31: 0   (wh = half(w), wl = half(w - wh))
+void conv1a_pack_split_weights(const float* w, const float* bias, uint16_t* frag /*2*2*64*8*/) {
+    for (int j = 0; j < 2; ++j)
+        for (int m = 0; m < 2; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = m * 32 + (l & 31), kk = 16 * j + 8 * (l >> 5) + e;
+                    uint16_t v = 0;
+                    if (kk < 27) {
+                        const float wf = w[co * 9 + kk % 9];
+                        const uint16_t hi = f2h_bits(wf);
+                        v = (kk < 18) ? hi : f2h_bits(wf - h2f(hi));
+                    } else if (kk < 29) {                                     // slots 27 / 28: bias hi / lo, multiplied by x = 1.0
+                        const uint16_t hi = f2h_bits(bias[co]);
+                        v = (kk == 27) ? hi : f2h_bits(bias[co] - h2f(hi));
+                    }
+                    frag[((j * 2 + m) * 64 + l) * 8 + e] = v;
+                }
+}
+void conv1a_make_split_lut(uint32_t* lut /*256*/) {
+    for (int i = 0; i < 256; ++i) {
+        const float x = (float)((double)i * (1.0 / 255.0));                  // cv::Mat::convertTo(CV_32F, 1/255.0)
+        const uint16_t hi = f2h_bits(x);
+        lut[i] = (uint32_t)hi | ((uint32_t)f2h_bits(x - h2f(hi)) << 16);
+    }
 }
 
 int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {

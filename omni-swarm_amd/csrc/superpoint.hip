@@ -37,6 +37,9 @@ struct omni_sp {
     float *wPbA = nullptr, *wPbDust = nullptr; // convPb in MFMA A-fragment order + the dustbin row
     float* bias_heads = nullptr;             // [512]
     float* lut = nullptr;
+    uint16_t* w1a_frag = nullptr;            // conv1a split-fp16 A fragments (fused conv1a+conv1b, fp16 path)
+    uint32_t* lut_hl = nullptr;              // u8 -> (half hi, half lo) table
+    bool fuse1a = false;
     float* pca_compT = nullptr;
     float* pca_mean = nullptr;
     // activations
@@ -88,6 +91,14 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         float lut[256];
         for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i * (1.0 / 255.0));
         if ((rc = dev_upload((void**)&s->lut, lut, sizeof(lut), st))) return rc;
+    }
+    if (s->precision == OMNI_PREC_F16) {
+        std::vector<uint16_t> fr(2048);
+        conv1a_pack_split_weights(w->weight[L1A], w->bias[L1A], fr.data());
+        if ((rc = dev_upload((void**)&s->w1a_frag, fr.data(), fr.size() * 2, st))) return rc;
+        uint32_t lh[256];
+        conv1a_make_split_lut(lh);
+        if ((rc = dev_upload((void**)&s->lut_hl, lh, sizeof(lh), st))) return rc;
     }
     // packed MFMA weights
     auto pack_upload = [&](int l, const float* w_oihw, int cin, int cout, int ks) -> int {
@@ -178,9 +189,15 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         return conv_mfma(st, P, a);
     };
     if ((rc = mark())) return rc;
-    if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc;
+    s->fuse1a = (P == OMNI_PREC_F16 && s->conv_variant == 0 && stride % 4 == 0 && ((uintptr_t)gray_dev & 3) == 0);   // else: separate conv1a
+    if (!s->fuse1a) { if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
     if ((rc = mark())) return rc;
-    if ((rc = conv(L1B, s->a1a, s->a1b, s->bias[L1B], H, W, 64, 64, 3, true, true, false))) return rc;
+    if (s->fuse1a) {   // conv1a is computed inside conv1b's kernel: the conv1a activation tensor is never materialised
+        ConvArgs a;
+        a.in = nullptr; a.out = s->a1b; a.w_packed = s->wpk[L1B]; a.bias = s->bias[L1B]; a.batch = batch; a.H = H; a.W = W; a.cin = 64;
+        a.cout = 64; a.ksize = 3; a.relu = true; a.pool = true; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount;
+        if ((rc = conv1ab_fused(st, a, gray_dev, stride, fisheye_mask, reinterpret_cast<const _Float16*>(s->w1a_frag), s->bias[L1A], s->lut_hl))) return rc;
+    } else if ((rc = conv(L1B, s->a1a, s->a1b, s->bias[L1B], H, W, 64, 64, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;
     if ((rc = conv(L2A, s->a1b, s->a2a, s->bias[L2A], H / 2, W / 2, 64, 64, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
@@ -272,7 +289,7 @@ omni_sp* omni_sp_create(omni_ctx* ctx, const omni_sp_weights* w, const float* pc
     s->ctx = ctx; s->W = width; s->H = height; s->Hc = height / 8; s->Wc = width / 8; s->thres = thres; s->max_num = max_num;
     s->max_batch = max_batch; s->precision = precision; s->esz = precision == OMNI_PREC_F16 ? 2 : 4;
     s->pca_dim = pca_comp ? pca_dim : 0; s->desc_dim = pca_comp ? pca_dim : 256;
-    { const char* e = getenv("OMNI_CONV_V1"); s->conv_variant = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0; }
+    { const char* e = getenv("OMNI_CONV_V1"); s->conv_variant = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0; }
     if (omni::sp_init(s, w, pca_comp, pca_mean) != OMNI_OK) { omni_sp_destroy(s); return nullptr; }
     return s;
 }
@@ -282,7 +299,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
-    void* ptrs[] = {s->w1a, s->wPbT, s->wPbA, s->wPbDust, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
+    void* ptrs[] = {s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
                     s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -378,6 +395,7 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
                        {"desc", s->draw, 256, 8, OMNI_PREC_F32}};
     for (const Ent& e : tab) {
         if (strcmp(e.n, name) != 0) continue;
+        if (e.p == s->a1a && s->fuse1a) { omni::set_error("conv1a is fused into conv1b on this path and not materialised (OMNI_CONV_V1=3 keeps it)"); return OMNI_ERR_INVALID; }
         const int h = s->H / e.div, w = s->W / e.div;
         if (C) *C = e.c;
         if (Hl) *Hl = h;
