@@ -54,10 +54,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
+    # OMNI_BENCH_ONE_GPU=1 (bring-up only): run the N > 1 code path with every rank on GPU 0 and gloo instead of RCCL, to
+    # exercise the sharded step on a 1-GPU box; the result is NOT a scaling number
+    one_gpu = os.environ.get("OMNI_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import omni_loader
@@ -106,7 +114,8 @@ def main():
         swarm = None
     else:
         det = None
-        swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, torch.device("cuda", local_rank))
+        coll_dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)     # where the all_gather payloads live
+        swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, coll_dev)
         per_rank = 4 * args.db_keyframes // world
         swarm.preload_local(random_rows(per_rank), per_rank * world)
 
@@ -158,7 +167,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=torch.device("cuda", local_rank))
+        t = torch.tensor([dt], device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kfps = args.steps * world / dt
@@ -185,7 +194,7 @@ def main():
         midx.add(random_rows(min(8192, rows_here - s)))
     mq = random_rows(1)
     if world > 1:
-        big = shard.ShardedIndex(midx, rank, world, dist, torch.device("cuda", local_rank))
+        big = shard.ShardedIndex(midx, rank, world, dist, coll_dev)
         search = lambda: big.search(mq, K_SEARCH)
     else:
         search = lambda: midx.search(mq, K_SEARCH)
@@ -199,7 +208,7 @@ def main():
         scan.append(midx.last_scan_ms())
     lat, scan = lat[10:], scan[10:]
     if dist is not None:
-        t = torch.tensor([float(np.median(lat))], device=torch.device("cuda", local_rank))
+        t = torch.tensor([float(np.median(lat))], device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         p50 = float(t.item())
     else:

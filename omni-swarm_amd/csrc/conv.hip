@@ -434,21 +434,36 @@ __device__ __forceinline__ float vrelu(float a) { const int b = __builtin_bit_ca
 __device__ __forceinline__ float dpp_swap_pairs(float v) {      // value of lane ^ 1 (quad_perm [1,0,3,2]): a VALU modifier, no LDS
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
+// two floats -> packed halfs (RNE) -> ReLU.  relu(cvt(x)) == cvt(relu(x)) exactly (rounding is monotone and keeps the sign), and
+// on the packed bit patterns ReLU is one v_pk_max_i16 (negative halfs and -0 are negative 16-bit integers)
+typedef short short2_t __attribute__((ext_vector_type(2)));
+// PK = false: ReLU on the floats first (two v_max_i32).  Measured A/B on MI355X (tools/ab.sh): the packed form wins in the pooled
+// conv1b kernel (0.146 -> 0.139 ms), the unpacked one in the non-pooled layers (conv2a 0.054 -> 0.050 ms) -- scheduling next to
+// the partner wave's MFMA stream, not instruction count, decides.
+template <bool PK = true>
 __device__ __forceinline__ uint32_t pack_relu_f16(float a, float b, int relu) {
-    if (relu) { a = vrelu(a); b = vrelu(b); }
+    if constexpr (!PK) {
+        if (relu) { a = vrelu(a); b = vrelu(b); }
+        float2_t f0; f0[0] = a; f0[1] = b;
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f0, half2_t));
+    }
     float2_t f; f[0] = a; f[1] = b;
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2_t));
+    const half2_t h = __builtin_convertvector(f, half2_t);
+    if (!relu) return __builtin_bit_cast(uint32_t, h);
+    const short2_t z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(short2_t, h), z));
 }
 // 16 accumulator values of one 32-channel M-fragment (+ bias) -> two 16-byte NHWC stores per lane: the lower half-wave
 // (hh = 0) ends up with channels [16 gp, 16 gp + 8) and the upper one with [16 gp + 8, 16 gp + 16) of pair gp after one
 // v_permlane32_swap per dword (the half-waves hold interleaved 4-channel runs of the same pixel).
+template <bool PK>
 __device__ __forceinline__ void store_frag16(const float (&v)[16], const float4 (&bs)[4], _Float16* __restrict__ pix_base /* + m*32 */, int hh,
                                              int relu, bool pred) {
     uint32_t d[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        d[g][0] = pack_relu_f16(v[4 * g + 0] + bs[g].x, v[4 * g + 1] + bs[g].y, relu);
-        d[g][1] = pack_relu_f16(v[4 * g + 2] + bs[g].z, v[4 * g + 3] + bs[g].w, relu);
+        d[g][0] = pack_relu_f16<PK>(v[4 * g + 0] + bs[g].x, v[4 * g + 1] + bs[g].y, relu);
+        d[g][1] = pack_relu_f16<PK>(v[4 * g + 2] + bs[g].z, v[4 * g + 3] + bs[g].w, relu);
     }
 #pragma unroll
     for (int gp = 0; gp < 2; ++gp) {
@@ -668,6 +683,9 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         fr_iy[fi] = p / C64_ITW; fr_ix[fi] = p - fr_iy[fi] * C64_ITW;
     }
     unsigned char* const patch = reinterpret_cast<unsigned char*>(lut_lds + 256) + wl * 240;
+    int tap_off[5];                          // patch offsets of this half-wave's taps: 0-4 (lanes 0-31) or 5-8 (+ a dummy) (lanes 32-63)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int tp = hh ? (k < 4 ? 5 + k : 8) : k; tap_off[k] = (tp / 3) * 40 + tp % 3; }
     auto build_issue = [&](int t, uint32_t& pv) {
         int b, ty0, tx0;
         tile_origin(t, b, ty0, tx0);
@@ -699,33 +717,31 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
 #pragma unroll
             for (int m = 0; m < 2; ++m) wa[j][m] = *reinterpret_cast<const half8_t*>(fz.w1a_frag + ((j * 2 + m) * 64 + lane) * 8);
         const int nf = (3 * wl + 2) * 32 < C64_PIX ? 3 : 2;                   // wave-uniform: fragments 0..10 over 4 waves
-        uint32_t T[3][9], pinm[3];
-#pragma unroll
-        for (int fi = 0; fi < 3; ++fi) {
-            const int gy = ty0 - 1 + fr_iy[fi], gx = tx0 - 1 + fr_ix[fi];
-            // halo pixels outside the image are conv1b's zero padding: every tap and the bias slot read as 0
-            pinm[fi] = (fr_iy[fi] < C64_ITH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xFFFFFFFFu : 0u;
-            int iyc = fr_iy[fi] - fr_r0;                                      // tail lanes of fragment 10 (p >= 340): stay inside the patch
-            iyc = iyc > 3 ? 3 : iyc;
-            const unsigned char* pb = patch + iyc * 40 + fr_ix[fi] + xsh;
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) T[fi][tp] = lut_lds[pb[(tp / 3) * 40 + tp % 3]] & pinm[fi];
-        }
+        // K slots are split between the half-waves so that a lane touches only its own taps: lanes 0-31 own taps 0-4, lanes 32-63
+        // taps 5-8 and the bias.  Per MFMA a lane supplies 8 slots = 4 dwords:
+        //   hh = 0:  [xh0 xl0][xh1 xl1][xh2 xl2][xh3 xl3] | [xh4 xl4][xh0 xh1][xh2 xh3][xh4 0]     (weights wh,wh per tap | wh4 wh4 wl0..wl4 0)
+        //   hh = 1:  [xh5 xl5][xh6 xl6][xh7 xl7][xh8 xl8] | [xh5 xh6][xh7 xh8][1 1][0 0]           (weights wh,wh per tap | wl5..wl8 bias_hi bias_lo 0 0)
+        // and the table entry (xh | xl << 16) IS the first kind of dword.
         half8_t B0[3], B1[3];
 #pragma unroll
         for (int fi = 0; fi < 3; ++fi) {
-            const uint32_t one = 0x3C00u & pinm[fi];                          // K slots 27/28 carry the bias (hi, lo) times 1.0
-            auto Hh = [&](int x, int y) { return (T[fi][x] & 0xFFFFu) | (T[fi][y] << 16); };
-            auto Ll = [&](int x, int y) { return (T[fi][x] >> 16) | (T[fi][y] & 0xFFFF0000u); };
-            uint32_t b0[4], b1[4];
-            if (hh == 0) {
-                b0[0] = Hh(0, 1); b0[1] = Hh(2, 3); b0[2] = Hh(4, 5); b0[3] = Hh(6, 7);
-                b1[0] = Ll(7, 8); b1[1] = Hh(0, 1); b1[2] = Hh(2, 3); b1[3] = Hh(4, 5);
-            } else {
-                b0[0] = (T[fi][8] & 0xFFFFu) | (T[fi][0] & 0xFFFF0000u); b0[1] = Ll(1, 2); b0[2] = Ll(3, 4); b0[3] = Ll(5, 6);
-                b1[0] = Hh(6, 7); b1[1] = (T[fi][8] & 0xFFFFu) | (one << 16); b1[2] = one; b1[3] = 0u;
-            }
-            B0[fi] = __builtin_bit_cast(half8_t, make_uint4(b0[0], b0[1], b0[2], b0[3]));
+            const int gy = ty0 - 1 + fr_iy[fi], gx = tx0 - 1 + fr_ix[fi];
+            // halo pixels outside the image are conv1b's zero padding: every tap and the bias slots read as 0
+            const uint32_t pinm = (fr_iy[fi] < C64_ITH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xFFFFFFFFu : 0u;
+            int iyc = fr_iy[fi] - fr_r0;                                      // tail lanes of fragment 10 (p >= 340): stay inside the patch
+            iyc = iyc > 3 ? 3 : iyc;
+            const unsigned char* pb = patch + iyc * 40 + fr_ix[fi] + xsh;
+            uint32_t T[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) T[k] = lut_lds[pb[tap_off[k]]] & pinm;
+            const uint32_t h01 = (T[0] & 0xFFFFu) | (T[1] << 16), h23 = (T[2] & 0xFFFFu) | (T[3] << 16);
+            const uint32_t one2 = 0x3C003C00u & pinm;
+            uint32_t b1[4];
+            b1[0] = hh ? h01 : T[4];
+            b1[1] = hh ? h23 : h01;
+            b1[2] = hh ? one2 : h23;
+            b1[3] = hh ? 0u : (T[4] & 0xFFFFu);
+            B0[fi] = __builtin_bit_cast(half8_t, make_uint4(T[0], T[1], T[2], T[3]));
             B1[fi] = __builtin_bit_cast(half8_t, make_uint4(b1[0], b1[1], b1[2], b1[3]));
         }
 #pragma unroll
@@ -835,13 +851,14 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                     float v[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
+                        // (sending only the fragment the partner keeps -- one exchange instead of two -- measured slower: 0.158 vs 0.139 ms)
                         float q0 = vmax(acc[0][0][i], acc[0][1][i]), q1 = vmax(acc[1][0][i], acc[1][1][i]);
                         q0 = vmax(q0, dpp_swap_pairs(q0));
                         q1 = vmax(q1, dpp_swap_pairs(q1));
                         v[i] = odd ? q1 : q0;
                     }
                     _Float16* o = out + (((int64_t)b * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * cout + ct * 64 + (odd ? 32 : 0);
-                    store_frag16(v, bs[0], o, hh, relu, (oy < H) && (ox < W));
+                    store_frag16<true>(v, bs[0], o, hh, relu, (oy < H) && (ox < W));
                 } else {
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
@@ -852,7 +869,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
 #pragma unroll
                             for (int i = 0; i < 16; ++i) v[i] = acc[m][f][i];
                             _Float16* o = out + (((int64_t)b * H + oy) * W + ox) * cout + ct * 64 + m * 32;
-                            store_frag16(v, bs[m], o, hh, relu, (oy < H) && (ox < W));
+                            store_frag16<false>(v, bs[m], o, hh, relu, (oy < H) && (ox < W));
                         }
                     }
                 }
@@ -959,23 +976,22 @@ int conv1ab_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gs
 
 static inline uint16_t f2h_bits(float v) { const __half h = __float2half_rn(v); uint16_t u; memcpy(&u, &h, 2); return u; }
 static inline float h2f(uint16_t u) { __half h; memcpy(&h, &u, 2); return __half2float(h); }
-// w [64][9] fp32 -> A fragments [j][m][lane = hh*32 + i][e] of the split weights over K slots kk = 16 j + 8 hh + e:
-// kk 0-8: wh[kk], 9-17: wh[kk-9], 18-26: wl[kk-18], 27: bias hi, 28: bias lo, 29-31: 0   (wh = half(w), wl = half(w - wh))
+// w [64][9] fp32, bias [64] -> A fragments [j][m][lane = hh*32 + i][e] of the split weights (wh = half(w), wl = half(w - wh)); the K
+// slot (j, hh, e) pairs with the B operand built in the fused kernel:
+//   hh = 0:  j = 0: wh0 wh0 wh1 wh1 wh2 wh2 wh3 wh3      j = 1: wh4 wh4 wl0 wl1 wl2 wl3 wl4 0
+//   hh = 1:  j = 0: wh5 wh5 wh6 wh6 wh7 wh7 wh8 wh8      j = 1: wl5 wl6 wl7 wl8 bias_hi bias_lo 0 0
 void conv1a_pack_split_weights(const float* w, const float* bias, uint16_t* frag /*2*2*64*8*/) {
     for (int j = 0; j < 2; ++j)
         for (int m = 0; m < 2; ++m)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 8; ++e) {
-                    const int co = m * 32 + (l & 31), kk = 16 * j + 8 * (l >> 5) + e;
+                    const int co = m * 32 + (l & 31), hh = l >> 5;
+                    auto hi = [&](int t) { return f2h_bits(w[co * 9 + t]); };
+                    auto lo = [&](int t) { return f2h_bits(w[co * 9 + t] - h2f(f2h_bits(w[co * 9 + t]))); };
                     uint16_t v = 0;
-                    if (kk < 27) {
-                        const float wf = w[co * 9 + kk % 9];
-                        const uint16_t hi = f2h_bits(wf);
-                        v = (kk < 18) ? hi : f2h_bits(wf - h2f(hi));
-                    } else if (kk < 29) {                                     // slots 27 / 28: bias hi / lo, multiplied by x = 1.0
-                        const uint16_t hi = f2h_bits(bias[co]);
-                        v = (kk == 27) ? hi : f2h_bits(bias[co] - h2f(hi));
-                    }
+                    if (j == 0) v = hi((hh ? 5 : 0) + e / 2);
+                    else if (hh == 0) v = e < 2 ? hi(4) : (e < 7 ? lo(e - 2) : 0);
+                    else v = e < 4 ? lo(5 + e) : (e == 4 ? f2h_bits(bias[co]) : (e == 5 ? f2h_bits(bias[co] - h2f(f2h_bits(bias[co]))) : 0));
                     frag[((j * 2 + m) * 64 + l) * 8 + e] = v;
                 }
 }
