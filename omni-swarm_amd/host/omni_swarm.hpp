@@ -6,6 +6,7 @@
 //   omni::IndexFlatIP          <-> faiss::IndexFlatIP             (add / search / ntotal; loop_detector.cpp:166-170,213,232,291)
 //   omni::BFMatcherL2X         <-> cv::BFMatcher(NORM_L2, true)   (match; loop_cam.cpp:147-150, loop_detector.cpp:564-567)
 //   omni::LoopDetectorCore     <-> LoopDetector's DB + decision rules (loop_detector.cpp:11-287), geometry via callback
+//   omni::LoopCamHIP           <-> the CNN + matching work of LoopCam::on_flattened_images (loop_cam.cpp:178-229) as one async unit
 //
 // Compiles with plain g++ (no HIP, ROS, OpenCV or faiss headers); link with -lomni_hip.  Define OMNI_WITH_OPENCV to get
 // the cv::Mat / cv::Point2f / cv::DMatch overloads the reference call sites use verbatim.
@@ -223,6 +224,8 @@ public:
 #ifdef OMNI_WITH_OPENCV
     std::vector<float> inference(const cv::Mat& input) { return inference(input.data, (int)input.step); }
 #endif
+    omni_vlad* handle() const { return h_; }
+    int out_dim() const { return out_dim_; }
     int last_status = OMNI_OK;
 private:
     omni_vlad* h_ = nullptr;
@@ -232,6 +235,53 @@ private:
 }  // namespace Swarm
 
 namespace omni {
+
+// The CNN + matching part of LoopCam::on_flattened_images (loop_cam.cpp:178-229): SuperPoint on the 2*n_dirs images of one
+// fisheye key frame (up cameras, then down cameras), MobileNetVLAD on the n_dirs up images, BFMatcher(L2, crossCheck) up <->
+// down per direction -- one asynchronous unit on the GPU (omni_cam_*), results in one pinned host block.  The reference runs
+// these 12 engine calls and 4 matches strictly serially; camera lifting / triangulation stay in LoopCam.
+//   superpoint_net must have been created with max_batch >= 2*n_dirs (on sp_ctx), netvlad_net with max_batch >= n_dirs (on
+//   vlad_ctx; a second Context = a second HIP stream lets the two networks overlap).
+class LoopCamHIP {
+public:
+    LoopCamHIP(Context& sp_ctx, Swarm::SuperPointHIP& superpoint_net, Context& vlad_ctx, Swarm::MobileNetVLADHIP& netvlad_net, int n_dirs,
+               int max_num, int width, int height)
+        : ctx_(sp_ctx), n_(n_dirs), w_(width), h_img_(height) {
+        h_ = omni_cam_create(sp_ctx.get(), superpoint_net.handle(), vlad_ctx.get(), netvlad_net.handle(), n_dirs, max_num, netvlad_net.out_dim(),
+                             OMNI_BF_OPENCV);
+        if (!h_) throw std::runtime_error(std::string("omni_cam_create: ") + omni_last_error());
+        gray_dev_ = static_cast<uint8_t*>(omni_dev_alloc(sp_ctx.get(), (size_t)2 * n_dirs * width * height));
+        if (!gray_dev_) { omni_cam_destroy(h_); throw std::runtime_error(std::string("omni_dev_alloc: ") + omni_last_error()); }
+    }
+    ~LoopCamHIP() { omni_cam_destroy(h_); omni_dev_free(ctx_.get(), gray_dev_); }
+    LoopCamHIP(const LoopCamHIP&) = delete;
+    LoopCamHIP& operator=(const LoopCamHIP&) = delete;
+
+    // images[0..n_dirs) = up cameras, images[n_dirs..2*n_dirs) = down cameras; each H rows of `stride` bytes (u8 gray).
+    // Uploads and enqueues; returns at once.  fisheye_mask zeroes rows [3H/4, H) (loop_cam.cpp:536-539).
+    void enqueue(const uint8_t* const* images, int stride, bool fisheye_mask = true) {
+        stage_.resize((size_t)2 * n_ * w_ * h_img_);
+        for (int i = 0; i < 2 * n_; ++i)
+            for (int y = 0; y < h_img_; ++y) std::memcpy(stage_.data() + ((size_t)i * h_img_ + y) * w_, images[i] + (size_t)y * stride, w_);
+        check(omni_memcpy_h2d(ctx_.get(), gray_dev_, stage_.data(), stage_.size()), "LoopCamHIP upload");
+        check(omni_cam_enqueue_dev(h_, gray_dev_, w_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_dev");
+    }
+    void enqueue_dev(const uint8_t* gray_dev, int stride, bool fisheye_mask = true) {      // images already in HBM
+        check(omni_cam_enqueue_dev(h_, gray_dev, stride, fisheye_mask ? 1 : 0), "omni_cam_enqueue_dev");
+    }
+    // blocks until the key frame is done; pointers stay valid until the next enqueue on this object
+    omni_cam_result wait() {
+        omni_cam_result r{};
+        check(omni_cam_wait(h_, &r), "omni_cam_wait");
+        return r;
+    }
+private:
+    Context& ctx_;
+    omni_cam* h_ = nullptr;
+    uint8_t* gray_dev_ = nullptr;
+    int n_, w_, h_img_;
+    std::vector<uint8_t> stage_;
+};
 
 // faiss::IndexFlatIP(d): the members LoopDetector touches
 class IndexFlatIP {

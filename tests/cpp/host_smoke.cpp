@@ -84,6 +84,23 @@ int main(int argc, char** argv) {
         std::printf(" %lld %d %d %d %lld %d %d", (long long)f.msg_id, (int)r.added, (int)r.queried, r.image_id, (long long)r.old_msg_id,
                     r.direction_old, (int)r.loop);
     }
+    // --- LoopCam::on_flattened_images as one asynchronous unit: one direction, the image as both the up and the down camera
+    {
+        omni::Context vctx(0);
+        Swarm::SuperPointHIP sp2(ctx, argv[1], argv[2], argv[3], W, H, 0.015f, 200, false, OMNI_PREC_F32, 2);
+        Swarm::MobileNetVLADHIP vl2(vctx, argv[4], W, H, false, 1);
+        omni::LoopCamHIP cam(ctx, sp2, vctx, vl2, 1, 200, W, H);
+        const uint8_t* imgs[2] = {img.data(), img.data()};
+        cam.enqueue(imgs, W, false);
+        const omni_cam_result r = cam.wait();
+        int same = r.n_kps[0] == (int)features.size() && r.n_kps[1] == r.n_kps[0];
+        for (int i = 0; same && i < r.n_kps[0]; ++i) same = r.kps_xy[2 * i] == features[i].x && r.kps_xy[2 * i + 1] == features[i].y;
+        for (size_t i = 0; same && i < feature_descriptor.size(); ++i) same = r.desc[i] == feature_descriptor[i];
+        for (int i = 0; same && i < r.global_dim; ++i) same = r.global_desc[i] == image_desc[i];
+        int diag = r.n_matches[0] == r.n_kps[0];                 // identical descriptor sets: every point matches itself at distance 0
+        for (int i = 0; diag && i < r.n_matches[0]; ++i) diag = r.match_up[i] == i && r.match_down[i] == i && r.match_dist[i] == 0.f;
+        std::printf("\nCAM %d %d %d", same, diag, r.n_matches[0]);
+    }
     std::printf("\nOK\n");
     return 0;
 }
