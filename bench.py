@@ -33,6 +33,20 @@ SP_FLOP_PER_IMAGE = 48.85e9   # SURVEY.md 2.3 @600x480
 KF_IMAGES = 8                 # reference-faithful key frame: 8 SuperPoint + 4 MobileNetVLAD
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of a kernel from the newest committed PMC pass (profiles/*_traffic.json, written from
+    `tools/profile_gpu.sh` output: bench.py cannot collect PMC counters on itself).  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1]))
+        return {"bytes_per_launch": t[key]["bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,7 +196,8 @@ def main():
     achieved = c1b_flop / (c1b["ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 "
                                           "in one launch; FLOP counted for conv1b only", "achieved": round(achieved, 1),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": pmc_traffic("conv3x3_c64_pp_kernel<POOL,FUSE1A>") if args.precision == "f16" else None,
                 "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4),
                 "conv_stack_tflops": round(SP_FLOP_PER_IMAGE * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
                 "stages_ms": {p["stage"]: round(p["ms"], 4) for p in prof}, "superpoint_batch8_ms": round(sp_ms, 3)}
@@ -216,7 +231,8 @@ def main():
     scan_ms = float(np.median(scan))
     gbs = rows_here * 4096 * 4 / (scan_ms * 1e-3) / 1e9
     roofline_knn = {"bound": "hbm", "kernel": "ip_scan_kernel<float,1>", "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": rows_here * 16384,
+                    "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "traffic": pmc_traffic("ip_scan_kernel<float,1>") if rows_here == 100_000 else None, "bytes_per_launch": rows_here * 16384,
                     "launch_ms": round(scan_ms, 4), "rows_per_gpu": rows_here}
     loop_match = {"p50_ms": round(p50, 4), "db_rows_node": args.match_db_rows, "db_rows_per_gpu": rows_here, "k": K_SEARCH,
                   "includes": "H2D query, scan, top-k, D2H result" + (", all_gather + merge" if world > 1 else "")}
