@@ -428,6 +428,9 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 // the epilogues below are instruction-count bound next to the partner wave's MFMA stream, so they use the bare instruction
 // (only on accumulators that were written a whole phase earlier: hipcc pads no MFMA hazard in front of inline asm)
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max(a, b) = median(a, b, +inf): one v_med3_f32, no canonicalisation, and visible to hipcc's hazard recogniser (usable right
+// behind the MFMAs that produced a and b)
+__device__ __forceinline__ float vmax_med3(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 // ReLU as an integer max on the bit pattern (negative floats and -0 are negative integers): one compiler-visible instruction,
 // so the MFMA -> VALU wait states in front of it are still inserted by hipcc (they are NOT for an inline-asm reader)
 __device__ __forceinline__ float vrelu(float a) { const int b = __builtin_bit_cast(int, a); return __builtin_bit_cast(float, b > 0 ? b : 0); }
@@ -929,6 +932,228 @@ static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v4 "register-stationary" kernel for the fp16 3x3 layers with 128 INPUT channels (conv3b, conv4a, conv4b, convPa|convDa:
+// 28 % of the FLOPs).  With 128 channels a halo pixel is 256 bytes: resident weights (147 KB per 64 output channels) and two
+// halo buffers no longer fit LDS together, and a 32-channel weight tile leaves too little register tiling for the LDS read
+// bandwidth.  So the weights leave LDS altogether:
+//   * 256 threads = 4 waves, ONE per SIMD with the whole 512-register file; wave w keeps the A fragments of ITS 32 output
+//     channels for all K = 9 x 128 in registers (72 fragments = 288 VGPRs, loaded once per workgroup) -- the four waves of a
+//     workgroup cover 128 output channels;
+//   * LDS holds only the input: two 8 x 34-pixel halo tiles (6 x 32 outputs, 69.6 KB each, 16-byte chunks XOR-swizzled with
+//     pixel & 15), filled by LDS-DMA for tile t+1 while tile t computes: one barrier per tile;
+//   * every wave sweeps the whole tile: per (kx, 16-channel group) the 8 halo rows are read ONCE (192 ds_read_b128 per tile) and
+//     each feeds up to three MFMAs (the three ky that map the row onto an output row): 432 MFMAs per tile per wave,
+//     0.44 LDS reads per MFMA.
+// ---------------------------------------------------------------------------------------------------------------
+#define RS_TH 6
+#define RS_TW 32
+#define RS_ITH (RS_TH + 2)
+#define RS_ITW (RS_TW + 2)
+#define RS_PIX (RS_ITH * RS_ITW)                 // 272 halo pixels
+#define RS_CHUNKS (RS_PIX * 16)                  // 4352 16-byte chunks = 68 wave-instructions of 1 KiB
+#define RS_BUF_BYTES (RS_PIX * 256)              // 69 632
+#define RS_SMEM (2 * RS_BUF_BYTES + 512)         // + this workgroup's 128 biases
+
+// read L = (kx * 8 + r) * 8 + kg: the 16-channel group kg is innermost so that eight consecutive reads share one address base
+// (computed on the fly: 24 resident bases would not fit next to 288 weight and 96 accumulator registers)
+template <int L>
+__device__ __forceinline__ void rs_read(uint32_t row_base /* lds + (n * 256) */, int n, int hh, half8_t& dst) {
+    constexpr int kx = L / 64, r = (L / 8) % 8, kg = L % 8;
+    constexpr int pc = r * RS_ITW + kx;
+    const uint32_t addr = (row_base + pc * 256 + ((((pc + n) & 15) ^ hh) << 4)) ^ (kg << 5);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int N>
+__device__ __forceinline__ void rs_wait(half8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(N)); }
+
+template <int L, typename IssueFn>
+__device__ __forceinline__ void rs_steps(uint32_t row_base, int n, int hh, const half8_t (&wreg)[72], floatx16 (&acc)[RS_TH], half8_t (&fb)[3],
+                                         IssueFn& issue_piece) {
+    if constexpr (L < 192) {
+        constexpr int kx = L / 64, r = (L / 8) % 8, kg = L % 8;
+        if constexpr (L + 2 < 192) rs_read<L + 2>(row_base, n, hh, fb[(L + 2) % 3]);
+        rs_wait<(L + 2 < 192) ? 2 : (L + 1 < 192 ? 1 : 0)>(fb[L % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (r >= 0 && r < RS_TH) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(0 * 3 + kx) * 8 + kg], fb[L % 3], acc[r], 0, 0, 0);
+        if constexpr (r - 1 >= 0 && r - 1 < RS_TH) acc[r - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(1 * 3 + kx) * 8 + kg], fb[L % 3], acc[r - 1], 0, 0, 0);
+        if constexpr (r - 2 >= 0 && r - 2 < RS_TH) acc[r - 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(2 * 3 + kx) * 8 + kg], fb[L % 3], acc[r - 2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rs_steps<L + 1>(row_base, n, hh, wreg, acc, fb, issue_piece);
+    }
+}
+
+template <bool POOL>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
+                       const float* __restrict__ bias, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hh = lane >> 5;
+    const int cg = blockIdx.x % n_cg, wg = blockIdx.x / n_cg, nwg = gridDim.x / n_cg;
+    const int tiles_per_img = tiles_x * tiles_y;
+    const int total = batch * tiles_per_img;
+    const int g32 = cg * 4 + wave;                 // this wave's group of 32 output channels
+
+    // A fragments: the generic packed layout [cout tile 64][cin chunk 64][tap][kg4][m][lane][8]; k-step s = tap * 8 + chunk * 4 + kg4
+    half8_t wreg[72];
+    {
+        const _Float16* wbase = wp + (int64_t)(g32 >> 1) * 2 * 9 * 4096 + (g32 & 1) * 512 + lane * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 72; ++s2) {
+            const int tap = s2 >> 3, ch = (s2 >> 2) & 1, kg4 = s2 & 3;
+            wreg[s2] = *reinterpret_cast<const half8_t*>(wbase + ((ch * 9 + tap) * 4 + kg4) * 1024);
+        }
+    }
+    float* const bias_lds = reinterpret_cast<float*>(smem_raw + 2 * RS_BUF_BYTES);
+    if (tid < 128) bias_lds[tid] = bias[cg * 128 + tid];
+
+    auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
+        b = t / tiles_per_img;
+        const int r = t - b * tiles_per_img;
+        ty0 = (r / tiles_x) * RS_TH; tx0 = (r % tiles_x) * RS_TW;
+    };
+    // DMA instruction wi = 17 wave + j of tile t into buffer `which` (68 wave-instructions of 1 KiB per tile)
+    int lane_o = lane;                        // re-blinded per tile: keeps the 17 per-piece address terms from being hoisted into registers
+    auto issue_one = [&](int t, int which, int j) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int y0 = ty0 - 1, x0 = tx0 - 1;
+        const _Float16* img = in + (int64_t)b * H * W * 128;
+        char* base = smem_raw + which * RS_BUF_BYTES;
+        const int wi = wave * 17 + j;
+        const int idx = wi * 64 + lane_o;
+        const int pix = idx >> 4, phys = idx & 15;
+        const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
+        int gy = y0 + iy, gx = x0 + ix;
+        gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);            // clamped to a valid address, zero-fixed after landing
+        gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+        const int logical = phys ^ (pix & 15);
+        const _Float16* g = img + ((int64_t)gy * W + gx) * 128 + logical * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(base + wi * 1024), 16, 0, 0);
+    };
+    uint32_t goff[17];                        // interior tiles: byte offset of this lane's chunk of piece j relative to the halo origin
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {
+        const int idx = (wave * 17 + j) * 64 + lane;
+        const int pix = idx >> 4, phys = idx & 15;
+        const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
+        goff[j] = (uint32_t)((iy * W + ix) * 256 + ((phys ^ (pix & 15)) << 4));
+    }
+    auto issue = [&](int t, int which) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int y0 = ty0 - 1, x0 = tx0 - 1;
+        if (y0 >= 0 && y0 + RS_ITH <= H && x0 >= 0 && x0 + RS_ITW <= W) {       // interior (wave-uniform): base + 32-bit lane offset
+            const char* org = reinterpret_cast<const char*>(in + ((int64_t)b * H * W + (int64_t)y0 * W + x0) * 128);
+            char* base = smem_raw + which * RS_BUF_BYTES + wave * 17 * 1024;
+#pragma unroll
+            for (int j = 0; j < 17; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(org + goff[j]),
+                                                 (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+            return;
+        }
+#pragma unroll 1
+        for (int j = 0; j < 17; ++j) issue_one(t, which, j);
+    };
+    auto zero_fix = [&](int t, int which) {                      // every wave fixes the chunks its own DMA instructions wrote
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int y0 = ty0 - 1, x0 = tx0 - 1;
+        if (y0 >= 0 && y0 + RS_ITH <= H && x0 >= 0 && x0 + RS_ITW <= W) return;
+        char* base = smem_raw + which * RS_BUF_BYTES;
+#pragma unroll 1
+        for (int j = 0; j < 17; ++j) {
+            const int idx = (wave * 17 + j) * 64 + lane;
+            const int pix = idx >> 4;
+            const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
+            const int gy = y0 + iy, gx = x0 + ix;
+            if (gy < 0 || gy >= H || gx < 0 || gx >= W) *reinterpret_cast<uint4*>(base + idx * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    int t = wg;
+    if (t < total) issue(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t < total) zero_fix(t, 0);
+    __syncthreads();
+
+    int cur = 0;
+    for (; t < total; t += nwg, cur ^= 1) {
+        const int tn = t + nwg;
+        // (issuing these 17 DMA instructions from inside the MFMA loop, one every 10 reads, measured SLOWER: conv3b 0.055 -> 0.063 ms --
+        // an in-order wave pays for every instruction placed between its MFMAs)
+        if (tn < total) issue(tn, cur ^ 1);
+        auto issue_piece = [&](int) {};
+        const uint32_t row_base = lds0 + cur * RS_BUF_BYTES + n * 256;
+        floatx16 acc[RS_TH];
+#pragma unroll
+        for (int f = 0; f < RS_TH; ++f)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+        half8_t fb[3];
+        rs_read<0>(row_base, n, hh, fb[0]);
+        rs_read<1>(row_base, n, hh, fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        rs_steps<0>(row_base, n, hh, wreg, acc, fb, issue_piece);
+
+        {   // epilogue: (2x2 max-pool) + bias + ReLU, 16-byte NHWC stores
+            int b, ty0, tx0;
+            tile_origin(t, b, ty0, tx0);
+            const int ox = tx0 + n;
+            float4 bs[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const float4*>(bias_lds + wave * 32 + 8 * g + 4 * hh);
+            if constexpr (POOL) {
+#pragma unroll
+                for (int f2 = 0; f2 < RS_TH / 2; ++f2) {
+                    const int oy = ty0 + 2 * f2;
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float q = vmax_med3(acc[2 * f2][i], acc[2 * f2 + 1][i]);
+                        v[i] = vmax_med3(q, dpp_swap_pairs(q));
+                    }
+                    _Float16* o = out + (((int64_t)b * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * cout + g32 * 32;
+                    store_frag16<false>(v, bs, o, hh, relu, (oy < H) && (ox < W) && !(n & 1));
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < RS_TH; ++f) {
+                    const int oy = ty0 + f;
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = acc[f][i];
+                    _Float16* o = out + (((int64_t)b * H + oy) * W + ox) * cout + g32 * 32;
+                    store_frag16<false>(v, bs, o, hh, relu, (oy < H) && (ox < W));
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile landed (and this tile's stores retired)
+        if (tn < total) zero_fix(tn, cur ^ 1);
+        __syncthreads();
+    }
+}
+
+template <bool POOL>
+static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
+    auto kfn = conv3x3_c128_rs_kernel<POOL>;
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_SMEM));
+    const int tiles_x = cdiv(a.W, RS_TW), tiles_y = cdiv(a.H, RS_TH), n_cg = a.cout / 128;
+    const int total = a.batch * tiles_x * tiles_y;
+    int per_cg = n_cu / n_cg;
+    if (per_cg < 1) per_cg = 1;
+    if (per_cg > total) per_cg = total;
+    hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), RS_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
+                       reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_cg,
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 template <typename T, int KS, bool POOL>
 static int launch_conv(hipStream_t st, const ConvArgs& a) {
     const size_t smem = conv_smem_bytes<T, KS>();
@@ -1013,6 +1238,9 @@ int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {
         if (a.variant == 2) return a.pool ? launch_conv_c64<true>(st, a, a.n_cu) : launch_conv_c64<false>(st, a, a.n_cu);
         return a.pool ? launch_conv_pp<true>(st, a, a.n_cu) : launch_conv_pp<false>(st, a, a.n_cu);
     }
+    if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 128 && a.cout % 128 == 0 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 128) &&
+        a.n_cu > 0 && a.variant == 0 && (!a.pool || a.H % 2 == 0))
+        return a.pool ? launch_conv_rs<true>(st, a, a.n_cu) : launch_conv_rs<false>(st, a, a.n_cu);
     if (precision == OMNI_PREC_F16) {
         if (a.ksize == 3) return a.pool ? launch_conv<_Float16, 3, true>(st, a) : launch_conv<_Float16, 3, false>(st, a);
         return launch_conv<_Float16, 1, false>(st, a);

@@ -130,7 +130,8 @@ def test_f16_path_tolerances(omni, ctx):
 def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, monkeypatch):
     """The cin=64 kernels (v3 8-wave ping-pong, v2 persistent LDS-DMA) and the generic kernel accumulate K in the same
     order: same bits.  Odd sizes exercise border tiles, partial tiles and workgroups with a single tile.
-    OMNI_CONV_V1: 3 = ping-pong without the conv1a fusion, 1 = generic kernels, 2 = v2, 0 = default (conv1a fused into conv1b)."""
+    OMNI_CONV_V1: 3 = ping-pong without the conv1a fusion, 1 = generic kernels, 2 = v2, 0 = default (conv1a fused into conv1b,
+    cin=128 layers on the register-stationary kernel)."""
     weights = S.synth_weights(0)
     for (h, w, nb) in ((480, 600, 2), (72, 104, 1), (208, 400, 3)):
         imgs = np.stack([synth.image_u8(30 + i, h, w) for i in range(nb)])
@@ -154,6 +155,10 @@ def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, m
         d = np.abs(outs["0"][0] - outs["3"][0])
         assert d.max() < 2e-2 * max(1.0, np.abs(outs["3"][0]).max()) and d.mean() < 1e-5, (d.max(), d.mean())
         assert np.abs(outs["0"][4] - outs["3"][4]).max() < 5e-3              # heat map (the f16 path's tolerance vs the fp32 oracle)
+        # variant 0 also runs the cin=128 layers on the register-stationary kernel (another K order): dense descriptors agree
+        # to fp16-path accuracy
+        rel = np.linalg.norm(outs["0"][5] - outs["3"][5], axis=1) / np.linalg.norm(outs["3"][5], axis=1)
+        assert np.percentile(rel, 99) < 2e-3, np.percentile(rel, 99)
 
 
 def test_bad_arguments_return_errors_not_aborts(omni, ctx):
