@@ -1238,8 +1238,9 @@ int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {
         if (a.variant == 2) return a.pool ? launch_conv_c64<true>(st, a, a.n_cu) : launch_conv_c64<false>(st, a, a.n_cu);
         return a.pool ? launch_conv_pp<true>(st, a, a.n_cu) : launch_conv_pp<false>(st, a, a.n_cu);
     }
+    static const bool no_rs = [] { const char* e = getenv("OMNI_CONV_RS"); return e && e[0] == '0'; }();     // A/B hook
     if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 128 && a.cout % 128 == 0 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 128) &&
-        a.n_cu > 0 && a.variant == 0 && (!a.pool || a.H % 2 == 0))
+        a.n_cu > 0 && a.variant == 0 && !no_rs && (!a.pool || a.H % 2 == 0))
         return a.pool ? launch_conv_rs<true>(st, a, a.n_cu) : launch_conv_rs<false>(st, a, a.n_cu);
     if (precision == OMNI_PREC_F16) {
         if (a.ksize == 3) return a.pool ? launch_conv<_Float16, 3, true>(st, a) : launch_conv<_Float16, 3, false>(st, a);

@@ -17,11 +17,13 @@ struct VladFusedBlock {      // one inverted-residual block = [expand] + depthwi
     int cin, hid, cout, stride, expand, res, hin, win, hout, wout;
     const float* bp;
     float* blob;             // device: packed per-chunk weights (see VladBlockArgs)
+    const float *we_t, *be, *wd_t, *bd, *wp_t;   // the layers' own device weights ([cin][hid], [9][hid], [hid][cout]) for the MFMA path
 };
 
 struct omni_vlad {
     omni_ctx* ctx = nullptr;
     bool fused = false;                       // every block has a fused kernel (OMNI_VLAD_UNFUSED=1 forces the layer-by-layer path)
+    bool mfma_late = true;                    // low-resolution blocks on the f32-MFMA pointwise path (OMNI_VLAD_MFMA=0 disables)
     std::vector<VladFusedBlock> blocks;
     int W = 0, H = 0, max_batch = 0, K = 0, Dm = 0, out_dim = 0, hf = 0, wf = 0;
     std::vector<VladLayerDev> layers;
@@ -266,7 +268,7 @@ struct VladBlockArgs {
 template <int CIN, int CP, int TILE>
 __global__ void __launch_bounds__(256)
 vlad_block_kernel(VladBlockArgs a) {
-    constexpr int TW = 8, TH = TILE / TW;
+    constexpr int TW = TILE >= 128 ? 16 : 8, TH = TILE / TW;
     constexpr int NACC = TILE * CP / 256;
     constexpr int NLD = (32 * (CIN + 11 + CP) / 4 + 255) / 256;      // float4 per thread that cover the largest blob
     static_assert(NACC >= 1, "tile too small for this cout");
@@ -321,20 +323,34 @@ vlad_block_kernel(VladBlockArgs a) {
 #pragma unroll
             for (int k = 0; k < CIN; ++k) we[k] = w_we[k * 32 + c];
             const float be = w_be[c];
-            for (int r = rg; r < R; r += 8) {
-                const int gy = iy0 + r / RW, gx = ix0 + r % RW;
-                float v = 0.f;
-                if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
-                    float t = be;
+            // U region pixels at a time: U independent FMA chains (a 256-thread workgroup per CU has no other wave to hide
+            // the latency of one dependent chain of CIN FMAs behind)
+            constexpr int U = CIN >= 48 ? 2 : 4;
+            for (int r0 = rg; r0 < R; r0 += 8 * U) {
+                float t[U];
+                bool inb[U];
 #pragma unroll
-                    for (int k4 = 0; k4 < CIN / 4; ++k4) {
-                        const float4 x = *reinterpret_cast<const float4*>(xin + r * CIN + k4 * 4);
-                        t = fmaf(x.x, we[k4 * 4 + 0], t); t = fmaf(x.y, we[k4 * 4 + 1], t);
-                        t = fmaf(x.z, we[k4 * 4 + 2], t); t = fmaf(x.w, we[k4 * 4 + 3], t);
-                    }
-                    v = relu6f(t);
+                for (int u = 0; u < U; ++u) {
+                    const int r = r0 + 8 * u;
+                    const int gy = iy0 + r / RW, gx = ix0 + r % RW;
+                    inb[u] = r < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
+                    t[u] = be;
                 }
-                h[r * 32 + c] = v;
+#pragma unroll
+                for (int k4 = 0; k4 < CIN / 4; ++k4) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int r = (r0 + 8 * u) < R ? (r0 + 8 * u) : rg;
+                        const float4 x = *reinterpret_cast<const float4*>(xin + r * CIN + k4 * 4);
+                        t[u] = fmaf(x.x, we[k4 * 4 + 0], t[u]); t[u] = fmaf(x.y, we[k4 * 4 + 1], t[u]);
+                        t[u] = fmaf(x.z, we[k4 * 4 + 2], t[u]); t[u] = fmaf(x.w, we[k4 * 4 + 3], t[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int r = r0 + 8 * u;
+                    if (r < R) h[r * 32 + c] = inb[u] ? relu6f(t[u]) : 0.f;
+                }
             }
         } else {
             const int cc = ci * 32 + c;
@@ -394,13 +410,85 @@ vlad_block_kernel(VladBlockArgs a) {
 
 template <int CIN, int CP, int TILE>
 static int launch_vlad_block(hipStream_t st, const VladBlockArgs& a) {
-    constexpr int TW = 8, TH = TILE / TW;
+    constexpr int TW = TILE >= 128 ? 16 : 8, TH = TILE / TW;
     const int RW = TW * a.stride + 2, RH = TH * a.stride + 2;
     const size_t smem = ((size_t)RW * RH * (CIN + 32) + TILE * 32 + 2 * 32 * (CIN + 11 + a.cout)) * 4;
     auto kfn = vlad_block_kernel<CIN, CP, TILE>;
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int tiles = cdiv(a.Wo, TW) * cdiv(a.Ho, TH);
     hipLaunchKernelGGL(kfn, dim3(tiles * a.batch), dim3(256), smem, st, a);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1) convolution on the matrix cores, exact f32: out[p][co] = act(sum_k x[p][k] W[k][co] + b[co]) (+ res).
+// v_mfma_f32_32x32x2_f32 (an fmaf chain, bit-exact f32): one 32-pixel x 32-channel tile per workgroup, M = pixels (A = the
+// activations), N = output channels (B = weights [cin][cout]); the K range is split over the workgroup's SPLITK waves, inside a
+// wave the two half-waves take alternate k; partial tiles are summed through LDS in a fixed order.  No LDS staging of operands:
+// the low-resolution MobileNetV2 blocks (19x15 ... 38x30 pixels per image) are a few hundred such tiles, the 6x-expanded
+// tensors are a few MB and stay in L2 between the three launches of a block.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float floatx16v __attribute__((ext_vector_type(16)));
+template <int SPLITK>
+__global__ void __launch_bounds__(64 * SPLITK)
+vlad_pw_mfma_kernel(const float* __restrict__ in, int64_t P, int cin, int cout, const float* __restrict__ wT /*[cin][cout]*/,
+                    const float* __restrict__ bias, const float* __restrict__ res, int act, float* __restrict__ out) {
+    __shared__ float part[SPLITK > 1 ? SPLITK - 1 : 1][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int64_t pr = (p0 + i < P) ? (p0 + i) : (P - 1);          // clamped row for the A loads
+    const int cc = c0 + i;                                           // this lane's output channel (B column)
+    const bool cval = cc < cout;
+    const int kq = ((cin / 2 + SPLITK - 1) / SPLITK) * 2;            // even k count per wave
+    const int ks = wave * kq, ke = (ks + kq < cin) ? ks + kq : cin;
+    const float* xa = in + pr * cin;
+    const float* wb = wT + (cval ? cc : 0);
+    floatx16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk = (ke - ks) >> 1;                                   // MFMAs of this wave (cin and the per-wave k count are even)
+    for (int t = 0; t < nk; ++t) {
+        const int k = ks + 2 * t + kk;
+        const float a = xa[k];
+        const float b = cval ? wb[(int64_t)k * cout] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if constexpr (SPLITK > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < SPLITK - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += part[w][r][lane];
+    }
+    if (!cval) return;
+    const float bs = bias[cc];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t p = p0 + (r & 3) + 8 * (r >> 2) + 4 * kk;     // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col = lane & 31
+        if (p < P) {
+            float v = acc[r] + bs;
+            if (res) v += res[p * cout + cc];
+            if (act == 1) v = relu6f(v);
+            out[p * cout + cc] = v;
+        }
+    }
+}
+
+static int vlad_pw_mfma(hipStream_t st, const float* in, int64_t P, int cin, int cout, const float* wT, const float* bias, const float* res,
+                        int act, float* out) {
+    dim3 grid((unsigned)cdiv64(P, 32), cdiv(cout, 32));
+    if (cin >= 128)
+        hipLaunchKernelGGL(vlad_pw_mfma_kernel<4>, grid, dim3(256), 0, st, in, P, cin, cout, wT, bias, res, act, out);
+    else
+        hipLaunchKernelGGL(vlad_pw_mfma_kernel<1>, grid, dim3(64), 0, st, in, P, cin, cout, wT, bias, res, act, out);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
@@ -414,7 +502,15 @@ static bool vlad_block_supported(int cin, int cout) {
 }
 static int vlad_block(hipStream_t st, int cin, const VladBlockArgs& a) {
     const int cp = a.cout <= 8 ? 8 : a.cout <= 16 ? 16 : a.cout <= 32 ? 32 : a.cout <= 64 ? 64 : 128;
+    // tile size by output resolution: every workgroup pays two global round trips (input region, first weight blob) before it
+    // computes, so the high-resolution blocks use 128- / 64-pixel tiles (still > 1000 workgroups per 4 images), the rest 32 / 16
+    const int64_t px = (int64_t)a.batch * a.Ho * a.Wo;
+    // (measured: 128- / 64-pixel tiles are SLOWER for the 300x240 / 150x120 blocks -- 54 -> 70 us, 38 -> 46 us: their LDS footprint
+    // halves the resident workgroups and with them the latency hiding; kept instantiated for other image sizes only)
+    const int big = 0; (void)px;
 #define VB(CI, CPV, T) if (cin == CI && cp == CPV) return launch_vlad_block<CI, CPV, T>(st, a)
+    if (big == 128) { VB(16, 8, 128); VB(8, 8, 128); VB(16, 16, 128); }
+    if (big >= 64) { VB(16, 8, 64); VB(8, 8, 64); VB(8, 16, 64); VB(16, 16, 64); }
     VB(8, 8, 32); VB(8, 16, 32); VB(16, 8, 32); VB(16, 16, 32); VB(16, 32, 32); VB(24, 32, 16); VB(32, 32, 16); VB(32, 64, 16);
     VB(56, 64, 16); VB(56, 128, 16);
 #undef VB
@@ -618,13 +714,27 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
     OMNI_LAUNCH_CHECK();
     int cur = 0, rc;
     for (const VladFusedBlock& B : v->blocks) {
+        const int64_t Pin = (int64_t)batch * B.hin * B.win, Pout = (int64_t)batch * B.hout * B.wout;
+        if (B.expand && B.cin % 2 == 0 && B.hid % 4 == 0 && B.hin * B.win <= 2048 && v->mfma_late) {     // per-image size: batch-independent numerics
+            // low-resolution block: expand / project as f32-MFMA pointwise GEMMs, depthwise in between (three launches; the fused
+            // VALU kernel has too few workgroups at these sizes and is latency-bound)
+            const int e = (cur + 1) % 3, d = (cur + 2) % 3;
+            if ((rc = vlad_pw_mfma(st, v->buf[cur], Pin, B.cin, B.hid, B.we_t, B.be, nullptr, 1, v->buf[e]))) return rc;
+            const int64_t total = Pout * (B.hid / 4);
+            hipLaunchKernelGGL(vlad_dw_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, v->buf[e], B.hin, B.win, B.hid, B.hout, B.wout,
+                               B.stride, B.wd_t, B.bd, v->buf[d], total);
+            OMNI_LAUNCH_CHECK();
+            if ((rc = vlad_pw_mfma(st, v->buf[d], Pout, B.hid, B.cout, B.wp_t, B.bp, B.res ? v->buf[cur] : nullptr, 0, v->buf[e]))) return rc;
+            cur = e;
+            continue;
+        }
         VladBlockArgs a;
-        a.in = v->buf[cur]; a.out = v->buf[cur ^ 1];
+        a.in = v->buf[cur]; a.out = v->buf[(cur + 1) % 3];
         a.blob = B.blob; a.bp = B.bp;
         a.Hi = B.hin; a.Wi = B.win; a.Ho = B.hout; a.Wo = B.wout; a.hid = B.hid; a.cout = B.cout; a.stride = B.stride;
         a.expand = B.expand; a.res = B.res; a.batch = batch;
         if ((rc = vlad_block(st, B.cin, a))) return rc;
-        cur ^= 1;
+        cur = (cur + 1) % 3;
     }
     *cur_out = cur;
     return OMNI_OK;
@@ -736,6 +846,7 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
             B.cin = e ? e->cin : dwl.cin; B.hid = dwl.cin; B.cout = pl.cout; B.stride = dwl.stride; B.expand = e ? 1 : 0;
             B.res = pl.kind == OMNI_VLAD_PW_LINEAR_RES; B.hin = dwl.hin; B.win = dwl.win; B.hout = dwl.hout; B.wout = dwl.wout;
             B.bp = pl.b; B.blob = nullptr;
+            B.we_t = e ? e->w : nullptr; B.be = e ? e->b : nullptr; B.wd_t = dwl.w; B.bd = dwl.b; B.wp_t = pl.w;
             if (!omni::vlad_block_supported(B.cin, B.cout) || B.cout % 4 || (B.res && (B.stride != 1 || B.cin != B.cout)) || (!e && B.hid > 32)) { fusable = false; break; }
             {   // pack the block's weights per 32-channel chunk of the hidden layer (host copies of the layer weights, OIHW)
                 const omni_vlad_layer* Le = e ? &w->layers[i - 1] : nullptr;
@@ -758,6 +869,8 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
         }
         const char* env = getenv("OMNI_VLAD_UNFUSED");
         v->fused = fusable && !(env && env[0] == '1');
+        const char* env2 = getenv("OMNI_VLAD_MFMA");
+        v->mfma_late = !(env2 && env2[0] == '0');
     }
     if (ok) {
         v->hf = h; v->wf = wd; v->buf_elems = max_elems * max_batch;
