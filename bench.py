@@ -55,7 +55,11 @@ def parse():
     ap.add_argument("--precision", choices=["f16", "f32"], default="f16")
     ap.add_argument("--db-keyframes", type=int, default=1000, help="key frames pre-loaded in the index (x4 rows) for the throughput loop")
     ap.add_argument("--match-db-rows", type=int, default=100_000, help="index rows for the p50 loop-match measurement (node total)")
-    ap.add_argument("--pipelines", type=int, default=2, help="key frames in flight per GPU (separate HIP streams)")
+    ap.add_argument("--pipelines", type=int, default=3, help="micro-batches in flight per GPU (separate HIP streams)")
+    ap.add_argument("--microbatch", type=int, default=4,
+                    help="consecutive key frames enqueued together (one SuperPoint launch over 8*MB images, one MobileNetVLAD launch over 4*MB): "
+                         "the low-resolution layers of both nets are launch/latency-bound at one key frame.  When --steps is not a "
+                         "multiple the last micro-batch is still processed in full inside the timed region (extra work, not counted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-keyframes", type=int, default=4, help="key frames timed on the host cores for cpu_baseline")
     return ap.parse_args()
@@ -91,6 +95,7 @@ def main():
     MATCH_INDEX_DIST, QUERY_THRES = 5, 0.3   # launch values
     K_SEARCH = 5 + MATCH_INDEX_DIST
 
+    MB = max(1, args.microbatch)
     sp_w = weights.superpoint_synth_weights(0)
     comp, mean = synth.pca()
     vl_w = weights.mobilenetvlad_synth_weights()
@@ -99,14 +104,16 @@ def main():
     ictx = capi.Context(local_rank)
     info = ictx.device_info()
     cams = [frontend.LoopCam(c, sp_w, comp, mean, vl_w, vl_specs, (weights.VLAD_N_CLUSTERS, weights.VLAD_FEAT_DIM, weights.VLAD_OUT_DIM),
-                             W, H, THRES, MAXN, prec) for c in ctxs]
+                             W, H, THRES, MAXN, prec, n_dirs=4 * MB) for c in ctxs]
 
     # ---- synthetic key-frame pool, resident in HBM ---------------------------------------------------------------
     POOL = 4
     pool = []
-    for p in range(POOL):
-        imgs = np.stack([synth.image_u8(1000 * rank + 8 * p + i, H, W) for i in range(KF_IMAGES)])
+    for p in range(POOL):      # one entry = MB key frames: [up cameras of all MB frames | down cameras of all MB frames] (LoopCam's image order)
+        kf = [[synth.image_u8(1000 * rank + 8 * (p * MB + m) + i, H, W) for i in range(KF_IMAGES)] for m in range(MB)]
+        imgs = np.stack([kf[m][i] for m in range(MB) for i in range(4)] + [kf[m][4 + i] for m in range(MB) for i in range(4)])
         pool.append(ictx.to_device(imgs))
+    pool1 = ictx.to_device(np.stack([synth.image_u8(1000 * rank + i, H, W) for i in range(KF_IMAGES)]))   # one key frame, for the stage profile
 
     # ---- index: local (world 1) or row-sharded --------------------------------------------------------------------
     rng = np.random.default_rng(7)
@@ -137,19 +144,21 @@ def main():
 
     def finish(cam, step):
         out = cam.fetch()
-        if world == 1:
-            fr = detector.FisheyeFrameDescriptor(
-                msg_id=step, drone_id=1, landmark_num=out["landmark_num"], prevent_adding_db=False,
-                images=[detector.ImageDescriptor(drone_id=1, landmark_num=i["landmark_num"], image_desc=i["image_desc"],
-                                                 feature_descriptor=i["feature_descriptor"], landmarks_2d=i["landmarks_2d"])
-                        for i in out["images"]])
-            rec = det.on_image_recv(fr)
-            hits[0] += int(rec["old_msg_id"] != -1)
-        else:
-            rows = np.stack([i["image_desc"] for i in out["images"]])
-            D, I = swarm.step(rows, query_row=1, k=K_SEARCH)                # add world*4 rows, query direction 1
-            ok = (I[0] >= 0) & (I[0] <= swarm.ntotal - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
-            hits[0] += int(ok.any())
+        for m in range(MB):                     # the MB key frames of the micro-batch reach the detector one by one, in order
+            ims = out["images"][4 * m:4 * m + 4]
+            if world == 1:
+                fr = detector.FisheyeFrameDescriptor(
+                    msg_id=step + m, drone_id=1, landmark_num=int(sum(i["landmark_num"] for i in ims)), prevent_adding_db=False,
+                    images=[detector.ImageDescriptor(drone_id=1, landmark_num=i["landmark_num"], image_desc=i["image_desc"],
+                                                     feature_descriptor=i["feature_descriptor"], landmarks_2d=i["landmarks_2d"])
+                            for i in ims])
+                rec = det.on_image_recv(fr)
+                hits[0] += int(rec["old_msg_id"] != -1)
+            else:
+                rows = np.stack([i["image_desc"] for i in ims])
+                D, I = swarm.step(rows, query_row=1, k=K_SEARCH)                # add world*4 rows, query direction 1
+                ok = (I[0] >= 0) & (I[0] <= swarm.ntotal - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
+                hits[0] += int(ok.any())
         return out
 
     def run(n_steps, first_step):
@@ -157,10 +166,10 @@ def main():
         waits for key frame s - pipelines + 1, so the GPU always has queued work while the host runs the detector."""
         from collections import deque
         pending = deque()
-        for s in range(n_steps):
+        for s in range((n_steps + MB - 1) // MB):          # one pass = MB key frames (a trailing partial micro-batch runs in full)
             cam = cams[s % len(cams)]
-            cam.enqueue_dev(pool[(first_step + s) % POOL], W)
-            pending.append((cam, first_step + s))
+            cam.enqueue_dev(pool[((first_step + MB - 1) // MB + s) % POOL], W)
+            pending.append((cam, first_step + s * MB))
             if len(pending) >= len(cams):
                 finish(*pending.popleft())
         while pending:
@@ -187,7 +196,7 @@ def main():
     kfps = args.steps * world / dt
 
     # ---- roofline of the dominant kernel (conv1b + pool, 43 % of the FLOPs): HIP events on the kernel's own stream --
-    prof = cams[0].sp.profile(pool[0], W, KF_IMAGES, reps=10)
+    prof = cams[0].sp.profile(pool1, W, KF_IMAGES, reps=10)      # stage times of ONE key frame (8 images), whatever the micro-batch
     conv_ms = sum(p["ms"] for p in prof if p["stage"].startswith("conv"))
     sp_ms = sum(p["ms"] for p in prof)
     c1b = next(p for p in prof if p["stage"].startswith("conv1b"))
@@ -253,6 +262,7 @@ def main():
                                    "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query; "
                                    f"{args.db_keyframes}-keyframe DB ({4 * args.db_keyframes} rows); seeded synthetic weights",
                        "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": args.pipelines,
+                       "keyframes_per_microbatch": MB,
                        "parallelism": f"dp{world} keyframes + {world}-way row-sharded index" if world > 1 else "single GPU",
                        "device": info["name"], "n_cu": info["n_cu"]},
             "loop_candidates_found": hits[0],
