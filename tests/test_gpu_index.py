@@ -84,6 +84,19 @@ def test_ties_go_to_lower_row_and_row_by_row_add(omni, ctx):
     assert idx.ntotal == 0
 
 
+def test_massive_ties_and_the_small_k_boundary(omni, ctx):
+    """k <= 64 takes the radix-select top-k: thousands of rows tied at the cut-off overflow its gather buffer and fall back to the
+    in-place sort; ids must still come out in ascending order.  k = 64 / 65 straddle the two kernels."""
+    db = synth.global_db(6000, seed=12)
+    db[1000:5000] = db[1000]                           # 4000 identical rows: two whole 2048-key chunks of ties
+    idx = omni.capi.IndexFlatIP(ctx, DIM)
+    idx.add(db)
+    D, I = idx.search(db[1000], 10)
+    assert I[0].tolist() == list(range(1000, 1010)) and np.allclose(D[0], D[0, 0])
+    for k in (64, 65):
+        _check(idx, db, db[[7, 5500]], k)
+
+
 @pytest.mark.parametrize("nq", [1, 2, 7, 8, 9, 17])
 def test_query_batches(omni, ctx, nq):
     db = synth.global_db(4500, seed=6)
