@@ -180,6 +180,11 @@ int         omni_index_set_shard(omni_index* idx, int rank, int world);
  * same ordering rule (score desc, id asc), entries with I < 0 ignored */
 int         omni_topk_merge(int n_lists, int nq, int k_each, const float* D_lists, const int64_t* I_lists,
                             int k_out, float* D, int64_t* I);
+/* Shard checkpoint (new -- the reference keeps its database in RAM only and loses it on restart):
+ * "OMNX1" file = header {magic, dim, storage, ntotal} + the raw row matrix as stored (fp32 or fp16), streamed through a pinned
+ * staging buffer.  load() replaces the handle's contents; dim and storage must match the handle. */
+int         omni_index_save(omni_index* idx, const char* path);
+int         omni_index_load(omni_index* idx, const char* path);
 /* device time of the dominant scan kernel for the last search on this handle (HIP events on the ctx stream) */
 int         omni_index_last_scan_ms(omni_index* idx, float* ms);
 

@@ -33,6 +33,7 @@ SYMBOLS = [
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset",
     "omni_index_search", "omni_index_search_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
+    "omni_index_save", "omni_index_load",
     "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_wait",
 ]
 
@@ -129,6 +130,8 @@ def lib():
     sig("omni_index_set_shard", C.c_int, [_vp, C.c_int, C.c_int])
     sig("omni_topk_merge", C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _i64p, C.c_int, _fp, _i64p])
     sig("omni_index_last_scan_ms", C.c_int, [_vp, _fp])
+    sig("omni_index_save", C.c_int, [_vp, C.c_char_p])
+    sig("omni_index_load", C.c_int, [_vp, C.c_char_p])
     sig("omni_bf_match", C.c_int, [_vp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _ip, _ip, _fp, _ip])
     sig("omni_bf_match_batched_dev", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, C.c_int64,
                                                _vp, _vp, _vp, _vp, _vp])
@@ -400,6 +403,13 @@ class IndexFlatIP:
 
     def reset(self):
         _check(lib().omni_index_reset(self.h))
+
+    def save(self, path: str):
+        """Shard checkpoint (OMNX1): header + the raw row matrix as stored."""
+        _check(lib().omni_index_save(self.h, path.encode()))
+
+    def load(self, path: str):
+        _check(lib().omni_index_load(self.h, path.encode()))
 
     def set_shard(self, rank: int, world: int):
         _check(lib().omni_index_set_shard(self.h, rank, world))

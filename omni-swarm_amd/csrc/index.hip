@@ -330,6 +330,60 @@ int omni_index_search(omni_index* ix, int nq, const float* q_host, int k, float*
     return OMNI_OK;
 }
 
+namespace {
+struct OmnxHeader { char magic[8]; int32_t dim, storage; int64_t ntotal; };
+}
+
+int omni_index_save(omni_index* ix, const char* path) {
+    OMNI_REQUIRE(ix && path, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    (void)hipSetDevice(ix->ctx->device);
+    FILE* f = fopen(path, "wb");
+    OMNI_REQUIRE(f, OMNI_ERR_INVALID, "cannot open %s for writing", path);
+    OmnxHeader h{};
+    memcpy(h.magic, "OMNX1\0\0", 8); h.dim = ix->dim; h.storage = ix->storage; h.ntotal = ix->ntotal;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    const size_t row = (size_t)ix->dim * ix->elem(), slab_rows = 4096;
+    int rc = ix->hout.ensure(slab_rows * row);
+    for (int64_t s = 0; ok && rc == OMNI_OK && s < ix->ntotal; s += slab_rows) {
+        const size_t m = (size_t)(ix->ntotal - s < (int64_t)slab_rows ? ix->ntotal - s : slab_rows);
+        if (hipMemcpyAsync(ix->hout.p, (const char*)ix->db + (size_t)s * row, m * row, hipMemcpyDeviceToHost, ix->ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ix->ctx->stream) != hipSuccess) { omni::set_error("device read failed while saving"); rc = OMNI_ERR_HIP; break; }
+        ok = fwrite(ix->hout.p, row, m, f) == m;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (rc) return rc;
+    OMNI_REQUIRE(ok, OMNI_ERR_INVALID, "short write to %s", path);
+    return OMNI_OK;
+}
+
+int omni_index_load(omni_index* ix, const char* path) {
+    OMNI_REQUIRE(ix && path, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    (void)hipSetDevice(ix->ctx->device);
+    FILE* f = fopen(path, "rb");
+    OMNI_REQUIRE(f, OMNI_ERR_INVALID, "cannot open %s", path);
+    OmnxHeader h{};
+    int rc = OMNI_OK;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "OMNX1\0\0", 8) != 0) { omni::set_error("%s is not an OMNX1 snapshot", path); rc = OMNI_ERR_INVALID; }
+    else if (h.dim != ix->dim || h.storage != ix->storage || h.ntotal < 0) {
+        omni::set_error("snapshot %s is dim=%d storage=%d, the handle is dim=%d storage=%d", path, h.dim, h.storage, ix->dim, ix->storage);
+        rc = OMNI_ERR_INVALID;
+    }
+    const size_t row = (size_t)ix->dim * ix->elem(), slab_rows = 4096;
+    if (!rc) rc = omni::ensure_capacity(ix, h.ntotal > 0 ? h.ntotal : 1);
+    if (!rc) rc = ix->hout.ensure(slab_rows * row);
+    for (int64_t s = 0; !rc && s < h.ntotal; s += slab_rows) {
+        const size_t m = (size_t)(h.ntotal - s < (int64_t)slab_rows ? h.ntotal - s : slab_rows);
+        if (fread(ix->hout.p, row, m, f) != m) { omni::set_error("%s is truncated", path); rc = OMNI_ERR_INVALID; break; }
+        if (hipMemcpyAsync((char*)ix->db + (size_t)s * row, ix->hout.p, m * row, hipMemcpyHostToDevice, ix->ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ix->ctx->stream) != hipSuccess) { omni::set_error("device write failed while loading"); rc = OMNI_ERR_HIP; }
+    }
+    fclose(f);
+    if (!rc) ix->ntotal = h.ntotal;
+    return rc;
+}
+
 int omni_index_last_scan_ms(omni_index* ix, float* ms) {
     OMNI_REQUIRE(ix && ms, OMNI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(ix->mu);

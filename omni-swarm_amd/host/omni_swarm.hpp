@@ -298,6 +298,9 @@ public:
         check(omni_index_search(h_, (int)n, x, (int)k, distances, labels), "IndexFlatIP::search");
     }
     void reset() { check(omni_index_reset(h_), "IndexFlatIP::reset"); ntotal = 0; }
+    // shard checkpoint / restore (new: the reference's database lives in RAM only)
+    void save(const std::string& path) const { check(omni_index_save(h_, path.c_str()), "IndexFlatIP::save"); }
+    void load(const std::string& path) { check(omni_index_load(h_, path.c_str()), "IndexFlatIP::load"); ntotal = omni_index_ntotal(h_); }
     int d;
     idx_t ntotal = 0;                            // public data member, as in faiss
     omni_index* handle() const { return h_; }

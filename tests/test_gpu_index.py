@@ -118,6 +118,40 @@ def test_fp16_storage(omni, ctx):
     assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=1e-6)
 
 
+def test_64_concurrent_queries_fp16_storage(omni, ctx):
+    """BASELINE config 5 shape in miniature: 64 queries (one per concurrent key frame) against an fp16 shard in one call."""
+    db = synth.global_db(9000, seed=13)
+    q, rows = synth.queries_from_db(db, 64, seed=14)
+    idx = omni.capi.IndexFlatIP(ctx, DIM, omni.capi.STORE_F16)
+    idx.add(db)
+    D, I = idx.search(q, 15)
+    Dr, Ir = M.ip_search(db.astype(np.float16).astype(np.float32), q, 15)
+    assert np.array_equal(I[:, 0], rows) and np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=1e-6)
+
+
+def test_snapshot_roundtrip(omni, ctx, tmp_path):
+    """omni_index_save / omni_index_load: a shard checkpoint restores rows, storage type and search results bit for bit."""
+    db = synth.global_db(3000, seed=15)
+    q, _ = synth.queries_from_db(db, 3, seed=16)
+    for storage in (omni.capi.STORE_F32, omni.capi.STORE_F16):
+        idx = omni.capi.IndexFlatIP(ctx, DIM, storage)
+        idx.add(db)
+        D, I = idx.search(q, 12)
+        path = str(tmp_path / f"shard{storage}.omnx")
+        idx.save(path)
+        idx2 = omni.capi.IndexFlatIP(ctx, DIM, storage)
+        idx2.load(path)
+        assert idx2.ntotal == 3000
+        D2, I2 = idx2.search(q, 12)
+        assert np.array_equal(I, I2) and np.array_equal(D, D2)
+        idx2.add(db[:5])                                              # still appendable after a restore
+        assert idx2.ntotal == 3005
+        with pytest.raises(omni.capi.OmniError):
+            omni.capi.IndexFlatIP(ctx, DIM, 1 - storage).load(path)   # storage type mismatch is an error, not a reinterpretation
+    with pytest.raises(omni.capi.OmniError):
+        omni.capi.IndexFlatIP(ctx, DIM).load(str(tmp_path / "missing.omnx"))
+
+
 def test_shard_ids_and_merge_equals_unsharded(omni, ctx):
     db = synth.global_db(4001, seed=10)
     db[3000] = db[11]

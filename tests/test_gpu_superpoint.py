@@ -48,7 +48,7 @@ def _oracle_layers(w, x):
     return semi, desc, out
 
 
-@pytest.mark.parametrize("shape", [(64, 96), (72, 104), (480, 600)])
+@pytest.mark.parametrize("shape", [(64, 96), (72, 104), (480, 600), (480, 640)])    # last: BASELINE config 1 (pinhole 640x480)
 def test_f32_layers_and_dense_outputs(omni, ctx, shape):
     h, w = shape
     weights = S.synth_weights(0)

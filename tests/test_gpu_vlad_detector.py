@@ -43,3 +43,14 @@ def test_loop_detector_trace_equals_oracle(omni, ctx, golden):
     assert np.array_equal(tr, golden("detector.npz")["trace"])
     frames2 = DS.make_stream(seed=12, n_frames=60)
     assert np.array_equal(DS.trace(DS.run_product(frames2, ctx, detector)), DS.trace(DS.run_oracle(frames2)))
+
+
+def test_long_replay_match_ids_equal_oracle(omni, ctx):
+    """BASELINE config 3 in miniature: a 1500-key-frame, 3-drone replay (up to 6000 index rows, ~1000 queries) through the HIP
+    index + host rules gives the same decision trace (added / queried / image id / matched frame / direction / loop) as the
+    oracle's literal LoopDetector, including the recency rule and the init-mode thresholds."""
+    from omni_swarm_amd import detector
+    frames = DS.make_stream(seed=21, n_frames=1500, n_places=60)
+    got, ref = DS.trace(DS.run_product(frames, ctx, detector)), DS.trace(DS.run_oracle(frames))
+    assert np.array_equal(got, ref)
+    assert (ref[:, 4] != -1).sum() > 100                              # the stream does close loops
