@@ -434,6 +434,14 @@ __device__ __forceinline__ float vmax_med3(float a, float b) { return __builtin_
 // ReLU as an integer max on the bit pattern (negative floats and -0 are negative integers): one compiler-visible instruction,
 // so the MFMA -> VALU wait states in front of it are still inserted by hipcc (they are NOT for an inline-asm reader)
 __device__ __forceinline__ float vrelu(float a) { const int b = __builtin_bit_cast(int, a); return __builtin_bit_cast(float, b > 0 ? b : 0); }
+// max(v, value of lane ^ 1) in ONE instruction (v_max_f32 with a DPP source).  Inline asm: the 2 wait states a DPP read needs after
+// the VALU write of its source are NOT inserted by hipcc here -- callers must produce v at least two instructions earlier
+// (the pooling code computes all 32 vertical maxima first, then the 32 horizontal ones).
+__device__ __forceinline__ float vmax_swap_pairs(float v) {
+    float r;
+    asm("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ float dpp_swap_pairs(float v) {      // value of lane ^ 1 (quad_perm [1,0,3,2]): a VALU modifier, no LDS
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
@@ -851,14 +859,15 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                     // Even lanes then store M-fragment 0 and odd lanes M-fragment 1 of pooled pixel n >> 1.
                     const int oy = ty0 + 2 * wl;
                     const bool odd = n & 1;
-                    float v[16];
+                    float v[16], q0[16], q1[16];
+                    // (sending only the fragment the partner keeps -- one exchange instead of two -- measured slower: 0.158 vs 0.139 ms)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { q0[i] = vmax(acc[0][0][i], acc[0][1][i]); q1[i] = vmax(acc[1][0][i], acc[1][1][i]); }
+                    __builtin_amdgcn_sched_barrier(0);                // all 32 vertical maxima issue before the first DPP read (wait states)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        // (sending only the fragment the partner keeps -- one exchange instead of two -- measured slower: 0.158 vs 0.139 ms)
-                        float q0 = vmax(acc[0][0][i], acc[0][1][i]), q1 = vmax(acc[1][0][i], acc[1][1][i]);
-                        q0 = vmax(q0, dpp_swap_pairs(q0));
-                        q1 = vmax(q1, dpp_swap_pairs(q1));
-                        v[i] = odd ? q1 : q0;
+                        const float h0 = vmax_swap_pairs(q0[i]), h1 = vmax_swap_pairs(q1[i]);
+                        v[i] = odd ? h1 : h0;
                     }
                     _Float16* o = out + (((int64_t)b * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * cout + ct * 64 + (odd ? 32 : 0);
                     store_frag16<true>(v, bs[0], o, hh, relu, (oy < H) && (ox < W));
