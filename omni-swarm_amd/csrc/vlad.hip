@@ -24,6 +24,7 @@ struct omni_vlad {
     omni_ctx* ctx = nullptr;
     bool fused = false;                       // every block has a fused kernel (OMNI_VLAD_UNFUSED=1 forces the layer-by-layer path)
     bool mfma_late = true;                    // low-resolution blocks on the f32-MFMA pointwise path (OMNI_VLAD_MFMA=0 disables)
+    int mfma_max_px = 2048;                   // ... = blocks whose input has at most this many pixels per image (OMNI_VLAD_MFMA_PX)
     std::vector<VladFusedBlock> blocks;
     int W = 0, H = 0, max_batch = 0, K = 0, Dm = 0, out_dim = 0, hf = 0, wf = 0;
     std::vector<VladLayerDev> layers;
@@ -442,19 +443,32 @@ vlad_pw_mfma_kernel(const float* __restrict__ in, int64_t P, int cin, int cout, 
     const int64_t pr = (p0 + i < P) ? (p0 + i) : (P - 1);          // clamped row for the A loads
     const int cc = c0 + i;                                           // this lane's output channel (B column)
     const bool cval = cc < cout;
-    const int kq = ((cin / 2 + SPLITK - 1) / SPLITK) * 2;            // even k count per wave
-    const int ks = wave * kq, ke = (ks + kq < cin) ? ks + kq : cin;
-    const float* xa = in + pr * cin;
-    const float* wb = wT + (cval ? cc : 0);
+    // K split: wave w takes [ks, ke) (a multiple of 8 wide), inside it half-wave kk the contiguous half [ks + kk nk, ks + (kk+1) nk)
+    // -- the A operand is then 16-byte loads, and the loads of the next four k are issued before the four MFMAs of the current
+    // ones (a single accumulator chain: MFMAs are dependent, so the loads are all that can overlap)
+    const int kq = ((cin + SPLITK * 8 - 1) / (SPLITK * 8)) * 8;
+    const int ks = wave * kq < cin ? wave * kq : cin, ke = (ks + kq < cin) ? ks + kq : cin;
+    const int nk = (ke - ks) >> 1;                                   // k per half-wave: a multiple of 4 (cin % 8 == 0)
+    const float* xa = in + pr * cin + ks + kk * nk;
+    const float* wb = wT + (cval ? cc : 0) + (int64_t)(ks + kk * nk) * cout;
     floatx16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nk = (ke - ks) >> 1;                                   // MFMAs of this wave (cin and the per-wave k count are even)
-    for (int t = 0; t < nk; ++t) {
-        const int k = ks + 2 * t + kk;
-        const float a = xa[k];
-        const float b = cval ? wb[(int64_t)k * cout] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+    auto load4 = [&](int t, float4& a, float4& b) {
+        a = *reinterpret_cast<const float4*>(xa + t);
+        const float* w = wb + (int64_t)t * cout;
+        b = cval ? make_float4(w[0], w[cout], w[2 * (int64_t)cout], w[3 * (int64_t)cout]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (nk > 0) load4(0, a4, b4);
+    for (int t = 0; t < nk; t += 4) {
+        float4 an = a4, bn = b4;
+        if (t + 4 < nk) load4(t + 4, an, bn);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        a4 = an; b4 = bn;
     }
     if constexpr (SPLITK > 1) {
         if (wave > 0) {
@@ -715,7 +729,7 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
     int cur = 0, rc;
     for (const VladFusedBlock& B : v->blocks) {
         const int64_t Pin = (int64_t)batch * B.hin * B.win, Pout = (int64_t)batch * B.hout * B.wout;
-        if (B.expand && B.cin % 2 == 0 && B.hid % 4 == 0 && B.hin * B.win <= 2048 && v->mfma_late) {     // per-image size: batch-independent numerics
+        if (B.expand && B.cin % 8 == 0 && B.hid % 8 == 0 && B.hin * B.win <= v->mfma_max_px && v->mfma_late) {     // per-image size: batch-independent numerics
             // low-resolution block: expand / project as f32-MFMA pointwise GEMMs, depthwise in between (three launches; the fused
             // VALU kernel has too few workgroups at these sizes and is latency-bound)
             const int e = (cur + 1) % 3, d = (cur + 2) % 3;
@@ -871,6 +885,8 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
         v->fused = fusable && !(env && env[0] == '1');
         const char* env2 = getenv("OMNI_VLAD_MFMA");
         v->mfma_late = !(env2 && env2[0] == '0');
+        const char* env4 = getenv("OMNI_VLAD_MFMA_PX");
+        if (env4 && atoi(env4) > 0) v->mfma_max_px = atoi(env4);
     }
     if (ok) {
         v->hf = h; v->wf = wd; v->buf_elems = max_elems * max_batch;
