@@ -42,7 +42,8 @@ def pmc_traffic(key):
         return None
     try:
         t = json.load(open(files[-1]))
-        return {"bytes_per_launch": t[key]["bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
+        return {"bytes_per_launch": t[key]["bytes_per_launch"], "images_per_launch": t[key].get("images_per_launch"),
+                "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
 
@@ -196,20 +197,23 @@ def main():
     kfps = args.steps * world / dt
 
     # ---- roofline of the dominant kernel (conv1b + pool, 43 % of the FLOPs): HIP events on the kernel's own stream --
-    prof = cams[0].sp.profile(pool1, W, KF_IMAGES, reps=10)      # stage times of ONE key frame (8 images), whatever the micro-batch
-    conv_ms = sum(p["ms"] for p in prof if p["stage"].startswith("conv"))
-    sp_ms = sum(p["ms"] for p in prof)
+    # same launch shape as in the timed loop: one micro-batch = 8 * MB images per launch (HIP events between the stages, on the
+    # kernels' own stream); stage times are then quoted per key frame (8 images)
+    n_img = KF_IMAGES * MB
+    prof = cams[0].sp.profile(pool[0], W, n_img, reps=10)
+    conv_ms = sum(p["ms"] for p in prof if p["stage"].startswith("conv")) / MB
+    sp_ms = sum(p["ms"] for p in prof) / MB
     c1b = next(p for p in prof if p["stage"].startswith("conv1b"))
-    c1b_flop = c1b["flops_per_image"] * KF_IMAGES
+    c1b_flop = c1b["flops_per_image"] * n_img
     peak = PEAK_F16_TFLOPS if args.precision == "f16" else PEAK_F32_TFLOPS
     achieved = c1b_flop / (c1b["ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 "
                                           "in one launch; FLOP counted for conv1b only", "achieved": round(achieved, 1),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": pmc_traffic("conv3x3_c64_pp_kernel<POOL,FUSE1A>") if args.precision == "f16" else None,
-                "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4),
+                "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
                 "conv_stack_tflops": round(SP_FLOP_PER_IMAGE * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
-                "stages_ms": {p["stage"]: round(p["ms"], 4) for p in prof}, "superpoint_batch8_ms": round(sp_ms, 3)}
+                "stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof}, "superpoint_ms_per_keyframe": round(sp_ms, 3)}
 
     # ---- p50 loop-match latency on a big DB (node total rows = --match-db-rows, sharded when N > 1) -----------------
     rows_here = args.match_db_rows // world

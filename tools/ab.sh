@@ -6,6 +6,6 @@ for r in $(seq 1 $R); do
     if [ $v = cur ]; then unset OMNI_LIB; else export OMNI_LIB=$PWD/omni-swarm_amd/lib/libomni_hip_$v.so; fi
     timeout 200 python bench.py --no-cpu-baseline --steps 40 --warmup 10 --match-db-rows 8192 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); r=d['roofline']; s=r['stages_ms']; print('$v', d['value'], s['conv1b+pool'], s['conv2a'], s['conv2b+pool'], s['conv3a'], r['superpoint_batch8_ms'])"
+d=json.loads(sys.stdin.read()); r=d['roofline']; s=r['stages_ms_per_keyframe']; print('$v', d['value'], s['conv1b+pool'], s['conv2a'], s['conv2b+pool'], s['conv3a'], r['superpoint_ms_per_keyframe'])"
   done
 done
