@@ -61,6 +61,8 @@ def parse():
                     help="consecutive key frames enqueued together (one SuperPoint launch over 8*MB images, one MobileNetVLAD launch over 4*MB): "
                          "the low-resolution layers of both nets are launch/latency-bound at one key frame.  When --steps is not a "
                          "multiple the last micro-batch is still processed in full inside the timed region (extra work, not counted)")
+    ap.add_argument("--batched-rows", type=int, default=125_000,
+                    help="fp16 rows per GPU for the 64-concurrent-query search measurement (configs[4]: 1 M key frames over 8 GPUs); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-keyframes", type=int, default=4, help="key frames timed on the host cores for cpu_baseline")
     return ap.parse_args()
@@ -251,6 +253,28 @@ def main():
                   "includes": "H2D query, scan, top-k, D2H result" + (", all_gather + merge" if world > 1 else "")}
     midx.close()
 
+    # ---- BASELINE config 5 per-GPU shard: 64 concurrent queries against 1 M key frames / 8 GPUs = 125 000 fp16 rows --------------
+    batched = None
+    if args.batched_rows > 0:
+        bidx = capi.IndexFlatIP(ictx, 4096, capi.STORE_F16, args.batched_rows)
+        for s in range(0, args.batched_rows, 8192):
+            bidx.add(random_rows(min(8192, args.batched_rows - s)))
+        bq = random_rows(64)
+        blat, bscan = [], []
+        for i in range(30):
+            t = time.perf_counter()
+            bidx.search(bq, K_SEARCH)
+            blat.append((time.perf_counter() - t) * 1e3)
+            bscan.append(bidx.last_scan_ms())
+        b_ms, b_p50 = float(np.median(bscan[8:])), float(np.median(blat[8:]))
+        b_bytes = args.batched_rows * (4096 * 2 + 64 * 8)            # every fp16 row read once + one 64-bit key per (query, row)
+        batched = {"bound": "hbm", "kernel": "ip_scan_mq_kernel (64 queries, fp16 rows, v_mfma_f32_16x16x32_f16)",
+                   "achieved": round(b_bytes / (b_ms * 1e-3) / 1e9, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": round(b_bytes / (b_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("ip_scan_mq_kernel"),
+                   "bytes_per_launch": b_bytes, "launch_ms": round(b_ms, 4), "rows_per_gpu": args.batched_rows, "queries": 64,
+                   "search_p50_ms": round(b_p50, 4), "queries_per_s": round(64 / (b_p50 * 1e-3), 0)}
+        bidx.close()
+
     # ---- CPU baseline: the reference's PyTorch-CPU SuperPoint path + oracle post-processing, same host ---------------
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -272,7 +296,8 @@ def main():
             "loop_candidates_found": hits[0],
             "gflop_per_keyframe_superpoint": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
             "achieved_tflops_end_to_end": round(kfps * SP_FLOP_PER_IMAGE * KF_IMAGES / 1e12 / world, 1),
-            "roofline": roofline, "roofline_knn": roofline_knn, "loop_match": loop_match, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

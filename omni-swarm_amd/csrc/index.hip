@@ -3,8 +3,13 @@
 //   search : swarm_loop/src/loop_detector.cpp:213       (IndexFlatIP::search(1, q, k, D, I))
 //   ntotal : swarm_loop/src/loop_detector.cpp:167,170,232,291
 //
-// HBM layout: one row-major [capacity][dim] matrix (fp32 or fp16), rows appended in insertion order
-// (the recency rule `label <= ntotal - max_index`, loop_detector.cpp:232, needs insertion order).
+// HBM layout, rows appended in insertion order (the recency rule `label <= ntotal - max_index`, loop_detector.cpp:232, needs it):
+//   fp32 shard: one row-major [capacity][dim] matrix;
+//   fp16 shard: "T16" blocks of 16 rows, 16-byte k-chunks interleaved over the rows of a block,
+//                 half index(row, k) = (row / 16) * 16 * dim + ((k / 8) * 16 + row % 16) * 8 + k % 8
+//               -- exactly the A-operand order of v_mfma_f32_16x16x32_f16 (lane = row % 16 + 16 * (chunk % 4)): every wave instruction
+//               of both scan kernels reads ONE contiguous KiB (with row-major rows the matrix-core kernel touched 64 cache lines per
+//               instruction and stalled on the L1 tag rate at 4.8 TB/s).
 // Search = one streaming scan kernel (HBM-bound: dim*sizeof(elem) bytes per row, read exactly once)
 // that writes one 64-bit sortable key per (query,row), then the exact hierarchical top-k of topk.h.
 #include "common.h"
@@ -18,7 +23,7 @@ struct omni_index {
     int64_t ntotal = 0;
     int rank = 0, world = 1;
     void* db = nullptr;
-    omni::DevBuf qbuf, keys_a, keys_b, out_d, out_i, stage;
+    omni::DevBuf qbuf, keys_a, keys_b, out_d, out_i, stage, mq_q, mq_inv;
     omni::HostBuf hq, hout;
     hipEvent_t scan0 = nullptr, scan1 = nullptr;
     bool scan_timed = false;
@@ -43,12 +48,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// One wave per row at a time, QB queries resident in LDS.  Each lane streams 16 B per load (1 KiB per wave
-// instruction, fully coalesced).  keys[q][row] = make_key(dot(q, row), row).
+// fp32 shard: one wave per row at a time, QB queries resident in LDS.  Each lane streams 16 B per load (1 KiB per wave instruction, fully
+// coalesced).  keys[q][row] = make_key(dot(q, row), row).
 template <typename T, int QB>
 __global__ void __launch_bounds__(SCAN_THREADS)
 ip_scan_kernel(const T* __restrict__ db, int64_t n_rows, int dim, const float* __restrict__ queries,
                uint64_t* __restrict__ keys, int64_t key_stride) {
+    static_assert(sizeof(T) == 4, "fp16 shards use the T16 layout (ip_scan_t16_kernel / ip_scan_mq_kernel)");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sq = reinterpret_cast<float*>(smem_raw);             // [QB][dim]
     for (int i = threadIdx.x * 4; i < QB * dim; i += SCAN_THREADS * 4)
@@ -56,42 +62,26 @@ ip_scan_kernel(const T* __restrict__ db, int64_t n_rows, int dim, const float* _
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    constexpr int EPL = 16 / sizeof(T);                          // elements per lane per load (4 or 8)
     const int64_t wave_global = (int64_t)blockIdx.x * SCAN_WAVES + wave;
     const int64_t wave_stride = (int64_t)gridDim.x * SCAN_WAVES;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
     for (int64_t row = wave_global; row < n_rows; row += wave_stride) {
         const T* rp = db + row * dim;
         float acc[QB];
 #pragma unroll
         for (int q = 0; q < QB; ++q) acc[q] = 0.f;
 #pragma unroll 4
-        for (int c = lane * EPL; c < dim; c += 64 * EPL) {
-            float v[EPL];
+        for (int c = lane * 4; c < dim; c += 64 * 4) {
             // every DB byte is read exactly once per scan: non-temporal loads keep the stream out of the way of the LDS-resident
             // queries' neighbours in L2 (MI355X guide: streamed-once operands measure 6.5-6.8 vs 6.4 TB/s with nt)
-            typedef float f32x4_t __attribute__((ext_vector_type(4)));
-            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-            if constexpr (sizeof(T) == 4) {
-                const f32x4_t x = NT_LOAD(reinterpret_cast<const f32x4_t*>(rp + c));
-                v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-            } else {
-                const u32x4_t xx = NT_LOAD(reinterpret_cast<const u32x4_t*>(rp + c));
-                const uint4 x = make_uint4(xx[0], xx[1], xx[2], xx[3]);
-                const __half2* h = reinterpret_cast<const __half2*>(&x);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float2 f = __half22float2(h[e]); v[2 * e] = f.x; v[2 * e + 1] = f.y; }
-            }
+            const f32x4_t x = NT_LOAD(reinterpret_cast<const f32x4_t*>(rp + c));
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
-                const float* qp = sq + q * dim + c;
-#pragma unroll
-                for (int e = 0; e < EPL; e += 4) {
-                    const float4 qq = *reinterpret_cast<const float4*>(qp + e);
-                    acc[q] = fmaf(v[e], qq.x, acc[q]);
-                    acc[q] = fmaf(v[e + 1], qq.y, acc[q]);
-                    acc[q] = fmaf(v[e + 2], qq.z, acc[q]);
-                    acc[q] = fmaf(v[e + 3], qq.w, acc[q]);
-                }
+                const float4 qq = *reinterpret_cast<const float4*>(sq + q * dim + c);
+                acc[q] = fmaf(x[0], qq.x, acc[q]);
+                acc[q] = fmaf(x[1], qq.y, acc[q]);
+                acc[q] = fmaf(x[2], qq.z, acc[q]);
+                acc[q] = fmaf(x[3], qq.w, acc[q]);
             }
         }
 #pragma unroll
@@ -100,6 +90,252 @@ ip_scan_kernel(const T* __restrict__ db, int64_t n_rows, int dim, const float* _
             if (lane == 0) keys[(int64_t)q * key_stride + row] = omni_make_key(s, (uint32_t)row);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batched search (BASELINE config 5: 64 concurrent key frames against an fp16 shard).  The VALU scan above is compute bound beyond
+// a handful of queries (64 queries x 4096 FMAs per row); here the dot products run on the matrix cores and the kernel is back on the
+// HBM roofline: DB rows are the A operand of v_mfma_f32_16x16x32_f16 (lane = row l&15, 16 B = 8 halfs at k = 8*(l>>4)), read
+// straight from HBM exactly once (64 B per row per instruction, non-temporal, MQ_RING k-steps in flight per wave); the 64 queries
+// are the B operand, split once per search into fp16 hi + lo (q * 2^s = hi + lo, s per query so that max|q| lands in
+// [2^13, 2^14): 22 significant bits, products exact in the fp32 accumulator -- the same fp32-class scores as the VALU path)
+// and laid out by mq_prep_kernel so that one 256-k slice (64 KB: [hi|lo][64 q][32 x 16 B], chunk position XOR (q & 15) ->
+// conflict-free ds_read_b128) is a LINEAR 64 KB copy: the next slice streams into the other LDS buffer by LDS-DMA while the
+// current one feeds the MFMAs.  A workgroup = 8 waves x MQ_RT row tiles of 16 rows; each wave keeps MQ_RT x 4 accumulator tiles
+// (16 rows x 64 queries) across the 16 k-slices of a pass, then writes 64-bit keys for topk.h.
+//   algorithmic bytes: rows x dim x 2 (read once) + rows x nq x 8 (keys);  MFMA work 2 x 2 x 64 x dim flop per row ~ 41 % of the
+//   matrix peak at 8 TB/s, so the bound is HBM.
+#define MQ_THREADS 512
+#define MQ_WAVES 8
+#define MQ_RT 4
+#define MQ_NQ 64
+#define MQ_KS 256
+#define MQ_SLICE_BYTES (2 * MQ_NQ * MQ_KS * 2)
+#define MQ_SMEM (2 * MQ_SLICE_BYTES)
+#define MQ_RING 4
+#define MQ_SLICE_STRIDE (MQ_KS * 2 * 16)     // bytes between consecutive k-slices of a 16-row block (T16 layout): 8 KiB, 1 KiB per k-step
+typedef _Float16 mq_half8 __attribute__((ext_vector_type(8)));
+typedef float mq_f32x4 __attribute__((ext_vector_type(4)));
+
+// one block per query slot (64): power-of-two scale, hi/lo split, swizzled slice layout; slots >= nq are zero queries
+__global__ void __launch_bounds__(256)
+mq_prep_kernel(const float* __restrict__ q, int nq, int dim, uint4* __restrict__ qp, float* __restrict__ inv_scale) {
+    const int qi = blockIdx.x;
+    __shared__ float red[4];
+    float m = 0.f;
+    if (qi < nq)
+        for (int i = threadIdx.x; i < dim; i += 256) m = fmaxf(m, fabsf(q[(int64_t)qi * dim + i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float scale = 1.f, inv = qi < nq ? 1.f : 0.f;
+    if (qi < nq && m > 0.f && m < 3.0e38f) {
+        int sh = 13 - ilogbf(m);
+        sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+        scale = ldexpf(1.f, sh);
+        inv = ldexpf(1.f, -sh);
+    }
+    if (threadIdx.x == 0) inv_scale[qi] = inv;
+    for (int c = threadIdx.x; c < dim / 8; c += 256) {
+        mq_half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = qi < nq ? q[(int64_t)qi * dim + c * 8 + j] * scale : 0.f;
+            const _Float16 h = (_Float16)v;
+            hi[j] = h;
+            lo[j] = (_Float16)(v - (float)h);
+        }
+        const int slice = c >> 5, pos = (c & 31) ^ (qi & 15);
+        uint4* dst = qp + ((int64_t)(slice * 2) * MQ_NQ + qi) * 32 + pos;
+        dst[0] = *reinterpret_cast<uint4*>(&hi);
+        dst[MQ_NQ * 32] = *reinterpret_cast<uint4*>(&lo);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void mq_read(uint32_t addr, mq_half8& dst) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+__device__ __forceinline__ void mq_wait(mq_half8 (&b)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+__device__ __forceinline__ void mq_read_step(uint32_t addr, mq_half8 (&b)[8]) {
+    // b[2t + hl]: queries 16t .. 16t+15, hl = 0 hi / 1 lo
+    mq_read<0 * 8192>(addr, b[0]);          mq_read<32768 + 0 * 8192>(addr, b[1]);
+    mq_read<1 * 8192>(addr, b[2]);          mq_read<32768 + 1 * 8192>(addr, b[3]);
+    mq_read<2 * 8192>(addr, b[4]);          mq_read<32768 + 2 * 8192>(addr, b[5]);
+    mq_read<3 * 8192>(addr, b[6]);          mq_read<32768 + 3 * 8192>(addr, b[7]);
+}
+// Row loads and their waits are inline asm with hand-counted vmcnt: with an LDS-DMA in flight hipcc turns every vmcnt wait it inserts
+// itself into vmcnt(0) (the DMA counts as a pending FLAT access), which would drain the prefetch ring at every k-step.
+template <int OFF>
+__device__ __forceinline__ void mq_load_a(uint64_t p, mq_half8& dst) {       // non-temporal: every block byte is read once (measured +15 %)
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(dst) : "v"(p), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void mq_wait_a(mq_half8 (&a)[MQ_RT]) {
+    static_assert(MQ_RT == 4, "operand list below");
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(N));
+}
+
+// k-step S of a slice: ring slot S%4 was filled 4 k-steps ago
+// (younger VMEM ops at its wait: 3 slots x 4 loads, plus the 8 DMA instructions issued at the top of the slice for S < 4) and is
+// refilled right after its MFMAs with the block data MQ_RING k-steps ahead (next slice / next pass for the second half).  The prologue
+// in the kernel issues its loads in the same slot-major order: the counts are only valid for that order.  Offsets: 1 KiB per k-step; the
+// instruction's signed 13-bit immediate covers -4096..4095, so the block pointers are biased to the MIDDLE of their 8 KiB slice.
+template <int S>
+__device__ __forceinline__ void mq_step(uint32_t bx, const uint64_t (&cur)[MQ_RT], const uint64_t (&nxt)[MQ_RT], mq_half8 (&a)[MQ_RING][MQ_RT],
+                                        mq_half8 (&b)[8], mq_f32x4 (&acc)[MQ_RT][4]) {
+    mq_wait(b);
+    mq_wait_a<3 * MQ_RT + (S < 4 ? 8 : 0)>(a[S % MQ_RING]);
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+        for (int i = 0; i < MQ_RT; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[2 * t + hl], a[S % MQ_RING][i], acc[i][t], 0, 0, 0);
+    // query fragments of the next k-step: ONE register set (the ring and the accumulators leave no room for two) -- the reads are issued
+    // behind the last MFMA that consumes the old fragments (in-order issue; LDS returns >= 64 cycles later), their latency is covered by
+    // the other wave of the SIMD, and the matrix pipe is only ~30 % busy at the HBM roofline anyway
+    if constexpr (S + 1 < 8) mq_read_step(bx ^ (64 * (S + 1)), b);
+#pragma unroll
+    for (int i = 0; i < MQ_RT; ++i) {
+        if constexpr (S + MQ_RING < 8) mq_load_a<(S + MQ_RING) * 1024 - 4096>(cur[i], a[S % MQ_RING][i]);
+        else mq_load_a<(S + MQ_RING - 8) * 1024 - 4096>(nxt[i], a[S % MQ_RING][i]);
+    }
+    if constexpr (S + 1 < 8) mq_step<S + 1>(bx, cur, nxt, a, b, acc);
+}
+
+__global__ void __launch_bounds__(MQ_THREADS, 1)
+ip_scan_mq_kernel(const _Float16* __restrict__ db, int64_t n_rows, int dim, const char* __restrict__ qp,
+                  const float* __restrict__ inv_scale, int nq, uint64_t* __restrict__ keys, int64_t key_stride, int rotate) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const int64_t total_tiles = (n_rows + 15) >> 4;
+    constexpr int BT = MQ_WAVES * MQ_RT;                          // 32 tiles = 512 rows per block
+    const int64_t blocks = (total_tiles + BT - 1) / BT;
+    const int passes = (int)((blocks - blockIdx.x + gridDim.x - 1) / gridDim.x);   // blocks blockIdx.x, +gridDim.x, ... (>= 1)
+    const int S = dim / MQ_KS;
+    const int U = passes * S;                                    // slice units this workgroup walks through
+    // Every block walks the k-slices in its own rotation (block index mod S, a function of the ROW only, so a row's score does not
+    // depend on the shard size or the launch grid): with all workgroups at the same k offset of 8 KB-strided rows the requests of the
+    // whole chip would fall on a few HBM channels at a time.
+    auto blk_of = [&](int p) { return (int64_t)blockIdx.x + (int64_t)p * gridDim.x; };
+    auto rot_of = [&](int p) { return rotate ? (int)(blk_of(p) % S) : 0; };
+
+    auto dma = [&](int slice, int buf) {                          // 64 KB linear copy, 8 wave-instructions of 1 KiB per wave
+        const char* g = qp + (size_t)slice * MQ_SLICE_BYTES + wave * 8192 + lane * 16;
+        char* l = smem_raw + buf * MQ_SLICE_BYTES + wave * 8192;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + j * 1024),
+                                             (__attribute__((address_space(3))) void*)(l + j * 1024), 16, 0, 0);
+    };
+    // block pointers of pass p (T16 layout: a 16-row tile is 16*dim contiguous halfs, k-step s of it the KiB at s*1024, lane-linear);
+    // out-of-range tiles are clamped to the last one
+    auto row_ptrs = [&](int p, uint64_t (&rp)[MQ_RT]) {
+        const int64_t tile0 = blk_of(p) * BT;
+#pragma unroll
+        for (int i = 0; i < MQ_RT; ++i) {
+            int64_t t = tile0 + i * MQ_WAVES + wave;
+            t = t < total_tiles ? t : total_tiles - 1;
+            rp[i] = (uint64_t)(uintptr_t)(db + t * 16 * dim + lane * 8) + 4096;     // biased to the middle of a slice (see mq_step)
+        }
+    };
+
+    // query-operand address: query row n = r16 (+16t by immediate), chunk (4s + c4) ^ n -> ((n*512 + ((c4 ^ (n&3)) << 4) + ((n&12) << 4)) ^ (64 s)
+    const uint32_t bbase = lds0 + r16 * 512 + ((c4 ^ (r16 & 3)) << 4) + ((r16 & 12) << 4);
+
+    mq_f32x4 acc[MQ_RT][4];
+#pragma unroll
+    for (int i = 0; i < MQ_RT; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = mq_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint64_t cur[MQ_RT];                                          // this unit's rows at its k-slice (the only pointers carried across units)
+    row_ptrs(0, cur);
+    int rot = rot_of(0);
+    dma(rot, 0);
+    mq_half8 a[MQ_RING][MQ_RT];
+#pragma unroll
+    for (int i = 0; i < MQ_RT; ++i) cur[i] += (uint64_t)rot * MQ_SLICE_STRIDE;
+#pragma unroll
+    for (int i = 0; i < MQ_RT; ++i) mq_load_a<-4096>(cur[i], a[0][i]);      // slot-major, the issue order of mq_step's refills
+#pragma unroll
+    for (int i = 0; i < MQ_RT; ++i) mq_load_a<-3072>(cur[i], a[1][i]);
+#pragma unroll
+    for (int i = 0; i < MQ_RT; ++i) mq_load_a<-2048>(cur[i], a[2][i]);
+#pragma unroll
+    for (int i = 0; i < MQ_RT; ++i) mq_load_a<-1024>(cur[i], a[3][i]);
+
+    int j = 0, p = 0;
+    for (int u = 0; u < U; ++u) {
+        // slice u sits in buffer u&1 once every wave's DMA part has landed: loads retire in order, the MQ_RING*MQ_RT row loads issued
+        // after the DMA may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MQ_RING * MQ_RT) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        const bool last_slice = j + 1 == S;
+        const int pn = p + 1 < passes ? p + 1 : p;
+        const int rot_n = last_slice ? rot_of(pn) : rot;
+        int sl = j + rot;                 sl = sl >= S ? sl - S : sl;        // this unit's k-slice
+        int sn = (last_slice ? 0 : j + 1) + rot_n; sn = sn >= S ? sn - S : sn;   // the next unit's
+        // next slice into the other buffer (every wave is past its reads of slice u-1).  Issued unconditionally -- after the last unit it
+        // is a harmless copy -- so that the vmcnt distances below are constants.
+        dma(sn, (u + 1) & 1);
+        asm volatile("" ::: "memory");                             // the DMA stays in front of the row loads below (vmcnt distances)
+        uint64_t nxt[MQ_RT];                                      // the next unit's rows at its k-slice
+        if (last_slice) {
+            row_ptrs(pn, nxt);
+#pragma unroll
+            for (int i = 0; i < MQ_RT; ++i) nxt[i] += (uint64_t)sn * MQ_SLICE_STRIDE;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MQ_RT; ++i) nxt[i] = cur[i] + (int64_t)(sn - sl) * MQ_SLICE_STRIDE;
+        }
+        const uint32_t bx = bbase + ((u & 1) ? MQ_SLICE_BYTES : 0);
+        mq_half8 b[8];
+        mq_read_step(bx, b);
+        mq_step<0>(bx, cur, nxt, a, b, acc);
+        if (last_slice) {
+            // pass done: keys[q][row] for this wave's tiles.  The queries are the A operand, the DB rows the B operand, so in the C layout
+            // of the 16x16 tile a lane holds row l&15 of queries 4*(l>>4)+e: every store instruction writes four full 128-byte lines
+            // (16 consecutive rows of one query each).
+            // Stores share vmcnt with loads and retire out of order with them: drain the ring first so that the counted waits of the
+            // next unit only ever have loads younger than the ones they wait for.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qq = 16 * t + 4 * c4 + e;
+                    const float inv = inv_scale[qq];
+                    uint64_t* kq = keys + (int64_t)qq * key_stride;
+#pragma unroll
+                    for (int i = 0; i < MQ_RT; ++i) {
+                        const int64_t row = (blk_of(p) * BT + i * MQ_WAVES + wave) * 16 + r16;
+                        if (qq < nq && row < n_rows)
+                            kq[row] = omni_make_key(acc[i][t][e] * inv, (uint32_t)row);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // one (t, e) at a time: the ring and the accumulators leave few free registers
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MQ_RT; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[i][t] = mq_f32x4{0.f, 0.f, 0.f, 0.f};
+            j = 0; ++p; rot = rot_n;
+        } else {
+            ++j;
+        }
+#pragma unroll
+        for (int i = 0; i < MQ_RT; ++i) cur[i] = nxt[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // trailing ring refills (harmless re-reads) retire before the wave ends
 }
 
 __global__ void decode_topk_kernel(const uint64_t* __restrict__ keys, int nq, int k, int rank, int world,
@@ -114,24 +350,102 @@ __global__ void decode_topk_kernel(const uint64_t* __restrict__ keys, int nq, in
     I[i] = (int64_t)local * world + rank;
 }
 
-__global__ void f32_to_f16_kernel(const float* __restrict__ in, __half* __restrict__ out, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __float2half_rn(in[i]);
+// half index of (row, 16-byte chunk) in the T16 layout
+__device__ __forceinline__ int64_t t16_chunk(int64_t row, int chunk, int dim) {
+    return (row >> 4) * 16 * (int64_t)dim + ((int64_t)chunk * 16 + (row & 15)) * 8;
+}
+// in: n x dim fp32 rows -> T16 rows row0 .. row0+n-1 (one thread per 8-element chunk)
+__global__ void f32_to_t16_kernel(const float* __restrict__ in, __half* __restrict__ db, int64_t row0, int64_t n, int dim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpr = dim >> 3;
+    if (i >= n * cpr) return;
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr);
+    const float4 lo = *reinterpret_cast<const float4*>(in + r * dim + c * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(in + r * dim + c * 8 + 4);
+    __half2 h[4] = {__floats2half2_rn(lo.x, lo.y), __floats2half2_rn(lo.z, lo.w), __floats2half2_rn(hi.x, hi.y), __floats2half2_rn(hi.z, hi.w)};
+    *reinterpret_cast<uint4*>(db + t16_chunk(row0 + r, c, dim)) = *reinterpret_cast<uint4*>(h);
+}
+// snapshots hold plain row-major fp16 rows: T16 <-> rows (TO_ROWS: db -> rows, else rows -> db)
+template <bool TO_ROWS>
+__global__ void t16_rows_kernel(__half* __restrict__ db, __half* __restrict__ rows, int64_t row0, int64_t n, int dim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpr = dim >> 3;
+    if (i >= n * cpr) return;
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr);
+    uint4* a = reinterpret_cast<uint4*>(db + t16_chunk(row0 + r, c, dim));
+    uint4* b = reinterpret_cast<uint4*>(rows + r * dim + c * 8);
+    if (TO_ROWS) *b = *a; else *a = *b;
 }
 
-template <typename T>
+// fp16 shard, up to SCAN_MAX_QB queries on the VALU: one wave per 16-row block at a time, lane = (row r = l & 15, chunk c = l >> 4) --
+// each wave instruction streams one contiguous KiB of the block; a row's dot product sits in its 4 lanes (r, r+16, r+32, r+48).
+template <int QB>
+__global__ void __launch_bounds__(SCAN_THREADS)
+ip_scan_t16_kernel(const __half* __restrict__ db, int64_t n_rows, int dim, const float* __restrict__ queries,
+                   uint64_t* __restrict__ keys, int64_t key_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sq = reinterpret_cast<float*>(smem_raw);             // [QB][dim]
+    for (int i = threadIdx.x * 4; i < QB * dim; i += SCAN_THREADS * 4)
+        *reinterpret_cast<float4*>(sq + i) = *reinterpret_cast<const float4*>(queries + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const int64_t n_blocks = (n_rows + 15) >> 4;
+    const int steps = dim >> 5;                                   // 32 k (4 chunks) per step
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    for (int64_t blk = (int64_t)blockIdx.x * SCAN_WAVES + wave; blk < n_blocks; blk += (int64_t)gridDim.x * SCAN_WAVES) {
+        const u32x4_t* bp = reinterpret_cast<const u32x4_t*>(db + blk * 16 * dim) + lane;
+        float acc[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = 0.f;
+#pragma unroll 4
+        for (int st = 0; st < steps; ++st) {
+            const u32x4_t xx = NT_LOAD(bp + st * 64);
+            const uint4 x = make_uint4(xx[0], xx[1], xx[2], xx[3]);
+            const __half2* h = reinterpret_cast<const __half2*>(&x);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float2 f = __half22float2(h[e]); v[2 * e] = f.x; v[2 * e + 1] = f.y; }
+            const int k0 = (st * 4 + c4) * 8;
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const float4 q0 = *reinterpret_cast<const float4*>(sq + q * dim + k0);
+                const float4 q1 = *reinterpret_cast<const float4*>(sq + q * dim + k0 + 4);
+                acc[q] = fmaf(v[0], q0.x, acc[q]); acc[q] = fmaf(v[1], q0.y, acc[q]);
+                acc[q] = fmaf(v[2], q0.z, acc[q]); acc[q] = fmaf(v[3], q0.w, acc[q]);
+                acc[q] = fmaf(v[4], q1.x, acc[q]); acc[q] = fmaf(v[5], q1.y, acc[q]);
+                acc[q] = fmaf(v[6], q1.z, acc[q]); acc[q] = fmaf(v[7], q1.w, acc[q]);
+            }
+        }
+        const int64_t row = blk * 16 + r16;
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            float sum = acc[q];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (c4 == 0 && row < n_rows) keys[(int64_t)q * key_stride + row] = omni_make_key(sum, (uint32_t)row);
+        }
+    }
+}
+
 static int launch_scan(hipStream_t st, const omni_index* ix, int qb, const float* q_dev, uint64_t* keys, int64_t key_stride) {
     const int64_t n = ix->ntotal;
+    const bool f16 = ix->storage == OMNI_STORE_F16;
     int cus = ix->ctx->prop.multiProcessorCount > 0 ? ix->ctx->prop.multiProcessorCount : 256;
-    int64_t want = cdiv64(n, SCAN_WAVES);
+    int64_t want = cdiv64(f16 ? cdiv64(n, 16) : n, SCAN_WAVES);      // a wave walks rows (fp32) or 16-row blocks (fp16)
     int grid = (int)(want < (int64_t)cus * 8 ? want : (int64_t)cus * 8);
     if (grid < 1) grid = 1;
     size_t smem = (size_t)qb * ix->dim * sizeof(float);
-    const T* db = reinterpret_cast<const T*>(ix->db);
-#define OMNI_SCAN_CASE(QB)                                                                                   \
-    case QB:                                                                                                 \
-        hipLaunchKernelGGL((ip_scan_kernel<T, QB>), dim3(grid), dim3(SCAN_THREADS), smem, st, db, n, ix->dim, \
-                           q_dev, keys, key_stride);                                                         \
+#define OMNI_SCAN_CASE(QB)                                                                                              \
+    case QB:                                                                                                            \
+        if (f16)                                                                                                        \
+            hipLaunchKernelGGL((ip_scan_t16_kernel<QB>), dim3(grid), dim3(SCAN_THREADS), smem, st,                      \
+                               reinterpret_cast<const __half*>(ix->db), n, ix->dim, q_dev, keys, key_stride);           \
+        else                                                                                                            \
+            hipLaunchKernelGGL((ip_scan_kernel<float, QB>), dim3(grid), dim3(SCAN_THREADS), smem, st,                   \
+                               reinterpret_cast<const float*>(ix->db), n, ix->dim, q_dev, keys, key_stride);            \
         break;
     switch (qb) {
         OMNI_SCAN_CASE(1) OMNI_SCAN_CASE(2) OMNI_SCAN_CASE(3) OMNI_SCAN_CASE(4)
@@ -143,14 +457,48 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int qb, const float
     return OMNI_OK;
 }
 
+// up to MQ_NQ queries in one pass over an fp16 shard (ip_scan_mq_kernel)
+static int launch_scan_mq(hipStream_t st, omni_index* ix, int nq, const float* q_dev, uint64_t* keys, int64_t key_stride) {
+    auto kfn = ip_scan_mq_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MQ_SMEM));
+        attr_set = true;
+    }
+    const int slices = ix->dim / MQ_KS;
+    int rc;
+    if ((rc = ix->mq_q.ensure((size_t)slices * MQ_SLICE_BYTES))) return rc;
+    if ((rc = ix->mq_inv.ensure(MQ_NQ * sizeof(float)))) return rc;
+    hipLaunchKernelGGL(mq_prep_kernel, dim3(MQ_NQ), dim3(256), 0, st, q_dev, nq, ix->dim, ix->mq_q.as<uint4>(), ix->mq_inv.as<float>());
+    OMNI_LAUNCH_CHECK();
+    const int64_t tiles = cdiv64(ix->ntotal, 16);
+    const int cus = ix->ctx->prop.multiProcessorCount > 0 ? ix->ctx->prop.multiProcessorCount : 256;
+    // one workgroup per CU (128 KB of LDS each) walking 512-row blocks b, b + grid, ...
+    const int64_t blocks = cdiv64(tiles, MQ_WAVES * MQ_RT);
+    const int64_t grid = blocks < cus ? blocks : cus;
+    static const int rotate = getenv("OMNI_MQ_ROT") ? atoi(getenv("OMNI_MQ_ROT")) : 1;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(MQ_THREADS), MQ_SMEM, st, reinterpret_cast<const _Float16*>(ix->db),
+                       ix->ntotal, ix->dim, ix->mq_q.as<char>(), ix->mq_inv.as<float>(), nq, keys, key_stride, rotate);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+// number of queries from which an fp16 shard is searched on the matrix cores (OMNI_MQ_MIN overrides: 1 = always, 0 = never)
+static int mq_min_queries() {
+    const char* e = getenv("OMNI_MQ_MIN");
+    int v = e ? atoi(e) : 4;
+    return v <= 0 ? (1 << 30) : v;
+}
+
 static int ensure_capacity(omni_index* ix, int64_t rows) {
     if (rows <= ix->capacity) return OMNI_OK;
     int64_t cap = ix->capacity > 0 ? ix->capacity : 1024;
     while (cap < rows) cap *= 2;
+    cap = (cap + 15) & ~(int64_t)15;                             // whole 16-row blocks (fp16 T16 layout)
     void* nd = nullptr;
     OMNI_HIP_TRY(hipMalloc(&nd, (size_t)cap * ix->dim * ix->elem()));
     if (ix->db && ix->ntotal > 0)
-        OMNI_HIP_TRY(hipMemcpyAsync(nd, ix->db, (size_t)ix->ntotal * ix->dim * ix->elem(), hipMemcpyDeviceToDevice,
+        OMNI_HIP_TRY(hipMemcpyAsync(nd, ix->db, (size_t)((ix->ntotal + 15) & ~(int64_t)15) * ix->dim * ix->elem(), hipMemcpyDeviceToDevice,
                                     ix->ctx->stream));
     OMNI_HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
     if (ix->db) (void)hipFree(ix->db);
@@ -169,8 +517,8 @@ static int append_dev(omni_index* ix, int64_t n, const float* x_dev) {
         OMNI_HIP_TRY(hipMemcpyAsync((float*)ix->db + ix->ntotal * ix->dim, x_dev, (size_t)cnt * 4,
                                     hipMemcpyDeviceToDevice, st));
     } else {
-        hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)cdiv64(cnt, 256)), dim3(256), 0, st, x_dev,
-                           (__half*)ix->db + ix->ntotal * ix->dim, cnt);
+        hipLaunchKernelGGL(f32_to_t16_kernel, dim3((unsigned)cdiv64(cnt / 8, 256)), dim3(256), 0, st, x_dev, (__half*)ix->db, ix->ntotal, n,
+                           ix->dim);
         OMNI_LAUNCH_CHECK();
     }
     ix->ntotal += n;
@@ -189,12 +537,14 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
     uint64_t* kb = ix->keys_b.as<uint64_t>();
     if (n > 0) {
         OMNI_HIP_TRY(hipEventRecord(ix->scan0, st));
-        for (int q0 = 0; q0 < nq; q0 += SCAN_MAX_QB) {
+        const bool mq = ix->storage == OMNI_STORE_F16 && nq >= mq_min_queries();
+        for (int q0 = 0; mq && q0 < nq; q0 += MQ_NQ) {
+            const int qb = nq - q0 < MQ_NQ ? nq - q0 : MQ_NQ;
+            if ((rc = launch_scan_mq(st, ix, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n))) return rc;
+        }
+        for (int q0 = 0; !mq && q0 < nq; q0 += SCAN_MAX_QB) {
             int qb = nq - q0 < SCAN_MAX_QB ? nq - q0 : SCAN_MAX_QB;
-            if (ix->storage == OMNI_STORE_F32)
-                rc = launch_scan<float>(st, ix, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n);
-            else
-                rc = launch_scan<__half>(st, ix, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n);
+            rc = launch_scan(st, ix, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n);
             if (rc) return rc;
         }
         OMNI_HIP_TRY(hipEventRecord(ix->scan1, st));
@@ -235,7 +585,7 @@ void omni_index_destroy(omni_index* ix) {
     (void)hipStreamSynchronize(ix->ctx->stream);
     if (ix->db) (void)hipFree(ix->db);
     ix->qbuf.release(); ix->keys_a.release(); ix->keys_b.release(); ix->out_d.release(); ix->out_i.release();
-    ix->stage.release(); ix->hq.release(); ix->hout.release();
+    ix->stage.release(); ix->mq_q.release(); ix->mq_inv.release(); ix->hq.release(); ix->hout.release();
     if (ix->scan0) (void)hipEventDestroy(ix->scan0);
     if (ix->scan1) (void)hipEventDestroy(ix->scan1);
     delete ix;
@@ -345,9 +695,15 @@ int omni_index_save(omni_index* ix, const char* path) {
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     const size_t row = (size_t)ix->dim * ix->elem(), slab_rows = 4096;
     int rc = ix->hout.ensure(slab_rows * row);
+    const bool f16 = ix->storage == OMNI_STORE_F16;              // snapshots hold plain row-major rows: de-block the T16 layout per slab
+    if (!rc && f16) rc = ix->stage.ensure(slab_rows * row);
     for (int64_t s = 0; ok && rc == OMNI_OK && s < ix->ntotal; s += slab_rows) {
         const size_t m = (size_t)(ix->ntotal - s < (int64_t)slab_rows ? ix->ntotal - s : slab_rows);
-        if (hipMemcpyAsync(ix->hout.p, (const char*)ix->db + (size_t)s * row, m * row, hipMemcpyDeviceToHost, ix->ctx->stream) != hipSuccess ||
+        if (f16)
+            hipLaunchKernelGGL((omni::t16_rows_kernel<true>), dim3((unsigned)omni::cdiv64((int64_t)m * (ix->dim / 8), 256)), dim3(256), 0,
+                               ix->ctx->stream, (__half*)ix->db, ix->stage.as<__half>(), s, (int64_t)m, ix->dim);
+        if (hipMemcpyAsync(ix->hout.p, f16 ? (const char*)ix->stage.p : (const char*)ix->db + (size_t)s * row, m * row, hipMemcpyDeviceToHost,
+                           ix->ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ix->ctx->stream) != hipSuccess) { omni::set_error("device read failed while saving"); rc = OMNI_ERR_HIP; break; }
         ok = fwrite(ix->hout.p, row, m, f) == m;
     }
@@ -373,11 +729,17 @@ int omni_index_load(omni_index* ix, const char* path) {
     const size_t row = (size_t)ix->dim * ix->elem(), slab_rows = 4096;
     if (!rc) rc = omni::ensure_capacity(ix, h.ntotal > 0 ? h.ntotal : 1);
     if (!rc) rc = ix->hout.ensure(slab_rows * row);
+    const bool f16 = ix->storage == OMNI_STORE_F16;
+    if (!rc && f16) rc = ix->stage.ensure(slab_rows * row);
     for (int64_t s = 0; !rc && s < h.ntotal; s += slab_rows) {
         const size_t m = (size_t)(h.ntotal - s < (int64_t)slab_rows ? h.ntotal - s : slab_rows);
         if (fread(ix->hout.p, row, m, f) != m) { omni::set_error("%s is truncated", path); rc = OMNI_ERR_INVALID; break; }
-        if (hipMemcpyAsync((char*)ix->db + (size_t)s * row, ix->hout.p, m * row, hipMemcpyHostToDevice, ix->ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ix->ctx->stream) != hipSuccess) { omni::set_error("device write failed while loading"); rc = OMNI_ERR_HIP; }
+        bool okc = hipMemcpyAsync(f16 ? (char*)ix->stage.p : (char*)ix->db + (size_t)s * row, ix->hout.p, m * row, hipMemcpyHostToDevice,
+                                  ix->ctx->stream) == hipSuccess;
+        if (okc && f16)
+            hipLaunchKernelGGL((omni::t16_rows_kernel<false>), dim3((unsigned)omni::cdiv64((int64_t)m * (ix->dim / 8), 256)), dim3(256), 0,
+                               ix->ctx->stream, (__half*)ix->db, ix->stage.as<__half>(), s, (int64_t)m, ix->dim);
+        if (!okc || hipStreamSynchronize(ix->ctx->stream) != hipSuccess) { omni::set_error("device write failed while loading"); rc = OMNI_ERR_HIP; }
     }
     fclose(f);
     if (!rc) ix->ntotal = h.ntotal;

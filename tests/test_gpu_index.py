@@ -118,6 +118,23 @@ def test_fp16_storage(omni, ctx):
     assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=1e-6)
 
 
+def test_fp16_row_by_row_add_across_reallocation(omni, ctx):
+    """fp16 shards live in 16-row blocks (k-chunks interleaved over the rows of a block): rows appended one at a time, the way
+    LoopDetector adds them (loop_detector.cpp:166), across two capacity doublings and a partially filled last block."""
+    db = synth.global_db(2500, seed=17)
+    idx = omni.capi.IndexFlatIP(ctx, DIM, omni.capi.STORE_F16)            # default capacity 1024 rows
+    db16 = db.astype(np.float16).astype(np.float32)
+    for i, r in enumerate(db):
+        idx.add(r)
+        if i in (0, 14, 15, 16, 1023, 1024, 2047, 2048):                   # block and capacity boundaries
+            q = db[[i, i // 2]]
+            _check(idx, db16[:i + 1], q, min(6, i + 1))
+    assert idx.ntotal == 2500
+    q, rows = synth.queries_from_db(db, 5, seed=18)
+    _check(idx, db16, q, 15)                                               # 5 queries: matrix-core kernel
+    _check(idx, db16, q[:2], 15)                                           # 2 queries: VALU kernel on the same blocks
+
+
 def test_64_concurrent_queries_fp16_storage(omni, ctx):
     """BASELINE config 5 shape in miniature: 64 queries (one per concurrent key frame) against an fp16 shard in one call."""
     db = synth.global_db(9000, seed=13)
@@ -127,6 +144,67 @@ def test_64_concurrent_queries_fp16_storage(omni, ctx):
     D, I = idx.search(q, 15)
     Dr, Ir = M.ip_search(db.astype(np.float16).astype(np.float32), q, 15)
     assert np.array_equal(I[:, 0], rows) and np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,nq", [(5, 9), (16, 12), (1000, 33), (4099, 64), (9000, 65), (20011, 130)])
+def test_batched_matrix_core_search_fp16(omni, ctx, n, nq):
+    """Four or more queries against an fp16 shard run on the matrix cores (ip_scan_mq_kernel: queries split into fp16 hi + lo, so the
+    scores stay fp32-class).  Ragged row counts (tiles of 16, passes of 512 rows), query counts around the 64-slot block, k from the
+    reference's 5 + max_index up to the 1000 cap."""
+    db = synth.global_db(n, seed=20 + n % 7)
+    if n > 100:
+        db[n // 2] = db[3]                                  # an exact tie across tiles: lower row first
+    rng = np.random.default_rng(nq)
+    rows = rng.integers(0, n, nq)
+    q = db[rows] + 0.02 * rng.standard_normal((nq, DIM)).astype(np.float32)
+    q[0] *= 37.5                                            # per-query power-of-two scaling: magnitudes far from 1 keep their accuracy
+    q[1] *= 1e-3
+    idx = omni.capi.IndexFlatIP(ctx, DIM, omni.capi.STORE_F16)
+    idx.add(db)
+    db16 = db.astype(np.float16).astype(np.float32)
+    for k in (6, 15) if n < 9000 else (10,):
+        _check(idx, db16, q, k)
+    if n == 4099:
+        _check(idx, db16, q[:9], 1000)
+
+
+def test_batched_search_equals_the_per_query_path(omni, ctx, monkeypatch):
+    """Same shard, same queries: the matrix-core kernel (OMNI_MQ_MIN=1 forces it even for one query) and the VALU kernel agree on
+    ids and on scores to fp32 summation noise."""
+    db = synth.global_db(7000, seed=31)
+    q, rows = synth.queries_from_db(db, 20, seed=32)
+    idx = omni.capi.IndexFlatIP(ctx, DIM, omni.capi.STORE_F16)
+    idx.add(db)
+    monkeypatch.setenv("OMNI_MQ_MIN", "0")
+    Dv, Iv = idx.search(q, 12)
+    monkeypatch.setenv("OMNI_MQ_MIN", "1")
+    Dm, Im = idx.search(q, 12)
+    D1, I1 = idx.search(q[:1], 12)
+    assert np.array_equal(Iv, Im) and np.allclose(Dv, Dm, rtol=1e-5, atol=2e-6)
+    assert np.array_equal(I1, Im[:1]) and np.array_equal(D1, Dm[:1])          # a query's result does not depend on its batch
+
+
+def test_batched_search_full_shard_properties(omni, ctx):
+    """BASELINE config 5 per-GPU shard (1 M key frames / 8 GPUs = 125 000 fp16 rows, 64 concurrent queries): planted rows first,
+    idempotent, descending, unique ids."""
+    n = 125_000
+    idx = omni.capi.IndexFlatIP(ctx, DIM, omni.capi.STORE_F16, capacity=n)
+    rng = np.random.default_rng(5)
+    planted = []
+    for s in range(0, n, 12_500):
+        blk = rng.standard_normal((12_500, DIM), dtype=np.float32)
+        blk /= np.linalg.norm(blk, axis=1, keepdims=True)
+        for off in (7, 6001, 12_499):
+            planted.append((s + off, blk[off].copy()))
+        idx.add(blk)
+    planted = planted[:64] if len(planted) >= 64 else planted
+    q = np.stack([v for _, v in planted])
+    rows = [r for r, _ in planted]
+    D, I = idx.search(q, 10)
+    assert I[:, 0].tolist() == rows and np.allclose(D[:, 0], 1.0, atol=2e-3)       # fp16 rows: |row|^2 is 1 to ~1e-3
+    assert (np.diff(D, axis=1) <= 0).all() and all(len(set(r)) == 10 for r in I.tolist())
+    D2, I2 = idx.search(q, 10)
+    assert np.array_equal(I, I2) and np.array_equal(D, D2)
 
 
 def test_snapshot_roundtrip(omni, ctx, tmp_path):
