@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--precision", choices=["f16", "f32"], default="f16")
     ap.add_argument("--db-keyframes", type=int, default=1000, help="key frames pre-loaded in the index (x4 rows) for the throughput loop")
     ap.add_argument("--match-db-rows", type=int, default=100_000, help="index rows for the p50 loop-match measurement (node total)")
-    ap.add_argument("--pipelines", type=int, default=3, help="micro-batches in flight per GPU (separate HIP streams)")
-    ap.add_argument("--microbatch", type=int, default=4,
+    ap.add_argument("--pipelines", type=int, default=2, help="micro-batches in flight per GPU (separate HIP streams)")
+    ap.add_argument("--microbatch", type=int, default=8,
                     help="consecutive key frames enqueued together (one SuperPoint launch over 8*MB images, one MobileNetVLAD launch over 4*MB): "
                          "the low-resolution layers of both nets are launch/latency-bound at one key frame.  When --steps is not a "
                          "multiple the last micro-batch is still processed in full inside the timed region (extra work, not counted)")
@@ -147,17 +147,27 @@ def main():
 
     def finish(cam, step):
         out = cam.fetch()
-        for m in range(MB):                     # the MB key frames of the micro-batch reach the detector one by one, in order
-            ims = out["images"][4 * m:4 * m + 4]
-            if world == 1:
-                fr = detector.FisheyeFrameDescriptor(
+        if os.environ.get("OMNI_BENCH_SKIP_DETECTOR") == "1":      # diagnostic only (host/index share of a step); never a reported number
+            return out
+        if world == 1:
+            # the MB key frames of the micro-batch reach the detector in order, as one batch: rows and queries are taken from
+            # MobileNetVLAD's output buffer in HBM ([4*MB][4096], key-frame major), one host synchronisation for all of them
+            frames = []
+            for m in range(MB):
+                ims = out["images"][4 * m:4 * m + 4]
+                frames.append(detector.FisheyeFrameDescriptor(
                     msg_id=step + m, drone_id=1, landmark_num=int(sum(i["landmark_num"] for i in ims)), prevent_adding_db=False,
                     images=[detector.ImageDescriptor(drone_id=1, landmark_num=i["landmark_num"], image_desc=i["image_desc"],
                                                      feature_descriptor=i["feature_descriptor"], landmarks_2d=i["landmarks_2d"])
-                            for i in ims])
-                rec = det.on_image_recv(fr)
-                hits[0] += int(rec["old_msg_id"] != -1)
+                            for i in ims]))
+            if os.environ.get("OMNI_BENCH_DETECTOR_PER_FRAME") == "1":      # A/B: the reference's call pattern, ~6 host syncs per key frame
+                recs = [det.on_image_recv(fr) for fr in frames]
             else:
+                recs = det.on_images_recv_batch(frames, rows_dev=cam.vlad.dev_output())
+            hits[0] += sum(int(r["old_msg_id"] != -1) for r in recs)
+        else:
+            for m in range(MB):
+                ims = out["images"][4 * m:4 * m + 4]
                 rows = np.stack([i["image_desc"] for i in ims])
                 D, I = swarm.step(rows, query_row=1, k=K_SEARCH)                # add world*4 rows, query direction 1
                 ok = (I[0] >= 0) & (I[0] <= swarm.ntotal - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)

@@ -173,6 +173,12 @@ int         omni_index_reset(omni_index* idx);
  * missing results padded with I = -1, D = -FLT_MAX.  k <= 1024 (the reference caps at 1000, loop_detector.cpp:200). */
 int         omni_index_search(omni_index* idx, int nq, const float* q_host, int k, float* D, int64_t* I);
 int         omni_index_search_dev(omni_index* idx, int nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev);
+/* search_dev restricted to the first n_limit local rows (the index as it was when it held n_limit rows).  Lets a caller enqueue
+ * "add, query, add, query, ..." for several key frames -- LoopDetector::on_image_recv adds a frame's rows BEFORE querying
+ * (loop_detector.cpp:89-98) -- on the stream without a host synchronisation in between: all adds first, then every query with the
+ * ntotal it would have seen.  An empty prefix (n_limit == 0) fills the outputs with I = -1, D = -FLT_MAX. */
+int         omni_index_search_prefix_dev(omni_index* idx, int nq, const float* q_dev, int k, int64_t n_limit, float* D_dev,
+                                         int64_t* I_dev);
 /* row sharding across GPUs: this handle holds rows g with g % world == rank at local slot g / world;
  * search then reports GLOBAL ids (local * world + rank).  Default rank 0, world 1. */
 int         omni_index_set_shard(omni_index* idx, int rank, int world);

@@ -32,7 +32,7 @@ SYMBOLS = [
     "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy",
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset",
-    "omni_index_search", "omni_index_search_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
+    "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
     "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_wait",
 ]
@@ -127,6 +127,7 @@ def lib():
     sig("omni_index_reset", C.c_int, [_vp])
     sig("omni_index_search", C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp, _i64p])
     sig("omni_index_search_dev", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp])
+    sig("omni_index_search_prefix_dev", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp])
     sig("omni_index_set_shard", C.c_int, [_vp, C.c_int, C.c_int])
     sig("omni_topk_merge", C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _i64p, C.c_int, _fp, _i64p])
     sig("omni_index_last_scan_ms", C.c_int, [_vp, _fp])
@@ -423,6 +424,10 @@ class IndexFlatIP:
 
     def search_dev(self, nq: int, q_dev: int, k: int, D_dev: int, I_dev: int):
         _check(lib().omni_index_search_dev(self.h, nq, q_dev, k, D_dev, I_dev))
+
+    def search_prefix_dev(self, nq: int, q_dev: int, k: int, n_limit: int, D_dev: int, I_dev: int):
+        """search_dev over the first n_limit rows only (asynchronous; see include/omni_hip.h)."""
+        _check(lib().omni_index_search_prefix_dev(self.h, nq, q_dev, k, n_limit, D_dev, I_dev))
 
     def last_scan_ms(self) -> float:
         ms = C.c_float()

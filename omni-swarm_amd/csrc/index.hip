@@ -430,8 +430,7 @@ ip_scan_t16_kernel(const __half* __restrict__ db, int64_t n_rows, int dim, const
     }
 }
 
-static int launch_scan(hipStream_t st, const omni_index* ix, int qb, const float* q_dev, uint64_t* keys, int64_t key_stride) {
-    const int64_t n = ix->ntotal;
+static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, const float* q_dev, uint64_t* keys, int64_t key_stride) {
     const bool f16 = ix->storage == OMNI_STORE_F16;
     int cus = ix->ctx->prop.multiProcessorCount > 0 ? ix->ctx->prop.multiProcessorCount : 256;
     int64_t want = cdiv64(f16 ? cdiv64(n, 16) : n, SCAN_WAVES);      // a wave walks rows (fp32) or 16-row blocks (fp16)
@@ -458,7 +457,7 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int qb, const float
 }
 
 // up to MQ_NQ queries in one pass over an fp16 shard (ip_scan_mq_kernel)
-static int launch_scan_mq(hipStream_t st, omni_index* ix, int nq, const float* q_dev, uint64_t* keys, int64_t key_stride) {
+static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, const float* q_dev, uint64_t* keys, int64_t key_stride) {
     auto kfn = ip_scan_mq_kernel;
     static bool attr_set = false;
     if (!attr_set) {
@@ -471,14 +470,14 @@ static int launch_scan_mq(hipStream_t st, omni_index* ix, int nq, const float* q
     if ((rc = ix->mq_inv.ensure(MQ_NQ * sizeof(float)))) return rc;
     hipLaunchKernelGGL(mq_prep_kernel, dim3(MQ_NQ), dim3(256), 0, st, q_dev, nq, ix->dim, ix->mq_q.as<uint4>(), ix->mq_inv.as<float>());
     OMNI_LAUNCH_CHECK();
-    const int64_t tiles = cdiv64(ix->ntotal, 16);
+    const int64_t tiles = cdiv64(n, 16);
     const int cus = ix->ctx->prop.multiProcessorCount > 0 ? ix->ctx->prop.multiProcessorCount : 256;
     // one workgroup per CU (128 KB of LDS each) walking 512-row blocks b, b + grid, ...
     const int64_t blocks = cdiv64(tiles, MQ_WAVES * MQ_RT);
     const int64_t grid = blocks < cus ? blocks : cus;
     static const int rotate = getenv("OMNI_MQ_ROT") ? atoi(getenv("OMNI_MQ_ROT")) : 1;
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(MQ_THREADS), MQ_SMEM, st, reinterpret_cast<const _Float16*>(ix->db),
-                       ix->ntotal, ix->dim, ix->mq_q.as<char>(), ix->mq_inv.as<float>(), nq, keys, key_stride, rotate);
+                       n, ix->dim, ix->mq_q.as<char>(), ix->mq_inv.as<float>(), nq, keys, key_stride, rotate);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
@@ -525,9 +524,9 @@ static int append_dev(omni_index* ix, int64_t n, const float* x_dev) {
     return OMNI_OK;
 }
 
-static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev) {
+static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev, int64_t n_limit = -1) {
     hipStream_t st = ix->ctx->stream;
-    const int64_t n = ix->ntotal;
+    const int64_t n = n_limit >= 0 && n_limit < ix->ntotal ? n_limit : ix->ntotal;      // rows [0, n) take part
     const int64_t chunks = cdiv64(n > 0 ? n : 1, TOPK_CHUNK);
     const int64_t per_q = (n > chunks * k ? n : chunks * k);
     int rc;
@@ -540,11 +539,11 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
         const bool mq = ix->storage == OMNI_STORE_F16 && nq >= mq_min_queries();
         for (int q0 = 0; mq && q0 < nq; q0 += MQ_NQ) {
             const int qb = nq - q0 < MQ_NQ ? nq - q0 : MQ_NQ;
-            if ((rc = launch_scan_mq(st, ix, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n))) return rc;
+            if ((rc = launch_scan_mq(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n))) return rc;
         }
         for (int q0 = 0; !mq && q0 < nq; q0 += SCAN_MAX_QB) {
             int qb = nq - q0 < SCAN_MAX_QB ? nq - q0 : SCAN_MAX_QB;
-            rc = launch_scan(st, ix, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n);
+            rc = launch_scan(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n);
             if (rc) return rc;
         }
         OMNI_HIP_TRY(hipEventRecord(ix->scan1, st));
@@ -648,6 +647,16 @@ int omni_index_search_dev(omni_index* ix, int nq, const float* q_dev, int k, flo
     std::lock_guard<std::mutex> lk(ix->mu);
     (void)hipSetDevice(ix->ctx->device);
     return omni::search_dev(ix, nq, q_dev, k, D_dev, I_dev);
+}
+
+int omni_index_search_prefix_dev(omni_index* ix, int nq, const float* q_dev, int k, int64_t n_limit, float* D_dev, int64_t* I_dev) {
+    OMNI_REQUIRE(ix && q_dev && D_dev && I_dev, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(nq >= 1 && nq <= 4096, OMNI_ERR_CAPACITY, "nq=%d outside [1,4096]", nq);
+    OMNI_REQUIRE(k >= 1 && k <= TOPK_MAX_K, OMNI_ERR_CAPACITY, "k=%d outside [1,%d]", k, TOPK_MAX_K);
+    OMNI_REQUIRE(n_limit >= 0, OMNI_ERR_INVALID, "n_limit=%lld < 0", (long long)n_limit);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    (void)hipSetDevice(ix->ctx->device);
+    return omni::search_dev(ix, nq, q_dev, k, D_dev, I_dev, n_limit);
 }
 
 int omni_index_search(omni_index* ix, int nq, const float* q_host, int k, float* D, int64_t* I) {

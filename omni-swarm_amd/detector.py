@@ -69,11 +69,22 @@ class LoopDetector:
         self.compute_loop = compute_loop or (lambda *a: False)
         self.log: list[dict] = []
         self._mu = threading.Lock()
+        self._deferred = None          # results of searches enqueued ahead by on_images_recv_batch
+        self._batch_bufs = None
 
     def database_size(self) -> int:
+        if self._deferred is not None:                 # replaying a batch: the sizes as of this frame's turn, not the final ones
+            return self._sim_local + self._sim_remote
         return self.local_index.ntotal + self.remote_index.ntotal
 
     def _add_image(self, img: ImageDescriptor) -> int:
+        if self._deferred is not None:                 # on_images_recv_batch: the row is already in the index, appended ahead in this order
+            row = self._row_ids.pop(0)
+            if row >= REMOTE_MAGIN_NUMBER:
+                self._sim_remote += 1
+            else:
+                self._sim_local += 1
+            return row
         if img.drone_id == self.self_id:
             self.local_index.add(img.image_desc)
             return self.local_index.ntotal - 1
@@ -90,12 +101,19 @@ class LoopDetector:
         return frame.msg_id
 
     def _query_index(self, img, index, remote_db: bool, thres: float, max_index: int, distance: list) -> int:
-        index_offset = REMOTE_MAGIN_NUMBER if remote_db else 0
         search_num = SEARCH_NEAREST_NUM + max_index
-        D, I = index.search(img.image_desc, search_num)
+        if self._deferred is not None:                 # on_images_recv_batch: the search ran ahead on the stream, over the rows of its turn
+            D, I, ntotal = self._deferred.pop(0)
+        else:
+            D, I = index.search(img.image_desc, search_num)
+            ntotal = index.ntotal
+        return self._decide(D, I, ntotal, remote_db, thres, max_index, distance)
+
+    def _decide(self, D, I, ntotal: int, remote_db: bool, thres: float, max_index: int, distance: list) -> int:
+        """The scan over the top-(5 + max_index) list, loop_detector.cpp:215-241 (incl. its fall-through return)."""
+        index_offset = REMOTE_MAGIN_NUMBER if remote_db else 0
         return_msg_id = -1
-        ntotal = index.ntotal
-        for i in range(search_num):
+        for i in range(SEARCH_NEAREST_NUM + max_index):
             label = int(I[0, i])
             if label < 0:
                 continue
@@ -172,3 +190,97 @@ class LoopDetector:
                     self.inter_drone_loop_count[(b, a)] = self.inter_drone_loop_count.get((b, a), 0) + 1
                     rec["loop"] = True
         return rec
+
+    def on_images_recv_batch(self, frames: list, rows_dev: int | None = None) -> list:
+        """on_image_recv for several frames in arrival order with ONE host synchronisation instead of ~6 per frame (4 row appends,
+        1-2 searches): which rows a frame appends and which searches it runs (loop_detector.cpp:36-98) does not depend on any search
+        RESULT, so the whole batch is planned first, enqueued on the index stream -- all appends, then every search restricted to the
+        rows its frame would have seen (omni_index_search_prefix_dev) -- fetched with one copy, and the decision rules are then replayed
+        frame by frame through the unchanged _on_image_recv.  Records are identical to calling on_image_recv per frame.
+        rows_dev: optional device pointer to the frames' global descriptors, [sum of len(f.images)][4096] fp32 in frame order (e.g.
+        MobileNetVLAD's output buffer, still in HBM): rows are then appended and queried without touching the host copies."""
+        with self._mu:
+            return self._recv_batch(frames, rows_dev)
+
+    def _recv_batch(self, frames, rows_dev):
+        ctx = self.local_index.ctx
+        # ---- plan: the gating of _on_image_recv with simulated index sizes (no GPU work)
+        sim_local, sim_remote = self.local_index.ntotal, self.remote_index.ntotal
+        nodes = set(self.all_nodes)
+        adds, searches, row_ids = [], [], []      # adds: (index, flat image row); searches: (index, flat row, max_index, n_limit)
+        base = 0
+        for f in frames:
+            first = base
+            base += len(f.images)
+            if len(f.images) == 0 or (f.drone_id != self.self_id and sim_local + sim_remote == 0):
+                continue
+            new_node = f.drone_id not in nodes
+            nodes.add(f.drone_id)
+            if sum(1 for img in f.images if img.landmark_num > 0) < self.MIN_DIRECTION_LOOP or f.landmark_num < self.MIN_LOOP_NUM:
+                continue
+            if (not f.prevent_adding_db) or new_node:
+                for i, img in enumerate(f.images):
+                    if img.landmark_num > 0:
+                        if img.drone_id == self.self_id:
+                            adds.append((self.local_index, first + i)); row_ids.append(sim_local); sim_local += 1
+                        else:
+                            adds.append((self.remote_index, first + i)); row_ids.append(sim_remote + REMOTE_MAGIN_NUMBER); sim_remote += 1
+            # `database_size() > MATCH_INDEX_DIST || init_mode || drone_id != self_id`: init_mode implies a remote drone
+            if sim_local + sim_remote > self.MATCH_INDEX_DIST or f.drone_id != self.self_id:
+                d = 1 if self.camera_configuration == STEREO_FISHEYE else 0
+                img = f.images[d]
+                if img.landmark_num > 0:
+                    if img.drone_id == self.self_id:
+                        searches.append((self.remote_index, first + d, 1, sim_remote))
+                        if not f.prevent_adding_db:
+                            searches.append((self.local_index, first + d, self.MATCH_INDEX_DIST, sim_local))
+                    else:
+                        searches.append((self.local_index, first + d, 1, sim_local))
+        # ---- enqueue: rows to HBM (unless they are there already), appends, prefix searches, one result copy
+        kmax = SEARCH_NEAREST_NUM + max(self.MATCH_INDEX_DIST, 1)
+        row_bytes = DEEP_DESC_SIZE * 4
+        own_rows = None
+        if rows_dev is None and (adds or searches):
+            own_rows = rows_dev = ctx.to_device(np.stack([np.asarray(img.image_desc, np.float32) for f in frames for img in f.images]))
+        start_local, start_remote = self.local_index.ntotal, self.remote_index.ntotal
+        a = 0
+        while a < len(adds):                                # consecutive rows of one index go in as one append
+            b = a + 1
+            while b < len(adds) and adds[b][0] is adds[a][0] and adds[b][1] == adds[b - 1][1] + 1:
+                b += 1
+            adds[a][0].add_dev(b - a, rows_dev + adds[a][1] * row_bytes)
+            a = b
+        live = [s for s in searches if s[3] > 0]
+        if live:
+            need = len(live) * kmax * 12
+            if self._batch_bufs is None or self._batch_bufs[1] < need:
+                if self._batch_bufs is not None:
+                    ctx.free(self._batch_bufs[0])
+                self._batch_bufs = (ctx.alloc(need), need)
+            buf = self._batch_bufs[0]
+            for j, (index, row, max_index, n_limit) in enumerate(live):
+                index.search_prefix_dev(1, rows_dev + row * row_bytes, SEARCH_NEAREST_NUM + max_index, n_limit,
+                                        buf + len(live) * kmax * 8 + j * kmax * 4, buf + j * kmax * 8)
+            raw = ctx.from_device(buf, (need,), np.uint8)                                   # the batch's only synchronisation
+            I_all = raw[:len(live) * kmax * 8].view(np.int64).reshape(len(live), kmax)
+            D_all = raw[len(live) * kmax * 8:].view(np.float32).reshape(len(live), kmax)
+        elif adds:
+            ctx.sync()
+        results, j = [], 0
+        for (index, row, max_index, n_limit) in searches:
+            k = SEARCH_NEAREST_NUM + max_index
+            if n_limit > 0:
+                results.append((D_all[j:j + 1, :k], I_all[j:j + 1, :k], n_limit)); j += 1
+            else:                                            # faiss pads an empty index's result with -1 labels
+                results.append((np.full((1, k), -3.4028235e38, np.float32), np.full((1, k), -1, np.int64), 0))
+        if own_rows is not None:
+            ctx.free(own_rows)
+        # ---- replay the decision rules frame by frame on the fetched results
+        self._deferred, self._row_ids, self._sim_local, self._sim_remote = results, row_ids, start_local, start_remote
+        try:
+            out = [self._on_image_recv(f) for f in frames]
+            assert not self._deferred and not self._row_ids, "plan and replay diverged"
+            return out
+        finally:
+            self._deferred = None
+

@@ -69,6 +69,26 @@ def run_product(frames, ctx, det_mod, **kw):
     return det.log
 
 
+def run_product_batched(frames, ctx, det_mod, batch=4, rows_on_device=False, **kw):
+    """The same stream through LoopDetector.on_images_recv_batch, `batch` frames per call (one host synchronisation each)."""
+    det = det_mod.LoopDetector(ctx, SELF_ID, compute_loop=lambda n, o, dn, do, im: loop_ok(n.msg_id, o.msg_id), **PARAMS, **kw)
+    for s in range(0, len(frames), batch):
+        chunk = [det_mod.FisheyeFrameDescriptor(
+            msg_id=fr["msg_id"], drone_id=fr["drone_id"], landmark_num=fr["landmark_num"], prevent_adding_db=fr["prevent_adding_db"],
+            images=[det_mod.ImageDescriptor(drone_id=i["drone_id"], landmark_num=i["landmark_num"], image_desc=i["image_desc"])
+                    for i in fr["images"]]) for fr in frames[s:s + batch]]
+        if rows_on_device:      # descriptors handed over in HBM (as MobileNetVLAD leaves them); the host copies are poisoned
+            dev = ctx.to_device(np.stack([i.image_desc for f in chunk for i in f.images]))
+            for f in chunk:
+                for i in f.images:
+                    i.image_desc = None
+            det.on_images_recv_batch(chunk, rows_dev=dev)
+            ctx.free(dev)
+        else:
+            det.on_images_recv_batch(chunk)
+    return det.log
+
+
 def trace(log):
     return np.array([[r["msg_id"], int(r["added"]), int(r["queried"]), r["image_id"], r["old_msg_id"], r["dir_old"],
                       int(r["loop"])] for r in log], np.int64)

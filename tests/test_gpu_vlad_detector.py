@@ -54,3 +54,17 @@ def test_long_replay_match_ids_equal_oracle(omni, ctx):
     got, ref = DS.trace(DS.run_product(frames, ctx, detector)), DS.trace(DS.run_oracle(frames))
     assert np.array_equal(got, ref)
     assert (ref[:, 4] != -1).sum() > 100                              # the stream does close loops
+
+
+@pytest.mark.parametrize("batch,on_device", [(1, False), (4, False), (4, True), (7, True)])
+def test_batched_detector_equals_frame_by_frame(omni, ctx, batch, on_device):
+    """on_images_recv_batch (all appends + prefix-restricted searches of several frames enqueued ahead, one host sync per batch; rows
+    taken from HBM when on_device) gives the decision trace of on_image_recv called frame by frame -- and of the oracle."""
+    from omni_swarm_amd import detector
+    frames = DS.make_stream(seed=31, n_frames=240, n_places=20)
+    seq = DS.trace(DS.run_product(frames, ctx, detector))
+    got = DS.trace(DS.run_product_batched(frames, ctx, detector, batch=batch, rows_on_device=on_device))
+    assert np.array_equal(got, seq)
+    assert np.array_equal(got, DS.trace(DS.run_oracle(frames)))
+    assert (seq[:, 4] != -1).sum() > 10
+
