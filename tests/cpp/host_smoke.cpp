@@ -84,6 +84,36 @@ int main(int argc, char** argv) {
         std::printf(" %lld %d %d %d %lld %d %d", (long long)f.msg_id, (int)r.added, (int)r.queried, r.image_id, (long long)r.old_msg_id,
                     r.direction_old, (int)r.loop);
     }
+    // --- the same stream through on_images_recv_batch, 5 frames per call (one host synchronisation each): identical decisions
+    {
+        omni::LoopDetectorCore detb(ctx, 1);
+        detb.INNER_PRODUCT_THRES = 0.6; detb.INIT_MODE_PRODUCT_THRES = 0.3; detb.MATCH_INDEX_DIST = 5; detb.MIN_LOOP_NUM = 30;
+        detb.MIN_DIRECTION_LOOP = 3; detb.inter_drone_init_frames = 3;
+        detb.compute_loop = det.compute_loop;
+        std::vector<omni::FisheyeFrameDescriptor> chunk;
+        std::printf("\nDETB");
+        auto flush = [&]() {
+            auto rs = detb.on_images_recv_batch(chunk);
+            for (size_t i = 0; i < rs.size(); ++i)
+                std::printf(" %lld %d %d %d %lld %d %d", (long long)chunk[i].msg_id, (int)rs[i].added, (int)rs[i].queried, rs[i].image_id,
+                            (long long)rs[i].old_msg_id, rs[i].direction_old, (int)rs[i].loop);
+            chunk.clear();
+        };
+        for (size_t off = 0; off + per <= s.size(); off += per) {
+            omni::FisheyeFrameDescriptor f;
+            f.msg_id = (int64_t)s[off]; f.drone_id = (int)s[off + 1]; f.landmark_num = (int)s[off + 2]; f.prevent_adding_db = s[off + 3] != 0;
+            for (int d = 0; d < 4; ++d) {
+                omni::ImageDescriptor im;
+                const float* p = s.data() + off + 4 + d * 4097;
+                im.drone_id = f.drone_id; im.landmark_num = (int)p[0];
+                im.image_desc.assign(p + 1, p + 1 + 4096);
+                f.images.push_back(std::move(im));
+            }
+            chunk.push_back(std::move(f));
+            if (chunk.size() == 5) flush();
+        }
+        flush();
+    }
     // --- LoopCam::on_flattened_images as one asynchronous unit: one direction, the image as both the up and the down camera
     {
         omni::Context vctx(0);

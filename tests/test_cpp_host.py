@@ -91,5 +91,6 @@ def test_cpp_host_matches_oracle(tmp_path, omni, ctx, golden):
     assert np.array_equal(bf[:, 0].astype(int), qi) and np.array_equal(bf[:, 1].astype(int), ti) and np.allclose(bf[:, 2], dd, rtol=1e-7)
     tr = DS.trace(DS.run_oracle(frames))
     assert np.array_equal(np.array(out["DET"], np.int64).reshape(-1, 7), tr)
+    assert np.array_equal(np.array(out["DETB"], np.int64).reshape(-1, 7), tr)      # on_images_recv_batch: same decisions
     # omni::LoopCamHIP (omni_cam): same key points / descriptors / global descriptor as the blocking calls, self-match diagonal
     assert out["CAM"][:2] == ["1", "1"] and int(out["CAM"][2]) == n, out["CAM"]
