@@ -166,11 +166,12 @@ def main():
                 recs = det.on_images_recv_batch(frames, rows_dev=cam.vlad.dev_output())
             hits[0] += sum(int(r["old_msg_id"] != -1) for r in recs)
         else:
-            for m in range(MB):
-                ims = out["images"][4 * m:4 * m + 4]
-                rows = np.stack([i["image_desc"] for i in ims])
-                D, I = swarm.step(rows, query_row=1, k=K_SEARCH)                # add world*4 rows, query direction 1
-                ok = (I[0] >= 0) & (I[0] <= swarm.ntotal - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
+            # the micro-batch's MB steps (each: add world*4 rows, query direction 1) in two collectives + one index sync
+            rows = np.stack([np.stack([i["image_desc"] for i in out["images"][4 * m:4 * m + 4]]) for m in range(MB)])
+            base = swarm.ntotal
+            for m, (D, I) in enumerate(swarm.step_batch(rows, query_row=1, k=K_SEARCH)):
+                nt = base + (m + 1) * world * 4                                 # ntotal as of this key frame's step
+                ok = (I[0] >= 0) & (I[0] <= nt - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
                 hits[0] += int(ok.any())
         return out
 

@@ -429,6 +429,31 @@ class IndexFlatIP:
         """search_dev over the first n_limit rows only (asynchronous; see include/omni_hip.h)."""
         _check(lib().omni_index_search_prefix_dev(self.h, nq, q_dev, k, n_limit, D_dev, I_dev))
 
+    def search_prefix_many(self, q: np.ndarray, k: int, limits) -> tuple:
+        """q [F][nq][d], limits [F]: F searches, search f over this shard's first limits[f] rows only; all enqueued back to back,
+        ONE host synchronisation.  Returns D [F][nq][k], I [F][nq][k] (global ids under set_shard)."""
+        q = _f32(q)
+        F, nq = q.shape[0], q.shape[1]
+        D = np.full((F, nq, k), -3.4028235e38, np.float32)
+        I = np.full((F, nq, k), -1, np.int64)
+        live = [f for f in range(F) if int(limits[f]) > 0]
+        if not live:
+            return D, I
+        qd = self.ctx.to_device(q)
+        buf = self.ctx.alloc(F * nq * k * 12)
+        try:
+            for f in live:
+                self.search_prefix_dev(nq, qd + f * nq * self.d * 4, k, int(limits[f]), buf + F * nq * k * 8 + f * nq * k * 4, buf + f * nq * k * 8)
+            raw = self.ctx.from_device(buf, (F * nq * k * 12,), np.uint8)
+        finally:
+            self.ctx.free(qd)
+            self.ctx.free(buf)
+        Ia = raw[:F * nq * k * 8].view(np.int64).reshape(F, nq, k)
+        Da = raw[F * nq * k * 8:].view(np.float32).reshape(F, nq, k)
+        for f in live:
+            D[f], I[f] = Da[f], Ia[f]
+        return D, I
+
     def last_scan_ms(self) -> float:
         ms = C.c_float()
         _check(lib().omni_index_last_scan_ms(self.h, C.byref(ms)))

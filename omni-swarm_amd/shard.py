@@ -112,3 +112,31 @@ class SwarmIndex:
         Dl = np.ascontiguousarray(allp[:, self.rank, :, 0].astype(np.int32)).view(np.float32)[:, None, :]
         Il = np.ascontiguousarray(allp[:, self.rank, :, 1])[:, None, :]
         return capi.topk_merge(Dl, Il, k)
+
+    def step_batch(self, rows: np.ndarray, query_row: int, k: int):
+        """F consecutive steps in two collectives and one index synchronisation.  rows [F][m][d]: this rank's m new rows of each of
+        its next F key frames.  Step f's rows of all ranks get the global ids base + f*world*m ..., exactly as F calls of step()
+        would number them, and step f's queries only see rows up to and including step f's (the shard's prefix search): the
+        returned [F] lists of (D [1][k], I [1][k]) equal those of F step() calls."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        F, m, d = rows.shape
+        assert self._ntotal % self.world == 0
+        allrows = self._all_gather(rows)                                   # [world][F][m][d]
+        ordered = np.ascontiguousarray(allrows.transpose(1, 0, 2, 3)).reshape(F * self.world * m, d)   # global id order
+        g = self._ntotal + np.arange(F * self.world * m)
+        self.local.add(ordered[(g % self.world) == self.rank])
+        queries = np.ascontiguousarray(allrows[:, :, query_row].transpose(1, 0, 2))      # [F][world][d]
+        limits = [(self._ntotal + (f + 1) * self.world * m - self.rank + self.world - 1) // self.world for f in range(F)]
+        D, I = self.local.search_prefix_many(queries, k, limits)          # [F][world][k], global ids
+        self._ntotal += F * self.world * m
+        packed = np.empty((F, self.world, k, 2), np.int64)
+        packed[..., 0] = D.view(np.int32).astype(np.int64)
+        packed[..., 1] = I
+        allp = self._all_gather(packed)                                    # [shard][F][query][k][2]
+        out = []
+        for f in range(F):
+            Dl = np.ascontiguousarray(allp[:, f, self.rank, :, 0].astype(np.int32)).view(np.float32)[:, None, :]
+            Il = np.ascontiguousarray(allp[:, f, self.rank, :, 1])[:, None, :]
+            out.append(capi.topk_merge(Dl, Il, k))
+        return out
+

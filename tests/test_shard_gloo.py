@@ -28,10 +28,15 @@ class _CpuShard:
     def add(self, x):
         self.rows += [r.copy() for r in np.atleast_2d(x)]
 
-    def search(self, q, k):
-        db = np.stack(self.rows) if self.rows else np.zeros((0, self.d), np.float32)
+    def search(self, q, k, n_limit=None):
+        rows = self.rows if n_limit is None else self.rows[:n_limit]
+        db = np.stack(rows) if rows else np.zeros((0, self.d), np.float32)
         D, I = self._M.ip_search(db, q, k)
         return D, np.where(I >= 0, I * self.world + self.rank, -1)
+
+    def search_prefix_many(self, q, k, limits):
+        res = [self.search(q[f], k, int(limits[f])) for f in range(len(limits))]
+        return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
 
 
 def _worker(rank, world, port, out):
@@ -69,6 +74,24 @@ def _worker(rank, world, port, out):
         Dr, Ir = M.ip_search(np.stack(ref_db), new[rank, 1], 7)
         ok = ok and bool(np.array_equal(I, Ir) and np.array_equal(D, Dr)) and sw.ntotal == len(ref_db)
         ok = ok and sw.local.ntotal == len(ref_db) // world
+    # step_batch: three more steps in two collectives; must equal three step() calls (ids numbered per step, queries see only the
+    # rows up to their own step)
+    sw2 = shard.SwarmIndex(_CpuShard(128), rank, world, dist)
+    sw2.preload_local(pre[rank::world], 40)
+    news = [np.random.default_rng(100 + step).standard_normal((world, 4, 128)).astype(np.float32) for step in range(3)]
+    news[1][1, 1] = pre[6] * 1.01
+    news[2][0, 1] = news[0][1, 2] * 0.99                               # step 2's query of rank 0 hits a row added in step 0 by rank 1
+    seq = []
+    sw3 = shard.SwarmIndex(_CpuShard(128), rank, world, dist)
+    sw3.preload_local(pre[rank::world], 40)
+    for step in range(3):
+        seq.append(sw3.step(news[step][rank], query_row=1, k=7))
+    got = sw2.step_batch(np.stack([n[rank] for n in news]), query_row=1, k=7)
+    for (Db, Ib), (Ds, Is) in zip(got, seq):
+        ok = ok and bool(np.array_equal(Ib, Is) and np.array_equal(Db, Ds))
+    ok = ok and sw2.ntotal == sw3.ntotal and sw2.local.ntotal == sw3.local.ntotal
+    if rank == 0:
+        ok = ok and int(got[2][1][0, 0]) == 40 + 0 * world * 4 + 1 * 4 + 2   # the planted row's global id (step 0, rank 1, row 2)
     out[rank] = ok
     dist.destroy_process_group()
 
