@@ -67,6 +67,11 @@ int detector_head_mfma(hipStream_t stream, int precision, const void* in, int in
 
 // desc = desc / ||desc||_2 over the 256 channels of every coarse cell (superpoint.ipynb:187-188); fp32 NHWC in place.
 int l2norm_channels(hipStream_t stream, float* desc_nhwc, int64_t n_cells);
+// convDb + channel L2 norm fused (fp16 activations): in = NHWC fp16 with pixel stride in_cstride halfs, already offset to the 256 input
+// channels; wfrag from convdb_pack_weights; out = [n_pixels][256] f32, unit-norm per pixel
+void convdb_pack_weights(const float* w /*[256][256]*/, uint16_t* frag /*[65536]*/);
+int convdb_l2norm(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, int in_cstride, const void* wfrag, const float* bias,
+                  float* out, int64_t n_pixels);
 
 // test hook: NHWC (fp16 or fp32) -> NCHW fp32
 int nhwc_any_to_nchw_f32(hipStream_t stream, int precision_of_in, const void* in, float* out, int batch, int C, int HW);

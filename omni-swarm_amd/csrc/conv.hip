@@ -1571,6 +1571,109 @@ int detector_head_mfma(hipStream_t st, int precision, const void* in, int in_str
     return OMNI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// convDb (1x1, 256 -> 256, f32 out) + the descriptor L2 normalisation over the 256 channels in ONE pass (fp16 path).  The pair is
+// HBM bound (0.59 GFLOP but 2.3 MB read + 4.6 MB written per image); run separately the f32 map made a second round trip
+// (write 4.6, read 4.6, write 4.6 MB).  A workgroup = 8 waves, wave w owns output channels 32w..32w+31 with their A fragments
+// RESIDENT IN REGISTERS (16 k-steps x 4 VGPRs); it walks 32-pixel tiles: the 32 x 256-channel fp16 tile (16 KB)
+// goes global -> registers (prefetched two tiles ahead) -> LDS (chunks XOR-swizzled with pixel & 15 so the B-operand ds_read_b128 of
+// 16 consecutive pixels hit 16 distinct slots), 16 MFMAs per wave, bias, per-pixel sum of squares (lane pair by shuffle, the 8 waves
+// through LDS), scale, 16-byte stores.  No LDS-DMA here: plain loads keep hipcc's counted waits exact.
+//   algorithmic bytes per image: 4500 px x (512 B read + 1024 B written) = 6.9 MB
+#define CDB_PX 32
+#define CDB_WAVES 8
+void convdb_pack_weights(const float* w /*[256 cout][256 cin]*/, uint16_t* frag /*[8][16][64][8]*/) {
+    for (int wv = 0; wv < CDB_WAVES; ++wv)
+        for (int ks = 0; ks < 16; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = 32 * wv + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                    frag[(((size_t)wv * 16 + ks) * 64 + lane) * 8 + j] = f2h_bits(w[(size_t)co * 256 + k]);
+                }
+}
+
+__global__ void __launch_bounds__(64 * CDB_WAVES)
+convdb_l2norm_kernel(const _Float16* __restrict__ in, int in_cstride, const _Float16* __restrict__ wfrag, const float* __restrict__ bias,
+                     float* __restrict__ out, int64_t n_pixels) {
+    __shared__ __attribute__((aligned(16))) char tile[2][CDB_PX * 512];
+    __shared__ float part[2][CDB_WAVES][CDB_PX];
+    __shared__ float sbias[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kg = lane >> 5;
+    half8_t wa[16];                                                       // this wave's 32 output channels, all K = 256
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) wa[ks] = *reinterpret_cast<const half8_t*>(wfrag + (((size_t)wave * 16 + ks) * 64 + lane) * 8);
+    if (tid < 256) sbias[tid] = bias[tid];
+    const int64_t n_tiles = (n_pixels + CDB_PX - 1) / CDB_PX;
+    const int64_t G = gridDim.x;
+    // staging: thread -> 2 of the tile's 1024 16-byte chunks (q = tid + 512 j: pixel q >> 5, chunk q & 31), coalesced 512 B per pixel
+    const int spx0 = tid >> 5, spx1 = spx0 + 16, sc = tid & 31;
+    auto load_chunk = [&](int64_t t, int spx) -> uint4 {
+        int64_t px = t * CDB_PX + spx;
+        px = px < n_pixels ? px : n_pixels - 1;                           // ragged last tile: duplicates, never stored
+        return *reinterpret_cast<const uint4*>(in + px * in_cstride + sc * 8);
+    };
+    const int soff0 = spx0 * 512 + ((sc ^ (spx0 & 15)) << 4), soff1 = spx1 * 512 + ((sc ^ (spx1 & 15)) << 4);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    int64_t t = blockIdx.x;
+    uint4 ra0 = t < n_tiles ? load_chunk(t, spx0) : zero4, ra1 = t < n_tiles ? load_chunk(t, spx1) : zero4;
+    uint4 rb0 = t + G < n_tiles ? load_chunk(t + G, spx0) : zero4, rb1 = t + G < n_tiles ? load_chunk(t + G, spx1) : zero4;
+    int buf = 0;
+    for (; t < n_tiles; t += G) {
+        *reinterpret_cast<uint4*>(tile[buf] + soff0) = ra0;
+        *reinterpret_cast<uint4*>(tile[buf] + soff1) = ra1;
+        ra0 = rb0; ra1 = rb1;
+        if (t + 2 * G < n_tiles) { rb0 = load_chunk(t + 2 * G, spx0); rb1 = load_chunk(t + 2 * G, spx1); }
+        __syncthreads();              // tile visible (the buffer's previous readers are two barriers behind)
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const char* bp = tile[buf] + n * 512;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const half8_t b = *reinterpret_cast<const half8_t*>(bp + (((2 * ks + kg) ^ (n & 15)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks], b, acc, 0, 0, 0);
+        }
+        // C layout: channel (r & 3) + 8 (r >> 2) + 4 kg of the wave's 32, pixel n
+        float ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + sbias[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg];
+            acc[r] = v;
+            ss = fmaf(v, v, ss);
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        if (lane < 32) part[buf][wave][n] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < CDB_WAVES; ++w) tot += part[buf][w][n];
+        const float nrm = sqrtf(tot);
+        const int64_t px = t * CDB_PX + n;
+        if (px < n_pixels) {
+            float* op = out + px * 256 + 32 * wave + 4 * kg;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = acc[4 * g] / nrm; v.y = acc[4 * g + 1] / nrm; v.z = acc[4 * g + 2] / nrm; v.w = acc[4 * g + 3] / nrm;
+                *reinterpret_cast<float4*>(op + 8 * g) = v;
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+int convdb_l2norm(hipStream_t st, const omni_ctx* ctx, const void* in_f16, int in_cstride, const void* wfrag, const float* bias, float* out,
+                  int64_t n_pixels) {
+    const int64_t tiles = cdiv64(n_pixels, CDB_PX);
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const int64_t grid = tiles < cus ? tiles : cus;                     // one persistent workgroup per CU (152 VGPRs x 8 waves)
+    hipLaunchKernelGGL(convdb_l2norm_kernel, dim3((unsigned)grid), dim3(64 * CDB_WAVES), 0, st, (const _Float16*)in_f16, in_cstride,
+                       (const _Float16*)wfrag, bias, out, n_pixels);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 // desc / ||desc||_2 per coarse cell: one wave per cell, lane holds 4 channels
 __global__ void __launch_bounds__(256)
 l2norm_kernel(float* __restrict__ d, int64_t n_cells) {

@@ -35,6 +35,7 @@ struct omni_sp {
     float* w1a = nullptr;                    // [64][9]
     float* wPbT = nullptr;                   // [256][65]
     float *wPbA = nullptr, *wPbDust = nullptr; // convPb in MFMA A-fragment order + the dustbin row
+    void* wDbFrag = nullptr;                    // convDb as register-resident fp16 A fragments (fused convDb + L2 norm, fp16 path)
     float* bias_heads = nullptr;             // [512]
     float* lut = nullptr;
     uint16_t* w1a_frag = nullptr;            // conv1a split-fp16 A fragments (fused conv1a+conv1b, fp16 path)
@@ -91,6 +92,11 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         float lut[256];
         for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i * (1.0 / 255.0));
         if ((rc = dev_upload((void**)&s->lut, lut, sizeof(lut), st))) return rc;
+    }
+    if (s->precision == OMNI_PREC_F16) {
+        std::vector<uint16_t> db(65536);
+        convdb_pack_weights(w->weight[LDB], db.data());
+        if ((rc = dev_upload(&s->wDbFrag, db.data(), db.size() * 2, st))) return rc;
     }
     if (s->precision == OMNI_PREC_F16) {
         std::vector<uint16_t> fr(2048);
@@ -217,15 +223,20 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     else if ((rc = detector_head_mfma(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
                                       s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
-    {   // convDb reads channels [256,512) (cDa) of the fused heads buffer: input pointer offset by 256 channels,
+    if (s->precision == OMNI_PREC_F16 && s->conv_variant == 0) {
+        // convDb + descriptor L2 norm in one HBM pass (channels [256,512) = cDa of the fused heads buffer, pixel stride 512)
+        if ((rc = convdb_l2norm(st, s->ctx, (const char*)s->heads + (size_t)256 * s->esz, 512, s->wDbFrag, s->bias[LDB], s->draw,
+                                (int64_t)batch * s->Hc * s->Wc))) return rc;
+    } else {
+        // convDb reads channels [256,512) (cDa) of the fused heads buffer: input pointer offset by 256 channels,
         // pixel stride 512
         ConvArgs a;
         a.in = (const char*)s->heads + (size_t)256 * s->esz; a.out = s->draw; a.w_packed = s->wpk[LDB]; a.bias = s->bias[LDB];
         a.batch = batch; a.H = s->Hc; a.W = s->Wc; a.cin = 256; a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false;
         a.out_f32 = true; a.in_cstride = 512;
         if ((rc = conv_mfma(st, P, a))) return rc;
+        if ((rc = l2norm_channels(st, s->draw, (int64_t)batch * s->Hc * s->Wc))) return rc;
     }
-    if ((rc = l2norm_channels(st, s->draw, (int64_t)batch * s->Hc * s->Wc))) return rc;
     if ((rc = mark())) return rc;
     if (run_post) {
         if ((rc = sp_postprocess(st, post_params(s), s->pb, s->semi, s->draw, batch))) return rc;
@@ -299,7 +310,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
-    void* ptrs[] = {s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
+    void* ptrs[] = {s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
                     s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
