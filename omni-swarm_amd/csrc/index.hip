@@ -541,8 +541,10 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
             const int qb = nq - q0 < MQ_NQ ? nq - q0 : MQ_NQ;
             if ((rc = launch_scan_mq(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n))) return rc;
         }
-        for (int q0 = 0; !mq && q0 < nq; q0 += SCAN_MAX_QB) {
-            int qb = nq - q0 < SCAN_MAX_QB ? nq - q0 : SCAN_MAX_QB;
+        int max_qb = (int)(131072 / ((size_t)ix->dim * 4));       // the query block lives in LDS: <= 128 KB of it
+        max_qb = max_qb > SCAN_MAX_QB ? SCAN_MAX_QB : (max_qb < 1 ? 1 : max_qb);
+        for (int q0 = 0; !mq && q0 < nq; q0 += max_qb) {
+            int qb = nq - q0 < max_qb ? nq - q0 : max_qb;
             rc = launch_scan(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n);
             if (rc) return rc;
         }

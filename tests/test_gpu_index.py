@@ -207,6 +207,23 @@ def test_batched_search_full_shard_properties(omni, ctx):
     assert np.array_equal(I, I2) and np.array_equal(D, D2)
 
 
+@pytest.mark.parametrize("dim", [512, 1024, 8192])
+def test_other_dimensions_fp32_and_fp16(omni, ctx, dim):
+    """The reference only ever uses 4096; the handle accepts any multiple of 512 up to 8192 (k-slices of 256, 16-row blocks)."""
+    rng = np.random.default_rng(dim)
+    db = rng.standard_normal((1500, dim)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = db[[3, 700, 1499, 8, 9]] + 0.05 * rng.standard_normal((5, dim)).astype(np.float32)
+    for storage in (omni.capi.STORE_F32, omni.capi.STORE_F16):
+        idx = omni.capi.IndexFlatIP(ctx, dim, storage)
+        idx.add(db)
+        ref = db if storage == omni.capi.STORE_F32 else db.astype(np.float16).astype(np.float32)
+        for nq in (1, 5):                                      # 5 queries: matrix cores on the fp16 shard
+            D, I = idx.search(q[:nq], 7)
+            Dr, Ir = M.ip_search(ref, q[:nq], 7)
+            assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=2e-6)
+
+
 def test_snapshot_roundtrip(omni, ctx, tmp_path):
     """omni_index_save / omni_index_load: a shard checkpoint restores rows, storage type and search results bit for bit."""
     db = synth.global_db(3000, seed=15)
