@@ -995,12 +995,15 @@ __device__ __forceinline__ void rs_steps(uint32_t row_base, int n, int hh, const
 template <bool POOL>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
-                       const float* __restrict__ bias, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu) {
+                       const float* __restrict__ bias, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu,
+                       unsigned long long* trace /* OMNI_RS_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hh = lane >> 5;
+    const bool tr = trace != nullptr && blockIdx.x == 0 && tid == 0;
+    int tk = 0;
     const int cg = blockIdx.x % n_cg, wg = blockIdx.x / n_cg, nwg = gridDim.x / n_cg;
     const int tiles_per_img = tiles_x * tiles_y;
     const int total = batch * tiles_per_img;
@@ -1024,26 +1027,7 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
         const int r = t - b * tiles_per_img;
         ty0 = (r / tiles_x) * RS_TH; tx0 = (r % tiles_x) * RS_TW;
     };
-    // DMA instruction wi = 17 wave + j of tile t into buffer `which` (68 wave-instructions of 1 KiB per tile)
-    int lane_o = lane;                        // re-blinded per tile: keeps the 17 per-piece address terms from being hoisted into registers
-    auto issue_one = [&](int t, int which, int j) {
-        int b, ty0, tx0;
-        tile_origin(t, b, ty0, tx0);
-        const int y0 = ty0 - 1, x0 = tx0 - 1;
-        const _Float16* img = in + (int64_t)b * H * W * 128;
-        char* base = smem_raw + which * RS_BUF_BYTES;
-        const int wi = wave * 17 + j;
-        const int idx = wi * 64 + lane_o;
-        const int pix = idx >> 4, phys = idx & 15;
-        const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
-        int gy = y0 + iy, gx = x0 + ix;
-        gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);            // clamped to a valid address, zero-fixed after landing
-        gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-        const int logical = phys ^ (pix & 15);
-        const _Float16* g = img + ((int64_t)gy * W + gx) * 128 + logical * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(base + wi * 1024), 16, 0, 0);
-    };
+    // DMA: 68 wave-instructions of 1 KiB per tile, wave w issues pieces 17 w .. 17 w + 16 into buffer `which`
     uint32_t goff[17];                        // interior tiles: byte offset of this lane's chunk of piece j relative to the halo origin
 #pragma unroll
     for (int j = 0; j < 17; ++j) {
@@ -1065,37 +1049,65 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
                                                  (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
             return;
         }
-#pragma unroll 1
-        for (int j = 0; j < 17; ++j) issue_one(t, which, j);
+        // border tile: clamp per piece (addresses stay valid, the halo pixels outside the image are zeroed after landing).  Unrolled:
+        // halo pixel of this lane's chunk = 4 (17 wave + j) + (lane >> 4); the per-lane term is re-blinded per tile so that the 17
+        // coordinate pairs are recomputed (a few VALU each) rather than hoisted into registers the kernel does not have
+        int lq = lane >> 4;
+        asm volatile("" : "+v"(lq));
+        const char* img = reinterpret_cast<const char*>(in + (int64_t)b * H * W * 128);
+        char* base = smem_raw + which * RS_BUF_BYTES + wave * 17 * 1024;
+#pragma unroll
+        for (int j = 0; j < 17; ++j) {
+            const int pix = (wave * 17 + j) * 4 + lq;
+            const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
+            int gy = y0 + iy, gx = x0 + ix;
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const uint32_t off = (uint32_t)(gy * W + gx) * 256u + (uint32_t)(((lane & 15) ^ (pix & 15)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + off),
+                                             (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+        }
     };
-    auto zero_fix = [&](int t, int which) {                      // every wave fixes the chunks its own DMA instructions wrote
+    // Border tiles: halo pixels outside the image were loaded from a clamped address and are zeroed after landing.  Thread = halo pixel
+    // (its 16 chunks are 256 contiguous bytes whatever the swizzle), which needs every wave's DMA to have landed first: one extra
+    // workgroup barrier on border tiles -- measured (s_memtime): 4 500 cycles for the former per-piece loop over each wave's own chunks
+    // vs 350 for an interior tile, on 73 % of the tiles of a 60x75 layer.
+    auto is_border = [&](int t) {
         int b, ty0, tx0;
         tile_origin(t, b, ty0, tx0);
         const int y0 = ty0 - 1, x0 = tx0 - 1;
-        if (y0 >= 0 && y0 + RS_ITH <= H && x0 >= 0 && x0 + RS_ITW <= W) return;
+        return !(y0 >= 0 && y0 + RS_ITH <= H && x0 >= 0 && x0 + RS_ITW <= W);
+    };
+    auto zero_fix = [&](int t, int which) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const int y0 = ty0 - 1, x0 = tx0 - 1;
         char* base = smem_raw + which * RS_BUF_BYTES;
-#pragma unroll 1
-        for (int j = 0; j < 17; ++j) {
-            const int idx = (wave * 17 + j) * 64 + lane;
-            const int pix = idx >> 4;
+        for (int pix = tid; pix < RS_PIX; pix += 256) {
             const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
             const int gy = y0 + iy, gx = x0 + ix;
-            if (gy < 0 || gy >= H || gx < 0 || gx >= W) *reinterpret_cast<uint4*>(base + idx * 16) = make_uint4(0u, 0u, 0u, 0u);
+            if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
+                uint4* p = reinterpret_cast<uint4*>(base + pix * 256);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) p[(c + lane) & 15] = make_uint4(0u, 0u, 0u, 0u);   // rotated: pixels are 256 B apart = one bank group
+            }
         }
     };
 
     int t = wg;
     if (t < total) issue(t, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t < total) zero_fix(t, 0);
+    if (t < total && is_border(t)) { __syncthreads(); zero_fix(t, 0); }
     __syncthreads();
 
     int cur = 0;
     for (; t < total; t += nwg, cur ^= 1) {
         const int tn = t + nwg;
+        if (tr && tk < 8) { trace[tk * 8 + 0] = __builtin_amdgcn_s_memtime(); trace[tk * 8 + 6] = (unsigned long long)t; }
         // (issuing these 17 DMA instructions from inside the MFMA loop, one every 10 reads, measured SLOWER: conv3b 0.055 -> 0.063 ms --
         // an in-order wave pays for every instruction placed between its MFMAs)
         if (tn < total) issue(tn, cur ^ 1);
+        if (tr && tk < 8) trace[tk * 8 + 1] = __builtin_amdgcn_s_memtime();
         auto issue_piece = [&](int) {};
         const uint32_t row_base = lds0 + cur * RS_BUF_BYTES + n * 256;
         floatx16 acc[RS_TH];
@@ -1108,6 +1120,7 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
         rs_read<1>(row_base, n, hh, fb[1]);
         __builtin_amdgcn_sched_barrier(0);
         rs_steps<0>(row_base, n, hh, wreg, acc, fb, issue_piece);
+        if (tr && tk < 8) trace[tk * 8 + 2] = __builtin_amdgcn_s_memtime();
 
         {   // epilogue: (2x2 max-pool) + bias + ReLU, 16-byte NHWC stores
             int b, ty0, tx0;
@@ -1141,9 +1154,12 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
                 }
             }
         }
+        if (tr && tk < 8) trace[tk * 8 + 3] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile landed (and this tile's stores retired)
-        if (tn < total) zero_fix(tn, cur ^ 1);
+        if (tr && tk < 8) trace[tk * 8 + 4] = __builtin_amdgcn_s_memtime();
+        if (tn < total && is_border(tn)) { __syncthreads(); zero_fix(tn, cur ^ 1); }
         __syncthreads();
+        if (tr && tk < 8) { trace[tk * 8 + 5] = __builtin_amdgcn_s_memtime(); ++tk; }
     }
 }
 
@@ -1156,10 +1172,28 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     int per_cg = n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
     if (per_cg > total) per_cg = total;
+    static const bool want_trace = [] { const char* e = getenv("OMNI_RS_TRACE"); return e && e[0] == '1'; }();
+    static unsigned long long* trace_dev = nullptr;
+    if (want_trace) {
+        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
+        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * 8, st));
+    }
     hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), RS_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_cg,
-                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0);
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, want_trace ? trace_dev : nullptr);
     OMNI_LAUNCH_CHECK();
+    if (want_trace) {
+        unsigned long long h[64];
+        OMNI_HIP_TRY(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, st));
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
+        static int launches = 0;
+        if (launches++ / 4 == 5)                                 // the sixth forward pass: conv3b, conv4a, conv4b, heads
+            for (int k = 0; k < 8; ++k)
+                fprintf(stderr, "rs trace H=%d W=%d cout=%d pool=%d tile %llu (ty %llu tx %llu): issue %llu mfma %llu epilogue %llu wait %llu zerofix+barrier %llu | total %llu\n",
+                        a.H, a.W, a.cout, (int)POOL, h[k * 8 + 6], (h[k * 8 + 6] % (tiles_x * tiles_y)) / tiles_x, (h[k * 8 + 6] % (tiles_x * tiles_y)) % tiles_x,
+                        h[k * 8 + 1] - h[k * 8], h[k * 8 + 2] - h[k * 8 + 1], h[k * 8 + 3] - h[k * 8 + 2], h[k * 8 + 4] - h[k * 8 + 3],
+                        h[k * 8 + 5] - h[k * 8 + 4], h[k * 8 + 5] - h[k * 8]);
+    }
     return OMNI_OK;
 }
 
