@@ -200,6 +200,8 @@ class LoopDetector:
         rows_dev: optional device pointer to the frames' global descriptors, [sum of len(f.images)][4096] fp32 in frame order (e.g.
         MobileNetVLAD's output buffer, still in HBM): rows are then appended and queried without touching the host copies."""
         with self._mu:
+            if not all(hasattr(ix, "search_prefix_dev") and hasattr(ix, "add_dev") for ix in (self.local_index, self.remote_index)):
+                return [self._on_image_recv(f) for f in frames]        # e.g. a sharded index factory: frame by frame
             return self._recv_batch(frames, rows_dev)
 
     def _recv_batch(self, frames, rows_dev):
