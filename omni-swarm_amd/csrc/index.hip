@@ -93,18 +93,20 @@ ip_scan_kernel(const T* __restrict__ db, int64_t n_rows, int dim, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Batched search (BASELINE config 5: 64 concurrent key frames against an fp16 shard).  The VALU scan above is compute bound beyond
+// Batched search (BASELINE config 5: 64 concurrent key frames against an fp16 shard).  The VALU scans are compute bound beyond
 // a handful of queries (64 queries x 4096 FMAs per row); here the dot products run on the matrix cores and the kernel is back on the
-// HBM roofline: DB rows are the A operand of v_mfma_f32_16x16x32_f16 (lane = row l&15, 16 B = 8 halfs at k = 8*(l>>4)), read
-// straight from HBM exactly once (64 B per row per instruction, non-temporal, MQ_RING k-steps in flight per wave); the 64 queries
-// are the B operand, split once per search into fp16 hi + lo (q * 2^s = hi + lo, s per query so that max|q| lands in
+// HBM roofline.  v_mfma_f32_16x16x32_f16 with the QUERIES as the A operand (16 queries x 32 k, from LDS) and a 16-row block of the
+// shard as the B operand: the T16 layout stores a block in exactly that operand order, so k-step s of a block is the contiguous KiB
+// at s * 1024, lane-linear, read straight from HBM exactly once (non-temporal, MQ_RING k-steps in flight per wave).  In the C
+// fragment a lane then holds ONE row (lane & 15) for 4 queries: key stores are 128-byte lines of 16 consecutive rows.
+// The <= 64 queries are split once per search into fp16 hi + lo (q * 2^s = hi + lo, s per query so that max|q| lands in
 // [2^13, 2^14): 22 significant bits, products exact in the fp32 accumulator -- the same fp32-class scores as the VALU path)
 // and laid out by mq_prep_kernel so that one 256-k slice (64 KB: [hi|lo][64 q][32 x 16 B], chunk position XOR (q & 15) ->
 // conflict-free ds_read_b128) is a LINEAR 64 KB copy: the next slice streams into the other LDS buffer by LDS-DMA while the
-// current one feeds the MFMAs.  A workgroup = 8 waves x MQ_RT row tiles of 16 rows; each wave keeps MQ_RT x 4 accumulator tiles
+// current one feeds the MFMAs.  A workgroup = 8 waves x MQ_RT tiles of 16 rows; each wave keeps MQ_RT x 4 accumulator tiles
 // (16 rows x 64 queries) across the 16 k-slices of a pass, then writes 64-bit keys for topk.h.
-//   algorithmic bytes: rows x dim x 2 (read once) + rows x nq x 8 (keys);  MFMA work 2 x 2 x 64 x dim flop per row ~ 41 % of the
-//   matrix peak at 8 TB/s, so the bound is HBM.
+//   algorithmic bytes: rows x dim x 2 (read once) + rows x nq x 8 (keys);  MFMA work 2 x 2 x 64 x dim flop per row ~ 28 % of the
+//   matrix peak at 5.3 TB/s, so the bound is HBM.
 #define MQ_THREADS 512
 #define MQ_WAVES 8
 #define MQ_RT 4
@@ -180,7 +182,7 @@ __device__ __forceinline__ void mq_wait_a(mq_half8 (&a)[MQ_RT]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(N));
 }
 
-// k-step S of a slice: ring slot S%4 was filled 4 k-steps ago
+// k-step S of a slice (a = ring of DB-block fragments, b = the query fragments of this step): ring slot S%4 was filled 4 k-steps ago
 // (younger VMEM ops at its wait: 3 slots x 4 loads, plus the 8 DMA instructions issued at the top of the slice for S < 4) and is
 // refilled right after its MFMAs with the block data MQ_RING k-steps ahead (next slice / next pass for the second half).  The prologue
 // in the kernel issues its loads in the same slot-major order: the counts are only valid for that order.  Offsets: 1 KiB per k-step; the
@@ -223,8 +225,8 @@ ip_scan_mq_kernel(const _Float16* __restrict__ db, int64_t n_rows, int dim, cons
     const int S = dim / MQ_KS;
     const int U = passes * S;                                    // slice units this workgroup walks through
     // Every block walks the k-slices in its own rotation (block index mod S, a function of the ROW only, so a row's score does not
-    // depend on the shard size or the launch grid): with all workgroups at the same k offset of 8 KB-strided rows the requests of the
-    // whole chip would fall on a few HBM channels at a time.
+    // depend on the shard size or the launch grid): the workgroups of the chip do not all sit at the same offset of their 128 KB blocks
+    // at the same time (worth a few percent with row-major rows, within noise with T16 blocks; OMNI_MQ_ROT=0 switches it off).
     auto blk_of = [&](int p) { return (int64_t)blockIdx.x + (int64_t)p * gridDim.x; };
     auto rot_of = [&](int p) { return rotate ? (int)(blk_of(p) % S) : 0; };
 
