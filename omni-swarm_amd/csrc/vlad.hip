@@ -717,17 +717,129 @@ static int vlad_backbone_unfused(omni_vlad* v, const uint8_t* gray_dev, int stri
     return OMNI_OK;
 }
 
+// Stem conv3x3 stride 2 (u8 -> 16 channels, ReLU6) + block 0 (t = 1: depthwise 3x3 + ReLU6, projection 16 -> 8) in ONE pass.  Run
+// separately the 16-channel stem map makes an HBM round trip at the network's highest resolution (4.6 MB per image written, read back
+// by block 0, whose 32-pixel tiles are mostly fixed cost): 163 + 223 us per 32 images, the two most expensive MobileNetVLAD launches.
+// A workgroup = 16x8 output pixels: the 37x21 input patch is normalised into LDS once ((x - 128) / 128, zero padding applied AFTER
+// normalisation, fisheye rows read as 0), the stem is evaluated on the 18x10 halo region (zero outside the stem map = the depthwise
+// conv's padding), then depthwise and projection -- the same FMA order as vlad_stem4_kernel / vlad_block_kernel: bit-identical.
+#define SB_TW 16
+#define SB_TH 8
+__global__ void __launch_bounds__(256)
+vlad_stem_b0_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, int mask0, int mask1, int Ho, int Wo,
+                    const float* __restrict__ ws /*[16][9]*/, const float* __restrict__ bs, const float* __restrict__ wd_t /*[9][16]*/,
+                    const float* __restrict__ bd, const float* __restrict__ wp_t /*[16][8]*/, const float* __restrict__ bp,
+                    float* __restrict__ out /*[B][Ho][Wo][8]*/) {
+    constexpr int RW = SB_TW + 2, RH = SB_TH + 2, R = RW * RH;           // 18 x 10 stem pixels
+    constexpr int PW = 2 * RW + 1, PH = 2 * RH + 1;                       // 37 x 21 input pixels
+    __shared__ float patch[PH * PW];
+    __shared__ __attribute__((aligned(16))) float h[R * 16];
+    __shared__ __attribute__((aligned(16))) float d[SB_TW * SB_TH * 16];
+    __shared__ float s_ws[16 * 9], s_bs[16], s_wd[9 * 16], s_bd[16];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tiles_x = (Wo + SB_TW - 1) / SB_TW;
+    const int oy0 = (blockIdx.x / tiles_x) * SB_TH, ox0 = (blockIdx.x % tiles_x) * SB_TW;
+    const int sy0 = oy0 - 1, sx0 = ox0 - 1;                              // halo region origin in the stem map
+    const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;                      // patch origin in the image (stride 2, pad 1)
+    if (tid < 144) { s_ws[tid] = ws[tid]; s_wd[tid] = wd_t[tid]; }
+    if (tid < 16) { s_bs[tid] = bs[tid]; s_bd[tid] = bd[tid]; }
+    const uint8_t* g = gray + (int64_t)b * stride * H;
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int y = iy0 + i / PW, x = ix0 + i % PW;
+        float px = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float raw = (y >= mask0 && y < mask1) ? 0.f : (float)g[(int64_t)y * stride + x];
+            px = (raw - 128.0f) / 128.0f;
+        }
+        patch[i] = px;
+    }
+    __syncthreads();
+    for (int i = tid; i < R * 4; i += 256) {                              // stem: (region pixel, 4 channels)
+        const int r = i >> 2, c4 = (i & 3) * 4;
+        const int ry = r / RW, rx = r - ry * RW;
+        const int sy = sy0 + ry, sx = sx0 + rx;
+        float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sy >= 0 && sy < Ho && sx >= 0 && sx < Wo) {
+            float v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = patch[(2 * ry + t / 3) * PW + 2 * rx + t % 3];
+            float rr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = s_bs[c4 + j];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(v[t], s_ws[(c4 + j) * 9 + t], acc);
+                rr[j] = relu6f(acc);
+            }
+            res = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        }
+        *reinterpret_cast<float4*>(h + r * 16 + c4) = res;
+    }
+    __syncthreads();
+    for (int i = tid; i < SB_TW * SB_TH * 4; i += 256) {                  // depthwise 3x3 + ReLU6: (output pixel, 4 channels)
+        const int o = i >> 2, c4 = (i & 3) * 4;
+        const int oy = o / SB_TW, ox = o - oy * SB_TW;
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = s_bd[c4 + j];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float4 x = *reinterpret_cast<const float4*>(h + ((oy + dy) * RW + ox + dx) * 16 + c4);
+                const float* wv = s_wd + (dy * 3 + dx) * 16 + c4;
+                t[0] = fmaf(x.x, wv[0], t[0]); t[1] = fmaf(x.y, wv[1], t[1]); t[2] = fmaf(x.z, wv[2], t[2]); t[3] = fmaf(x.w, wv[3], t[3]);
+            }
+        *reinterpret_cast<float4*>(d + o * 16 + c4) = make_float4(relu6f(t[0]), relu6f(t[1]), relu6f(t[2]), relu6f(t[3]));
+    }
+    __syncthreads();
+    {                                                                     // projection 16 -> 8: thread = (output channel, 4 pixels)
+        const int co = tid & 7, og = tid >> 3;
+        float wp[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wp[k] = wp_t[k * 8 + co];
+        const float bpv = bp[co];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = og + 32 * i;
+            float acc = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float4 x = *reinterpret_cast<const float4*>(d + o * 16 + k4 * 4);
+                acc = fmaf(x.x, wp[k4 * 4 + 0], acc); acc = fmaf(x.y, wp[k4 * 4 + 1], acc);
+                acc = fmaf(x.z, wp[k4 * 4 + 2], acc); acc = fmaf(x.w, wp[k4 * 4 + 3], acc);
+            }
+            const int oy = oy0 + o / SB_TW, ox = ox0 + o % SB_TW;
+            if (oy < Ho && ox < Wo) out[(((int64_t)b * Ho + oy) * Wo + ox) * 8 + co] = acc + bpv;
+        }
+    }
+}
+
 // stem + one fused kernel per inverted-residual block (v->blocks, built at create time)
 static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, int* cur_out) {
     hipStream_t st = v->ctx->stream;
     const int H = v->H, W = v->W;
     const int m0 = fisheye_mask ? H * 3 / 4 : H, m1 = fisheye_mask ? H * 3 / 4 + H / 4 : H;
     const VladLayerDev& S = v->layers[0];
-    hipLaunchKernelGGL(vlad_stem4_kernel, dim3(cdiv(S.hout * S.wout * (S.cout / 4), 256), batch), dim3(256), 0, st, gray_dev, stride, H, W, m0, m1,
-                       S.hout, S.wout, S.cout, S.stride, S.w, S.b, v->buf[0]);
-    OMNI_LAUNCH_CHECK();
     int cur = 0, rc;
-    for (const VladFusedBlock& B : v->blocks) {
+    size_t first = 0;
+    const char* sf = getenv("OMNI_VLAD_STEM_FUSE");                      // "0": stem and block 0 as two kernels (A/B and parity tests)
+    const bool stem_fuse = !(sf && sf[0] == '0');
+    const VladFusedBlock* B0 = v->blocks.empty() ? nullptr : &v->blocks[0];
+    if (stem_fuse && B0 && S.cout == 16 && S.stride == 2 && !B0->expand && !B0->res && B0->cin == 16 && B0->hid == 16 && B0->cout == 8 &&
+        B0->stride == 1) {
+        // stem + block 0 in one kernel: the 16-channel stem map never reaches HBM
+        hipLaunchKernelGGL(vlad_stem_b0_kernel, dim3(cdiv(B0->wout, SB_TW) * cdiv(B0->hout, SB_TH), batch), dim3(256), 0, st, gray_dev, stride, H,
+                           W, m0, m1, S.hout, S.wout, S.w, S.b, B0->wd_t, B0->bd, B0->wp_t, B0->bp, v->buf[1]);
+        OMNI_LAUNCH_CHECK();
+        cur = 1; first = 1;
+    } else {
+        hipLaunchKernelGGL(vlad_stem4_kernel, dim3(cdiv(S.hout * S.wout * (S.cout / 4), 256), batch), dim3(256), 0, st, gray_dev, stride, H, W, m0,
+                           m1, S.hout, S.wout, S.cout, S.stride, S.w, S.b, v->buf[0]);
+        OMNI_LAUNCH_CHECK();
+    }
+    for (size_t bi = first; bi < v->blocks.size(); ++bi) {
+        const VladFusedBlock& B = v->blocks[bi];
         const int64_t Pin = (int64_t)batch * B.hin * B.win, Pout = (int64_t)batch * B.hout * B.wout;
         if (B.expand && B.cin % 8 == 0 && B.hid % 8 == 0 && B.hin * B.win <= v->mfma_max_px && v->mfma_late) {     // per-image size: batch-independent numerics
             // low-resolution block: expand / project as f32-MFMA pointwise GEMMs, depthwise in between (three launches; the fused

@@ -36,6 +36,21 @@ def test_vlad_full_size_batch_and_mask(omni, ctx):
     assert np.array_equal(y1[0], y[2])
 
 
+def test_fused_stem_block0_is_bit_identical(omni, ctx, monkeypatch):
+    """vlad_stem_b0_kernel (stem + block 0 in one pass, the stem map never reaches HBM) keeps the FMA order of the two separate kernels:
+    same descriptors bit for bit, odd sizes (partial tiles, image borders) and the fisheye mask included."""
+    vw = V.synth_weights()
+    for (h, w, nb, mask) in ((96, 128, 2, False), (104, 136, 1, True), (480, 600, 2, True)):
+        imgs = np.stack([synth.image_u8(700 + i, h, w, n_shapes=80) for i in range(nb)])
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("OMNI_VLAD_STEM_FUSE", flag)
+            net = omni.capi.MobileNetVLAD(ctx, vw, V.layer_specs(), V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM, w, h, nb)
+            outs.append(net.inference(imgs, fisheye_mask=mask))
+            net.close()
+        assert np.array_equal(outs[0], outs[1])
+
+
 def test_loop_detector_trace_equals_oracle(omni, ctx, golden):
     from omni_swarm_amd import detector
     frames = DS.make_stream(seed=11)
