@@ -33,6 +33,15 @@ SP_FLOP_PER_IMAGE = 48.85e9   # SURVEY.md 2.3 @600x480
 KF_IMAGES = 8                 # reference-faithful key frame: 8 SuperPoint + 4 MobileNetVLAD
 
 
+def traffic_fields(key, enabled=True, images_per_launch=None):
+    """{"traffic": HBM bytes per launch (a number, or None), "traffic_detail": where the number comes from}.  The committed PMC pass
+    only applies to the launch shape it was collected at."""
+    t = pmc_traffic(key) if enabled else None
+    if t and images_per_launch is not None and t.get("images_per_launch") not in (None, images_per_launch):
+        t = None
+    return {"traffic": t["bytes_per_launch"] if t else None, "traffic_detail": t}
+
+
 def pmc_traffic(key):
     """HBM bytes per launch of a kernel from the newest committed PMC pass (profiles/*_traffic.json, written from
     `tools/profile_gpu.sh` output: bench.py cannot collect PMC counters on itself).  None when no profile is committed."""
@@ -223,7 +232,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 "
                                           "in one launch; FLOP counted for conv1b only", "achieved": round(achieved, 1),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": pmc_traffic("conv3x3_c64_pp_kernel<POOL,FUSE1A>") if args.precision == "f16" else None,
+                **traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", args.precision == "f16", n_img),
                 "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
                 "conv_stack_tflops": round(SP_FLOP_PER_IMAGE * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
                 "stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof}, "superpoint_ms_per_keyframe": round(sp_ms, 3)}
@@ -258,7 +267,7 @@ def main():
     gbs = rows_here * 4096 * 4 / (scan_ms * 1e-3) / 1e9
     roofline_knn = {"bound": "hbm", "kernel": "ip_scan_kernel<float,1>", "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "traffic": pmc_traffic("ip_scan_kernel<float,1>") if rows_here == 100_000 else None, "bytes_per_launch": rows_here * 16384,
+                    **traffic_fields("ip_scan_kernel<float,1>", rows_here == 100_000), "bytes_per_launch": rows_here * 16384,
                     "launch_ms": round(scan_ms, 4), "rows_per_gpu": rows_here}
     loop_match = {"p50_ms": round(p50, 4), "db_rows_node": args.match_db_rows, "db_rows_per_gpu": rows_here, "k": K_SEARCH,
                   "includes": "H2D query, scan, top-k, D2H result" + (", all_gather + merge" if world > 1 else "")}
@@ -281,7 +290,7 @@ def main():
         b_bytes = args.batched_rows * (4096 * 2 + 64 * 8)            # every fp16 row read once + one 64-bit key per (query, row)
         batched = {"bound": "hbm", "kernel": "ip_scan_mq_kernel (64 queries, fp16 rows, v_mfma_f32_16x16x32_f16)",
                    "achieved": round(b_bytes / (b_ms * 1e-3) / 1e9, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                   "frac": round(b_bytes / (b_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("ip_scan_mq_kernel"),
+                   "frac": round(b_bytes / (b_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), **traffic_fields("ip_scan_mq_kernel", args.batched_rows == 125_000),
                    "bytes_per_launch": b_bytes, "launch_ms": round(b_ms, 4), "rows_per_gpu": args.batched_rows, "queries": 64,
                    "search_p50_ms": round(b_p50, 4), "queries_per_s": round(64 / (b_p50 * 1e-3), 0)}
         bidx.close()
