@@ -521,7 +521,9 @@ static int vlad_block(hipStream_t st, int cin, const VladBlockArgs& a) {
     const int64_t px = (int64_t)a.batch * a.Ho * a.Wo;
     // (measured: 128- / 64-pixel tiles are SLOWER for the 300x240 / 150x120 blocks -- 54 -> 70 us, 38 -> 46 us: their LDS footprint
     // halves the resident workgroups and with them the latency hiding; kept instantiated for other image sizes only)
-    const int big = 0; (void)px;
+    // OMNI_VLAD_BIG=64|128 re-enables them for A/B at other batch sizes (numerics do not depend on the tile size)
+    const char* be = getenv("OMNI_VLAD_BIG");
+    const int big = be ? atoi(be) : 0; (void)px;
 #define VB(CI, CPV, T) if (cin == CI && cp == CPV) return launch_vlad_block<CI, CPV, T>(st, a)
     if (big == 128) { VB(16, 8, 128); VB(8, 8, 128); VB(16, 16, 128); }
     if (big >= 64) { VB(16, 8, 64); VB(8, 8, 64); VB(8, 16, 64); VB(16, 16, 64); }
