@@ -286,3 +286,61 @@ class LoopDetector:
         finally:
             self._deferred = None
 
+    # ---- checkpoint / resume (new: the reference's key-frame database lives in RAM only) --------------------
+    def save(self, prefix: str):
+        """Everything on_image_recv depends on: the two index shards (OMNX1 snapshots, omni_index_save) and `prefix`.state.npz with the
+        id maps, inter-drone loop counters, known nodes and the stored frames (global + local descriptors, key points).  Plain arrays
+        only (no pickle)."""
+        with self._mu:
+            self.local_index.save(prefix + ".local.omnx")
+            self.remote_index.save(prefix + ".remote.omnx")
+            ids = sorted(self.imgid2fisheye)
+            frames = [self.fisheyeframe_database[k] for k in sorted(self.fisheyeframe_database)]
+            imgs = [im for f in frames for im in f.images]
+            feat = [np.asarray(im.feature_descriptor, np.float32).reshape(-1) for im in imgs]
+            kps = [np.asarray(im.landmarks_2d, np.float32).reshape(-1) for im in imgs]
+            pairs = sorted(self.inter_drone_loop_count)
+            np.savez(prefix + ".state.npz",
+                     params=np.array([self.self_id, self.camera_configuration], np.int64),
+                     imgid=np.array(ids, np.int64), imgid_fisheye=np.array([self.imgid2fisheye[i] for i in ids], np.int64),
+                     imgid_dir=np.array([self.imgid2dir[i] for i in ids], np.int64),
+                     loop_pairs=np.array(pairs, np.int64).reshape(-1, 2),
+                     loop_counts=np.array([self.inter_drone_loop_count[p] for p in pairs], np.int64),
+                     nodes=np.array(sorted(self.all_nodes), np.int64),
+                     frame_meta=np.array([[f.msg_id, f.drone_id, f.landmark_num, int(f.prevent_adding_db), len(f.images)] for f in frames],
+                                         np.int64).reshape(-1, 5),
+                     img_meta=np.array([[im.drone_id, im.landmark_num] for im in imgs], np.int64).reshape(-1, 2),
+                     img_desc=(np.stack([np.asarray(im.image_desc, np.float32) for im in imgs]) if imgs
+                               else np.zeros((0, DEEP_DESC_SIZE), np.float32)),
+                     feat=np.concatenate(feat) if feat else np.zeros(0, np.float32),
+                     feat_len=np.array([len(x) for x in feat], np.int64),
+                     kps=np.concatenate(kps) if kps else np.zeros(0, np.float32),
+                     kps_len=np.array([len(x) for x in kps], np.int64))
+
+    def load(self, prefix: str):
+        """Restores a save() into this (freshly constructed, same parameters) detector."""
+        with self._mu:
+            z = np.load(prefix + ".state.npz", allow_pickle=False)
+            if int(z["params"][0]) != self.self_id or int(z["params"][1]) != self.camera_configuration:
+                raise ValueError("snapshot was written by a detector with another self_id / camera configuration")
+            self.local_index.load(prefix + ".local.omnx")
+            self.remote_index.load(prefix + ".remote.omnx")
+            self.imgid2fisheye = {int(i): int(f) for i, f in zip(z["imgid"], z["imgid_fisheye"])}
+            self.imgid2dir = {int(i): int(d) for i, d in zip(z["imgid"], z["imgid_dir"])}
+            self.inter_drone_loop_count = {(int(a), int(b)): int(c) for (a, b), c in zip(z["loop_pairs"], z["loop_counts"])}
+            self.all_nodes = {int(n) for n in z["nodes"]}
+            self.fisheyeframe_database = {}
+            fo = np.concatenate([[0], np.cumsum(z["feat_len"])])
+            ko = np.concatenate([[0], np.cumsum(z["kps_len"])])
+            j = 0
+            for msg_id, drone_id, lm, prevent, n_img in z["frame_meta"]:
+                images = []
+                for _ in range(int(n_img)):
+                    images.append(ImageDescriptor(drone_id=int(z["img_meta"][j, 0]), landmark_num=int(z["img_meta"][j, 1]),
+                                                  image_desc=z["img_desc"][j].copy(),
+                                                  feature_descriptor=z["feat"][fo[j]:fo[j + 1]].reshape(-1, 64).copy(),
+                                                  landmarks_2d=z["kps"][ko[j]:ko[j + 1]].reshape(-1, 2).copy()))
+                    j += 1
+                self.fisheyeframe_database[int(msg_id)] = FisheyeFrameDescriptor(msg_id=int(msg_id), drone_id=int(drone_id), landmark_num=int(lm),
+                                                                                prevent_adding_db=bool(prevent), images=images)
+

@@ -67,6 +67,12 @@ class HostIndex:
     def add_dev(self, n, x_dev):
         self.rows = np.concatenate([self.rows, self.ctx.view(x_dev, n * DIM * 4).view(np.float32).reshape(n, DIM)])
 
+    def save(self, path):
+        np.save(path + ".npy", self.rows)
+
+    def load(self, path):
+        self.rows = np.load(path + ".npy")
+
     def search_prefix_dev(self, nq, q_dev, k, n_limit, D_dev, I_dev):
         q = self.ctx.view(q_dev, nq * DIM * 4).view(np.float32).reshape(nq, DIM)
         D, I = M.ip_search(self.rows[:min(n_limit, len(self.rows))], q, k)
@@ -108,3 +114,36 @@ def test_batch_with_nothing_to_do(detector_mod):
         images=[detector_mod.ImageDescriptor(drone_id=2, landmark_num=100, image_desc=np.ones(DIM, np.float32)) for _ in range(4)])
     recs = det.on_images_recv_batch([empty, remote_first])              # remote frame while the database is empty: dropped (:36-38)
     assert [r["added"] for r in recs] == [False, False] and det.database_size() == 0 and ctx.syncs == 0
+
+
+def test_checkpoint_resume_continues_the_same_trace(detector_mod, tmp_path):
+    """save() half-way through a stream, load() into a fresh detector, feed the rest to both: identical decisions (id maps, init-mode
+    counters, known nodes, stored frames and both index shards all survive)."""
+    frames = DS.make_stream(seed=51, n_frames=120, n_places=12)
+
+    def mk(fr):
+        return detector_mod.FisheyeFrameDescriptor(
+            msg_id=fr["msg_id"], drone_id=fr["drone_id"], landmark_num=fr["landmark_num"], prevent_adding_db=fr["prevent_adding_db"],
+            images=[detector_mod.ImageDescriptor(drone_id=i["drone_id"], landmark_num=i["landmark_num"], image_desc=i["image_desc"],
+                                                 feature_descriptor=np.full((3, 64), float(fr["msg_id"] % 7), np.float32),
+                                                 landmarks_2d=np.array([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]], np.float32)) for i in fr["images"]])
+
+    loop = lambda n, o, dn, do, im: DS.loop_ok(n.msg_id, o.msg_id)
+    ctx = ArenaCtx()
+    a = detector_mod.LoopDetector(ctx, DS.SELF_ID, compute_loop=loop, index_factory=lambda: HostIndex(ctx), **DS.PARAMS)
+    for fr in frames[:70]:
+        a.on_image_recv(mk(fr))
+    prefix = str(tmp_path / "det")
+    a.save(prefix)
+    b = detector_mod.LoopDetector(ctx, DS.SELF_ID, compute_loop=loop, index_factory=lambda: HostIndex(ctx), **DS.PARAMS)
+    b.load(prefix)
+    assert b.database_size() == a.database_size() and b.imgid2fisheye == a.imgid2fisheye and b.all_nodes == a.all_nodes
+    some = next(iter(a.fisheyeframe_database))
+    assert np.array_equal(b.fisheyeframe_database[some].images[1].feature_descriptor, a.fisheyeframe_database[some].images[1].feature_descriptor)
+    ra = [a.on_image_recv(mk(fr)) for fr in frames[70:]]
+    rb = b.on_images_recv_batch([mk(fr) for fr in frames[70:]])       # and the resumed one through the batched entry point
+    assert np.array_equal(DS.trace(ra), DS.trace(rb))
+    assert (DS.trace(ra)[:, 4] != -1).any()
+    with pytest.raises(ValueError):
+        detector_mod.LoopDetector(ctx, 2, index_factory=lambda: HostIndex(ctx), **DS.PARAMS).load(prefix)
+
