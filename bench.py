@@ -2,23 +2,30 @@
 """bench.py -- keyframes/sec of the swarm_loop hot path on MI355X + p50 loop-match latency.
 
 A "step" is ONE fisheye key frame through the whole hot path (BASELINE.json configs[1]):
+    upload of its 8 images (pinned host -> HBM, inside the timed region; the reference does one H2D per engine call, tensorrt_generic.cpp:58-75)
     8 SuperPoint images (4 directions x up/down, 600x480 u8, fisheye-masked) + 4 MobileNetVLAD images
     + 4 up<->down descriptor cross-check matches                    (LoopCam::on_flattened_images, loop_cam.cpp:178-229)
     + <=4 row inserts into the 4096-d global index and the top-k inner-product query with the recency/threshold rule
                                                                     (LoopDetector::on_image_recv, loop_detector.cpp:11-137)
-Inputs are resident in HBM before the timed region (a pool of distinct synthetic key frames); results (key points,
-descriptors, global descriptors, match lists, query result) are copied back to the host inside it.
+    + the D2H copy of every result (key points, descriptors, global descriptors, match lists, query result).
+The timed host loop is C++ (omni-swarm_amd/host/keyframe_pipeline.hpp, the flow of SwarmLoop::VIOKF_callback swarm_loop.cpp:140-170);
+Python prepares the synthetic inputs, starts the run and brackets it with barrier + synchronize.  EXACTLY --steps key frames are
+processed per timed region (a trailing partial micro-batch runs as its own smaller unit); when one region is shorter than --min-time
+it is repeated and the MEDIAN region is reported (`repeats`, `ms_per_step_minmax` say so).
 
-One process per GPU.  N > 1 (launched by torch.distributed.run): key frames are data parallel, the global index is
-row-sharded across ranks and every step has one exchange (all_gather of the new rows, all_gather of per-shard top-k).
+One process per GPU.  N > 1 (launched by torch.distributed.run): key frames are data parallel, the global index is row-sharded across
+ranks and every micro-batch has one exchange (all_gather of the new rows, all_gather of per-shard top-k).
 
-Prints ONE JSON line on rank 0 (see the task contract) with the extra objects `roofline` (dominant kernel),
-`roofline_knn`, `loop_match` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (see the task contract) with the extra objects `roofline` (dominant kernel), `roofline_knn`,
+`roofline_knn_batched`, `loop_match`, `db100k` (the same loop against a 100k-key-frame = 400k-row database, fp16 and fp32 rows),
+`value_f32`, `python_host`, `parity` and `cpu_baseline`.
 """
 import argparse
 import json
+import math
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -63,18 +70,49 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", choices=["f16", "f32"], default="f16")
+    ap.add_argument("--host", choices=["cpp", "python"], default="cpp", help="language of the timed host loop (N = 1; N > 1 runs the Python loop)")
+    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the timed region of --steps key frames until this many seconds were timed; the median region is reported")
     ap.add_argument("--db-keyframes", type=int, default=1000, help="key frames pre-loaded in the index (x4 rows) for the throughput loop")
     ap.add_argument("--match-db-rows", type=int, default=100_000, help="index rows for the p50 loop-match measurement (node total)")
     ap.add_argument("--pipelines", type=int, default=2, help="micro-batches in flight per GPU (separate HIP streams)")
     ap.add_argument("--microbatch", type=int, default=8,
                     help="consecutive key frames enqueued together (one SuperPoint launch over 8*MB images, one MobileNetVLAD launch over 4*MB): "
-                         "the low-resolution layers of both nets are launch/latency-bound at one key frame.  When --steps is not a "
-                         "multiple the last micro-batch is still processed in full inside the timed region (extra work, not counted)")
+                         "the low-resolution layers of both nets are launch/latency-bound at one key frame")
     ap.add_argument("--batched-rows", type=int, default=125_000,
                     help="fp16 rows per GPU for the 64-concurrent-query search measurement (configs[4]: 1 M key frames over 8 GPUs); 0 = skip")
+    ap.add_argument("--big-db-keyframes", type=int, default=100_000, help="key frames (x4 rows) of the big-database throughput legs; 0 = skip")
+    ap.add_argument("--big-db-steps", type=int, default=64, help="key frames per timed region of the big-database legs")
+    ap.add_argument("--f32-steps", type=int, default=16, help="key frames of the f32-precision leg (value_f32); 0 = skip")
+    ap.add_argument("--python-steps", type=int, default=64, help="key frames of the Python-host leg (python_host); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-keyframes", type=int, default=4, help="key frames timed on the host cores for cpu_baseline")
     return ap.parse_args()
+
+
+class RowFactory:
+    """Unit-norm pseudo-random 4096-d rows, fast enough for 400k-row databases: one seeded Gaussian block, re-used with a different
+    cyclic column shift and sign pattern per block (rows stay unit norm, distinct and mutually near-orthogonal)."""
+
+    def __init__(self, seed, block=8192):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal((block, 4096), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        self.base, self.block, self.n = x, block, 0
+        self.signs = (rng.integers(0, 2, (64, 4096)) * 2 - 1).astype(np.float32)
+
+    def rows(self, n):
+        out = []
+        while n > 0:
+            b = self.n // self.block
+            o = self.n % self.block
+            m = min(n, self.block - o)
+            blk = self.base[o:o + m]
+            if b:
+                blk = np.roll(blk, 37 * b, axis=1) * self.signs[b % 64]
+            out.append(blk)
+            self.n += m
+            n -= m
+        return out[0] if len(out) == 1 else np.concatenate(out)
 
 
 def main():
@@ -89,6 +127,7 @@ def main():
     one_gpu = os.environ.get("OMNI_BENCH_ONE_GPU", "0") == "1"
     if one_gpu:
         local_rank = 0
+    coll_dev = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -96,133 +135,243 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        coll_dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)     # where the all_gather payloads live
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import omni_loader
-    omni = omni_loader.load()
-    from omni_swarm_amd import capi, detector, frontend, shard, synth, weights
-    prec = capi.PREC_F16 if args.precision == "f16" else capi.PREC_F32
+    omni_loader.load()
+    from omni_swarm_amd import capi, detector, frontend, pipeline, shard, synth, weights
+    PREC = {"f16": capi.PREC_F16, "f32": capi.PREC_F32}
+    prec = PREC[args.precision]
     W, H, MAXN = 600, 480, 200
     THRES = 0.02                      # superpoint_thres of the fisheye launch files (nodelet-sfisheye.launch)
-    MATCH_INDEX_DIST, QUERY_THRES = 5, 0.3   # launch values
+    MATCH_INDEX_DIST, QUERY_THRES, INIT_THRES = 5, 0.3, 0.2   # launch values (SURVEY.md section 5)
     K_SEARCH = 5 + MATCH_INDEX_DIST
-
     MB = max(1, args.microbatch)
+    cpp_host = args.host == "cpp" and world == 1
+
     sp_w = weights.superpoint_synth_weights(0)
     comp, mean = synth.pca()
     vl_w = weights.mobilenetvlad_synth_weights()
     vl_specs = weights.mobilenetvlad_layer_specs()
-    ctxs = [capi.Context(local_rank) for _ in range(args.pipelines)]
+    vl_shape = (weights.VLAD_N_CLUSTERS, weights.VLAD_FEAT_DIM, weights.VLAD_OUT_DIM)
+    tmp = tempfile.TemporaryDirectory(prefix=f"omni_bench_r{rank}_")
+    files = weights.write_pipeline_files(tmp.name, sp_w, comp, mean, vl_w, vl_specs, capi.VLAD_KINDS)
     ictx = capi.Context(local_rank)
     info = ictx.device_info()
-    cams = [frontend.LoopCam(c, sp_w, comp, mean, vl_w, vl_specs, (weights.VLAD_N_CLUSTERS, weights.VLAD_FEAT_DIM, weights.VLAD_OUT_DIM),
-                             W, H, THRES, MAXN, prec, n_dirs=4 * MB) for c in ctxs]
 
-    # ---- synthetic key-frame pool, resident in HBM ---------------------------------------------------------------
+    # ---- synthetic key-frame pool in PINNED HOST memory: every micro-batch is uploaded inside the timed region -------------------
+    def micro_batch_images(first_seed, mb):
+        """[up cameras of the mb frames (4 each) | down cameras of the mb frames] -- LoopCam's image order"""
+        kf = [[synth.image_u8(first_seed + 8 * m + i, H, W) for i in range(KF_IMAGES)] for m in range(mb)]
+        return np.stack([kf[m][i] for m in range(mb) for i in range(4)] + [kf[m][4 + i] for m in range(mb) for i in range(4)])
+
     POOL = 4
-    pool = []
-    for p in range(POOL):      # one entry = MB key frames: [up cameras of all MB frames | down cameras of all MB frames] (LoopCam's image order)
-        kf = [[synth.image_u8(1000 * rank + 8 * (p * MB + m) + i, H, W) for i in range(KF_IMAGES)] for m in range(MB)]
-        imgs = np.stack([kf[m][i] for m in range(MB) for i in range(4)] + [kf[m][4 + i] for m in range(MB) for i in range(4)])
-        pool.append(ictx.to_device(imgs))
-    pool1 = ictx.to_device(np.stack([synth.image_u8(1000 * rank + i, H, W) for i in range(KF_IMAGES)]))   # one key frame, for the stage profile
+    img_cache = {}
 
-    # ---- index: local (world 1) or row-sharded --------------------------------------------------------------------
-    rng = np.random.default_rng(7)
+    def pinned_batch(first_seed, mb):
+        key = (first_seed, mb)
+        if key not in img_cache:
+            a = ictx.host_alloc((KF_IMAGES * mb, H, W), np.uint8)
+            a[:] = micro_batch_images(first_seed, mb)
+            img_cache[key] = a
+        return img_cache[key]
 
-    def random_rows(n):
-        x = rng.standard_normal((n, 4096), dtype=np.float32)
-        x /= np.linalg.norm(x, axis=1, keepdims=True)
-        return x
+    pool = [pinned_batch(1000 * rank + 8 * MB * p, MB) for p in range(POOL)]
+    pool_ptrs = [a.ctypes.data for a in pool]
 
-    if world == 1:
-        det = detector.LoopDetector(ictx, self_id=1, inner_product_thres=QUERY_THRES, init_mode_product_thres=0.2,
-                                    match_index_dist=MATCH_INDEX_DIST, min_loop_num=30, min_direction_loop=3)
-        base_rows = 4 * args.db_keyframes
-        for s in range(0, base_rows, 4096):
-            det.local_index.add(random_rows(min(4096, base_rows - s)))
-        for i in range(base_rows):      # bookkeeping for pre-loaded rows: frame ids / directions
-            det.imgid2fisheye[i] = -(i // 4) - 1
-            det.imgid2dir[i] = i % 4
-        swarm = None
-    else:
-        det = None
-        coll_dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)     # where the all_gather payloads live
-        swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, coll_dev)
-        per_rank = 4 * args.db_keyframes // world
-        swarm.preload_local(random_rows(per_rank), per_rank * world)
+    def tail_for(steps):
+        rem = steps % MB
+        return (pinned_batch(1000 * rank + 8 * MB * POOL, rem), rem) if rem else (None, 0)
 
-    hits = [0]
+    rowgen = RowFactory(7 + rank)
 
-    def finish(cam, step):
-        out = cam.fetch()
-        if os.environ.get("OMNI_BENCH_SKIP_DETECTOR") == "1":      # diagnostic only (host/index share of a step); never a reported number
-            return out
-        if world == 1:
-            # the MB key frames of the micro-batch reach the detector in order, as one batch: rows and queries are taken from
-            # MobileNetVLAD's output buffer in HBM ([4*MB][4096], key-frame major), one host synchronisation for all of them
-            frames = []
-            for m in range(MB):
-                ims = out["images"][4 * m:4 * m + 4]
-                frames.append(detector.FisheyeFrameDescriptor(
-                    msg_id=step + m, drone_id=1, landmark_num=int(sum(i["landmark_num"] for i in ims)), prevent_adding_db=False,
-                    images=[detector.ImageDescriptor(drone_id=1, landmark_num=i["landmark_num"], image_desc=i["image_desc"],
-                                                     feature_descriptor=i["feature_descriptor"], landmarks_2d=i["landmarks_2d"])
-                            for i in ims]))
-            if os.environ.get("OMNI_BENCH_DETECTOR_PER_FRAME") == "1":      # A/B: the reference's call pattern, ~6 host syncs per key frame
-                recs = [det.on_image_recv(fr) for fr in frames]
-            else:
-                recs = det.on_images_recv_batch(frames, rows_dev=cam.vlad.dev_output())
-            hits[0] += sum(int(r["old_msg_id"] != -1) for r in recs)
-        else:
-            # the micro-batch's MB steps (each: add world*4 rows, query direction 1) in two collectives + one index sync
-            rows = np.stack([np.stack([i["image_desc"] for i in out["images"][4 * m:4 * m + 4]]) for m in range(MB)])
-            base = swarm.ntotal
-            for m, (D, I) in enumerate(swarm.step_batch(rows, query_row=1, k=K_SEARCH)):
-                nt = base + (m + 1) * world * 4                                 # ntotal as of this key frame's step
-                ok = (I[0] >= 0) & (I[0] <= nt - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
-                hits[0] += int(ok.any())
-        return out
-
-    def run(n_steps, first_step):
-        """`pipelines` key frames in flight: key frame s is enqueued (kernels + D2H copies, no host sync) before the host
-        waits for key frame s - pipelines + 1, so the GPU always has queued work while the host runs the detector."""
-        from collections import deque
-        pending = deque()
-        for s in range((n_steps + MB - 1) // MB):          # one pass = MB key frames (a trailing partial micro-batch runs in full)
-            cam = cams[s % len(cams)]
-            cam.enqueue_dev(pool[((first_step + MB - 1) // MB + s) % POOL], W)
-            pending.append((cam, first_step + s * MB))
-            if len(pending) >= len(cams):
-                finish(*pending.popleft())
-        while pending:
-            finish(*pending.popleft())
-
-    def barrier():
-        for c in ctxs:
-            c.sync()
+    def barrier(*syncs):
+        for s in syncs:
+            s()
         ictx.sync()
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         if dist is not None:
             dist.barrier()
 
-    run(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=coll_dev)
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kfps = args.steps * world / dt
+        return float(t.item())
+
+    def timed_regions(run, sync, steps, warmup, min_time, max_repeats=200):
+        """run(n_steps) processes exactly n_steps key frames.  Warm-up, then regions of `steps` key frames, each bracketed by barrier +
+        synchronize on both sides and reduced with MAX over ranks; repeated until min_time seconds are covered; returns the list."""
+        if warmup > 0:
+            run(warmup)
+        dts = []
+        while True:
+            barrier(sync)
+            t0 = time.perf_counter()
+            run(steps)
+            barrier(sync)
+            dts.append(reduce_max(time.perf_counter() - t0))
+            if sum(dts) >= min_time or len(dts) >= max_repeats:
+                return dts
+
+    def summarize(dts, steps):
+        med = float(np.median(dts))
+        return {"value": round(steps * world / med, 2), "ms_per_step": round(med / steps * 1e3, 4), "repeats": len(dts),
+                "ms_per_step_minmax": [round(min(dts) / steps * 1e3, 4), round(max(dts) / steps * 1e3, 4)]}
+
+    # ---- the C++ host loop (N = 1) ------------------------------------------------------------------------------------------------
+    def cpp_leg(precision, storage, db_rows, steps, warmup, min_time):
+        pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, MB,
+                                       args.pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3)
+        gen = RowFactory(7 + rank)
+        for s in range(0, db_rows, 32768):
+            pl.preload(gen.rows(min(32768, db_rows - s)))
+        tail, _ = tail_for(steps)
+        wtail, _ = tail_for(warmup)
+        pl.prepare(steps)
+        pl.prepare(warmup)
+        state = {"id": 0, "slot": 0, "hits": 0}
+
+        def run(n):
+            t = tail if n == steps else wtail
+            state["hits"] += pl.run(n, state["id"], pool_ptrs, state["slot"], None if t is None else t.ctypes.data, True)
+            state["id"] += n
+            state["slot"] += n // MB
+        dts = timed_regions(run, pl.sync, steps, warmup, min_time)
+        out = summarize(dts, steps)
+        out.update(db_rows_start=db_rows, db_rows_end=int(pl.db_rows), loop_candidates_found=state["hits"])
+        pl.close()
+        return out
+
+    # ---- the Python host loop (N > 1, --host python, and the `python_host` comparison leg) -----------------------------------------
+    class PythonLoop:
+        def __init__(self, precision):
+            self.ctxs = [capi.Context(local_rank) for _ in range(args.pipelines)]
+            self.prec = precision
+            self.cams = [frontend.LoopCam(c, sp_w, comp, mean, vl_w, vl_specs, vl_shape, W, H, THRES, MAXN, precision, n_dirs=4 * MB) for c in self.ctxs]
+            self.tail_cam = None
+            self.hits, self.step = 0, 0
+            if world == 1:
+                self.det = detector.LoopDetector(ictx, self_id=1, inner_product_thres=QUERY_THRES, init_mode_product_thres=INIT_THRES,
+                                                 match_index_dist=MATCH_INDEX_DIST, min_loop_num=30, min_direction_loop=3)
+                base_rows = 4 * args.db_keyframes
+                gen = RowFactory(7 + rank)
+                for s in range(0, base_rows, 8192):
+                    self.det.local_index.add(gen.rows(min(8192, base_rows - s)))
+                for i in range(base_rows):      # bookkeeping for pre-loaded rows: frame ids / directions
+                    self.det.imgid2fisheye[i] = -(i // 4) - 1
+                    self.det.imgid2dir[i] = i % 4
+                    self.det.fisheyeframe_database.setdefault(-(i // 4) - 1, detector.FisheyeFrameDescriptor(msg_id=-(i // 4) - 1))
+                self.swarm = None
+            else:
+                self.det = None
+                self.swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, coll_dev)
+                per_rank = 4 * args.db_keyframes // world
+                self.swarm.preload_local(RowFactory(7 + rank).rows(per_rank), per_rank * world)
+
+        def finish(self, cam, step, mb):
+            out = cam.fetch()
+            if os.environ.get("OMNI_BENCH_SKIP_DETECTOR") == "1":      # diagnostic only (host/index share of a step); never a reported number
+                return
+            if world == 1:
+                # the mb key frames of the micro-batch reach the detector in order, as one batch: rows and queries are taken from
+                # MobileNetVLAD's output buffer in HBM ([4*mb][4096], key-frame major), one host synchronisation for all of them
+                frames = []
+                for m in range(mb):
+                    ims = out["images"][4 * m:4 * m + 4]
+                    frames.append(detector.FisheyeFrameDescriptor(
+                        msg_id=step + m, drone_id=1, landmark_num=int(sum(i["landmark_num"] for i in ims)), prevent_adding_db=False,
+                        images=[detector.ImageDescriptor(drone_id=1, landmark_num=i["landmark_num"], image_desc=i["image_desc"],
+                                                         feature_descriptor=i["feature_descriptor"], landmarks_2d=i["landmarks_2d"])
+                                for i in ims]))
+                if os.environ.get("OMNI_BENCH_DETECTOR_PER_FRAME") == "1":      # A/B: the reference's call pattern, ~6 host syncs per key frame
+                    recs = [self.det.on_image_recv(fr) for fr in frames]
+                else:
+                    recs = self.det.on_images_recv_batch(frames, rows_dev=cam.vlad.dev_output())
+                self.hits += sum(int(r["old_msg_id"] != -1) for r in recs)
+            else:
+                # the micro-batch's mb steps (each: add world*4 rows, query direction 1) in two collectives + one index sync
+                rows = np.stack([np.stack([i["image_desc"] for i in out["images"][4 * m:4 * m + 4]]) for m in range(mb)])
+                base = self.swarm.ntotal
+                for m, (D, I) in enumerate(self.swarm.step_batch(rows, query_row=1, k=K_SEARCH)):
+                    nt = base + (m + 1) * world * 4                                 # ntotal as of this key frame's step
+                    ok = (I[0] >= 0) & (I[0] <= nt - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
+                    self.hits += int(ok.any())
+
+        def run(self, n_steps):
+            """`pipelines` micro-batches in flight: micro-batch s is enqueued (upload + kernels + D2H copies, no host sync) before the host
+            waits for micro-batch s - pipelines + 1.  Exactly n_steps key frames: a trailing partial micro-batch is its own smaller unit."""
+            from collections import deque
+            pending = deque()
+            full, rem = n_steps // MB, n_steps % MB
+            slot0 = self.step // MB
+            for s in range(full):
+                cam = self.cams[s % len(self.cams)]
+                cam.enqueue_host(pool[(slot0 + s) % POOL])
+                pending.append((cam, self.step + s * MB, MB))
+                if len(pending) >= len(self.cams):
+                    self.finish(*pending.popleft())
+            if rem:
+                if self.tail_cam is None or self.tail_cam.n_dirs != 4 * rem:
+                    self.tail_ctx = capi.Context(local_rank)
+                    self.tail_cam = frontend.LoopCam(self.tail_ctx, sp_w, comp, mean, vl_w, vl_specs, vl_shape, W, H, THRES, MAXN, self.prec, n_dirs=4 * rem)
+                self.tail_cam.enqueue_host(tail_for(n_steps)[0])
+                pending.append((self.tail_cam, self.step + full * MB, rem))
+            while pending:
+                self.finish(*pending.popleft())
+            self.step += n_steps
+
+        def sync(self):
+            for c in self.ctxs:
+                c.sync()
+
+    hits = 0
+    pyloop = None
+    if cpp_host:
+        main_leg = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, args.steps, args.warmup, args.min_time)
+        hits = main_leg["loop_candidates_found"]
+    else:
+        pyloop = PythonLoop(prec)
+        dts = timed_regions(pyloop.run, pyloop.sync, args.steps, args.warmup, args.min_time)
+        main_leg = summarize(dts, args.steps)
+        hits = pyloop.hits
+    kfps = main_leg["value"]
+
+    # ---- comparison legs (N = 1 only; bounded) ----------------------------------------------------------------------------------------
+    python_host = value_f32 = db100k = None
+    if world == 1:
+        if cpp_host and args.python_steps > 0:
+            pyloop = PythonLoop(prec)
+            n = max(MB, args.python_steps // MB * MB)
+            python_host = summarize(timed_regions(pyloop.run, pyloop.sync, n, MB * args.pipelines, min(args.min_time, 0.5)), n)
+            python_host["steps"] = n
+        if args.f32_steps > 0 and args.precision == "f16":
+            n = max(MB, args.f32_steps // MB * MB)
+            if cpp_host:
+                value_f32 = cpp_leg(capi.PREC_F32, capi.STORE_F32, 4 * args.db_keyframes, n, MB * args.pipelines, 0.0)
+            else:
+                l32 = PythonLoop(capi.PREC_F32)
+                value_f32 = summarize(timed_regions(l32.run, l32.sync, n, MB * args.pipelines, 0.0), n)
+            value_f32.update(steps=n, dtype="f32", note="OMNI_PREC_F32: exact-f32 MFMA network (key points identical to the fp32 oracle), same workload")
+        if args.big_db_keyframes > 0 and cpp_host:
+            n = max(MB, args.big_db_steps // MB * MB)
+            db100k = {"db_keyframes": args.big_db_keyframes, "db_rows": 4 * args.big_db_keyframes, "steps": n,
+                      "note": "same key-frame loop, every key frame's query scans the whole database (one pass per micro-batch, per-query row limits)"}
+            for name, st in (("f16_rows", capi.STORE_F16), ("f32_rows", capi.STORE_F32)):
+                db100k[name] = cpp_leg(prec, st, 4 * args.big_db_keyframes, n, MB * args.pipelines, min(args.min_time, 0.5))
 
     # ---- roofline of the dominant kernel (conv1b + pool, 43 % of the FLOPs): HIP events on the kernel's own stream --
     # same launch shape as in the timed loop: one micro-batch = 8 * MB images per launch (HIP events between the stages, on the
     # kernels' own stream); stage times are then quoted per key frame (8 images)
     n_img = KF_IMAGES * MB
-    prof = cams[0].sp.profile(pool[0], W, n_img, reps=10)
+    if pyloop is not None:
+        prof_sp = pyloop.cams[0].sp
+    else:
+        prof_sp = capi.SuperPoint(ictx, sp_w, comp, mean, W, H, THRES, MAXN, prec, n_img)
+    pool_dev = ictx.to_device(pool[0])
+    prof = prof_sp.profile(pool_dev, W, n_img, reps=10)
     conv_ms = sum(p["ms"] for p in prof if p["stage"].startswith("conv")) / MB
     sp_ms = sum(p["ms"] for p in prof) / MB
     c1b = next(p for p in prof if p["stage"].startswith("conv1b"))
@@ -236,34 +385,35 @@ def main():
                 "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
                 "conv_stack_tflops": round(SP_FLOP_PER_IMAGE * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
                 "stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof}, "superpoint_ms_per_keyframe": round(sp_ms, 3)}
+    ictx.free(pool_dev)
 
-    # ---- p50 loop-match latency on a big DB (node total rows = --match-db-rows, sharded when N > 1) -----------------
-    rows_here = args.match_db_rows // world
-    midx = capi.IndexFlatIP(ictx, 4096, capi.STORE_F32, rows_here)
-    for s in range(0, rows_here, 8192):
-        midx.add(random_rows(min(8192, rows_here - s)))
-    mq = random_rows(1)
-    if world > 1:
-        big = shard.ShardedIndex(midx, rank, world, dist, coll_dev)
-        search = lambda: big.search(mq, K_SEARCH)
-    else:
-        search = lambda: midx.search(mq, K_SEARCH)
-    lat, scan = [], []
-    for i in range(60):
-        if dist is not None:
-            dist.barrier()
-        t = time.perf_counter()
-        search()
-        lat.append((time.perf_counter() - t) * 1e3)
-        scan.append(midx.last_scan_ms())
-    lat, scan = lat[10:], scan[10:]
-    if dist is not None:
-        t = torch.tensor([float(np.median(lat))], device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        p50 = float(t.item())
-    else:
-        p50 = float(np.median(lat))
-    scan_ms = float(np.median(scan))
+    # ---- p50 loop-match latency on big DBs (node total rows, sharded when N > 1): 100k rows and 100k key frames = 400k rows ----------
+    def p50_leg(total_rows):
+        rows_here = total_rows // world
+        midx = capi.IndexFlatIP(ictx, 4096, capi.STORE_F32, rows_here)
+        gen = RowFactory(11 + rank)
+        for s in range(0, rows_here, 32768):
+            midx.add(gen.rows(min(32768, rows_here - s)))
+        mq = RowFactory(99).rows(1)
+        if world > 1:
+            big = shard.ShardedIndex(midx, rank, world, dist, coll_dev)
+            search = lambda: big.search(mq, K_SEARCH)
+        else:
+            search = lambda: midx.search(mq, K_SEARCH)
+        lat, scan = [], []
+        for i in range(60):
+            if dist is not None:
+                dist.barrier()
+            t = time.perf_counter()
+            search()
+            lat.append((time.perf_counter() - t) * 1e3)
+            scan.append(midx.last_scan_ms())
+        p50 = reduce_max(float(np.median(lat[10:])))
+        scan_ms = float(np.median(scan[10:]))
+        midx.close()
+        return p50, scan_ms, rows_here
+
+    p50, scan_ms, rows_here = p50_leg(args.match_db_rows)
     gbs = rows_here * 4096 * 4 / (scan_ms * 1e-3) / 1e9
     roofline_knn = {"bound": "hbm", "kernel": "ip_scan_kernel<float,1>", "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
@@ -271,15 +421,19 @@ def main():
                     "launch_ms": round(scan_ms, 4), "rows_per_gpu": rows_here}
     loop_match = {"p50_ms": round(p50, 4), "db_rows_node": args.match_db_rows, "db_rows_per_gpu": rows_here, "k": K_SEARCH,
                   "includes": "H2D query, scan, top-k, D2H result" + (", all_gather + merge" if world > 1 else "")}
-    midx.close()
+    if args.match_db_rows != 400_000:
+        p50b, scan_b, rows_b = p50_leg(400_000)
+        loop_match["db_100k_keyframes"] = {"p50_ms": round(p50b, 4), "db_rows_node": 400_000, "db_rows_per_gpu": rows_b, "scan_ms": round(scan_b, 4),
+                                           "scan_gbs": round(rows_b * 16384 / (scan_b * 1e-3) / 1e9, 0)}
 
     # ---- BASELINE config 5 per-GPU shard: 64 concurrent queries against 1 M key frames / 8 GPUs = 125 000 fp16 rows --------------
     batched = None
     if args.batched_rows > 0:
         bidx = capi.IndexFlatIP(ictx, 4096, capi.STORE_F16, args.batched_rows)
-        for s in range(0, args.batched_rows, 8192):
-            bidx.add(random_rows(min(8192, args.batched_rows - s)))
-        bq = random_rows(64)
+        gen = RowFactory(13 + rank)
+        for s in range(0, args.batched_rows, 32768):
+            bidx.add(gen.rows(min(32768, args.batched_rows - s)))
+        bq = RowFactory(98).rows(64)
         blat, bscan = [], []
         for i in range(30):
             t = time.perf_counter()
@@ -295,29 +449,32 @@ def main():
                    "search_p50_ms": round(b_p50, 4), "queries_per_s": round(64 / (b_p50 * 1e-3), 0)}
         bidx.close()
 
-    # ---- CPU baseline: the reference's PyTorch-CPU SuperPoint path + oracle post-processing, same host ---------------
-    cpu = None
+    # ---- CPU baseline: the reference's PyTorch-CPU SuperPoint path + oracle post-processing, same host; and, with the oracle's outputs
+    # of that sample at hand, how far the GPU path at the benchmarked precision is from them (`parity`) -------------------------------
+    cpu = parity = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_keyframes, W, H, THRES, MAXN, comp, mean, sp_w, vl_w)
+        cpu, parity = cpu_baseline(args.cpu_keyframes, W, H, THRES, MAXN, comp, mean, sp_w, vl_w, vl_specs, vl_shape, capi, ictx, prec)
 
     if rank == 0:
         line = {
             "metric": "keyframes/sec (4x fisheye 600x480) + p50 loop-match ms @ 100k-frame DB",
-            "value": round(kfps, 2), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": kfps, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: reference-faithful fisheye key frame = 8 SuperPoint + 4 MobileNetVLAD(assumed arch) "
-                                   "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query; "
+            "repeats": main_leg["repeats"], "ms_per_step_minmax": main_leg["ms_per_step_minmax"],
+            "config": {"workload": "configs[1]: reference-faithful fisheye key frame = upload of 8 images + 8 SuperPoint + 4 MobileNetVLAD(assumed arch) "
+                                   "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query + results to host; "
                                    f"{args.db_keyframes}-keyframe DB ({4 * args.db_keyframes} rows); seeded synthetic weights",
                        "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": args.pipelines,
-                       "keyframes_per_microbatch": MB,
+                       "keyframes_per_microbatch": MB, "host_loop": "c++ (host/keyframe_pipeline.hpp)" if cpp_host else "python",
+                       "image_upload": "inside the timed region (pinned host -> HBM, one async copy per micro-batch)",
                        "parallelism": f"dp{world} keyframes + {world}-way row-sharded index" if world > 1 else "single GPU",
                        "device": info["name"], "n_cu": info["n_cu"]},
-            "loop_candidates_found": hits[0],
+            "loop_candidates_found": hits,
             "gflop_per_keyframe_superpoint": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
             "achieved_tflops_end_to_end": round(kfps * SP_FLOP_PER_IMAGE * KF_IMAGES / 1e12 / world, 1),
             "roofline": roofline, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
-            "cpu_baseline": cpu,
+            "db100k": db100k, "value_f32": value_f32, "python_host": python_host, "parity": parity, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -325,9 +482,10 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(n_kf, W, H, thres, max_num, comp, mean, sp_w, vl_w):
+def cpu_baseline(n_kf, W, H, thres, max_num, comp, mean, sp_w, vl_w, vl_specs, vl_shape, capi, ictx, prec):
     """The reference's CPU path restated (oracle): PyTorch SuperPointNet fp32 on all host cores + C post-processing +
-    MobileNetVLAD(assumed) + BF match + flat IP search, timed on a bounded sample of the same workload."""
+    MobileNetVLAD(assumed) + BF match + flat IP search, timed on a bounded sample of the same workload.  Second result: the GPU path at
+    the benchmarked precision on the same 8 images, compared with what the oracle just computed (the oracle is the checker here)."""
     import torch
     from oracle import match_ref, mobilenetvlad_ref, postproc_ref, superpoint_ref
     from omni_swarm_amd import synth
@@ -336,31 +494,58 @@ def cpu_baseline(n_kf, W, H, thres, max_num, comp, mean, sp_w, vl_w):
     torch.set_num_threads(cores)
     db = synth.global_db(4000, seed=3)
     imgs = np.stack([synth.image_u8(i, H, W) for i in range(8)])
+    last = {}
 
     def keyframe():
         x = superpoint_ref.preprocess_u8(imgs, fisheye_mask=True)
         semi, desc = superpoint_ref.forward(sp_w, x)            # the 8 images of the key frame as one batch
-        feats = []
+        feats, kps = [], []
         for b in range(8):
             xy, conf, _, _ = postproc_ref.get_keypoints(semi[b], thres, max_num)
             d64, _ = postproc_ref.compute_descriptors(desc[b], xy, W, H, comp, mean)
             feats.append(d64)
+            kps.append(xy)
         masked = imgs[:4].copy()
         masked[:, H * 3 // 4:] = 0
         g = mobilenetvlad_ref.forward(vl_w, masked)
         for d in range(4):
             match_ref.bf_match(feats[d], feats[4 + d], 0)
         match_ref.ip_search_numpy(db, g[1], 10)
+        last.update(kps=kps, feats=feats, g=g)
 
     keyframe()                                  # warm-up
     t = time.perf_counter()
     for _ in range(n_kf):
         keyframe()
     dt = (time.perf_counter() - t) / n_kf
-    return {"value": round(1.0 / dt, 4), "unit": "keyframes/s", "cores": cores, "kind": "port",
-            "sample": f"{n_kf} key frames (8 SuperPoint + 4 MobileNetVLAD 600x480, post-processing, 4 BF matches, 1 search over 4000 rows) "
-                      f"after 1 warm-up; torch {torch.__version__} fp32, {cores} threads of {avail} host CPUs",
-            "ms_per_keyframe": round(dt * 1e3, 1)}
+    cpu = {"value": round(1.0 / dt, 4), "unit": "keyframes/s", "cores": cores, "kind": "port",
+           "sample": f"{n_kf} key frames (8 SuperPoint + 4 MobileNetVLAD 600x480, post-processing, 4 BF matches, 1 search over 4000 rows) "
+                     f"after 1 warm-up (bounded sample, not the median-of-20 of SURVEY 8d); torch {torch.__version__} fp32, {cores} threads of {avail} host CPUs",
+           "ms_per_keyframe": round(dt * 1e3, 1)}
+    # GPU path on the same key frame vs the oracle's outputs
+    sp = capi.SuperPoint(ictx, sp_w, comp, mean, W, H, thres, max_num, prec, 8)
+    res = sp.inference(imgs, fisheye_mask=True)
+    sp.close()
+    vl = capi.MobileNetVLAD(ictx, vl_w, vl_specs, *vl_shape, W, H, 4)
+    g = vl.inference(imgs[:4], fisheye_mask=True)
+    vl.close()
+    overlap, derr = [], []
+    for b in range(8):
+        ref = {tuple(p): i for i, p in enumerate(last["kps"][b].tolist())}
+        got = res[b][0].astype(np.int32).tolist()
+        common = [(i, ref[tuple(p)]) for i, p in enumerate(got) if tuple(p) in ref]
+        overlap.append(len(common) / max(1, len(ref)))
+        if common:
+            gi, ri = zip(*common)
+            a, r = res[b][1][list(gi)], last["feats"][b][list(ri)]
+            derr.append(np.linalg.norm(a - r, axis=1) / np.maximum(np.linalg.norm(r, axis=1), 1e-12))
+    derr = np.concatenate(derr) if derr else np.zeros(1)
+    vrel = np.linalg.norm(g - last["g"], axis=1) / np.linalg.norm(last["g"], axis=1)
+    parity = {"vs": "CPU oracle (torch fp32 notebook graph + literal post-processing) on the cpu_baseline key frame, GPU path at the benchmarked precision",
+              "keypoint_overlap_min": round(float(min(overlap)), 4), "keypoint_overlap_mean": round(float(np.mean(overlap)), 4),
+              "desc64_rel_err_p50": float(np.round(np.percentile(derr, 50), 6)), "desc64_rel_err_p99": float(np.round(np.percentile(derr, 99), 6)),
+              "vlad_rel_err_max": float(np.round(vrel.max(), 7))}
+    return cpu, parity
 
 
 if __name__ == "__main__":

@@ -76,6 +76,8 @@ int       omni_ctx_device_info(omni_ctx* ctx, char* name, int name_len, int* n_c
 
 void* omni_dev_alloc(omni_ctx* ctx, size_t bytes);        /* HBM; NULL on failure */
 int   omni_dev_free(omni_ctx* ctx, void* p);
+void* omni_host_alloc(size_t bytes);                      /* pinned host memory (cudaMallocHost, tensorrt_generic.cpp:116-117); NULL on failure */
+int   omni_host_free(void* p);
 int   omni_memcpy_h2d(omni_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);  /* blocking */
 int   omni_memcpy_d2h(omni_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);  /* blocking */
 int   omni_timer_start(omni_ctx* ctx);                    /* hipEventRecord on the ctx stream */
@@ -169,6 +171,8 @@ int         omni_index_add(omni_index* idx, int64_t n, const float* x_host);    
 int         omni_index_add_dev(omni_index* idx, int64_t n, const float* x_dev);
 int64_t     omni_index_ntotal(const omni_index* idx);                              /* .ntotal */
 int         omni_index_reset(omni_index* idx);
+/* drop the rows appended last so that ntotal == n_rows again (undo of appends enqueued ahead by a batched caller that failed) */
+int         omni_index_truncate(omni_index* idx, int64_t n_rows);
 /* IndexFlatIP::search(nq, q, k, D, I): exact inner product, k best descending, ties -> lower row id,
  * missing results padded with I = -1, D = -FLT_MAX.  k <= 1024 (the reference caps at 1000, loop_detector.cpp:200). */
 int         omni_index_search(omni_index* idx, int nq, const float* q_host, int k, float* D, int64_t* I);
@@ -179,6 +183,14 @@ int         omni_index_search_dev(omni_index* idx, int nq, const float* q_dev, i
  * ntotal it would have seen.  An empty prefix (n_limit == 0) fills the outputs with I = -1, D = -FLT_MAX. */
 int         omni_index_search_prefix_dev(omni_index* idx, int nq, const float* q_dev, int k, int64_t n_limit, float* D_dev,
                                          int64_t* I_dev);
+/* Several prefix searches in ONE pass over the shard (a micro-batch of key frames: every frame's query must see exactly the rows that
+ * were in the index at its turn, loop_detector.cpp:89-98, but the rows are read from HBM once for all of them).  Query q is row
+ * row_idx[q] of rows_dev (row_idx == NULL: rows 0..nq-1) and sees local rows [0, n_limits[q]) only; row_idx / n_limits are HOST arrays
+ * read before the call returns.  nq <= 64.  Results as nq independent omni_index_search_prefix_dev calls would give them.
+ * Ordering: rows_dev must be complete with respect to the index context's stream (e.g. the producer was waited for, or it ran on that
+ * stream); the same holds for omni_index_add_dev / omni_index_search*_dev. */
+int         omni_index_search_batch_prefix_dev(omni_index* idx, int nq, const float* rows_dev, const int64_t* row_idx, int k,
+                                               const int64_t* n_limits, float* D_dev, int64_t* I_dev);
 /* row sharding across GPUs: this handle holds rows g with g % world == rank at local slot g / world;
  * search then reports GLOBAL ids (local * world + rank).  Default rank 0, world 1. */
 int         omni_index_set_shard(omni_index* idx, int rank, int world);
@@ -227,6 +239,11 @@ omni_cam* omni_cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omn
                           int global_dim, int bf_mode);
 void      omni_cam_destroy(omni_cam* cam);
 int       omni_cam_enqueue_dev(omni_cam* cam, const uint8_t* gray_dev, int stride, int fisheye_mask);   /* no host sync */
+/* same with the images in HOST memory, image i at gray_host + i*stride*height (the reference hands every engine call a host cv::Mat
+ * and copies it up synchronously, tensorrt_generic.cpp:58-75): ONE asynchronous upload of the 2*n_dirs images into a staging buffer
+ * owned by the handle, then the work of omni_cam_enqueue_dev.  gray_host should be pinned (omni_host_alloc) and must stay untouched
+ * until omni_cam_wait returns. */
+int       omni_cam_enqueue_host(omni_cam* cam, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask);
 int       omni_cam_wait(omni_cam* cam, omni_cam_result* out);                                          /* two event waits */
 
 #ifdef __cplusplus

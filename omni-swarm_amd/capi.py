@@ -26,15 +26,15 @@ VLAD_KINDS = {"conv3x3": 0, "pw_relu6": 1, "dw3x3_relu6": 2, "pw_linear": 3, "pw
 # every symbol include/omni_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "omni_abi_version", "omni_last_error", "omni_ctx_create", "omni_ctx_destroy", "omni_ctx_sync", "omni_ctx_stream",
-    "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
+    "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
     "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy",
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
-    "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset",
-    "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
+    "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset", "omni_index_truncate",
+    "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
-    "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_wait",
+    "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
     sig("omni_ctx_device_info", C.c_int, [_vp, C.c_char_p, C.c_int, _ip, _ip, C.POINTER(C.c_size_t)])
     sig("omni_dev_alloc", _vp, [_vp, C.c_size_t])
     sig("omni_dev_free", C.c_int, [_vp, _vp])
+    sig("omni_host_alloc", _vp, [C.c_size_t])
+    sig("omni_host_free", C.c_int, [_vp])
     sig("omni_memcpy_h2d", C.c_int, [_vp, _vp, _vp, C.c_size_t])
     sig("omni_memcpy_d2h", C.c_int, [_vp, _vp, _vp, C.c_size_t])
     sig("omni_timer_start", C.c_int, [_vp])
@@ -125,9 +127,11 @@ def lib():
     sig("omni_index_add_dev", C.c_int, [_vp, C.c_int64, _vp])
     sig("omni_index_ntotal", C.c_int64, [_vp])
     sig("omni_index_reset", C.c_int, [_vp])
+    sig("omni_index_truncate", C.c_int, [_vp, C.c_int64])
     sig("omni_index_search", C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp, _i64p])
     sig("omni_index_search_dev", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp])
     sig("omni_index_search_prefix_dev", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp])
+    sig("omni_index_search_batch_prefix_dev", C.c_int, [_vp, C.c_int, _vp, _i64p, C.c_int, _i64p, _vp, _vp])
     sig("omni_index_set_shard", C.c_int, [_vp, C.c_int, C.c_int])
     sig("omni_topk_merge", C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _i64p, C.c_int, _fp, _i64p])
     sig("omni_index_last_scan_ms", C.c_int, [_vp, _fp])
@@ -139,6 +143,7 @@ def lib():
     sig("omni_cam_create", _vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
     sig("omni_cam_destroy", None, [_vp])
     sig("omni_cam_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int])
+    sig("omni_cam_enqueue_host", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
     sig("omni_cam_wait", C.c_int, [_vp, C.POINTER(_CamResult)])
     if L.omni_abi_version() != 1:
         raise OmniError("libomni_hip.so ABI version mismatch")
@@ -207,6 +212,24 @@ class Context:
         out = np.empty(shape, dtype)
         _check(lib().omni_memcpy_d2h(self.h, out.ctypes.data_as(_vp), p, out.nbytes))
         return out
+
+    def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
+        """Pinned host array (hipHostMalloc): the source of asynchronous uploads (omni_cam_enqueue_host).  The array keeps no
+        reference to this context; free with host_free()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = lib().omni_host_alloc(n)
+        if not p:
+            raise OmniError(f"omni_host_alloc({n}) failed: {lib().omni_last_error().decode()}")
+        buf = (C.c_uint8 * n).from_address(p)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            _check(lib().omni_host_free(p))
 
     def timer_start(self):
         _check(lib().omni_timer_start(self.h))
@@ -405,6 +428,9 @@ class IndexFlatIP:
     def reset(self):
         _check(lib().omni_index_reset(self.h))
 
+    def truncate(self, n_rows: int):
+        _check(lib().omni_index_truncate(self.h, n_rows))
+
     def save(self, path: str):
         """Shard checkpoint (OMNX1): header + the raw row matrix as stored."""
         _check(lib().omni_index_save(self.h, path.encode()))
@@ -428,6 +454,14 @@ class IndexFlatIP:
     def search_prefix_dev(self, nq: int, q_dev: int, k: int, n_limit: int, D_dev: int, I_dev: int):
         """search_dev over the first n_limit rows only (asynchronous; see include/omni_hip.h)."""
         _check(lib().omni_index_search_prefix_dev(self.h, nq, q_dev, k, n_limit, D_dev, I_dev))
+
+    def search_batch_prefix_dev(self, rows_dev: int, row_idx, k: int, limits, D_dev: int, I_dev: int):
+        """len(limits) <= 64 prefix searches in ONE pass over the shard: query j = row row_idx[j] of rows_dev (None: rows 0..), it sees
+        local rows [0, limits[j]).  Asynchronous (see include/omni_hip.h)."""
+        lim = np.ascontiguousarray(limits, np.int64)
+        ri = None if row_idx is None else np.ascontiguousarray(row_idx, np.int64)
+        _check(lib().omni_index_search_batch_prefix_dev(self.h, len(lim), rows_dev, None if ri is None else ri.ctypes.data_as(_i64p), k,
+                                                        lim.ctypes.data_as(_i64p), D_dev, I_dev))
 
     def search_prefix_many(self, q: np.ndarray, k: int, limits) -> tuple:
         """q [F][nq][d], limits [F]: F searches, search f over this shard's first limits[f] rows only; all enqueued back to back,
@@ -513,6 +547,12 @@ class Cam:
 
     def enqueue_dev(self, gray_dev: int, stride: int, fisheye_mask: bool = True):
         _check(lib().omni_cam_enqueue_dev(self.h, gray_dev, stride, int(fisheye_mask)))
+
+    def enqueue_host(self, gray_host: np.ndarray, fisheye_mask: bool = True):
+        """gray_host [2*n_dirs][H][W] u8, ideally pinned (Context.host_alloc); must stay untouched until wait() returns."""
+        assert gray_host.dtype == np.uint8 and gray_host.ndim == 3 and gray_host.shape[0] == 2 * self.n and gray_host.flags.c_contiguous
+        _check(lib().omni_cam_enqueue_host(self.h, gray_host.ctypes.data_as(_vp), gray_host.shape[2], gray_host.shape[2], gray_host.shape[1],
+                                           int(fisheye_mask)))
 
     def wait(self) -> dict:
         r = self._res

@@ -21,7 +21,9 @@ struct omni_cam {
     const int* n_dev = nullptr;
     char* host = nullptr;
     size_t off_kps = 0, off_n = 0, off_desc = 0, off_sc = 0, off_g = 0, off_q = 0, off_t = 0, off_d = 0, off_nm = 0, host_bytes = 0;
-    hipEvent_t e1 = nullptr, e2 = nullptr;
+    hipEvent_t e1 = nullptr, e2 = nullptr, e_up = nullptr;
+    uint8_t* d_gray = nullptr;        // staging for omni_cam_enqueue_host: the key frame's images, rows packed to `width`
+    size_t d_gray_bytes = 0;
     bool pending = false;
     std::mutex mu;
 };
@@ -55,6 +57,7 @@ omni_cam* omni_cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omn
               hipMalloc((void**)&c->d_dist, n * M * 4) == hipSuccess && hipMalloc((void**)&c->d_nm, n * 4) == hipSuccess &&
               hipEventCreateWithFlags(&c->e1, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->e2, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->e_up, hipEventDisableTiming) == hipSuccess &&
               omni_sp_dev_outputs(sp, &c->kps_dev, &c->n_dev, &c->desc_dev, &c->sc_dev) == OMNI_OK &&
               omni_vlad_dev_output(vlad, &c->g_dev) == OMNI_OK;
     if (!ok) { omni::set_error("omni_cam_create: allocation failed"); omni_cam_destroy(c); return nullptr; }
@@ -67,18 +70,49 @@ void omni_cam_destroy(omni_cam* c) {
     (void)hipSetDevice(c->c1->device);
     (void)hipStreamSynchronize(c->c1->stream);
     (void)hipStreamSynchronize(c->c2->stream);
-    void* ptrs[] = {c->d_qidx, c->d_tidx, c->d_dist, c->d_nm};
+    void* ptrs[] = {c->d_qidx, c->d_tidx, c->d_dist, c->d_nm, c->d_gray};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->host) (void)hipHostFree(c->host);
     if (c->e1) (void)hipEventDestroy(c->e1);
     if (c->e2) (void)hipEventDestroy(c->e2);
+    if (c->e_up) (void)hipEventDestroy(c->e_up);
     delete c;
 }
+
+static int cam_enqueue_locked(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask);
 
 int omni_cam_enqueue_dev(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask) {
     OMNI_REQUIRE(c && gray_dev, OMNI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->c1->device);
+    return cam_enqueue_locked(c, gray_dev, stride, fisheye_mask);
+}
+
+int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask) {
+    OMNI_REQUIRE(c && gray_host, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(width > 0 && height > 0 && stride >= width, OMNI_ERR_INVALID, "bad image geometry %dx%d stride %d", width, height, stride);
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->c1->device);
+    const size_t need = (size_t)2 * c->n * width * height;
+    if (c->d_gray_bytes < need) {
+        (void)hipStreamSynchronize(c->c1->stream);
+        (void)hipStreamSynchronize(c->c2->stream);
+        if (c->d_gray) (void)hipFree(c->d_gray);
+        c->d_gray = nullptr; c->d_gray_bytes = 0;
+        OMNI_HIP_TRY(hipMalloc((void**)&c->d_gray, need));
+        c->d_gray_bytes = need;
+    }
+    // the reference uploads one image per engine call and blocks (tensorrt_generic.cpp:58-75); here the key frame's 2n images go up as one
+    // asynchronous copy on the SuperPoint stream (pinned source: the copy engine runs it next to the other pipelines' kernels) and the
+    // MobileNetVLAD stream waits for it on the device
+    OMNI_HIP_TRY(hipMemcpy2DAsync(c->d_gray, (size_t)width, gray_host, (size_t)stride, (size_t)width, (size_t)2 * c->n * height,
+                                  hipMemcpyHostToDevice, c->c1->stream));
+    OMNI_HIP_TRY(hipEventRecord(c->e_up, c->c1->stream));
+    OMNI_HIP_TRY(hipStreamWaitEvent(c->c2->stream, c->e_up, 0));
+    return cam_enqueue_locked(c, c->d_gray, width, fisheye_mask);
+}
+
+static int cam_enqueue_locked(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask) {
     const int n = c->n, M = c->M, D = c->D;
     int rc;
     // images 0..n-1 = "up" (main) camera of each direction, n..2n-1 = "down" camera (loop_cam.cpp:350-351)

@@ -82,6 +82,18 @@ int omni_dev_free(omni_ctx* c, void* p) {
     return OMNI_OK;
 }
 
+void* omni_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { omni::set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+int omni_host_free(void* p) {
+    if (p) OMNI_HIP_TRY(hipHostFree(p));
+    return OMNI_OK;
+}
+
 int omni_memcpy_h2d(omni_ctx* c, void* dst, const void* src, size_t bytes) {
     OMNI_REQUIRE(c && dst && src, OMNI_ERR_INVALID, "null argument");
     OMNI_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));

@@ -14,6 +14,8 @@
 // that writes one 64-bit sortable key per (query,row), then the exact hierarchical top-k of topk.h.
 #include "common.h"
 #include "topk.h"
+#include <sys/stat.h>
+#include <climits>
 
 struct omni_index {
     omni_ctx* ctx = nullptr;
@@ -41,6 +43,9 @@ namespace omni {
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / 64)
 #define SCAN_MAX_QB 8
+// per-query row limits of a batched prefix search (omni_index_search_batch_prefix_dev): query q only sees rows [0, v[q]); rows beyond
+// get the empty key.  Passed by value (kernel argument segment) so that back-to-back enqueues need no staging buffer.
+template <int N> struct ScanLimits { int64_t v[N]; };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -53,7 +58,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <typename T, int QB>
 __global__ void __launch_bounds__(SCAN_THREADS)
 ip_scan_kernel(const T* __restrict__ db, int64_t n_rows, int dim, const float* __restrict__ queries,
-               uint64_t* __restrict__ keys, int64_t key_stride) {
+               uint64_t* __restrict__ keys, int64_t key_stride, ScanLimits<SCAN_MAX_QB> lim) {
     static_assert(sizeof(T) == 4, "fp16 shards use the T16 layout (ip_scan_t16_kernel / ip_scan_mq_kernel)");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sq = reinterpret_cast<float*>(smem_raw);             // [QB][dim]
@@ -87,7 +92,7 @@ ip_scan_kernel(const T* __restrict__ db, int64_t n_rows, int dim, const float* _
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             float s = wave_sum(acc[q]);
-            if (lane == 0) keys[(int64_t)q * key_stride + row] = omni_make_key(s, (uint32_t)row);
+            if (lane == 0) keys[(int64_t)q * key_stride + row] = row < lim.v[q] ? omni_make_key(s, (uint32_t)row) : OMNI_KEY_EMPTY;
         }
     }
 }
@@ -213,7 +218,8 @@ __device__ __forceinline__ void mq_step(uint32_t bx, const uint64_t (&cur)[MQ_RT
 
 __global__ void __launch_bounds__(MQ_THREADS, 1)
 ip_scan_mq_kernel(const _Float16* __restrict__ db, int64_t n_rows, int dim, const char* __restrict__ qp,
-                  const float* __restrict__ inv_scale, int nq, uint64_t* __restrict__ keys, int64_t key_stride, int rotate) {
+                  const float* __restrict__ inv_scale, int nq, uint64_t* __restrict__ keys, int64_t key_stride, int rotate,
+                  ScanLimits<MQ_NQ> lim) {
     extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -316,12 +322,13 @@ ip_scan_mq_kernel(const _Float16* __restrict__ db, int64_t n_rows, int dim, cons
                 for (int e = 0; e < 4; ++e) {
                     const int qq = 16 * t + 4 * c4 + e;
                     const float inv = inv_scale[qq];
+                    const int64_t lim_q = lim.v[qq];
                     uint64_t* kq = keys + (int64_t)qq * key_stride;
 #pragma unroll
                     for (int i = 0; i < MQ_RT; ++i) {
                         const int64_t row = (blk_of(p) * BT + i * MQ_WAVES + wave) * 16 + r16;
                         if (qq < nq && row < n_rows)
-                            kq[row] = omni_make_key(acc[i][t][e] * inv, (uint32_t)row);
+                            kq[row] = row < lim_q ? omni_make_key(acc[i][t][e] * inv, (uint32_t)row) : OMNI_KEY_EMPTY;
                     }
                     __builtin_amdgcn_sched_barrier(0);          // one (t, e) at a time: the ring and the accumulators leave few free registers
                 }
@@ -350,6 +357,14 @@ __global__ void decode_topk_kernel(const uint64_t* __restrict__ keys, int nq, in
     uint32_t local = 0xFFFFFFFFu - inv;
     D[i] = omni_orderable_f32((uint32_t)(key >> 32));
     I[i] = (int64_t)local * world + rank;
+}
+
+// queries of a batched search picked out of a row buffer (e.g. MobileNetVLAD's output): dst[i] = src[idx.v[i]]
+struct GatherIdx { int64_t v[MQ_NQ]; };
+__global__ void gather_rows_kernel(const float* __restrict__ src, GatherIdx idx, int dim, float* __restrict__ dst) {
+    const float4* s = reinterpret_cast<const float4*>(src + idx.v[blockIdx.x] * dim);
+    float4* d = reinterpret_cast<float4*>(dst + (int64_t)blockIdx.x * dim);
+    for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) d[i] = s[i];
 }
 
 // half index of (row, 16-byte chunk) in the T16 layout
@@ -386,7 +401,7 @@ __global__ void t16_rows_kernel(__half* __restrict__ db, __half* __restrict__ ro
 template <int QB>
 __global__ void __launch_bounds__(SCAN_THREADS)
 ip_scan_t16_kernel(const __half* __restrict__ db, int64_t n_rows, int dim, const float* __restrict__ queries,
-                   uint64_t* __restrict__ keys, int64_t key_stride) {
+                   uint64_t* __restrict__ keys, int64_t key_stride, ScanLimits<SCAN_MAX_QB> lim) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sq = reinterpret_cast<float*>(smem_raw);             // [QB][dim]
     for (int i = threadIdx.x * 4; i < QB * dim; i += SCAN_THREADS * 4)
@@ -427,12 +442,15 @@ ip_scan_t16_kernel(const __half* __restrict__ db, int64_t n_rows, int dim, const
             float sum = acc[q];
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            if (c4 == 0 && row < n_rows) keys[(int64_t)q * key_stride + row] = omni_make_key(sum, (uint32_t)row);
+            if (c4 == 0 && row < n_rows) keys[(int64_t)q * key_stride + row] = row < lim.v[q] ? omni_make_key(sum, (uint32_t)row) : OMNI_KEY_EMPTY;
         }
     }
 }
 
-static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, const float* q_dev, uint64_t* keys, int64_t key_stride) {
+static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, const float* q_dev, uint64_t* keys, int64_t key_stride,
+                       const int64_t* limits) {
+    ScanLimits<SCAN_MAX_QB> lim;
+    for (int q = 0; q < SCAN_MAX_QB; ++q) lim.v[q] = limits && q < qb ? limits[q] : INT64_MAX;
     const bool f16 = ix->storage == OMNI_STORE_F16;
     int cus = ix->ctx->prop.multiProcessorCount > 0 ? ix->ctx->prop.multiProcessorCount : 256;
     int64_t want = cdiv64(f16 ? cdiv64(n, 16) : n, SCAN_WAVES);      // a wave walks rows (fp32) or 16-row blocks (fp16)
@@ -443,10 +461,10 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, 
     case QB:                                                                                                            \
         if (f16)                                                                                                        \
             hipLaunchKernelGGL((ip_scan_t16_kernel<QB>), dim3(grid), dim3(SCAN_THREADS), smem, st,                      \
-                               reinterpret_cast<const __half*>(ix->db), n, ix->dim, q_dev, keys, key_stride);           \
+                               reinterpret_cast<const __half*>(ix->db), n, ix->dim, q_dev, keys, key_stride, lim);      \
         else                                                                                                            \
             hipLaunchKernelGGL((ip_scan_kernel<float, QB>), dim3(grid), dim3(SCAN_THREADS), smem, st,                   \
-                               reinterpret_cast<const float*>(ix->db), n, ix->dim, q_dev, keys, key_stride);            \
+                               reinterpret_cast<const float*>(ix->db), n, ix->dim, q_dev, keys, key_stride, lim);       \
         break;
     switch (qb) {
         OMNI_SCAN_CASE(1) OMNI_SCAN_CASE(2) OMNI_SCAN_CASE(3) OMNI_SCAN_CASE(4)
@@ -459,7 +477,10 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, 
 }
 
 // up to MQ_NQ queries in one pass over an fp16 shard (ip_scan_mq_kernel)
-static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, const float* q_dev, uint64_t* keys, int64_t key_stride) {
+static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, const float* q_dev, uint64_t* keys, int64_t key_stride,
+                          const int64_t* limits) {
+    ScanLimits<MQ_NQ> lim;
+    for (int q = 0; q < MQ_NQ; ++q) lim.v[q] = limits && q < nq ? limits[q] : INT64_MAX;
     auto kfn = ip_scan_mq_kernel;
     static bool attr_set = false;
     if (!attr_set) {
@@ -479,7 +500,7 @@ static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, con
     const int64_t grid = blocks < cus ? blocks : cus;
     static const int rotate = getenv("OMNI_MQ_ROT") ? atoi(getenv("OMNI_MQ_ROT")) : 1;
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(MQ_THREADS), MQ_SMEM, st, reinterpret_cast<const _Float16*>(ix->db),
-                       n, ix->dim, ix->mq_q.as<char>(), ix->mq_inv.as<float>(), nq, keys, key_stride, rotate);
+                       n, ix->dim, ix->mq_q.as<char>(), ix->mq_inv.as<float>(), nq, keys, key_stride, rotate, lim);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
@@ -510,6 +531,7 @@ static int ensure_capacity(omni_index* ix, int64_t rows) {
 
 // x_dev: n x dim fp32 in HBM -> appended (converted when storage is fp16)
 static int append_dev(omni_index* ix, int64_t n, const float* x_dev) {
+    OMNI_REQUIRE(ix->ntotal + n < 0xFFFFFFFFll, OMNI_ERR_CAPACITY, "index full: row ids are packed into 32 bits (omni_make_key)");
     int rc = ensure_capacity(ix, ix->ntotal + n);
     if (rc) return rc;
     hipStream_t st = ix->ctx->stream;
@@ -526,7 +548,9 @@ static int append_dev(omni_index* ix, int64_t n, const float* x_dev) {
     return OMNI_OK;
 }
 
-static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev, int64_t n_limit = -1) {
+// limits (host, [nq], optional): query q only sees rows [0, limits[q]) -- the scan covers [0, n) once for all of them
+static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev, int64_t n_limit = -1,
+                      const int64_t* limits = nullptr) {
     hipStream_t st = ix->ctx->stream;
     const int64_t n = n_limit >= 0 && n_limit < ix->ntotal ? n_limit : ix->ntotal;      // rows [0, n) take part
     const int64_t chunks = cdiv64(n > 0 ? n : 1, TOPK_CHUNK);
@@ -541,13 +565,13 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
         const bool mq = ix->storage == OMNI_STORE_F16 && nq >= mq_min_queries();
         for (int q0 = 0; mq && q0 < nq; q0 += MQ_NQ) {
             const int qb = nq - q0 < MQ_NQ ? nq - q0 : MQ_NQ;
-            if ((rc = launch_scan_mq(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n))) return rc;
+            if ((rc = launch_scan_mq(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n, limits ? limits + q0 : nullptr))) return rc;
         }
         int max_qb = (int)(131072 / ((size_t)ix->dim * 4));       // the query block lives in LDS: <= 128 KB of it
         max_qb = max_qb > SCAN_MAX_QB ? SCAN_MAX_QB : (max_qb < 1 ? 1 : max_qb);
         for (int q0 = 0; !mq && q0 < nq; q0 += max_qb) {
             int qb = nq - q0 < max_qb ? nq - q0 : max_qb;
-            rc = launch_scan(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n);
+            rc = launch_scan(st, ix, n, qb, q_dev + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n, limits ? limits + q0 : nullptr);
             if (rc) return rc;
         }
         OMNI_HIP_TRY(hipEventRecord(ix->scan1, st));
@@ -603,6 +627,14 @@ int omni_index_reset(omni_index* ix) {
     return OMNI_OK;
 }
 
+int omni_index_truncate(omni_index* ix, int64_t n_rows) {
+    OMNI_REQUIRE(ix && n_rows >= 0, OMNI_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    OMNI_REQUIRE(n_rows <= ix->ntotal, OMNI_ERR_INVALID, "cannot truncate %lld rows to %lld", (long long)ix->ntotal, (long long)n_rows);
+    ix->ntotal = n_rows;            // stream order keeps earlier enqueued searches on their own prefix; later appends overwrite the tail
+    return OMNI_OK;
+}
+
 int omni_index_set_shard(omni_index* ix, int rank, int world) {
     OMNI_REQUIRE(ix && world >= 1 && rank >= 0 && rank < world, OMNI_ERR_INVALID, "bad shard %d/%d", rank, world);
     std::lock_guard<std::mutex> lk(ix->mu);
@@ -630,6 +662,7 @@ int omni_index_add(omni_index* ix, int64_t n, const float* x_host) {
         int64_t m = n - s < slab ? n - s : slab;
         size_t bytes = (size_t)m * ix->dim * 4;
         if (ix->storage == OMNI_STORE_F32) {
+            OMNI_REQUIRE(ix->ntotal + m < 0xFFFFFFFFll, OMNI_ERR_CAPACITY, "index full: row ids are packed into 32 bits (omni_make_key)");
             if ((rc = omni::ensure_capacity(ix, ix->ntotal + m))) return rc;
             OMNI_HIP_TRY(hipMemcpyAsync((float*)ix->db + ix->ntotal * ix->dim, x_host + s * ix->dim, bytes,
                                         hipMemcpyHostToDevice, ix->ctx->stream));
@@ -661,6 +694,32 @@ int omni_index_search_prefix_dev(omni_index* ix, int nq, const float* q_dev, int
     std::lock_guard<std::mutex> lk(ix->mu);
     (void)hipSetDevice(ix->ctx->device);
     return omni::search_dev(ix, nq, q_dev, k, D_dev, I_dev, n_limit);
+}
+
+int omni_index_search_batch_prefix_dev(omni_index* ix, int nq, const float* rows_dev, const int64_t* row_idx, int k,
+                                       const int64_t* n_limits, float* D_dev, int64_t* I_dev) {
+    OMNI_REQUIRE(ix && rows_dev && n_limits && D_dev && I_dev, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(nq >= 1 && nq <= MQ_NQ, OMNI_ERR_CAPACITY, "nq=%d outside [1,%d]", nq, MQ_NQ);
+    OMNI_REQUIRE(k >= 1 && k <= TOPK_MAX_K, OMNI_ERR_CAPACITY, "k=%d outside [1,%d]", k, TOPK_MAX_K);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    (void)hipSetDevice(ix->ctx->device);
+    int64_t lim[MQ_NQ], nmax = 0;
+    for (int q = 0; q < nq; ++q) {
+        OMNI_REQUIRE(n_limits[q] >= 0, OMNI_ERR_INVALID, "n_limits[%d]=%lld < 0", q, (long long)n_limits[q]);
+        lim[q] = n_limits[q] < ix->ntotal ? n_limits[q] : ix->ntotal;
+        nmax = lim[q] > nmax ? lim[q] : nmax;
+    }
+    const float* q_dev = rows_dev;
+    if (row_idx) {
+        omni::GatherIdx gi;
+        for (int q = 0; q < MQ_NQ; ++q) gi.v[q] = q < nq ? row_idx[q] : 0;
+        int rc = ix->qbuf.ensure((size_t)MQ_NQ * ix->dim * 4);
+        if (rc) return rc;
+        hipLaunchKernelGGL(omni::gather_rows_kernel, dim3(nq), dim3(256), 0, ix->ctx->stream, rows_dev, gi, ix->dim, ix->qbuf.as<float>());
+        OMNI_LAUNCH_CHECK();
+        q_dev = ix->qbuf.as<float>();
+    }
+    return omni::search_dev(ix, nq, q_dev, k, D_dev, I_dev, nmax, lim);
 }
 
 int omni_index_search(omni_index* ix, int nq, const float* q_host, int k, float* D, int64_t* I) {
@@ -734,29 +793,46 @@ int omni_index_load(omni_index* ix, const char* path) {
     OMNI_REQUIRE(f, OMNI_ERR_INVALID, "cannot open %s", path);
     OmnxHeader h{};
     int rc = OMNI_OK;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "OMNX1\0\0", 8) != 0) { omni::set_error("%s is not an OMNX1 snapshot", path); rc = OMNI_ERR_INVALID; }
-    else if (h.dim != ix->dim || h.storage != ix->storage || h.ntotal < 0) {
-        omni::set_error("snapshot %s is dim=%d storage=%d, the handle is dim=%d storage=%d", path, h.dim, h.storage, ix->dim, ix->storage);
-        rc = OMNI_ERR_INVALID;
-    }
     const size_t row = (size_t)ix->dim * ix->elem(), slab_rows = 4096;
-    if (!rc) rc = omni::ensure_capacity(ix, h.ntotal > 0 ? h.ntotal : 1);
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "OMNX1\0\0", 8) != 0) { omni::set_error("%s is not an OMNX1 snapshot", path); rc = OMNI_ERR_INVALID; }
+    else if (h.dim != ix->dim || h.storage != ix->storage || h.ntotal < 0 || h.ntotal >= 0xFFFFFFFFll) {
+        omni::set_error("snapshot %s is dim=%d storage=%d ntotal=%lld, the handle is dim=%d storage=%d", path, h.dim, h.storage, (long long)h.ntotal,
+                        ix->dim, ix->storage);
+        rc = OMNI_ERR_INVALID;
+    } else {
+        // the header is untrusted: the file must hold exactly ntotal rows before anything is allocated or overwritten
+        struct stat sb;
+        if (fstat(fileno(f), &sb) != 0 || (uint64_t)sb.st_size != sizeof(h) + (uint64_t)h.ntotal * row) {
+            omni::set_error("%s is truncated or corrupt: header says %lld rows, file size does not match", path, (long long)h.ntotal);
+            rc = OMNI_ERR_INVALID;
+        }
+    }
+    // load into a FRESH buffer and swap on success: a failed load leaves the handle as it was
+    void* nd = nullptr;
+    int64_t cap = 0;
+    if (!rc) {
+        cap = ((h.ntotal > 0 ? h.ntotal : 1) + 15) & ~(int64_t)15;
+        if (hipMalloc(&nd, (size_t)cap * row) != hipSuccess) { omni::set_error("hipMalloc(%zu) failed while loading", (size_t)cap * row); nd = nullptr; rc = OMNI_ERR_NOMEM; }
+    }
     if (!rc) rc = ix->hout.ensure(slab_rows * row);
     const bool f16 = ix->storage == OMNI_STORE_F16;
     if (!rc && f16) rc = ix->stage.ensure(slab_rows * row);
     for (int64_t s = 0; !rc && s < h.ntotal; s += slab_rows) {
         const size_t m = (size_t)(h.ntotal - s < (int64_t)slab_rows ? h.ntotal - s : slab_rows);
         if (fread(ix->hout.p, row, m, f) != m) { omni::set_error("%s is truncated", path); rc = OMNI_ERR_INVALID; break; }
-        bool okc = hipMemcpyAsync(f16 ? (char*)ix->stage.p : (char*)ix->db + (size_t)s * row, ix->hout.p, m * row, hipMemcpyHostToDevice,
+        bool okc = hipMemcpyAsync(f16 ? (char*)ix->stage.p : (char*)nd + (size_t)s * row, ix->hout.p, m * row, hipMemcpyHostToDevice,
                                   ix->ctx->stream) == hipSuccess;
         if (okc && f16)
             hipLaunchKernelGGL((omni::t16_rows_kernel<false>), dim3((unsigned)omni::cdiv64((int64_t)m * (ix->dim / 8), 256)), dim3(256), 0,
-                               ix->ctx->stream, (__half*)ix->db, ix->stage.as<__half>(), s, (int64_t)m, ix->dim);
+                               ix->ctx->stream, (__half*)nd, ix->stage.as<__half>(), s, (int64_t)m, ix->dim);
         if (!okc || hipStreamSynchronize(ix->ctx->stream) != hipSuccess) { omni::set_error("device write failed while loading"); rc = OMNI_ERR_HIP; }
     }
     fclose(f);
-    if (!rc) ix->ntotal = h.ntotal;
-    return rc;
+    if (rc) { if (nd) (void)hipFree(nd); return rc; }
+    (void)hipStreamSynchronize(ix->ctx->stream);
+    if (ix->db) (void)hipFree(ix->db);
+    ix->db = nd; ix->capacity = cap; ix->ntotal = h.ntotal;
+    return OMNI_OK;
 }
 
 int omni_index_last_scan_ms(omni_index* ix, float* ms) {

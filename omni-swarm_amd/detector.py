@@ -139,7 +139,7 @@ class LoopDetector:
 
     def query_fisheyeframe_from_database(self, frame, init_mode: bool, nonkeyframe: bool):
         direction_new = 1 if self.camera_configuration == STEREO_FISHEYE else 0
-        if frame.images[direction_new].landmark_num > 0:
+        if len(frame.images) > direction_new and frame.images[direction_new].landmark_num > 0:
             distance = [-1.0]
             _id = self.query_from_database(frame.images[direction_new], init_mode, nonkeyframe, distance)
             if _id != -1 and distance[0] > -1:
@@ -198,9 +198,11 @@ class LoopDetector:
         rows its frame would have seen (omni_index_search_prefix_dev) -- fetched with one copy, and the decision rules are then replayed
         frame by frame through the unchanged _on_image_recv.  Records are identical to calling on_image_recv per frame.
         rows_dev: optional device pointer to the frames' global descriptors, [sum of len(f.images)][4096] fp32 in frame order (e.g.
-        MobileNetVLAD's output buffer, still in HBM): rows are then appended and queried without touching the host copies."""
+        MobileNetVLAD's output buffer, still in HBM): rows are then appended and queried without touching the host copies.  ORDERING: the
+        index works on its own context's stream -- rows_dev must be complete before this call (LoopCam.fetch() has waited for the
+        MobileNetVLAD stream), there is no cross-stream wait inside."""
         with self._mu:
-            if not all(hasattr(ix, "search_prefix_dev") and hasattr(ix, "add_dev") for ix in (self.local_index, self.remote_index)):
+            if not all(hasattr(ix, "search_batch_prefix_dev") and hasattr(ix, "add_dev") for ix in (self.local_index, self.remote_index)):
                 return [self._on_image_recv(f) for f in frames]        # e.g. a sharded index factory: frame by frame
             return self._recv_batch(frames, rows_dev)
 
@@ -230,8 +232,8 @@ class LoopDetector:
             # `database_size() > MATCH_INDEX_DIST || init_mode || drone_id != self_id`: init_mode implies a remote drone
             if sim_local + sim_remote > self.MATCH_INDEX_DIST or f.drone_id != self.self_id:
                 d = 1 if self.camera_configuration == STEREO_FISHEYE else 0
-                img = f.images[d]
-                if img.landmark_num > 0:
+                img = f.images[d] if len(f.images) > d else None
+                if img is not None and img.landmark_num > 0:
                     if img.drone_id == self.self_id:
                         searches.append((self.remote_index, first + d, 1, sim_remote))
                         if not f.prevent_adding_db:
@@ -239,52 +241,102 @@ class LoopDetector:
                     else:
                         searches.append((self.local_index, first + d, 1, sim_local))
         # ---- enqueue: rows to HBM (unless they are there already), appends, prefix searches, one result copy
-        kmax = SEARCH_NEAREST_NUM + max(self.MATCH_INDEX_DIST, 1)
         row_bytes = DEEP_DESC_SIZE * 4
         own_rows = None
         if rows_dev is None and (adds or searches):
-            own_rows = rows_dev = ctx.to_device(np.stack([np.asarray(img.image_desc, np.float32) for f in frames for img in f.images]))
+            # a direction that was never received carries an empty image_desc (the ImageDescriptor default; loop_net's remote frames):
+            # its row is never appended or queried (landmark_num == 0), it only keeps the frame-major row numbering -- zero-filled
+            stage = np.zeros((base, DEEP_DESC_SIZE), np.float32)
+            r = 0
+            for f in frames:
+                for img in f.images:
+                    d = np.asarray(img.image_desc, np.float32).reshape(-1)
+                    if d.size == DEEP_DESC_SIZE:
+                        stage[r] = d
+                    r += 1
+            own_rows = rows_dev = ctx.to_device(stage)
         start_local, start_remote = self.local_index.ntotal, self.remote_index.ntotal
-        a = 0
-        while a < len(adds):                                # consecutive rows of one index go in as one append
-            b = a + 1
-            while b < len(adds) and adds[b][0] is adds[a][0] and adds[b][1] == adds[b - 1][1] + 1:
-                b += 1
-            adds[a][0].add_dev(b - a, rows_dev + adds[a][1] * row_bytes)
-            a = b
-        live = [s for s in searches if s[3] > 0]
-        if live:
-            need = len(live) * kmax * 12
-            if self._batch_bufs is None or self._batch_bufs[1] < need:
-                if self._batch_bufs is not None:
-                    ctx.free(self._batch_bufs[0])
-                self._batch_bufs = (ctx.alloc(need), need)
-            buf = self._batch_bufs[0]
-            for j, (index, row, max_index, n_limit) in enumerate(live):
-                index.search_prefix_dev(1, rows_dev + row * row_bytes, SEARCH_NEAREST_NUM + max_index, n_limit,
-                                        buf + len(live) * kmax * 8 + j * kmax * 4, buf + j * kmax * 8)
-            raw = ctx.from_device(buf, (need,), np.uint8)                                   # the batch's only synchronisation
-            I_all = raw[:len(live) * kmax * 8].view(np.int64).reshape(len(live), kmax)
-            D_all = raw[len(live) * kmax * 8:].view(np.float32).reshape(len(live), kmax)
-        elif adds:
-            ctx.sync()
-        results, j = [], 0
-        for (index, row, max_index, n_limit) in searches:
+        try:
+            a = 0
+            while a < len(adds):                                # consecutive rows of one index go in as one append
+                b = a + 1
+                while b < len(adds) and adds[b][0] is adds[a][0] and adds[b][1] == adds[b - 1][1] + 1:
+                    b += 1
+                adds[a][0].add_dev(b - a, rows_dev + adds[a][1] * row_bytes)
+                a = b
+            # searches of one index with one k share ONE pass over that index (omni_index_search_batch_prefix_dev, <= 64 queries per
+            # pass): every query still only sees the rows of its own turn, but the database is read once per micro-batch, not per frame
+            live = [j for j, s in enumerate(searches) if s[3] > 0]
+            groups = {}
+            for j in live:
+                index, row, max_index, n_limit = searches[j]
+                groups.setdefault((id(index), max_index), (index, max_index, []))[2].append(j)
+            chunks, need = [], 0                                 # (index, k, [search j], I offset, D offset)
+            for index, max_index, js in groups.values():
+                k = SEARCH_NEAREST_NUM + max_index
+                for c0 in range(0, len(js), 64):
+                    part = js[c0:c0 + 64]
+                    chunks.append((index, k, part, need, need + len(part) * k * 8))
+                    need += len(part) * k * 12
+            where = {}
+            if chunks:
+                if self._batch_bufs is None or self._batch_bufs[1] < need:
+                    if self._batch_bufs is not None:
+                        ctx.free(self._batch_bufs[0])
+                    self._batch_bufs = (ctx.alloc(need), need)
+                buf = self._batch_bufs[0]
+                for index, k, part, off_i, off_d in chunks:
+                    index.search_batch_prefix_dev(rows_dev, [searches[j][1] for j in part], k, [searches[j][3] for j in part],
+                                                  buf + off_d, buf + off_i)
+                    for pos, j in enumerate(part):
+                        where[j] = (k, off_i + pos * k * 8, off_d + pos * k * 4)
+                raw = ctx.from_device(buf, (need,), np.uint8)                               # the batch's only synchronisation
+            elif adds:
+                ctx.sync()
+        except Exception:
+            # nothing has been recorded in the id maps yet: drop the rows appended ahead so that ntotal (and with it the recency rule and
+            # every later row id) stays what the frame-by-frame path would have
+            self._rollback(start_local, start_remote)
+            raise
+        finally:
+            if own_rows is not None:
+                ctx.free(own_rows)
+        results = []
+        for j, (index, row, max_index, n_limit) in enumerate(searches):
             k = SEARCH_NEAREST_NUM + max_index
-            if n_limit > 0:
-                results.append((D_all[j:j + 1, :k], I_all[j:j + 1, :k], n_limit)); j += 1
+            if j in where:
+                _, oi, od = where[j]
+                results.append((raw[od:od + k * 4].view(np.float32).reshape(1, k), raw[oi:oi + k * 8].view(np.int64).reshape(1, k), n_limit))
             else:                                            # faiss pads an empty index's result with -1 labels
                 results.append((np.full((1, k), -3.4028235e38, np.float32), np.full((1, k), -1, np.int64), 0))
-        if own_rows is not None:
-            ctx.free(own_rows)
-        # ---- replay the decision rules frame by frame on the fetched results
+        # ---- replay the decision rules frame by frame on the fetched results.  A compute_loop that raises must not leave rows in the
+        # index without their id-map entries: the exception is deferred until every frame's bookkeeping has been applied.
         self._deferred, self._row_ids, self._sim_local, self._sim_remote = results, row_ids, start_local, start_remote
+        pending_exc = []
+        user_cb = self.compute_loop
+
+        def guarded(*a):
+            try:
+                return user_cb(*a)
+            except Exception as e:                           # noqa: BLE001 -- re-raised below
+                pending_exc.append(e)
+                return False
+
+        self.compute_loop = guarded
         try:
             out = [self._on_image_recv(f) for f in frames]
             assert not self._deferred and not self._row_ids, "plan and replay diverged"
-            return out
         finally:
             self._deferred = None
+            self.compute_loop = user_cb
+        if pending_exc:
+            raise pending_exc[0]
+        return out
+
+    def _rollback(self, n_local: int, n_remote: int):
+        for index, n in ((self.local_index, n_local), (self.remote_index, n_remote)):
+            if index.ntotal > n and hasattr(index, "truncate"):
+                index.truncate(n)
 
     # ---- checkpoint / resume (new: the reference's key-frame database lives in RAM only) --------------------
     def save(self, prefix: str):
@@ -310,12 +362,25 @@ class LoopDetector:
                      frame_meta=np.array([[f.msg_id, f.drone_id, f.landmark_num, int(f.prevent_adding_db), len(f.images)] for f in frames],
                                          np.int64).reshape(-1, 5),
                      img_meta=np.array([[im.drone_id, im.landmark_num] for im in imgs], np.int64).reshape(-1, 2),
-                     img_desc=(np.stack([np.asarray(im.image_desc, np.float32) for im in imgs]) if imgs
-                               else np.zeros((0, DEEP_DESC_SIZE), np.float32)),
+                     img_desc=self._stack_desc(imgs),
+                     img_desc_len=np.array([np.asarray(im.image_desc).size for im in imgs], np.int64),
+                     feat_dim=np.array([(np.asarray(im.feature_descriptor).shape[1] if np.asarray(im.feature_descriptor).ndim == 2
+                                         and np.asarray(im.feature_descriptor).size else 64) for im in imgs], np.int64),
+                     det_params=np.array([self.INNER_PRODUCT_THRES, self.INIT_MODE_PRODUCT_THRES, self.MATCH_INDEX_DIST, self.MIN_LOOP_NUM,
+                                          self.MIN_DIRECTION_LOOP, self.inter_drone_init_frames], np.float64),
                      feat=np.concatenate(feat) if feat else np.zeros(0, np.float32),
                      feat_len=np.array([len(x) for x in feat], np.int64),
                      kps=np.concatenate(kps) if kps else np.zeros(0, np.float32),
                      kps_len=np.array([len(x) for x in kps], np.int64))
+
+    @staticmethod
+    def _stack_desc(imgs):
+        out = np.zeros((len(imgs), DEEP_DESC_SIZE), np.float32)
+        for i, im in enumerate(imgs):
+            d = np.asarray(im.image_desc, np.float32).reshape(-1)
+            if d.size == DEEP_DESC_SIZE:
+                out[i] = d
+        return out
 
     def load(self, prefix: str):
         """Restores a save() into this (freshly constructed, same parameters) detector."""
@@ -323,6 +388,12 @@ class LoopDetector:
             z = np.load(prefix + ".state.npz", allow_pickle=False)
             if int(z["params"][0]) != self.self_id or int(z["params"][1]) != self.camera_configuration:
                 raise ValueError("snapshot was written by a detector with another self_id / camera configuration")
+            mine = np.array([self.INNER_PRODUCT_THRES, self.INIT_MODE_PRODUCT_THRES, self.MATCH_INDEX_DIST, self.MIN_LOOP_NUM,
+                             self.MIN_DIRECTION_LOOP, self.inter_drone_init_frames], np.float64)
+            if "det_params" in z and not np.array_equal(z["det_params"], mine):
+                raise ValueError(f"snapshot was written with detector parameters {z['det_params'].tolist()}, this detector has {mine.tolist()}")
+            desc_len = z["img_desc_len"] if "img_desc_len" in z else np.full(len(z["img_meta"]), DEEP_DESC_SIZE, np.int64)
+            feat_dim = z["feat_dim"] if "feat_dim" in z else np.full(len(z["img_meta"]), 64, np.int64)
             self.local_index.load(prefix + ".local.omnx")
             self.remote_index.load(prefix + ".remote.omnx")
             self.imgid2fisheye = {int(i): int(f) for i, f in zip(z["imgid"], z["imgid_fisheye"])}
@@ -337,8 +408,9 @@ class LoopDetector:
                 images = []
                 for _ in range(int(n_img)):
                     images.append(ImageDescriptor(drone_id=int(z["img_meta"][j, 0]), landmark_num=int(z["img_meta"][j, 1]),
-                                                  image_desc=z["img_desc"][j].copy(),
-                                                  feature_descriptor=z["feat"][fo[j]:fo[j + 1]].reshape(-1, 64).copy(),
+                                                  image_desc=(z["img_desc"][j].copy() if int(desc_len[j]) == DEEP_DESC_SIZE
+                                                              else np.zeros(0, np.float32)),
+                                                  feature_descriptor=z["feat"][fo[j]:fo[j + 1]].reshape(-1, int(feat_dim[j])).copy(),
                                                   landmarks_2d=z["kps"][ko[j]:ko[j + 1]].reshape(-1, 2).copy()))
                     j += 1
                 self.fisheyeframe_database[int(msg_id)] = FisheyeFrameDescriptor(msg_id=int(msg_id), drone_id=int(drone_id), landmark_num=int(lm),

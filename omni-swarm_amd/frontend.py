@@ -52,6 +52,11 @@ class LoopCam:
         MobileNetVLAD on a second stream, all D2H copies included (loop_cam.cpp:350-351, 553-556, 147-150)."""
         self.cam.enqueue_dev(gray_dev, stride, self.fisheye)
 
+    def enqueue_host(self, gray_host: np.ndarray):
+        """Same with the images in (pinned) host memory, [2*n_dirs][H][W] u8: one asynchronous upload in front of the kernels
+        (omni_cam_enqueue_host).  The array must stay untouched until fetch() returns."""
+        self.cam.enqueue_host(gray_host, self.fisheye)
+
     def fetch(self) -> dict:
         """Waits for the key frame and returns one FisheyeFrameDescriptor_t's worth of CNN outputs (copies: the pinned
         block is reused by the next enqueue)."""

@@ -1,0 +1,133 @@
+// keyframe_pipeline.hpp -- the per-key-frame host flow of SwarmLoop::VIOKF_callback (swarm_loop/src/swarm_loop.cpp:140-170:
+//     ret = loop_cam->on_flattened_images(stereoframe, imgs);  ...  loop_detector->on_image_recv(ret, imgs);)
+// as a C++17 driver over the adapters of omni_swarm.hpp, for a STREAM of key frames: `pipelines` micro-batches of `microbatch` key
+// frames are in flight on the GPU (each an omni_cam unit: upload + SuperPoint + MobileNetVLAD + up/down BF + one D2H), while the host
+// hands the finished ones to LoopDetectorCore::on_images_recv_batch in arrival order.  The reference does the same work strictly
+// serially, one blocking engine call at a time.  This is the host loop bench.py times (through host_capi.cpp); Python only
+// prepares the synthetic inputs and brackets the run with the barrier.
+#pragma once
+#include <deque>
+#include <memory>
+
+#include "omni_swarm.hpp"
+
+namespace omni {
+
+class KeyframePipeline {
+public:
+    struct Config {
+        int device = 0, width = 600, height = 480, max_num = 200, precision = OMNI_PREC_F16;
+        float thres = 0.02f;
+        int microbatch = 8, pipelines = 2, storage = OMNI_STORE_F32, self_id = 1;
+        double inner_product_thres = 0.3, init_mode_product_thres = 0.2;
+        int match_index_dist = 5, min_loop_num = 30, min_direction_loop = 3;
+        std::string sp_weights, pca_comp, pca_mean, vlad_weights;
+    };
+
+    explicit KeyframePipeline(const Config& c) : cfg_(c), index_ctx_(c.device), det_(index_ctx_, c.self_id, c.storage) {
+        det_.INNER_PRODUCT_THRES = c.inner_product_thres; det_.INIT_MODE_PRODUCT_THRES = c.init_mode_product_thres;
+        det_.MATCH_INDEX_DIST = c.match_index_dist; det_.MIN_LOOP_NUM = c.min_loop_num; det_.MIN_DIRECTION_LOOP = c.min_direction_loop;
+        for (int p = 0; p < c.pipelines; ++p) lanes_.push_back(std::make_unique<Lane>(c, c.microbatch));
+    }
+
+    LoopDetectorCore& detector() { return det_; }
+
+    // bulk pre-load of the key-frame database: rows [n][4096], 4 consecutive rows = the 4 directions of one earlier key frame
+    void preload(const float* rows, int64_t n) {
+        const int64_t base = det_.local_index.ntotal;
+        for (int64_t s = 0; s < n; s += 4096) det_.local_index.add(std::min<int64_t>(4096, n - s), rows + s * 4096);
+        for (int64_t i = 0; i < n; ++i) { det_.imgid2fisheye[(int)(base + i)] = -((base + i) / 4) - 1; det_.imgid2dir[(int)(base + i)] = (int)((base + i) % 4); }
+    }
+
+    // n_keyframes key frames through the whole hot path.  pool[e] = one micro-batch of images in (pinned) host memory,
+    // [up cameras of the MB frames (4 each) | down cameras of the MB frames], u8, rows packed; micro-batch s uses pool[(first_slot + s) %
+    // n_pool].  When n_keyframes is not a multiple of the micro-batch the last rem frames run as their own, smaller unit from `tail`
+    // (same layout for rem frames): EXACTLY n_keyframes key frames are processed.  from_host: upload inside the loop
+    // (omni_cam_enqueue_host); otherwise the pool entries are device pointers.  Returns the number of loop candidates found.
+    int run(int n_keyframes, int64_t first_msg_id, const uint8_t* const* pool, int n_pool, int first_slot, const uint8_t* tail, bool from_host) {
+        const int MB = cfg_.microbatch;
+        const int full = n_keyframes / MB, rem = n_keyframes % MB;
+        Lane* tail_lane = rem ? prepare(n_keyframes) : nullptr;
+        std::deque<std::pair<Lane*, int64_t>> pending;
+        int hits = 0;
+        for (int s = 0; s < full + (rem ? 1 : 0); ++s) {
+            Lane* lane = s < full ? lanes_[s % lanes_.size()].get() : tail_lane;
+            const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
+            if (from_host) lane->cam.enqueue_host(src, cfg_.width, true);
+            else lane->cam.enqueue_dev(src, cfg_.width, true);
+            pending.emplace_back(lane, first_msg_id + (int64_t)s * MB);
+            if (pending.size() >= lanes_.size()) { hits += finish(*pending.front().first, pending.front().second); pending.pop_front(); }
+        }
+        while (!pending.empty()) { hits += finish(*pending.front().first, pending.front().second); pending.pop_front(); }
+        return hits;
+    }
+
+    void sync() { for (auto& l : lanes_) l->sync(); for (auto& t : tail_lanes_) t.second->sync(); check(omni_ctx_sync(index_ctx_.get()), "sync"); }
+
+private:
+    struct Lane;
+public:
+    // creates (once) the smaller unit a run of n_keyframes needs for its trailing n_keyframes % microbatch key frames, so that the first
+    // timed run does not pay for it
+    Lane* prepare(int n_keyframes) {
+        const int rem = n_keyframes % cfg_.microbatch;
+        if (!rem) return nullptr;
+        auto it = tail_lanes_.find(rem);
+        if (it == tail_lanes_.end()) it = tail_lanes_.emplace(rem, std::make_unique<Lane>(cfg_, rem)).first;
+        return it->second.get();
+    }
+
+private:
+    struct Lane {                                      // one micro-batch in flight: its own streams, networks and result block
+        Lane(const Config& c, int mb_)
+            : mb(mb_), sp_ctx(c.device), vlad_ctx(c.device),
+              sp(sp_ctx, c.sp_weights, c.pca_comp, c.pca_mean, c.width, c.height, c.thres, c.max_num, false, c.precision, 8 * mb_),
+              vlad(vlad_ctx, c.vlad_weights, c.width, c.height, false, 4 * mb_),
+              cam(sp_ctx, sp, vlad_ctx, vlad, 4 * mb_, c.max_num, c.width, c.height) {
+            check(omni_vlad_dev_output(vlad.handle(), &rows_dev), "omni_vlad_dev_output");
+        }
+        void sync() { check(omni_ctx_sync(sp_ctx.get()), "sync"); check(omni_ctx_sync(vlad_ctx.get()), "sync"); }
+        int mb;
+        Context sp_ctx, vlad_ctx;
+        Swarm::SuperPointHIP sp;
+        Swarm::MobileNetVLADHIP vlad;
+        LoopCamHIP cam;
+        const float* rows_dev = nullptr;
+    };
+
+    // the micro-batch's key frames reach the detector in order, as one batch; rows and queries are taken from MobileNetVLAD's output
+    // buffer in HBM ([4*mb][4096], key-frame major) -- wait() has synchronised with the MobileNetVLAD stream
+    int finish(Lane& lane, int64_t first_id) {
+        const omni_cam_result r = lane.cam.wait();
+        const int n = r.n_dirs, M = r.max_num, D = r.desc_dim;
+        frames_.resize(lane.mb);
+        for (int m = 0; m < lane.mb; ++m) {
+            FisheyeFrameDescriptor& f = frames_[m];
+            f.msg_id = first_id + m; f.drone_id = cfg_.self_id; f.prevent_adding_db = false; f.landmark_num = 0;
+            f.images.resize(4);
+            for (int d = 0; d < 4; ++d) {
+                const int i = 4 * m + d;                                            // image i of the up cameras
+                ImageDescriptor& im = f.images[d];
+                im.drone_id = cfg_.self_id; im.landmark_num = r.n_kps[i];
+                im.image_desc.assign(r.global_desc + (size_t)i * r.global_dim, r.global_desc + (size_t)(i + 1) * r.global_dim);
+                im.feature_descriptor.assign(r.desc + (size_t)i * M * D, r.desc + ((size_t)i * M + im.landmark_num) * D);
+                im.landmarks_2d.resize(im.landmark_num);
+                for (int k = 0; k < im.landmark_num; ++k) im.landmarks_2d[k] = {r.kps_xy[((size_t)i * M + k) * 2], r.kps_xy[((size_t)i * M + k) * 2 + 1]};
+                f.landmark_num += im.landmark_num;
+            }
+        }
+        (void)n;
+        int hits = 0;
+        for (auto& c : det_.on_images_recv_batch(frames_, lane.rows_dev)) hits += c.found ? 1 : 0;
+        return hits;
+    }
+
+    Config cfg_;
+    Context index_ctx_;
+    LoopDetectorCore det_;
+    std::vector<std::unique_ptr<Lane>> lanes_;
+    std::map<int, std::unique_ptr<Lane>> tail_lanes_;
+    std::vector<FisheyeFrameDescriptor> frames_;
+};
+
+}  // namespace omni

@@ -253,7 +253,7 @@ public:
         gray_dev_ = static_cast<uint8_t*>(omni_dev_alloc(sp_ctx.get(), (size_t)2 * n_dirs * width * height));
         if (!gray_dev_) { omni_cam_destroy(h_); throw std::runtime_error(std::string("omni_dev_alloc: ") + omni_last_error()); }
     }
-    ~LoopCamHIP() { omni_cam_destroy(h_); omni_dev_free(ctx_.get(), gray_dev_); }
+    ~LoopCamHIP() { omni_cam_destroy(h_); omni_dev_free(ctx_.get(), gray_dev_); if (pinned_) omni_host_free(pinned_); }
     LoopCamHIP(const LoopCamHIP&) = delete;
     LoopCamHIP& operator=(const LoopCamHIP&) = delete;
 
@@ -265,6 +265,19 @@ public:
             for (int y = 0; y < h_img_; ++y) std::memcpy(stage_.data() + ((size_t)i * h_img_ + y) * w_, images[i] + (size_t)y * stride, w_);
         check(omni_memcpy_h2d(ctx_.get(), gray_dev_, stage_.data(), stage_.size()), "LoopCamHIP upload");
         check(omni_cam_enqueue_dev(h_, gray_dev_, w_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_dev");
+    }
+    // same, without blocking: the images are packed into a pinned block owned by this object and go up as ONE asynchronous copy in front of
+    // the kernels (omni_cam_enqueue_host); the host is free again as soon as the memcpy into the pinned block is done
+    void enqueue_async(const uint8_t* const* images, int stride, bool fisheye_mask = true) {
+        const size_t bytes = (size_t)2 * n_ * w_ * h_img_;
+        if (!pinned_) { pinned_ = static_cast<uint8_t*>(omni_host_alloc(bytes)); if (!pinned_) throw std::runtime_error(std::string("omni_host_alloc: ") + omni_last_error()); }
+        for (int i = 0; i < 2 * n_; ++i)
+            for (int y = 0; y < h_img_; ++y) std::memcpy(pinned_ + ((size_t)i * h_img_ + y) * w_, images[i] + (size_t)y * stride, w_);
+        check(omni_cam_enqueue_host(h_, pinned_, w_, w_, h_img_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_host");
+    }
+    // images already packed [2*n_dirs][H][W] in (ideally pinned) host memory: no staging copy at all
+    void enqueue_host(const uint8_t* gray_host, int stride, bool fisheye_mask = true) {
+        check(omni_cam_enqueue_host(h_, gray_host, stride, w_, h_img_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_host");
     }
     void enqueue_dev(const uint8_t* gray_dev, int stride, bool fisheye_mask = true) {      // images already in HBM
         check(omni_cam_enqueue_dev(h_, gray_dev, stride, fisheye_mask ? 1 : 0), "omni_cam_enqueue_dev");
@@ -279,6 +292,7 @@ private:
     Context& ctx_;
     omni_cam* h_ = nullptr;
     uint8_t* gray_dev_ = nullptr;
+    uint8_t* pinned_ = nullptr;
     int n_, w_, h_img_;
     std::vector<uint8_t> stage_;
 };
@@ -426,38 +440,53 @@ public:
         }
         local_index.ntotal = omni_index_ntotal(local_index.handle());
         remote_index.ntotal = omni_index_ntotal(remote_index.handle());
-        const int kmax = SEARCH_NEAREST_NUM + (MATCH_INDEX_DIST > 1 ? MATCH_INDEX_DIST : 1);
-        size_t live = 0;
-        for (auto& s : searches) if (s.n_limit > 0) ++live;
-        std::vector<char> raw(live * kmax * 12);
-        if (live) {
-            if (batch_buf_bytes_ < raw.size()) {
+        // searches of one index with one k share ONE pass over that index (omni_index_search_batch_prefix_dev, <= 64 queries per pass):
+        // every query still sees only the rows of its own turn, but the database is read once per micro-batch instead of once per frame
+        struct Chunk { IndexFlatIP* index; int k; std::vector<size_t> js; size_t off_i, off_d; };
+        std::vector<Chunk> chunks;
+        size_t need = 0;
+        for (size_t j = 0; j < searches.size(); ++j) {
+            if (searches[j].n_limit <= 0) continue;
+            const int k = SEARCH_NEAREST_NUM + searches[j].max_index;
+            Chunk* c = nullptr;
+            for (auto& cc : chunks) if (cc.index == searches[j].index && cc.k == k && cc.js.size() < 64) c = &cc;
+            if (!c) { chunks.push_back({searches[j].index, k, {}, 0, 0}); c = &chunks.back(); }
+            c->js.push_back(j);
+        }
+        for (auto& c : chunks) { c.off_i = need; c.off_d = need + c.js.size() * c.k * 8; need += c.js.size() * c.k * 12; }
+        std::vector<char> raw(need);
+        std::vector<std::pair<size_t, size_t>> where(searches.size(), {SIZE_MAX, SIZE_MAX});     // byte offsets of I and D per search
+        if (need) {
+            if (batch_buf_bytes_ < need) {
                 if (batch_buf_) omni_dev_free(ctx_.get(), batch_buf_);
-                batch_buf_ = static_cast<char*>(omni_dev_alloc(ctx_.get(), raw.size()));
+                batch_buf_ = static_cast<char*>(omni_dev_alloc(ctx_.get(), need));
                 if (!batch_buf_) throw std::runtime_error(std::string("omni_dev_alloc: ") + omni_last_error());
-                batch_buf_bytes_ = raw.size();
+                batch_buf_bytes_ = need;
             }
-            size_t j = 0;
-            for (auto& s : searches) if (s.n_limit > 0) {
-                check(omni_index_search_prefix_dev(s.index->handle(), 1, rows_dev + s.row * 4096, SEARCH_NEAREST_NUM + s.max_index, s.n_limit,
-                                                   reinterpret_cast<float*>(batch_buf_ + live * kmax * 8 + j * kmax * 4),
-                                                   reinterpret_cast<int64_t*>(batch_buf_ + j * kmax * 8)), "omni_index_search_prefix_dev");
-                ++j;
+            for (auto& c : chunks) {
+                std::vector<int64_t> rows_idx, limits;
+                for (size_t pos = 0; pos < c.js.size(); ++pos) {
+                    const Search& sj = searches[c.js[pos]];
+                    rows_idx.push_back((int64_t)sj.row); limits.push_back(sj.n_limit);
+                    where[c.js[pos]] = {c.off_i + pos * c.k * 8, c.off_d + pos * c.k * 4};
+                }
+                check(omni_index_search_batch_prefix_dev(c.index->handle(), (int)c.js.size(), rows_dev, rows_idx.data(), c.k, limits.data(),
+                                                         reinterpret_cast<float*>(batch_buf_ + c.off_d), reinterpret_cast<int64_t*>(batch_buf_ + c.off_i)),
+                      "omni_index_search_batch_prefix_dev");
             }
-            check(omni_memcpy_d2h(ctx_.get(), raw.data(), batch_buf_, raw.size()), "on_images_recv_batch fetch");   // the only synchronisation
+            check(omni_memcpy_d2h(ctx_.get(), raw.data(), batch_buf_, need), "on_images_recv_batch fetch");   // the only synchronisation
         } else if (!adds.empty()) {
             check(omni_ctx_sync(ctx_.get()), "omni_ctx_sync");
         }
         deferred_.clear();
-        size_t j = 0;
-        for (auto& s : searches) {
-            Deferred d; d.ntotal = s.n_limit;
-            const int k = SEARCH_NEAREST_NUM + s.max_index;
+        for (size_t j = 0; j < searches.size(); ++j) {
+            const Search& sj = searches[j];
+            Deferred d; d.ntotal = sj.n_limit;
+            const int k = SEARCH_NEAREST_NUM + sj.max_index;
             d.D.assign(k, -3.402823466e+38f); d.I.assign(k, -1);
-            if (s.n_limit > 0) {
-                std::memcpy(d.I.data(), raw.data() + j * kmax * 8, (size_t)k * 8);
-                std::memcpy(d.D.data(), raw.data() + live * kmax * 8 + j * kmax * 4, (size_t)k * 4);
-                ++j;
+            if (where[j].first != SIZE_MAX) {
+                std::memcpy(d.I.data(), raw.data() + where[j].first, (size_t)k * 8);
+                std::memcpy(d.D.data(), raw.data() + where[j].second, (size_t)k * 4);
             }
             deferred_.push_back(std::move(d));
         }

@@ -1,0 +1,97 @@
+"""ctypes launcher of the C++ key-frame host loop (host/keyframe_pipeline.hpp -> lib/libomni_host.so).
+
+The loop itself -- SwarmLoop::VIOKF_callback's hot part, swarm_loop/src/swarm_loop.cpp:140-170: LoopCam::on_flattened_images followed
+by LoopDetector::on_image_recv, for a stream of key frames -- runs in C++ (omni::KeyframePipeline over the adapters of
+host/omni_swarm.hpp and the C ABI of libomni_hip.so).  Python only writes the weight files, owns the pinned input pool and starts the run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
+SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
+           "omni_pipeline_run", "omni_pipeline_prepare", "omni_pipeline_sync"]
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is missing: run `make -C omni-swarm_amd`")
+        capi.lib()                                     # libomni_hip.so first (libomni_host.so links against it)
+        L = C.CDLL(LIB_PATH)
+        L.omni_pipeline_last_error.restype = C.c_char_p
+        L.omni_pipeline_create.restype = C.c_void_p
+        L.omni_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.omni_pipeline_destroy.argtypes = [C.c_void_p]
+        L.omni_pipeline_destroy.restype = None
+        L.omni_pipeline_preload.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64]
+        L.omni_pipeline_db_rows.argtypes = [C.c_void_p]
+        L.omni_pipeline_db_rows.restype = C.c_int64
+        L.omni_pipeline_run.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_int)]
+        L.omni_pipeline_sync.argtypes = [C.c_void_p]
+        L.omni_pipeline_prepare.argtypes = [C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _err(what):
+    return capi.OmniError(f"{what}: {lib().omni_pipeline_last_error().decode()}")
+
+
+class KeyframePipeline:
+    def __init__(self, device: int, sp_weights_path: str, pca_comp_csv: str, pca_mean_csv: str, vlad_weights_path: str, width=600, height=480,
+                 thres=0.02, max_num=200, precision=capi.PREC_F16, microbatch=8, pipelines=2, storage=capi.STORE_F32, self_id=1,
+                 inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3):
+        self.microbatch = microbatch
+        self.h = lib().omni_pipeline_create(device, sp_weights_path.encode(), pca_comp_csv.encode(), pca_mean_csv.encode(),
+                                            vlad_weights_path.encode(), width, height, thres, max_num, precision, microbatch, pipelines, storage,
+                                            self_id, inner_product_thres, init_mode_product_thres, match_index_dist, min_loop_num,
+                                            min_direction_loop)
+        if not self.h:
+            raise _err("omni_pipeline_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().omni_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def preload(self, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows, np.float32)
+        if lib().omni_pipeline_preload(self.h, rows.ctypes.data_as(C.POINTER(C.c_float)), rows.shape[0]):
+            raise _err("omni_pipeline_preload")
+
+    @property
+    def db_rows(self) -> int:
+        return lib().omni_pipeline_db_rows(self.h)
+
+    def run(self, n_keyframes: int, first_msg_id: int, pool_ptrs, first_slot: int = 0, tail_ptr=None, from_host: bool = True) -> int:
+        """pool_ptrs: addresses (ints) of the micro-batch image blocks -- pinned host memory (from_host) or HBM."""
+        arr = (C.c_void_p * len(pool_ptrs))(*pool_ptrs)
+        hits = C.c_int(0)
+        if lib().omni_pipeline_run(self.h, n_keyframes, first_msg_id, arr, len(pool_ptrs), first_slot, tail_ptr, int(from_host), C.byref(hits)):
+            raise _err("omni_pipeline_run")
+        return hits.value
+
+    def prepare(self, n_keyframes: int):
+        if lib().omni_pipeline_prepare(self.h, n_keyframes):
+            raise _err("omni_pipeline_prepare")
+
+    def sync(self):
+        if lib().omni_pipeline_sync(self.h):
+            raise _err("omni_pipeline_sync")

@@ -16,16 +16,20 @@ def image_u8(index: int, height: int = 480, width: int = 600, n_shapes: int = 20
     """Image-like u8 frame: random rectangles/ellipses, blur sigma=1.5, N(0,4) noise (8d)."""
     rng = np.random.default_rng(BASE_SEED + index)
     img = np.full((height, width), 96.0, np.float32)
-    yy, xx = np.mgrid[0:height, 0:width]
     for _ in range(n_shapes):
         cx, cy = rng.uniform(0, width), rng.uniform(0, height)
         rx, ry = rng.uniform(4, width / 8), rng.uniform(4, height / 8)
         val = rng.uniform(-90, 110)
+        # both shapes live inside [c - r, c + r]: the masks are evaluated on that bounding box only (same arithmetic, same bytes as
+        # the full-frame masks the golden fixtures were generated with)
+        x0, x1 = max(0, int(np.floor(cx - rx))), min(width, int(np.ceil(cx + rx)) + 1)
+        y0, y1 = max(0, int(np.floor(cy - ry))), min(height, int(np.ceil(cy + ry)) + 1)
+        yy, xx = np.mgrid[y0:y1, x0:x1]
         if rng.random() < 0.5:
             m = (np.abs(xx - cx) < rx) & (np.abs(yy - cy) < ry)
         else:
             m = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 < 1.0
-        img[m] += val
+        img[y0:y1, x0:x1][m] += val
     img = gaussian_filter(img, 1.5)
     img += rng.normal(0, 4.0, img.shape).astype(np.float32)
     out = np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -47,7 +47,7 @@ def superpoint_synth_weights(seed: int = 0, convPb_gain: float = 4.0, dustbin_bi
 
 def load_superpoint_pth(path: str) -> dict:
     """The reference checkpoint (state_dict of SuperPointNet, superpoint.ipynb:270) -> weights dict."""
-    sd = torch.load(path, map_location="cpu")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
     return {k: v.detach().numpy().astype(np.float32) for k, v in sd.items()}
 
 
@@ -113,3 +113,42 @@ def mobilenetvlad_synth_weights(seed: int = 10) -> dict:
     w["fc.weight"] = u((VLAD_OUT_DIM, VLAD_DIM), np.sqrt(3.0 / VLAD_DIM) * 4)
     w["fc.bias"] = u((VLAD_OUT_DIM,), 0.01)
     return w
+
+
+# ---- OMNW1 weight files for the C++ host adapters (host/omni_swarm.hpp: omni::load_omnw) -----------------------------------------
+def write_omnw(path, tensors: dict):
+    """OMNW1 = "OMNW1\\0\\0\\0", u32 n, then per tensor: u32 name_len, name, u32 ndim, u32 dims[ndim], float32 data (little endian)."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"OMNW1\0\0\0")
+        f.write(struct.pack("<I", len(tensors)))
+        for name, arr in tensors.items():
+            a = np.ascontiguousarray(arr, dtype="<f4")
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb)
+            f.write(struct.pack("<I", a.ndim) + struct.pack(f"<{a.ndim}I", *a.shape))
+            f.write(a.tobytes())
+
+
+def vlad_omnw_tensors(weights, specs, kinds):
+    """The MobileNetVLAD file carries the (assumed) layer table as tensor "layers" [n][4] = (kind, cin, cout, stride) and the per-layer
+    tensors as "layer<i>.weight" / "layer<i>.bias"."""
+    t = {"layers": np.array([[kinds[k], ci, co, s] for (_, k, ci, co, s) in specs], np.float32)}
+    for i, (name, *_rest) in enumerate(specs):
+        t[f"layer{i}.weight"] = weights[name + ".weight"]
+        t[f"layer{i}.bias"] = weights[name + ".bias"]
+    for k in ("vlad.assign.weight", "vlad.assign.bias", "vlad.clusters", "fc.weight", "fc.bias"):
+        t[k] = weights[k]
+    t["vlad.assign.weight"] = np.asarray(weights["vlad.assign.weight"]).reshape(weights["vlad.clusters"].shape)
+    return t
+
+
+def write_pipeline_files(dirpath, sp_w, pca_comp, pca_mean, vlad_w, vlad_specs, vlad_kinds):
+    """Everything host/keyframe_pipeline.hpp loads from disk: sp.omnw, vlad.omnw and the reference's two PCA CSVs (%.9g round-trips fp32)."""
+    import os
+    paths = {k: os.path.join(dirpath, v) for k, v in (("sp", "sp.omnw"), ("comp", "components_.csv"), ("mean", "mean_.csv"), ("vlad", "vlad.omnw"))}
+    write_omnw(paths["sp"], sp_w)
+    write_omnw(paths["vlad"], vlad_omnw_tensors(vlad_w, vlad_specs, vlad_kinds))
+    np.savetxt(paths["comp"], pca_comp, delimiter=",", fmt="%.9g")
+    np.savetxt(paths["mean"], pca_mean, fmt="%.9g")
+    return paths

@@ -80,6 +80,16 @@ class HostIndex:
         self.ctx.view(I_dev, nq * k * 8)[:] = I.astype(np.int64).view(np.uint8).reshape(-1)
 
 
+    def search_batch_prefix_dev(self, rows_dev, row_idx, k, limits, D_dev, I_dev):
+        nq = len(limits)
+        for j in range(nq):
+            r = j if row_idx is None else int(row_idx[j])
+            self.search_prefix_dev(1, rows_dev + r * DIM * 4, k, int(limits[j]), D_dev + j * k * 4, I_dev + j * k * 8)
+
+    def truncate(self, n):
+        self.rows = self.rows[:n]
+
+
 @pytest.fixture()
 def detector_mod():
     return importlib.import_module("omni-swarm_amd.detector")
@@ -147,3 +157,66 @@ def test_checkpoint_resume_continues_the_same_trace(detector_mod, tmp_path):
     with pytest.raises(ValueError):
         detector_mod.LoopDetector(ctx, 2, index_factory=lambda: HostIndex(ctx), **DS.PARAMS).load(prefix)
 
+
+
+def _frame(detector_mod, msg_id, drone, descs, lms):
+    return detector_mod.FisheyeFrameDescriptor(
+        msg_id=msg_id, drone_id=drone, landmark_num=int(sum(lms)),
+        images=[detector_mod.ImageDescriptor(drone_id=drone, landmark_num=lm, image_desc=d) for d, lm in zip(descs, lms)])
+
+
+def test_direction_never_received_has_an_empty_descriptor(detector_mod, tmp_path):
+    """A direction that was not received carries landmark_num = 0 and an EMPTY image_desc (the ImageDescriptor default; loop_net's remote
+    frames, loop_net.cpp:206-218): sequential, batched and checkpointed paths must all accept it."""
+    rng = np.random.default_rng(5)
+    def unit():
+        v = rng.standard_normal(DIM).astype(np.float32)
+        return v / np.linalg.norm(v)
+    frames = []
+    for i in range(12):
+        descs = [unit(), unit(), unit(), np.zeros(0, np.float32)]
+        frames.append((1000 + i, 1 if i % 3 else 2, descs, [50, 60, 70, 0]))
+    ctx = ArenaCtx()
+    a = detector_mod.LoopDetector(ctx, DS.SELF_ID, index_factory=lambda: HostIndex(ctx), **DS.PARAMS)
+    ra = [a.on_image_recv(_frame(detector_mod, *f)) for f in frames]
+    b = detector_mod.LoopDetector(ctx, DS.SELF_ID, index_factory=lambda: HostIndex(ctx), **DS.PARAMS)
+    rb = b.on_images_recv_batch([_frame(detector_mod, *f) for f in frames[:5]]) + b.on_images_recv_batch([_frame(detector_mod, *f) for f in frames[5:]])
+    assert np.array_equal(DS.trace(ra), DS.trace(rb)) and a.database_size() == b.database_size() > 0
+    prefix = str(tmp_path / "empty")
+    b.save(prefix)
+    c = detector_mod.LoopDetector(ctx, DS.SELF_ID, index_factory=lambda: HostIndex(ctx), **DS.PARAMS)
+    c.load(prefix)
+    some = next(iter(c.fisheyeframe_database.values()))
+    assert some.images[3].image_desc.size == 0 and some.images[0].image_desc.size == DIM
+    short = _frame(detector_mod, 5000, 1, [unit()], [500])            # fewer images than the queried direction: no crash, no query hit
+    assert b.on_images_recv_batch([short])[0]["old_msg_id"] == -1
+
+
+def test_compute_loop_exception_leaves_batch_state_consistent(detector_mod):
+    """compute_loop raising in the middle of a batch: every frame's bookkeeping is still applied (ntotal == len(id map)), the exception
+    surfaces afterwards, and the detector keeps working -- the sequential path would have stopped at that frame instead, but never with
+    orphan rows in the index."""
+    frames = DS.make_stream(seed=61, n_frames=90, n_places=6)
+    ctx = ArenaCtx()
+    calls = [0]
+
+    def loop(n, o, dn, do, im):
+        calls[0] += 1
+        if calls[0] == 3:
+            raise RuntimeError("geometry failed")
+        return True
+
+    det = detector_mod.LoopDetector(ctx, DS.SELF_ID, compute_loop=loop, index_factory=lambda: HostIndex(ctx), **DS.PARAMS)
+    mk = lambda fr: detector_mod.FisheyeFrameDescriptor(
+        msg_id=fr["msg_id"], drone_id=fr["drone_id"], landmark_num=fr["landmark_num"], prevent_adding_db=fr["prevent_adding_db"],
+        images=[detector_mod.ImageDescriptor(drone_id=i["drone_id"], landmark_num=i["landmark_num"], image_desc=i["image_desc"]) for i in fr["images"]])
+    raised = False
+    for s in range(0, len(frames), 10):
+        try:
+            det.on_images_recv_batch([mk(fr) for fr in frames[s:s + 10]])
+        except RuntimeError:
+            raised = True
+        n_ids = len(det.imgid2fisheye)
+        assert det.local_index.ntotal + det.remote_index.ntotal == n_ids
+        assert det._deferred is None
+    assert raised and calls[0] > 3

@@ -1,0 +1,173 @@
+"""GPU parity AT THE BENCHMARKED OPERATING POINT ("what's weak" 1-2): bench.py runs OMNI_PREC_F16, threshold 0.02, micro-batches
+of 8 key frames = 64 SuperPoint + 32 MobileNetVLAD images of 600x480 per launch sequence, uploaded from pinned host memory.  The persistent
+kernels distribute batch x tiles over the CUs, so the 64-image schedule is a different path through them than the batch <= 3 of the other tests.
+
+  * every image of the 64-/32-image launches is BIT-IDENTICAL to the same image run alone (batch 1);
+  * against the CPU oracle (torch fp32 notebook graph + literal post-processing) at this shape, with the f16 gate tightened to what is
+    measured: key-point overlap >= 0.97 per image, dense descriptors relative L2 p99 <= 1.5e-3, PCA descriptors of common key points
+    <= 1e-2 relative at p99; MobileNetVLAD (exact-f32 arithmetic) <= 1e-3 relative;
+  * the whole unit through omni_cam (enqueue_host) reproduces the stand-alone results, BF match lists included;
+  * the C++ host loop (libomni_host.so) and the Python host loop take the same decisions on the same key frames.
+"""
+import numpy as np
+import pytest
+
+from oracle import match_ref as M
+from oracle import mobilenetvlad_ref as V
+from oracle import postproc_ref as P
+from oracle import superpoint_ref as S
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+W, H, THR, MAXN, MB = 600, 480, 0.02, 200, 8
+
+
+def _microbatch(first_seed, mb=MB):
+    kf = [[synth.image_u8(first_seed + 8 * m + i, H, W) for i in range(8)] for m in range(mb)]
+    return np.stack([kf[m][i] for m in range(mb) for i in range(4)] + [kf[m][4 + i] for m in range(mb) for i in range(4)])
+
+
+@pytest.fixture(scope="module")
+def batch64():
+    return _microbatch(5000)
+
+
+def test_superpoint_64_images_f16_bit_identical_to_batch1_and_within_gate_of_oracle(omni, ctx, batch64):
+    c = omni.capi
+    weights = S.synth_weights(0)
+    comp, mean = synth.pca()
+    big = c.SuperPoint(ctx, weights, comp, mean, W, H, THR, MAXN, c.PREC_F16, 64)
+    one = c.SuperPoint(ctx, weights, comp, mean, W, H, THR, MAXN, c.PREC_F16, 1)
+    res = big.inference(batch64, fisheye_mask=True)
+    semi64, desc64 = big.get_dense(64)
+    for b in range(64):
+        (k1, d1, s1), = one.inference(batch64[b], fisheye_mask=True)
+        assert np.array_equal(res[b][0], k1) and np.array_equal(res[b][1], d1) and np.array_equal(res[b][2], s1), b
+        if b in (0, 17, 31, 32, 63):                       # dense outputs too (first / middle / last tiles of the persistent schedule)
+            semi1, desc1 = one.get_dense(1)
+            assert np.array_equal(semi64[b], semi1[0]) and np.array_equal(desc64[b], desc1[0]), b
+    assert min(len(r[0]) for r in res) == MAXN             # the operating point saturates max_num on every image
+    # vs the oracle on a sample of the batch (torch fp32 on the CPU: ~0.2 s per image)
+    overlaps = []
+    for b in (0, 9, 31, 40, 63):
+        semi_r, desc_r = S.forward(weights, S.preprocess_u8(batch64[b], True))
+        rel = np.linalg.norm(desc64[b] - desc_r[0], axis=0) / np.linalg.norm(desc_r[0], axis=0)
+        assert np.percentile(rel, 99) <= 1.5e-3, (b, np.percentile(rel, 99))
+        assert np.abs(semi64[b] - semi_r[0]).max() < 5e-3
+        xy, conf, _, _ = P.get_keypoints(semi_r[0], THR, MAXN)
+        ref = {tuple(p): i for i, p in enumerate(xy.tolist())}
+        got = res[b][0].astype(np.int32).tolist()
+        common = [(i, ref[tuple(p)]) for i, p in enumerate(got) if tuple(p) in ref]
+        overlaps.append(len(common) / len(ref))
+        d_r, _ = P.compute_descriptors(desc_r[0], xy, W, H, comp, mean)
+        gi, ri = zip(*common)
+        e = np.linalg.norm(res[b][1][list(gi)] - d_r[list(ri)], axis=1) / np.linalg.norm(d_r[list(ri)], axis=1)
+        assert np.percentile(e, 99) <= 1e-2, (b, np.percentile(e, 99))
+        # the post-processing itself is exact on the fp16 net's own heat map
+        xy16, conf16, _, _ = P.get_keypoints(semi64[b], THR, MAXN)
+        assert np.array_equal(res[b][0].astype(np.int32), xy16) and np.array_equal(res[b][2], conf16)
+    assert min(overlaps) >= 0.97, overlaps
+    big.close(); one.close()
+
+
+def test_mobilenetvlad_32_images_bit_identical_to_batch1_and_within_1e3_of_oracle(omni, ctx, batch64):
+    c = omni.capi
+    vw = V.synth_weights()
+    big = c.MobileNetVLAD(ctx, vw, V.layer_specs(), V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM, W, H, 32)
+    one = c.MobileNetVLAD(ctx, vw, V.layer_specs(), V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM, W, H, 1)
+    up = batch64[:32]
+    y = big.inference(up, fisheye_mask=True)
+    for b in range(32):
+        assert np.array_equal(one.inference(up[b], fisheye_mask=True)[0], y[b]), b
+    masked = up[[0, 13, 31]].copy()
+    masked[:, H * 3 // 4:] = 0
+    ref = V.forward(vw, masked)
+    rel = np.linalg.norm(y[[0, 13, 31]] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert rel.max() < 1e-3, rel
+    big.close(); one.close()
+
+
+def test_cam_unit_at_bench_shape_from_pinned_host(omni, ctx, batch64):
+    """omni_cam with n_dirs = 32 fed from pinned host memory (what bench.py times): same key points / descriptors / global descriptors as the
+    stand-alone handles on HBM-resident input, and the BF match lists of the oracle matcher on those descriptors."""
+    c = omni.capi
+    from omni_swarm_amd import frontend
+    weights, vw = S.synth_weights(0), V.synth_weights()
+    comp, mean = synth.pca()
+    cam = frontend.LoopCam(ctx, weights, comp, mean, vw, V.layer_specs(), (V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM), W, H, THR, MAXN, c.PREC_F16, n_dirs=32)
+    pinned = ctx.host_alloc(batch64.shape, np.uint8)
+    pinned[:] = batch64
+    cam.enqueue_host(pinned)
+    out = cam.fetch()
+    sp = c.SuperPoint(ctx, weights, comp, mean, W, H, THR, MAXN, c.PREC_F16, 64)
+    res = sp.inference(batch64, fisheye_mask=True)
+    vl = c.MobileNetVLAD(ctx, vw, V.layer_specs(), V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM, W, H, 32)
+    g = vl.inference(batch64[:32], fisheye_mask=True)
+    for d in range(32):
+        im = out["images"][d]
+        assert np.array_equal(im["landmarks_2d"], res[d][0]) and np.array_equal(im["feature_descriptor"], res[d][1])
+        assert np.array_equal(im["landmarks_2d_down"], res[32 + d][0]) and np.array_equal(im["feature_descriptor_down"], res[32 + d][1])
+        assert np.array_equal(im["image_desc"], g[d])
+        qi, ti, _ = M.bf_match(res[d][1], res[32 + d][1], 0)
+        assert np.array_equal(im["ids_up"], qi) and np.array_equal(im["ids_down"], ti)
+    # a second enqueue from the same pinned block gives the same bytes (no stale staging)
+    cam.enqueue_host(pinned)
+    out2 = cam.fetch()
+    assert all(np.array_equal(a["feature_descriptor"], b["feature_descriptor"]) and np.array_equal(a["image_desc"], b["image_desc"])
+               for a, b in zip(out["images"], out2["images"]))
+    ctx.host_free(pinned)
+    cam.close(); sp.close(); vl.close()
+
+
+def test_cpp_host_loop_equals_python_host_loop(omni, ctx, tmp_path):
+    """The C++ key-frame pipeline (host/keyframe_pipeline.hpp through libomni_host.so) against the Python LoopCam + LoopDetector loop on the
+    same 20 key frames (2 full micro-batches + a partial one of 4) over a pre-loaded database: same number of rows added, same loop
+    candidates."""
+    c = omni.capi
+    from omni_swarm_amd import detector, frontend, pipeline, weights
+    sp_w, vw = S.synth_weights(0), V.synth_weights()
+    comp, mean = synth.pca()
+    files = weights.write_pipeline_files(str(tmp_path), sp_w, comp, mean, vw, V.layer_specs(), c.VLAD_KINDS)
+    rng = np.random.default_rng(3)
+    db = rng.standard_normal((400, 4096), dtype=np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    # three micro-batch blocks; the pool is cycled so later key frames revisit earlier ones (loop candidates with score 1.0)
+    blocks = [_microbatch(7000), _microbatch(7000 + 64)]
+    tail = _microbatch(7000, mb=4)
+    pins = []
+    for b in blocks + [tail]:
+        p = ctx.host_alloc(b.shape, np.uint8)
+        p[:] = b
+        pins.append(p)
+    pl = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THR, MAXN, c.PREC_F16, MB, 2, c.STORE_F32,
+                                   1, 0.3, 0.2, 5, 30, 3)
+    pl.preload(db)
+    hits_cpp = pl.run(20, 0, [pins[0].ctypes.data, pins[1].ctypes.data], 0, pins[2].ctypes.data, True)
+    hits_cpp += pl.run(16, 20, [pins[0].ctypes.data, pins[1].ctypes.data], 0, None, True)
+    rows_cpp = pl.db_rows
+    pl.close()
+    # Python loop
+    det = detector.LoopDetector(ctx, 1, inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3)
+    det.local_index.add(db)
+    for i in range(len(db)):
+        det.imgid2fisheye[i] = -(i // 4) - 1
+        det.imgid2dir[i] = i % 4
+        det.fisheyeframe_database.setdefault(-(i // 4) - 1, detector.FisheyeFrameDescriptor(msg_id=-(i // 4) - 1))
+    hits_py, step = 0, 0
+    for blk, mb in ((pins[0], 8), (pins[1], 8), (pins[2], 4), (pins[0], 8), (pins[1], 8)):
+        cam = frontend.LoopCam(ctx, sp_w, comp, mean, vw, V.layer_specs(), (V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM), W, H, THR, MAXN, c.PREC_F16, n_dirs=4 * mb)
+        cam.enqueue_host(blk)
+        out = cam.fetch()
+        frames = []
+        for m in range(mb):
+            ims = out["images"][4 * m:4 * m + 4]
+            frames.append(detector.FisheyeFrameDescriptor(
+                msg_id=step + m, drone_id=1, landmark_num=int(sum(i["landmark_num"] for i in ims)),
+                images=[detector.ImageDescriptor(drone_id=1, landmark_num=i["landmark_num"], image_desc=i["image_desc"]) for i in ims]))
+        hits_py += sum(int(r["old_msg_id"] != -1) for r in det.on_images_recv_batch(frames, rows_dev=cam.vlad.dev_output()))
+        step += mb
+        cam.close()
+    assert rows_cpp == det.database_size() == 400 + 36 * 4
+    assert hits_cpp == hits_py and hits_py >= 16             # the second pass over blocks 0/1 revisits every key frame of the first
+    for p in pins:
+        ctx.host_free(p)

@@ -6,9 +6,10 @@ Tolerances (north_star: key points bit-exact after the fixed NMS ordering, descr
                 same key-point set as the oracle end-to-end, same order up to confidence ties below the fp32 noise
                 (bit-exact on the GPU's own heat map); 64-d descriptors 1e-4.
   OMNI_PREC_F16 (fp16 storage, fp32 accumulate -- the reference's own engines are fp16 TensorRT): dense descriptors
-                within 2e-3 relative L2 per cell at p99 (measured p50 1.0e-3, p99 1.3e-3); key-point set overlap with
-                the fp32 oracle >= 90 % (threshold / NMS decisions are discontinuous, fp16 noise flips borderline
-                candidates -- SURVEY.md section 7 "Hard parts").
+                within 1.5e-3 relative L2 per cell at p99 (measured p50 1.0e-3, p99 1.3e-3); key-point set overlap with
+                the fp32 oracle >= 97 % (measured 199/200; threshold / NMS decisions are discontinuous, fp16 noise flips borderline
+                candidates -- SURVEY.md section 7 "Hard parts").  The same gates at the benchmarked launch shape (64 images, threshold
+                0.02): tests/test_gpu_bench_shape.py.
 """
 import numpy as np
 import pytest
@@ -116,12 +117,12 @@ def test_f16_path_tolerances(omni, ctx):
     semi, desc = sp.get_dense(1)
     semi_r, desc_r = S.forward(weights, S.preprocess_u8(img))
     rel = np.linalg.norm(desc[0] - desc_r[0], axis=0) / np.linalg.norm(desc_r[0], axis=0)
-    assert np.percentile(rel, 99) < 2e-3, np.percentile(rel, 99)
+    assert np.percentile(rel, 99) <= 1.5e-3, np.percentile(rel, 99)        # measured 1.3e-3; the gate follows the measurement
     assert np.abs(semi - semi_r).max() < 5e-3
     xy, conf, _, _ = P.get_keypoints(semi_r[0], 0.015, 200)
     a = {tuple(p) for p in kps.astype(np.int32).tolist()}
     b = {tuple(p) for p in xy.tolist()}
-    assert len(a & b) >= 0.9 * len(b), len(a & b)
+    assert len(a & b) >= 0.97 * len(b), len(a & b)                           # measured 199/200
     # the post-processing itself is exact given the fp16 net's own heat map
     xy16, conf16, _, _ = P.get_keypoints(semi[0], 0.015, 200)
     assert np.array_equal(kps.astype(np.int32), xy16) and np.array_equal(sc, conf16)

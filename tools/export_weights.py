@@ -20,26 +20,17 @@ sys.path.insert(0, ROOT)
 
 
 def write_omnw(path, tensors: dict):
-    with open(path, "wb") as f:
-        f.write(b"OMNW1\0\0\0")
-        f.write(struct.pack("<I", len(tensors)))
-        for name, arr in tensors.items():
-            a = np.ascontiguousarray(arr, dtype="<f4")
-            nb = name.encode()
-            f.write(struct.pack("<I", len(nb)) + nb)
-            f.write(struct.pack("<I", a.ndim) + struct.pack(f"<{a.ndim}I", *a.shape))
-            f.write(a.tobytes())
+    import omni_loader
+    omni_loader.load()
+    from omni_swarm_amd import weights
+    weights.write_omnw(path, tensors)
 
 
-def vlad_tensors(weights, specs, kinds):
-    t = {"layers": np.array([[kinds[k], ci, co, s] for (_, k, ci, co, s) in specs], np.float32)}
-    for i, (name, *_rest) in enumerate(specs):
-        t[f"layer{i}.weight"] = weights[name + ".weight"]
-        t[f"layer{i}.bias"] = weights[name + ".bias"]
-    for k in ("vlad.assign.weight", "vlad.assign.bias", "vlad.clusters", "fc.weight", "fc.bias"):
-        t[k] = weights[k]
-    t["vlad.assign.weight"] = np.asarray(weights["vlad.assign.weight"]).reshape(weights["vlad.clusters"].shape)
-    return t
+def vlad_tensors(weights_dict, specs, kinds):
+    import omni_loader
+    omni_loader.load()
+    from omni_swarm_amd import weights
+    return weights.vlad_omnw_tensors(weights_dict, specs, kinds)
 
 
 def main(argv):
