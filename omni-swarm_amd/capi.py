@@ -168,13 +168,25 @@ class Context:
     """One HIP stream + scratch on one GPU (omni_ctx)."""
 
     def __init__(self, device_id: int = 0):
+        import weakref
         self.device_id = device_id
+        self._children = weakref.WeakSet()      # handles created on this context: closed before the context is (their destroy uses its stream)
         self.h = lib().omni_ctx_create(device_id)
         if not self.h:
             raise OmniError(f"omni_ctx_create failed: {lib().omni_last_error().decode()}")
 
+    def _adopt(self, child):
+        self._children.add(child)
+
     def close(self):
         if self.h:
+            for kind in ("Cam", None):              # omni_cam borrows the network handles: it goes first
+                for ch in list(self._children):
+                    if kind is None or type(ch).__name__ == kind:
+                        try:
+                            ch.close()
+                        except Exception:
+                            pass
             lib().omni_ctx_destroy(self.h)
             self.h = None
 
@@ -262,6 +274,7 @@ class SuperPoint:
                                       precision, max_batch)
         if not self.h:
             raise OmniError(f"omni_sp_create failed: {lib().omni_last_error().decode()}")
+        ctx._adopt(self)
         self.desc_dim = lib().omni_sp_desc_dim(self.h)
 
     def close(self):
@@ -359,6 +372,7 @@ class MobileNetVLAD:
         self.h = lib().omni_vlad_create(ctx.h, C.byref(vw), width, height, max_batch)
         if not self.h:
             raise OmniError(f"omni_vlad_create failed: {lib().omni_last_error().decode()}")
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -401,6 +415,7 @@ class IndexFlatIP:
         self.h = lib().omni_index_create(ctx.h, d, storage, capacity)
         if not self.h:
             raise OmniError(f"omni_index_create failed: {lib().omni_last_error().decode()}")
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -532,6 +547,8 @@ class Cam:
         self.h = lib().omni_cam_create(sp.ctx.h, sp.h, vlad.ctx.h, vlad.h, n_dirs, sp.max_num, global_dim, bf_mode)
         if not self.h:
             raise OmniError(f"omni_cam_create failed: {lib().omni_last_error().decode()}")
+        sp.ctx._adopt(self)
+        vlad.ctx._adopt(self)
         self._res = _CamResult()
 
     def close(self):

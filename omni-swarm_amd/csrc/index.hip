@@ -97,6 +97,65 @@ ip_scan_kernel(const T* __restrict__ db, int64_t n_rows, int dim, const float* _
     }
 }
 
+// fp32 shard, QB >= 4 queries (a micro-batch of key frames against a big database): the query block fills the CU's LDS (QB x 16 KB), so
+// only one workgroup = one wave per SIMD fits and the one-row-per-wave kernel above cannot keep enough loads in flight (measured 1.4 TB/s
+// at 8 queries x 400k rows).  Here a wave walks R rows at once: R x (unroll) 16-byte loads per lane in flight, and every query float4
+// read from LDS feeds R rows (LDS traffic / R).  Per row the lane-local fmaf chain and the wave reduction are those of ip_scan_kernel:
+// scores are bit-identical to the single-query path.
+template <int QB, int R>
+__global__ void __launch_bounds__(SCAN_THREADS)
+ip_scan_rows_kernel(const float* __restrict__ db, int64_t n_rows, int dim, const float* __restrict__ queries,
+                    uint64_t* __restrict__ keys, int64_t key_stride, ScanLimits<SCAN_MAX_QB> lim) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sq = reinterpret_cast<float*>(smem_raw);             // [QB][dim]
+    for (int i = threadIdx.x * 4; i < QB * dim; i += SCAN_THREADS * 4)
+        *reinterpret_cast<float4*>(sq + i) = *reinterpret_cast<const float4*>(queries + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_groups = (n_rows + R - 1) / R;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    for (int64_t g = (int64_t)blockIdx.x * SCAN_WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * SCAN_WAVES) {
+        const float* rp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = g * R + r;
+            rp[r] = db + (row < n_rows ? row : n_rows - 1) * dim + lane * 4;      // rows past the end re-read the last one (not written)
+        }
+        float acc[R][QB];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < QB; ++q) acc[r][q] = 0.f;
+#pragma unroll 2
+        for (int c = 0; c < dim; c += 64 * 4) {
+            f32x4_t x[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[r] = NT_LOAD(reinterpret_cast<const f32x4_t*>(rp[r] + c));
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const float4 qq = *reinterpret_cast<const float4*>(sq + q * dim + lane * 4 + c);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[r][q] = fmaf(x[r][0], qq.x, acc[r][q]);
+                    acc[r][q] = fmaf(x[r][1], qq.y, acc[r][q]);
+                    acc[r][q] = fmaf(x[r][2], qq.z, acc[r][q]);
+                    acc[r][q] = fmaf(x[r][3], qq.w, acc[r][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = g * R + r;
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const float s = wave_sum(acc[r][q]);
+                if (lane == 0 && row < n_rows) keys[(int64_t)q * key_stride + row] = row < lim.v[q] ? omni_make_key(s, (uint32_t)row) : OMNI_KEY_EMPTY;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Batched search (BASELINE config 5: 64 concurrent key frames against an fp16 shard).  The VALU scans are compute bound beyond
 // a handful of queries (64 queries x 4096 FMAs per row); here the dot products run on the matrix cores and the kernel is back on the
@@ -457,6 +516,28 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, 
     int grid = (int)(want < (int64_t)cus * 8 ? want : (int64_t)cus * 8);
     if (grid < 1) grid = 1;
     size_t smem = (size_t)qb * ix->dim * sizeof(float);
+    static const int rows_min_qb = getenv("OMNI_SCAN_ROWS_MIN") ? atoi(getenv("OMNI_SCAN_ROWS_MIN")) : 4;
+    if (!f16 && qb >= rows_min_qb && qb >= 4) {
+        constexpr int R = 4;
+        int64_t want_g = cdiv64(cdiv64(n, R), SCAN_WAVES);
+        int grid_g = (int)(want_g < (int64_t)cus * 8 ? want_g : (int64_t)cus * 8);
+        if (grid_g < 1) grid_g = 1;
+#define OMNI_ROWS_CASE(QB)                                                                                              \
+    case QB: {                                                                                                          \
+        auto kf = ip_scan_rows_kernel<QB, R>;                                                                           \
+        static size_t attr = 0;                                                                                         \
+        if (attr < smem) { OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = smem; } \
+        hipLaunchKernelGGL(kf, dim3(grid_g), dim3(SCAN_THREADS), smem, st, reinterpret_cast<const float*>(ix->db), n, ix->dim, q_dev, keys,  \
+                           key_stride, lim);                                                                            \
+        break; }
+        switch (qb) {
+            OMNI_ROWS_CASE(4) OMNI_ROWS_CASE(5) OMNI_ROWS_CASE(6) OMNI_ROWS_CASE(7) OMNI_ROWS_CASE(8)
+            default: set_error("internal: bad query block %d", qb); return OMNI_ERR_INVALID;
+        }
+#undef OMNI_ROWS_CASE
+        OMNI_LAUNCH_CHECK();
+        return OMNI_OK;
+    }
 #define OMNI_SCAN_CASE(QB)                                                                                              \
     case QB:                                                                                                            \
         if (f16)                                                                                                        \

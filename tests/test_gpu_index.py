@@ -286,3 +286,81 @@ def test_full_size_properties_100k_rows(omni, ctx):
     D2, I2 = idx.search(q, 10)
     assert np.array_equal(I, I2) and np.array_equal(D, D2)
     assert idx.last_scan_ms() > 0
+
+
+@pytest.mark.parametrize("storage,nq", [("f32", 8), ("f32", 3), ("f16", 8), ("f16", 2), ("f16", 40)])
+def test_batch_prefix_search_equals_one_prefix_search_per_query(omni, ctx, storage, nq):
+    """omni_index_search_batch_prefix_dev (one pass over the shard for a micro-batch of key frames, per-query row limits, queries gathered
+    out of a row buffer) == nq separate omni_index_search_prefix_dev calls == the oracle on the truncated database -- including empty
+    prefixes, limits beyond ntotal, and limits inside the last 16-row block of the fp16 layout."""
+    c = omni.capi
+    rng = np.random.default_rng(77)
+    n, k = 5003, 10
+    db = rng.standard_normal((n, DIM)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    idx = c.IndexFlatIP(ctx, DIM, c.STORE_F16 if storage == "f16" else c.STORE_F32)
+    idx.add(db)
+    ref_db = db.astype(np.float16).astype(np.float32) if storage == "f16" else db
+    rows = rng.standard_normal((4 * nq, DIM)).astype(np.float32)
+    rows[1::4] = db[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, DIM)).astype(np.float32)    # the queried direction: row 4j+1
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    row_idx = [4 * j + 1 for j in range(nq)]
+    limits = [int(x) for x in rng.integers(1, n, nq)]
+    limits[0] = 0
+    limits[-1] = n + 50
+    if nq > 2:
+        limits[1] = 4993          # inside a 16-row block
+    rows_dev = ctx.to_device(rows)
+    buf = ctx.alloc(nq * k * 12)
+    idx.search_batch_prefix_dev(rows_dev, row_idx, k, limits, buf + nq * k * 8, buf)
+    raw = ctx.from_device(buf, (nq * k * 12,), np.uint8)
+    I = raw[:nq * k * 8].view(np.int64).reshape(nq, k)
+    D = raw[nq * k * 8:].view(np.float32).reshape(nq, k)
+    one = ctx.alloc(k * 12)
+    for j in range(nq):
+        lim = min(limits[j], n)
+        if lim == 0:
+            assert (I[j] == -1).all() and (D[j] < -1e38).all()
+            continue
+        idx.search_prefix_dev(1, rows_dev + row_idx[j] * DIM * 4, k, lim, one + k * 8, one)
+        r1 = ctx.from_device(one, (k * 12,), np.uint8)
+        if storage == "f32" or nq < 4:                 # same scan kernel family: same bits
+            assert np.array_equal(I[j], r1[:k * 8].view(np.int64)) and np.allclose(D[j], r1[k * 8:].view(np.float32), rtol=1e-6, atol=1e-7)
+        Dr, Ir = M.ip_search(ref_db[:lim], rows[row_idx[j]][None], k)
+        assert np.array_equal(I[j], Ir[0]) and np.allclose(D[j], Dr[0], rtol=1e-5, atol=2e-6)
+    for p in (rows_dev, buf, one):
+        ctx.free(p)
+
+
+def test_truncate_and_corrupt_snapshot(omni, ctx, tmp_path):
+    c = omni.capi
+    rng = np.random.default_rng(5)
+    db = rng.standard_normal((300, DIM)).astype(np.float32)
+    idx = c.IndexFlatIP(ctx, DIM)
+    idx.add(db)
+    idx.truncate(200)
+    assert idx.ntotal == 200
+    D, I = idx.search(db[250][None], 3)
+    assert (I < 200).all()
+    idx.add(db[200:210] * 2)
+    D, I = idx.search(db[205][None] , 1)
+    assert I[0, 0] == 205
+    with pytest.raises(c.OmniError):
+        idx.truncate(1000)
+    path = str(tmp_path / "snap.omnx")
+    idx.save(path)
+    raw = bytearray(open(path, "rb").read())
+    # header claims far more rows than the file holds: rejected BEFORE anything is allocated, handle untouched (ADVICE r1)
+    bad = bytearray(raw)
+    bad[16:24] = (1 << 40).to_bytes(8, "little")
+    open(path + ".bad", "wb").write(bad)
+    with pytest.raises(c.OmniError):
+        idx.load(path + ".bad")
+    open(path + ".short", "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(c.OmniError):
+        idx.load(path + ".short")
+    assert idx.ntotal == 210
+    D2, I2 = idx.search(db[205][None], 1)
+    assert I2[0, 0] == 205
+    idx.load(path)
+    assert idx.ntotal == 210
