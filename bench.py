@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--big-db-keyframes", type=int, default=100_000, help="key frames (x4 rows) of the big-database throughput legs; 0 = skip")
     ap.add_argument("--big-db-steps", type=int, default=64, help="key frames per timed region of the big-database legs")
     ap.add_argument("--f32-steps", type=int, default=16, help="key frames of the f32-precision leg (value_f32); 0 = skip")
+    ap.add_argument("--geometry-steps", type=int, default=64, help="key frames of the leg with the geometric verification stage on (with_geometry); 0 = skip")
     ap.add_argument("--python-steps", type=int, default=64, help="key frames of the Python-host leg (python_host); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-keyframes", type=int, default=4, help="key frames timed on the host cores for cpu_baseline")
@@ -222,9 +223,9 @@ def main():
                 "ms_per_step_minmax": [round(min(dts) / steps * 1e3, 4), round(max(dts) / steps * 1e3, 4)]}
 
     # ---- the C++ host loop (N = 1) ------------------------------------------------------------------------------------------------
-    def cpp_leg(precision, storage, db_rows, steps, warmup, min_time):
+    def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False):
         pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, MB,
-                                       args.pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3)
+                                       args.pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
         gen = RowFactory(7 + rank)
         for s in range(0, db_rows, 32768):
             pl.preload(gen.rows(min(32768, db_rows - s)))
@@ -242,6 +243,9 @@ def main():
         dts = timed_regions(run, pl.sync, steps, warmup, min_time)
         out = summarize(dts, steps)
         out.update(db_rows_start=db_rows, db_rows_end=int(pl.db_rows), loop_candidates_found=state["hits"])
+        if geometry:
+            calls, edges = pl.geometry_stats()
+            out.update(compute_loop_calls=calls, loop_edges=edges)
         pl.close()
         return out
 
@@ -340,8 +344,13 @@ def main():
     kfps = main_leg["value"]
 
     # ---- comparison legs (N = 1 only; bounded) ----------------------------------------------------------------------------------------
-    python_host = value_f32 = db100k = None
+    python_host = value_f32 = db100k = with_geometry = None
     if world == 1:
+        if cpp_host and args.geometry_steps > 0:
+            n = max(MB, args.geometry_steps // MB * MB)
+            with_geometry = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, n, MB * args.pipelines, min(args.min_time, 0.5), geometry=True)
+            with_geometry.update(steps=n, note="same loop + the host geometry stage per candidate (lifting, up/down triangulation, BF + homography-RANSAC "
+                                               "mask, PnP-RANSAC; f64 on one host thread).  The synthetic images share no 3-D scene: candidates are rejected")
         if cpp_host and args.python_steps > 0:
             pyloop = PythonLoop(prec)
             n = max(MB, args.python_steps // MB * MB)
@@ -474,7 +483,7 @@ def main():
             "gflop_per_keyframe_superpoint": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
             "achieved_tflops_end_to_end": round(kfps * SP_FLOP_PER_IMAGE * KF_IMAGES / 1e12 / world, 1),
             "roofline": roofline, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
-            "db100k": db100k, "value_f32": value_f32, "python_host": python_host, "parity": parity, "cpu_baseline": cpu,
+            "db100k": db100k, "with_geometry": with_geometry, "value_f32": value_f32, "python_host": python_host, "parity": parity, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

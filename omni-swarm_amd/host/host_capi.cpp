@@ -20,14 +20,15 @@ const char* omni_pipeline_last_error(void) { return g_err.c_str(); }
 omni_pipeline* omni_pipeline_create(int device, const char* sp_weights, const char* pca_comp_csv, const char* pca_mean_csv, const char* vlad_weights,
                                     int width, int height, float thres, int max_num, int precision, int microbatch, int pipelines, int storage,
                                     int self_id, double inner_product_thres, double init_mode_product_thres, int match_index_dist, int min_loop_num,
-                                    int min_direction_loop) {
+                                    int min_direction_loop, int geometry) {
     try {
         omni::KeyframePipeline::Config c;
         c.device = device; c.sp_weights = sp_weights; c.pca_comp = pca_comp_csv ? pca_comp_csv : ""; c.pca_mean = pca_mean_csv ? pca_mean_csv : "";
         c.vlad_weights = vlad_weights; c.width = width; c.height = height; c.thres = thres; c.max_num = max_num; c.precision = precision;
         c.microbatch = microbatch; c.pipelines = pipelines; c.storage = storage; c.self_id = self_id;
         c.inner_product_thres = inner_product_thres; c.init_mode_product_thres = init_mode_product_thres; c.match_index_dist = match_index_dist;
-        c.min_loop_num = min_loop_num; c.min_direction_loop = min_direction_loop;
+        c.min_loop_num = min_loop_num; c.min_direction_loop = min_direction_loop; c.geometry = geometry != 0;
+        c.cx = width / 2.0; c.cy = height / 2.0; c.fx = c.fy = width / 2.0;      // 90 degree horizontal field of view
         return new omni_pipeline{new omni::KeyframePipeline(c)};
     } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
@@ -57,6 +58,14 @@ int omni_pipeline_run(omni_pipeline* h, int n_keyframes, int64_t first_msg_id, c
 // allocates whatever a later omni_pipeline_run(h, n_keyframes, ...) would allocate on first use (the unit for a partial micro-batch)
 int omni_pipeline_prepare(omni_pipeline* h, int n_keyframes) {
     try { h->p->prepare(n_keyframes); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// must be called before the first run: switches the geometric verification stage on (host/loop_geometry.hpp) with a pinhole model for the
+// flattened views.  omni_pipeline_geometry_stats: candidates handed to compute_loop / loop edges accepted so far.
+int omni_pipeline_geometry_stats(omni_pipeline* h, int* compute_loop_calls, int* edges) {
+    if (compute_loop_calls) *compute_loop_calls = h->p->geometry_calls();
+    if (edges) *edges = (int)h->p->edges().size();
+    return 0;
 }
 
 int omni_pipeline_sync(omni_pipeline* h) {

@@ -9,6 +9,7 @@
 #include <deque>
 #include <memory>
 
+#include "loop_geometry.hpp"
 #include "omni_swarm.hpp"
 
 namespace omni {
@@ -22,12 +23,35 @@ public:
         double inner_product_thres = 0.3, init_mode_product_thres = 0.2;
         int match_index_dist = 5, min_loop_num = 30, min_direction_loop = 3;
         std::string sp_weights, pca_comp, pca_mean, vlad_weights;
+        // geometric verification (f64, host): lift the key points of the flattened pinhole views, triangulate up/down matches
+        // (loop_cam.cpp:397-444, 558-569) and hand every candidate to LoopGeometry::compute_loop (loop_detector.cpp:627-836)
+        bool geometry = false;
+        double fx = 300, fy = 300, cx = 300, cy = 240, triangle_thres = 0.006, stereo_baseline = 0.10;
+        int accept_min_3d_pts = 50;
     };
 
     explicit KeyframePipeline(const Config& c) : cfg_(c), index_ctx_(c.device), det_(index_ctx_, c.self_id, c.storage) {
         det_.INNER_PRODUCT_THRES = c.inner_product_thres; det_.INIT_MODE_PRODUCT_THRES = c.init_mode_product_thres;
         det_.MATCH_INDEX_DIST = c.match_index_dist; det_.MIN_LOOP_NUM = c.min_loop_num; det_.MIN_DIRECTION_LOOP = c.min_direction_loop;
         for (int p = 0; p < c.pipelines; ++p) lanes_.push_back(std::make_unique<Lane>(c, c.microbatch));
+        if (c.geometry) {
+            geo_.self_id = c.self_id; geo_.MIN_LOOP_NUM = c.min_loop_num; geo_.MIN_DIRECTION_LOOP = c.min_direction_loop;
+            geo_.match = [this](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) { bf_.match(q, nq, t, nt, dim, out); };
+            auto inner = geo_.as_callback([this](const LoopEdge& e) { edges_.push_back(e); });
+            det_.compute_loop = [this, inner](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) { ++geometry_calls_; return inner(a, b, da, db, im); };
+        }
+    }
+    int geometry_calls() const { return geometry_calls_; }
+    const std::vector<LoopEdge>& edges() const { return edges_; }
+    // extrinsics of the virtual pinhole views of the stacked fisheye pair: direction d looks along the body x axis rotated by 90 deg * d,
+    // the up / down cameras sit +- baseline/2 along body z (camera axes: x right, y down, z forward)
+    geom::Pose view_extrinsic(int direction, bool up) const {
+        const double yaw = M_PI / 2 * direction, c = std::cos(yaw), s = std::sin(yaw);
+        geom::Mat3 R;            // Rz(yaw) * [[0,0,1],[-1,0,0],[0,-1,0]]
+        R.m[0][0] = s;  R.m[0][1] = 0;  R.m[0][2] = c;
+        R.m[1][0] = -c; R.m[1][1] = 0;  R.m[1][2] = s;
+        R.m[2][0] = 0;  R.m[2][1] = -1; R.m[2][2] = 0;
+        return {{0, 0, (up ? 0.5 : -0.5) * cfg_.stereo_baseline}, geom::quat_from_R(R)};
     }
 
     LoopDetectorCore& detector() { return det_; }
@@ -114,9 +138,24 @@ private:
                 im.landmarks_2d.resize(im.landmark_num);
                 for (int k = 0; k < im.landmark_num; ++k) im.landmarks_2d[k] = {r.kps_xy[((size_t)i * M + k) * 2], r.kps_xy[((size_t)i * M + k) * 2 + 1]};
                 f.landmark_num += im.landmark_num;
+                if (cfg_.geometry) {
+                    // the stereo half of generate_stereo_image_descriptor (loop_cam.cpp:341-454): the down image of this direction, lifting, triangulation
+                    ImageDescriptor down;
+                    const int j = n + i, nd = r.n_kps[j];
+                    down.landmarks_2d.resize(nd);
+                    for (int k = 0; k < nd; ++k) down.landmarks_2d[k] = {r.kps_xy[((size_t)j * M + k) * 2], r.kps_xy[((size_t)j * M + k) * 2 + 1]};
+                    auto lift = [&](ImageDescriptor& x) {
+                        x.landmarks_2d_norm.resize(x.landmarks_2d.size());
+                        for (size_t k = 0; k < x.landmarks_2d.size(); ++k) x.landmarks_2d_norm[k] = {(float)((x.landmarks_2d[k].x - cfg_.cx) / cfg_.fx), (float)((x.landmarks_2d[k].y - cfg_.cy) / cfg_.fy)};
+                    };
+                    lift(im); lift(down);
+                    im.pose_drone = down.pose_drone = f.pose_drone;
+                    im.camera_extrinsic = to_msg(view_extrinsic(d, true)); down.camera_extrinsic = to_msg(view_extrinsic(d, false));
+                    im.direction = d;
+                    fill_stereo_landmarks(im, down, r.match_up + (size_t)i * M, r.match_down + (size_t)i * M, r.n_matches[i], cfg_.triangle_thres, cfg_.accept_min_3d_pts);
+                }
             }
         }
-        (void)n;
         int hits = 0;
         for (auto& c : det_.on_images_recv_batch(frames_, lane.rows_dev)) hits += c.found ? 1 : 0;
         return hits;
@@ -125,6 +164,10 @@ private:
     Config cfg_;
     Context index_ctx_;
     LoopDetectorCore det_;
+    BFMatcherL2X bf_{index_ctx_};
+    LoopGeometry geo_;
+    std::vector<LoopEdge> edges_;
+    int geometry_calls_ = 0;
     std::vector<std::unique_ptr<Lane>> lanes_;
     std::map<int, std::unique_ptr<Lane>> tail_lanes_;
     std::vector<FisheyeFrameDescriptor> frames_;

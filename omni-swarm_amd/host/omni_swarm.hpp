@@ -348,16 +348,31 @@ private:
 };
 
 // ---- LoopDetector's database and decision rules (loop_detector.cpp:11-287), POD messages instead of swarm_msgs -------
-struct ImageDescriptor {                         // ImageDescriptor_t, fields used on this path
-    int drone_id = 0, landmark_num = 0;
-    std::vector<float> image_desc;               // 4096
-    std::vector<float> feature_descriptor;       // n x 64
-    std::vector<Point2f> landmarks_2d;
+struct Point3f { float x = 0, y = 0, z = 0; };
+struct PoseMsg { double position[3] = {0, 0, 0}; double quat_wxyz[4] = {1, 0, 0, 0}; };     // Pose_t as fromROSPose fills it (loop_cam.cpp:366-368)
+// ImageDescriptor_t (swarm_msgs, un-vendored): every field the reference reads or writes on this path -- loop_cam.cpp:529-585 (extractor),
+// :362-374,:434-440 (stereo part), loop_net.cpp:51-79,206-218 (wire split / reassembly), loop_detector.cpp:539-603 (matching)
+struct ImageDescriptor {
+    int drone_id = 0, landmark_num = 0, direction = 0;
+    int64_t msg_id = 0, frame_id = 0;
+    double timestamp = 0;                        // Time_t (sec, nsec) as seconds
+    bool prevent_adding_db = false;
+    std::vector<float> image_desc;               // 4096 (image_desc_size)
+    std::vector<float> feature_descriptor;       // n x 64 (feature_descriptor_size)
+    std::vector<Point2f> landmarks_2d;           // pixel key points
+    std::vector<Point2f> landmarks_2d_norm;      // camodocal liftProjective -> (x/z, y/z) (loop_cam.cpp:558-569)
+    std::vector<Point3f> landmarks_3d;           // triangulated, drone world frame (loop_cam.cpp:434-440); (0,0,0) when flag == 0
+    std::vector<uint8_t> landmarks_flag;         // 1 = has a 3-D point
+    PoseMsg pose_drone, camera_extrinsic;
+    int image_width = 0, image_height = 0;
+    std::vector<uint8_t> image;                  // optional JPEG (encode_image, loop_cam.cpp:49-71), opaque here
 };
 struct FisheyeFrameDescriptor {                  // FisheyeFrameDescriptor_t
     int64_t msg_id = 0;
-    int drone_id = 0, landmark_num = 0;
+    int drone_id = 0, landmark_num = 0, image_num = 0;
+    double timestamp = 0;
     bool prevent_adding_db = false;
+    PoseMsg pose_drone;
     std::vector<ImageDescriptor> images;
 };
 struct LoopCandidate { bool found = false; int64_t old_msg_id = -1; int image_id = -1, direction_new = -1, direction_old = -1; double distance = -1; bool added = false, queried = false, loop = false; };

@@ -16,7 +16,7 @@ from . import capi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
-           "omni_pipeline_run", "omni_pipeline_prepare", "omni_pipeline_sync"]
+           "omni_pipeline_run", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync"]
 _lib = None
 
 
@@ -30,7 +30,8 @@ def lib():
         L.omni_pipeline_last_error.restype = C.c_char_p
         L.omni_pipeline_create.restype = C.c_void_p
         L.omni_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int,
-                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.omni_pipeline_geometry_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.omni_pipeline_destroy.argtypes = [C.c_void_p]
         L.omni_pipeline_destroy.restype = None
         L.omni_pipeline_preload.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64]
@@ -51,12 +52,12 @@ def _err(what):
 class KeyframePipeline:
     def __init__(self, device: int, sp_weights_path: str, pca_comp_csv: str, pca_mean_csv: str, vlad_weights_path: str, width=600, height=480,
                  thres=0.02, max_num=200, precision=capi.PREC_F16, microbatch=8, pipelines=2, storage=capi.STORE_F32, self_id=1,
-                 inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3):
+                 inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3, geometry=False):
         self.microbatch = microbatch
         self.h = lib().omni_pipeline_create(device, sp_weights_path.encode(), pca_comp_csv.encode(), pca_mean_csv.encode(),
                                             vlad_weights_path.encode(), width, height, thres, max_num, precision, microbatch, pipelines, storage,
                                             self_id, inner_product_thres, init_mode_product_thres, match_index_dist, min_loop_num,
-                                            min_direction_loop)
+                                            min_direction_loop, int(geometry))
         if not self.h:
             raise _err("omni_pipeline_create")
 
@@ -91,6 +92,12 @@ class KeyframePipeline:
     def prepare(self, n_keyframes: int):
         if lib().omni_pipeline_prepare(self.h, n_keyframes):
             raise _err("omni_pipeline_prepare")
+
+    def geometry_stats(self):
+        """(candidates handed to compute_loop, loop edges accepted)"""
+        a, b = C.c_int(0), C.c_int(0)
+        lib().omni_pipeline_geometry_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def sync(self):
         if lib().omni_pipeline_sync(self.h):

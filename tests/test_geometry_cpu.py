@@ -1,0 +1,217 @@
+"""Host geometry (omni-swarm_amd/host/geometry.hpp, loop_geometry.hpp: triangulation + 3-D flags, homography-RANSAC mask, PnP-RANSAC,
+compute_loop -> LoopEdge; loop_cam.cpp:73-106,397-444, loop_detector.cpp:295-836) against the numpy oracle (oracle/geometry_ref.py: LAPACK
+instead of the product's Jacobi sweeps) and against the ground truth of seeded synthetic stereo-fisheye scenes.  CPU only: g++ builds
+tests/cpp/geometry_check.cpp, which talks a text protocol; the descriptor matcher there is the oracle's cv::BFMatcher restatement."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import geometry_ref as G
+from oracle import match_ref as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F, CX, CY = 300.0, 300.0, 240.0          # 600 x 480 virtual pinhole views with a 90 degree horizontal field of view
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("geom") / "geometry_check")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-o", out, os.path.join(ROOT, "tests", "cpp", "geometry_check.cpp"),
+                           "-L", os.path.join(ROOT, "oracle"), "-loracle", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}"])
+    return out
+
+
+def run(exe, text):
+    r = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return [ln.split() for ln in r.stdout.strip().split("\n")]
+
+
+def fmt(*arrs):
+    return " ".join(repr(float(x)) for a in arrs for x in np.asarray(a, np.float64).reshape(-1))
+
+
+def fpose(p):
+    return fmt(p[0], p[1])
+
+
+def rpy_quat(roll, pitch, yaw):
+    return G.qmul(G.qmul(G.q_from_yaw(yaw), np.array([math.cos(pitch / 2), 0, math.sin(pitch / 2), 0])), np.array([math.cos(roll / 2), math.sin(roll / 2), 0, 0]))
+
+
+R_BC = np.array([[0.0, 0, 1], [-1, 0, 0], [0, -1, 0]])       # camera (x right, y down, z forward) in the body (x forward, y left, z up)
+
+
+def extrinsics(direction, up):
+    yaw = math.pi / 2 * direction
+    Rz = np.array([[math.cos(yaw), -math.sin(yaw), 0], [math.sin(yaw), math.cos(yaw), 0], [0, 0, 1]])
+    return G.pose([0.0, 0.0, 0.05 if up else -0.05], G.q_from_R(Rz @ R_BC))
+
+
+def observe(world_pts, desc, pose_drone, ext, rng, max_num=200, desc_noise=0.05):
+    """Project landmarks into one virtual camera: integer pixel key points (as SuperPoint gives them), normalised points lifted from the
+    pixels, noisy unit descriptors.  Returns dict + the landmark id of every key point."""
+    cam = G.pmul(pose_drone, ext)
+    pc = (world_pts - cam[0]) @ G.qR(cam[1])                    # R^T (X - t)
+    vis = np.nonzero((pc[:, 2] > 0.3) & (np.abs(pc[:, 0] / pc[:, 2]) < 0.98) & (np.abs(pc[:, 1] / pc[:, 2]) < 0.78))[0]
+    vis = vis[:max_num]
+    px = np.rint(np.stack([F * pc[vis, 0] / pc[vis, 2] + CX, F * pc[vis, 1] / pc[vis, 2] + CY], 1))
+    norm = np.stack([(px[:, 0] - CX) / F, (px[:, 1] - CY) / F], 1)
+    d = desc[vis] + desc_noise * rng.standard_normal((len(vis), 64))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return {"landmark_num": len(vis), "camera_extrinsic": ext, "landmarks_2d": px.astype(np.float32).astype(np.float64), "landmarks_2d_norm": norm.astype(np.float32).astype(np.float64),
+            "feature_descriptor": d, "landmarks_3d": np.zeros((len(vis), 3)), "landmarks_flag": np.zeros(len(vis), np.uint8)}, vis
+
+
+def make_frame(world_pts, desc, pose_drone, msg_id, drone_id, rng, triangle_thres=0.006):
+    images = []
+    for d in range(4):
+        up, _ = observe(world_pts, desc, pose_drone, extrinsics(d, True), rng)
+        down, _ = observe(world_pts, desc, pose_drone, extrinsics(d, False), rng)
+        qi, ti, _ = M.bf_match(up["feature_descriptor"], down["feature_descriptor"], 0)
+        cnt, l3u, fu, _, _ = G.stereo_landmarks(pose_drone, up["camera_extrinsic"], down["camera_extrinsic"], up["landmarks_2d_norm"], down["landmarks_2d_norm"],
+                                                qi, ti, triangle_thres)
+        up["landmarks_3d"], up["landmarks_flag"] = l3u.astype(np.float32).astype(np.float64), fu
+        up["stereo"] = (down, qi, ti, cnt)
+        images.append(up)
+    return {"msg_id": msg_id, "drone_id": drone_id, "timestamp": 100.0 + msg_id, "pose_drone": pose_drone, "images": images,
+            "landmark_num": int(sum(i["landmark_num"] for i in images))}
+
+
+def frame_text(f):
+    out = [f"{f['msg_id']} {f['drone_id']} {f['timestamp']!r} {f['landmark_num']} {fpose(f['pose_drone'])} {len(f['images'])}"]
+    for im in f["images"]:
+        out.append(f"{im['landmark_num']} {fpose(im['camera_extrinsic'])}")
+        for i in range(im["landmark_num"]):
+            out.append(f"{fmt(im['landmarks_2d'][i], im['landmarks_2d_norm'][i], im['landmarks_3d'][i])} {int(im['landmarks_flag'][i])} {fmt(im['feature_descriptor'][i])}")
+    return "\n".join(out)
+
+
+@pytest.fixture(scope="module")
+def scene():
+    rng = np.random.default_rng(2026)
+    n = 1500
+    dirs = rng.standard_normal((n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    pts = dirs * rng.uniform(2.0, 7.0, (n, 1)) + np.array([0, 0, 1.0])
+    desc = rng.standard_normal((n, 64))
+    desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+    pose_old = G.pose([0.0, 0.0, 1.0], rpy_quat(0.01, -0.02, 0.10))
+    pose_new = G.pose([0.35, -0.25, 1.08], rpy_quat(-0.015, 0.01, 0.42))
+    return {"pts": pts, "desc": desc, "pose_old": pose_old, "pose_new": pose_new,
+            "old": make_frame(pts, desc, pose_old, 7, 1, rng), "new": make_frame(pts, desc, pose_new, 9, 1, rng), "rng": rng}
+
+
+def test_cv_rng_sequence(exe):
+    r = G.CvRng()
+    assert [int(x) for x in run(exe, "rng 40")[0][1:]] == [r.uniform(0, 1000) for _ in range(40)]
+
+
+def test_triangulate_point(exe):
+    rng = np.random.default_rng(1)
+    cases, text = [], ["tri 60"]
+    for _ in range(60):
+        X = rng.uniform(-3, 3, 3) + np.array([0, 0, 6.0])
+        a = G.pose(rng.uniform(-0.2, 0.2, 3), rpy_quat(*rng.uniform(-0.1, 0.1, 3)))
+        b = G.pose(rng.uniform(-0.2, 0.2, 3) + np.array([0, 0.1, 0]), rpy_quat(*rng.uniform(-0.1, 0.1, 3)))
+        pa, pb = (X - a[0]) @ G.qR(a[1]), (X - b[0]) @ G.qR(b[1])
+        p0, p1 = pa[:2] / pa[2] + rng.normal(0, 1e-4, 2), pb[:2] / pb[2] + rng.normal(0, 1e-4, 2)
+        cases.append((a, b, p0, p1, X))
+        text.append(f"{fpose(a)} {fpose(b)} {fmt(p0, p1)}")
+    out = run(exe, "\n".join(text))
+    for (a, b, p0, p1, X), ln in zip(cases, out):
+        err, Xr = G.triangulate_point(a[1], a[0], b[1], b[0], p0, p1)
+        got = np.array(ln[1:], np.float64)
+        assert abs(got[0] - err) < 1e-9 and np.abs(got[1:] - Xr).max() < 1e-7 * max(1.0, np.abs(Xr).max())
+        assert np.linalg.norm(got[1:] - X) < 0.2                      # 1e-4 noise at a 0.1-0.3 m baseline, 6 m away
+
+
+def test_stereo_landmarks_and_flags(exe, scene):
+    f = scene["new"]
+    n3d = 0
+    for d in range(4):
+        up = f["images"][d]
+        down, qi, ti, cnt = up["stereo"]
+        text = (f"stereo {fpose(f['pose_drone'])} {fpose(up['camera_extrinsic'])} {fpose(down['camera_extrinsic'])} {up['landmark_num']} {down['landmark_num']} "
+                f"{len(qi)} 0.006\n{fmt(up['landmarks_2d_norm'])}\n{fmt(down['landmarks_2d_norm'])}\n" + " ".join(f"{a} {b}" for a, b in zip(qi, ti)))
+        out = run(exe, text)
+        c, l3u, fu, l3d, fd = G.stereo_landmarks(f["pose_drone"], up["camera_extrinsic"], down["camera_extrinsic"], up["landmarks_2d_norm"], down["landmarks_2d_norm"], qi, ti, 0.006)
+        assert int(out[0][1]) == c == cnt
+        got = np.array(out[0][2:], np.float64).reshape(-1, 4)
+        assert np.array_equal(got[:, 0].astype(np.uint8), fu) and np.abs(got[:, 1:] - l3u).max() < 1e-6
+        assert np.array_equal(np.array(out[1][1:], np.uint8), fd)
+        n3d += c
+    assert n3d > 150                                                     # the scene does triangulate
+
+
+def test_homography_ransac_mask(exe):
+    rng = np.random.default_rng(3)
+    H = np.array([[1.02, 0.03, 12.0], [-0.02, 0.98, -7.0], [1e-5, -2e-5, 1.0]])
+    for n, n_out in ((60, 18), (25, 5), (9, 0), (4, 0)):
+        src = np.rint(rng.uniform([20, 20], [580, 460], (n, 2)))
+        w = src @ H[:2, :2].T + H[:2, 2]
+        dst = np.rint(w / (src @ H[2, :2] + 1.0)[:, None] + rng.normal(0, 0.3, (n, 2)))
+        bad = rng.choice(n, n_out, replace=False)
+        dst[bad] += rng.uniform(25, 80, (n_out, 2)) * rng.choice([-1, 1], (n_out, 2))
+        out = run(exe, f"homo {n} 3.0\n" + "\n".join(fmt(s, d) for s, d in zip(src, dst)))
+        Hr, mask = G.find_homography_ransac(src, dst, 3.0)
+        got = np.array(out[0][2:], np.uint8)
+        assert int(out[0][1]) == 1 and np.array_equal(got, mask), (n, got, mask)
+        assert not got[bad].any() and got.sum() >= n - n_out - 2
+        assert np.abs(np.array(out[1][1:], np.float64).reshape(3, 3) - Hr).max() < 1e-6 * np.abs(Hr).max()
+    # degenerate: all points on one line -> no model, mask all zero (OpenCV returns an empty H and a zero mask)
+    src = np.stack([np.arange(10.0) * 10, np.arange(10.0) * 5], 1)
+    out = run(exe, "homo 10 3.0\n" + "\n".join(fmt(s, s + 1) for s in src))
+    assert int(out[0][1]) == 0 and not any(int(x) for x in out[0][2:])
+    assert G.find_homography_ransac(src, src + 1, 3.0)[0] is None
+
+
+def test_pnp_ransac_pose(exe):
+    rng = np.random.default_rng(4)
+    for n, n_out, thr in ((80, 0, 3.0), (60, 12, 0.02), (12, 0, 3.0)):
+        X = rng.uniform(-3, 3, (n, 3)) + np.array([0.5, 0.2, 6.0])
+        R, t = G.rodrigues(rng.uniform(-0.3, 0.3, 3)), rng.uniform(-0.5, 0.5, 3)
+        c = X @ R.T + t
+        u = c[:, :2] / c[:, 2:3] + rng.normal(0, 2e-3, (n, 2))
+        bad = rng.choice(n, n_out, replace=False)
+        u[bad] += rng.uniform(0.1, 0.4, (n_out, 2))
+        out = run(exe, f"pnp {n} 100 {thr} 0.99\n" + "\n".join(fmt(a, b) for a, b in zip(X, u)))
+        (Rr, tr), inl = G.solve_pnp_ransac(X, u, 100, thr, 0.99)
+        got = np.array(out[0][3:], np.float64)
+        assert int(out[0][1]) == 1 and int(out[0][2]) == len(inl)
+        assert np.abs(got[:9].reshape(3, 3) - Rr).max() < 1e-7 and np.abs(got[9:] - tr).max() < 1e-7
+        assert np.abs(got[:9].reshape(3, 3) - R).max() < 5e-3 and np.abs(got[9:] - t).max() < 3e-2
+        if n_out:
+            assert not set(bad.tolist()) & set(inl)
+    assert run(exe, "pnp 5 100 3.0 0.99\n" + "\n".join(fmt(rng.uniform(0, 1, 5)) for _ in range(5)))[0][1] == "0"     # fewer than 6 points
+
+
+def test_compute_loop_end_to_end(exe, scene):
+    new, old = scene["new"], scene["old"]
+    for (dn, dold, init_mode, is4) in ((1, 1, 0, 1), (1, 1, 1, 0), (0, 0, 0, 1)):
+        out = run(exe, f"loop {dn} {dold} {init_mode} {is4}\n{frame_text(new)}\n{frame_text(old)}")[0]
+        ref = G.compute_loop(new, old, dn, dold, bool(init_mode), lambda a, b: M.bf_match(a, b, 0), is_4dof=bool(is4))
+        assert ref is not None and out[1] == "1"
+        assert int(out[2]) == ref["n_corr"] and int(out[3]) == ref["inliers"]
+        assert (int(out[4]), int(out[5]), int(out[6]), int(out[7])) == (old["msg_id"], new["msg_id"], old["drone_id"], new["drone_id"])
+        dp = np.array(out[8:], np.float64)
+        assert np.abs(dp[:3] - ref["relative_pose"][0]).max() < 1e-6 and min(np.abs(dp[3:] - ref["relative_pose"][1]).max(), np.abs(dp[3:] + ref["relative_pose"][1]).max()) < 1e-6
+        truth = G.delta_pose(scene["pose_old"], scene["pose_new"], bool(is4))
+        assert np.linalg.norm(dp[:3] - truth[0]) < 0.10, (dp[:3], truth[0])      # 10 cm stereo baseline, integer-pixel key points, landmarks 2-7 m away
+        assert abs(G.wrap_angle(G.quat2eulers(dp[3:])[2] - G.quat2eulers(truth[1])[2])) < math.radians(1.0)
+        assert int(out[3]) > 100
+    # a frame from another place (other landmarks, other descriptors): no loop, in both implementations
+    rng = np.random.default_rng(9)
+    pts2 = rng.standard_normal((800, 3)) * 3 + np.array([0, 0, 1.0])
+    d2 = rng.standard_normal((800, 64))
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    other = make_frame(pts2, d2, scene["pose_new"], 11, 1, rng)
+    out = run(exe, f"loop 1 1 0 1\n{frame_text(other)}\n{frame_text(old)}")[0]
+    assert out[1] == "0" and G.compute_loop(other, old, 1, 1, False, lambda a, b: M.bf_match(a, b, 0)) is None
+    # too few landmarks in the new frame (:633)
+    few = dict(new, landmark_num=10)
+    assert run(exe, f"loop 1 1 0 1\n{frame_text(few)}\n{frame_text(old)}")[0][1] == "0"

@@ -146,6 +146,16 @@ def test_cpp_host_loop_equals_python_host_loop(omni, ctx, tmp_path):
     hits_cpp += pl.run(16, 20, [pins[0].ctypes.data, pins[1].ctypes.data], 0, None, True)
     rows_cpp = pl.db_rows
     pl.close()
+    # the same stream with the geometric verification stage switched on (host/loop_geometry.hpp: lifting, up/down triangulation, BF + homography
+    # mask, PnP-RANSAC): every candidate whose old frame is our own reaches compute_loop; candidates themselves do not depend on its verdict
+    pg = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THR, MAXN, c.PREC_F16, MB, 2, c.STORE_F32,
+                                   1, 0.3, 0.2, 5, 30, 3, geometry=True)
+    pg.preload(db)
+    hits_geo = pg.run(20, 0, [pins[0].ctypes.data, pins[1].ctypes.data], 0, pins[2].ctypes.data, True)
+    hits_geo += pg.run(16, 20, [pins[0].ctypes.data, pins[1].ctypes.data], 0, None, True)
+    calls, edges = pg.geometry_stats()
+    assert hits_geo == hits_cpp and calls >= 16 and 0 <= edges <= calls
+    pg.close()
     # Python loop
     det = detector.LoopDetector(ctx, 1, inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3)
     det.local_index.add(db)
