@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", choices=["f16", "f32"], default="f16")
-    ap.add_argument("--host", choices=["cpp", "python"], default="cpp", help="language of the timed host loop (N = 1; N > 1 runs the Python loop)")
+    ap.add_argument("--host", choices=["cpp", "python"], default="cpp", help="language of the timed host loop")
     ap.add_argument("--min-time", type=float, default=1.0, help="repeat the timed region of --steps key frames until this many seconds were timed; the median region is reported")
     ap.add_argument("--db-keyframes", type=int, default=1000, help="key frames pre-loaded in the index (x4 rows) for the throughput loop")
     ap.add_argument("--match-db-rows", type=int, default=100_000, help="index rows for the p50 loop-match measurement (node total)")
@@ -149,7 +149,7 @@ def main():
     MATCH_INDEX_DIST, QUERY_THRES, INIT_THRES = 5, 0.3, 0.2   # launch values
     K_SEARCH = 5 + MATCH_INDEX_DIST
     MB = max(1, args.microbatch)
-    cpp_host = args.host == "cpp" and world == 1
+    cpp_host = args.host == "cpp" and (world == 1 or not one_gpu)      # N > 1: C++ loop + RCCL inside the library; gloo bring-up stays Python
 
     sp_w = weights.superpoint_synth_weights(0)
     comp, mean = synth.pca()
@@ -195,6 +195,12 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def shard_uid():
+        """ncclGetUniqueId of rank 0 for one omni_shard group, carried to the other ranks by torch.distributed (plumbing only)."""
+        box = [capi.shard_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
     def reduce_max(x):
         if dist is None:
             return x
@@ -227,8 +233,12 @@ def main():
         pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, MB,
                                        args.pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
         gen = RowFactory(7 + rank)
-        for s in range(0, db_rows, 32768):
-            pl.preload(gen.rows(min(32768, db_rows - s)))
+        if world > 1:
+            pl.attach_shard(rank, world, shard_uid())
+            pl.preload(gen.rows(db_rows // world))            # this rank's part of a db_rows-row database
+        else:
+            for s in range(0, db_rows, 32768):
+                pl.preload(gen.rows(min(32768, db_rows - s)))
         tail, _ = tail_for(steps)
         wtail, _ = tail_for(warmup)
         pl.prepare(steps)
@@ -271,7 +281,10 @@ def main():
                 self.swarm = None
             else:
                 self.det = None
-                self.swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, coll_dev)
+                if one_gpu:       # bring-up on one GPU: torch/gloo collectives over host copies
+                    self.swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, coll_dev)
+                else:             # the exchange inside libomni_hip.so: ncclAllGather on device buffers (csrc/shard.hip)
+                    self.swarm = shard.NativeSwarmIndex(ictx, capi.IndexFlatIP(ictx, 4096), rank, world, shard_uid())
                 per_rank = 4 * args.db_keyframes // world
                 self.swarm.preload_local(RowFactory(7 + rank).rows(per_rank), per_rank * world)
 
@@ -297,9 +310,13 @@ def main():
                 self.hits += sum(int(r["old_msg_id"] != -1) for r in recs)
             else:
                 # the micro-batch's mb steps (each: add world*4 rows, query direction 1) in two collectives + one index sync
-                rows = np.stack([np.stack([i["image_desc"] for i in out["images"][4 * m:4 * m + 4]]) for m in range(mb)])
                 base = self.swarm.ntotal
-                for m, (D, I) in enumerate(self.swarm.step_batch(rows, query_row=1, k=K_SEARCH)):
+                if one_gpu:
+                    rows = np.stack([np.stack([i["image_desc"] for i in out["images"][4 * m:4 * m + 4]]) for m in range(mb)])
+                    results = self.swarm.step_batch(rows, query_row=1, k=K_SEARCH)
+                else:             # rows and queries straight from MobileNetVLAD's output buffer in HBM ([mb][4][4096])
+                    results = self.swarm.step_batch_dev(mb, 4, cam.vlad.dev_output(), 1, K_SEARCH)
+                for m, (D, I) in enumerate(results):
                     nt = base + (m + 1) * world * 4                                 # ntotal as of this key frame's step
                     ok = (I[0] >= 0) & (I[0] <= nt - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
                     self.hits += int(ok.any())
@@ -401,11 +418,19 @@ def main():
         rows_here = total_rows // world
         midx = capi.IndexFlatIP(ictx, 4096, capi.STORE_F32, rows_here)
         gen = RowFactory(11 + rank)
-        for s in range(0, rows_here, 32768):
-            midx.add(gen.rows(min(32768, rows_here - s)))
+        if world == 1:
+            for s in range(0, rows_here, 32768):
+                midx.add(gen.rows(min(32768, rows_here - s)))
         mq = RowFactory(99).rows(1)
-        if world > 1:
+        if world > 1 and one_gpu:
             big = shard.ShardedIndex(midx, rank, world, dist, coll_dev)
+            for s in range(0, rows_here, 32768):
+                midx.add(gen.rows(min(32768, rows_here - s)))
+            search = lambda: big.search(mq, K_SEARCH)
+        elif world > 1:
+            big = capi.Shard(ictx, midx, rank, world, shard_uid())
+            for s in range(0, rows_here, 32768):
+                big.local.add(gen.rows(min(32768, rows_here - s)))
             search = lambda: big.search(mq, K_SEARCH)
         else:
             search = lambda: midx.search(mq, K_SEARCH)
@@ -419,6 +444,8 @@ def main():
             scan.append(midx.last_scan_ms())
         p50 = reduce_max(float(np.median(lat[10:])))
         scan_ms = float(np.median(scan[10:]))
+        if world > 1 and not one_gpu:
+            big.close()
         midx.close()
         return p50, scan_ms, rows_here
 

@@ -62,6 +62,7 @@ typedef struct omni_sp omni_sp;
 typedef struct omni_vlad omni_vlad;
 typedef struct omni_index omni_index;
 typedef struct omni_cam omni_cam;
+typedef struct omni_shard omni_shard;
 
 int         omni_abi_version(void);
 const char* omni_last_error(void);
@@ -205,6 +206,25 @@ int         omni_index_save(omni_index* idx, const char* path);
 int         omni_index_load(omni_index* idx, const char* path);
 /* device time of the dominant scan kernel for the last search on this handle (HIP events on the ctx stream) */
 int         omni_index_last_scan_ms(omni_index* idx, float* ms);
+
+/* ---- the database row-sharded over the GPUs of one node: one process per GPU, RCCL over xGMI (new: the reference is single-GPU;
+ * SURVEY.md 8e, BASELINE configs[3]/[4]).  Global row g lives on rank g % world at local slot g / world; every rank ends up with the
+ * faiss::IndexFlatIP::search result of the UNSHARDED index (global ids, score desc, ties -> lower id).  RCCL is resolved at run time
+ * (dlopen librccl.so.1); the launcher only has to carry the 128-byte unique id from rank 0 to the other ranks (any channel). */
+#define OMNI_SHARD_ID_BYTES 128
+int         omni_shard_unique_id(char* id_out /* [OMNI_SHARD_ID_BYTES], ncclGetUniqueId */);
+/* collective: every rank calls it with the same id; `local` must be an empty index on ctx; its rows/ids are managed by the shard from here on */
+omni_shard* omni_shard_create(omni_ctx* ctx, omni_index* local, int dim, int rank, int world, const char* unique_id);
+void        omni_shard_destroy(omni_shard* s);
+int64_t     omni_shard_ntotal(const omni_shard* s);                       /* GLOBAL row count */
+int         omni_shard_preload_local(omni_shard* s, const float* rows_host, int64_t n_local, int64_t ntotal_global);
+/* collective: F consecutive key-frame steps of every rank as ONE exchange unit.  rows_dev [F][m][dim] (HBM): this rank's m new rows of each
+ * of its next F key frames.  Step f's rows of all ranks get the global ids ntotal + (f*world + r)*m + j; rank r's query of step f is its row
+ * query_row of that step and sees exactly the rows up to and including step f (add before query, loop_detector.cpp:89-98).  Two
+ * ncclAllGather (rows; per-shard top-k), one pass over the shard, one D2H; D_host / I_host [F][k] = this rank's merged results. */
+int         omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k, float* D_host, int64_t* I_host);
+/* collective: the same nq <= 64 queries on every rank -> the unsharded index's top-k on every rank */
+int         omni_shard_search(omni_shard* s, int nq, const float* q_host, int k, float* D, int64_t* I);
 
 /* ---- local-descriptor matcher: cv::BFMatcher(cv::NORM_L2, crossCheck=true).match(query, train, matches) -----
  * out arrays sized >= nq; matches ordered by query index; *n_matches = count.  dim <= 256. */

@@ -35,6 +35,8 @@ SYMBOLS = [
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
     "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
+    "omni_shard_unique_id", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev",
+    "omni_shard_search",
 ]
 
 
@@ -145,6 +147,13 @@ def lib():
     sig("omni_cam_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int])
     sig("omni_cam_enqueue_host", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
     sig("omni_cam_wait", C.c_int, [_vp, C.POINTER(_CamResult)])
+    sig("omni_shard_unique_id", C.c_int, [C.c_char_p])
+    sig("omni_shard_create", _vp, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p])
+    sig("omni_shard_destroy", None, [_vp])
+    sig("omni_shard_ntotal", C.c_int64, [_vp])
+    sig("omni_shard_preload_local", C.c_int, [_vp, _fp, C.c_int64, C.c_int64])
+    sig("omni_shard_step_batch_dev", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _fp, _i64p])
+    sig("omni_shard_search", C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp, _i64p])
     if L.omni_abi_version() != 1:
         raise OmniError("libomni_hip.so ABI version mismatch")
     _lib = L
@@ -180,9 +189,9 @@ class Context:
 
     def close(self):
         if self.h:
-            for kind in ("Cam", None):              # omni_cam borrows the network handles: it goes first
+            for kind in ("Cam", "Shard", None):     # omni_cam / omni_shard borrow other handles: they go first
                 for ch in list(self._children):
-                    if kind is None or type(ch).__name__ == kind:
+                    if kind is None or type(ch).__name__ == kind:   # noqa: E721
                         try:
                             ch.close()
                         except Exception:
@@ -507,6 +516,60 @@ class IndexFlatIP:
         ms = C.c_float()
         _check(lib().omni_index_last_scan_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+SHARD_ID_BYTES = 128
+
+
+def shard_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: call on rank 0, carry the 128 bytes to the other ranks by any channel."""
+    buf = C.create_string_buffer(SHARD_ID_BYTES)
+    _check(lib().omni_shard_unique_id(buf))
+    return buf.raw
+
+
+class Shard:
+    """omni_shard: this rank's part of the row-sharded key-frame database; collectives are RCCL inside libomni_hip.so (csrc/shard.hip)."""
+
+    def __init__(self, ctx: Context, local: IndexFlatIP, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == SHARD_ID_BYTES
+        self.ctx, self.local, self.rank, self.world = ctx, local, rank, world
+        self.h = lib().omni_shard_create(ctx.h, local.h, local.d, rank, world, unique_id)
+        if not self.h:
+            raise OmniError(f"omni_shard_create failed: {lib().omni_last_error().decode()}")
+        ctx._adopt(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().omni_shard_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ntotal(self) -> int:
+        return lib().omni_shard_ntotal(self.h)
+
+    def preload_local(self, rows_local: np.ndarray, ntotal_global: int):
+        rows_local = _f32(rows_local)
+        _check(lib().omni_shard_preload_local(self.h, _pf(rows_local), rows_local.shape[0], ntotal_global))
+
+    def step_batch_dev(self, F: int, m: int, rows_dev: int, query_row: int, k: int):
+        D = np.empty((F, k), np.float32)
+        I = np.empty((F, k), np.int64)
+        _check(lib().omni_shard_step_batch_dev(self.h, F, m, rows_dev, query_row, k, _pf(D), I.ctypes.data_as(_i64p)))
+        return D, I
+
+    def search(self, q: np.ndarray, k: int):
+        q = _f32(np.atleast_2d(q))
+        D = np.empty((q.shape[0], k), np.float32)
+        I = np.empty((q.shape[0], k), np.int64)
+        _check(lib().omni_shard_search(self.h, q.shape[0], _pf(q), k, _pf(D), I.ctypes.data_as(_i64p)))
+        return D, I
 
 
 def topk_merge(D_lists: np.ndarray, I_lists: np.ndarray, k_out: int):

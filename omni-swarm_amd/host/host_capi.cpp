@@ -43,7 +43,13 @@ int omni_pipeline_preload(omni_pipeline* h, const float* rows, int64_t n) {
     try { h->p->preload(rows, n); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
-int64_t omni_pipeline_db_rows(omni_pipeline* h) { return h->p->detector().local_index.ntotal + h->p->detector().remote_index.ntotal; }
+int64_t omni_pipeline_db_rows(omni_pipeline* h) { return h->p->db_rows(); }
+
+// collective over all ranks (one process per GPU): switch the database to the row-sharded index (omni_shard_*, RCCL inside libomni_hip.so);
+// unique_id = omni_shard_unique_id() of rank 0.  Call before preload / run; preload then takes THIS rank's rows.
+int omni_pipeline_attach_shard(omni_pipeline* h, int rank, int world, const char* unique_id) {
+    try { h->p->attach_shard(rank, world, unique_id); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 
 // see omni::KeyframePipeline::run; *hits = loop candidates found.  Returns 0 on success.
 int omni_pipeline_run(omni_pipeline* h, int n_keyframes, int64_t first_msg_id, const uint8_t* const* pool, int n_pool, int first_slot,

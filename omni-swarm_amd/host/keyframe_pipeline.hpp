@@ -56,8 +56,22 @@ public:
 
     LoopDetectorCore& detector() { return det_; }
 
+    // N > 1 GPUs, one process per GPU: the database becomes one row-sharded index over all ranks (omni_shard_*, RCCL inside libomni_hip.so).
+    // Collective: every rank attaches with rank 0's unique id.  Each micro-batch is then one exchange unit (two ncclAllGather) and a key
+    // frame's candidate is decided on GLOBAL ids with the reference's rule (loop_detector.cpp:232: recency + threshold); the id maps of
+    // LoopDetectorCore describe one drone's own database and are not used in this mode.
+    void attach_shard(int rank, int world, const char* unique_id) {
+        shard_index_ = std::make_unique<IndexFlatIP>(index_ctx_, 4096, cfg_.storage);
+        shard_ = omni_shard_create(index_ctx_.get(), shard_index_->handle(), 4096, rank, world, unique_id);
+        if (!shard_) throw std::runtime_error(std::string("omni_shard_create: ") + omni_last_error());
+        world_ = world;
+    }
+    ~KeyframePipeline() { if (shard_) omni_shard_destroy(shard_); }
+    int64_t db_rows() const { return shard_ ? omni_shard_ntotal(shard_) : det_.local_index.ntotal + det_.remote_index.ntotal; }
+
     // bulk pre-load of the key-frame database: rows [n][4096], 4 consecutive rows = the 4 directions of one earlier key frame
     void preload(const float* rows, int64_t n) {
+        if (shard_) { check(omni_shard_preload_local(shard_, rows, n, n * world_), "omni_shard_preload_local"); return; }    // this rank's rows
         const int64_t base = det_.local_index.ntotal;
         for (int64_t s = 0; s < n; s += 4096) det_.local_index.add(std::min<int64_t>(4096, n - s), rows + s * 4096);
         for (int64_t i = 0; i < n; ++i) { det_.imgid2fisheye[(int)(base + i)] = -((base + i) / 4) - 1; det_.imgid2dir[(int)(base + i)] = (int)((base + i) % 4); }
@@ -123,6 +137,21 @@ private:
     // buffer in HBM ([4*mb][4096], key-frame major) -- wait() has synchronised with the MobileNetVLAD stream
     int finish(Lane& lane, int64_t first_id) {
         const omni_cam_result r = lane.cam.wait();
+        if (shard_) {
+            const int k = LoopDetectorCore::SEARCH_NEAREST_NUM + cfg_.match_index_dist;
+            D_.resize((size_t)lane.mb * k); I_.resize((size_t)lane.mb * k);
+            const int64_t base = omni_shard_ntotal(shard_);
+            check(omni_shard_step_batch_dev(shard_, lane.mb, 4, lane.rows_dev, 1, k, D_.data(), I_.data()), "omni_shard_step_batch_dev");
+            int hits = 0;
+            for (int m = 0; m < lane.mb; ++m) {
+                const int64_t nt = base + (int64_t)(m + 1) * world_ * 4;          // ntotal as of this key frame's step
+                for (int j = 0; j < k; ++j) {
+                    const int64_t id = I_[(size_t)m * k + j];
+                    if (id >= 0 && id <= nt - cfg_.match_index_dist && D_[(size_t)m * k + j] > cfg_.inner_product_thres) { ++hits; break; }
+                }
+            }
+            return hits;
+        }
         const int n = r.n_dirs, M = r.max_num, D = r.desc_dim;
         frames_.resize(lane.mb);
         for (int m = 0; m < lane.mb; ++m) {
@@ -171,6 +200,11 @@ private:
     std::vector<std::unique_ptr<Lane>> lanes_;
     std::map<int, std::unique_ptr<Lane>> tail_lanes_;
     std::vector<FisheyeFrameDescriptor> frames_;
+    std::unique_ptr<IndexFlatIP> shard_index_;
+    omni_shard* shard_ = nullptr;
+    int world_ = 1;
+    std::vector<float> D_;
+    std::vector<int64_t> I_;
 };
 
 }  // namespace omni

@@ -16,7 +16,7 @@ from . import capi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
-           "omni_pipeline_run", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync"]
+           "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync"]
 _lib = None
 
 
@@ -40,6 +40,7 @@ def lib():
         L.omni_pipeline_run.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int,
                                         C.POINTER(C.c_int)]
         L.omni_pipeline_sync.argtypes = [C.c_void_p]
+        L.omni_pipeline_attach_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
         L.omni_pipeline_prepare.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -71,6 +72,11 @@ class KeyframePipeline:
             self.close()
         except Exception:
             pass
+
+    def attach_shard(self, rank: int, world: int, unique_id: bytes):
+        """Collective: the database becomes the row-sharded index over `world` ranks (RCCL inside libomni_hip.so)."""
+        if lib().omni_pipeline_attach_shard(self.h, rank, world, unique_id):
+            raise _err("omni_pipeline_attach_shard")
 
     def preload(self, rows: np.ndarray):
         rows = np.ascontiguousarray(rows, np.float32)

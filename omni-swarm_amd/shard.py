@@ -140,3 +140,43 @@ class SwarmIndex:
             out.append(capi.topk_merge(Dl, Il, k))
         return out
 
+
+
+class NativeSwarmIndex:
+    """SwarmIndex with the exchange inside libomni_hip.so: ncclAllGather on device buffers on the index stream, no host bounce, no torch in
+    the data path (csrc/shard.hip, omni_shard_*).  Same numbering and results as SwarmIndex.step_batch (checked against it and against
+    the unsharded oracle by tests/test_gpu_shard_rccl.py).  unique_id: capi.shard_unique_id() of rank 0, carried to every rank by the
+    launcher (bench.py: torch.distributed.broadcast_object_list -- plumbing only)."""
+
+    def __init__(self, ctx, local_index, rank: int, world: int, unique_id: bytes):
+        self.local, self.rank, self.world = local_index, rank, world
+        self.shard = capi.Shard(ctx, local_index, rank, world, unique_id)
+        self._stage = None
+
+    @property
+    def ntotal(self) -> int:
+        return self.shard.ntotal
+
+    def preload_local(self, rows_local: np.ndarray, ntotal_global: int):
+        self.shard.preload_local(rows_local, ntotal_global)
+
+    def step_batch_dev(self, F: int, m: int, rows_dev: int, query_row: int, k: int):
+        """rows_dev: [F][m][d] fp32 in HBM (e.g. MobileNetVLAD's output buffer, complete w.r.t. the index stream).  -> [F] x (D [1][k], I [1][k])"""
+        D, I = self.shard.step_batch_dev(F, m, rows_dev, query_row, k)
+        return [(D[f:f + 1], I[f:f + 1]) for f in range(F)]
+
+    def step_batch(self, rows: np.ndarray, query_row: int, k: int):
+        rows = np.ascontiguousarray(rows, np.float32)
+        F, m, _ = rows.shape
+        ctx = self.shard.ctx
+        dev = ctx.to_device(rows)
+        try:
+            return self.step_batch_dev(F, m, dev, query_row, k)
+        finally:
+            ctx.free(dev)
+
+    def search(self, q: np.ndarray, k: int):
+        return self.shard.search(q, k)
+
+    def close(self):
+        self.shard.close()

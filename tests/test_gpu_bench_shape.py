@@ -156,6 +156,16 @@ def test_cpp_host_loop_equals_python_host_loop(omni, ctx, tmp_path):
     calls, edges = pg.geometry_stats()
     assert hits_geo == hits_cpp and calls >= 16 and 0 <= edges <= calls
     pg.close()
+    # and with the database behind omni_shard_* (a one-rank RCCL group: ncclAllGather of rows and of top-k lists inside the library): the
+    # recency + threshold rule on global ids finds the same candidates
+    ps = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THR, MAXN, c.PREC_F16, MB, 2, c.STORE_F32,
+                                   1, 0.3, 0.2, 5, 30, 3)
+    ps.attach_shard(0, 1, c.shard_unique_id())
+    ps.preload(db)
+    hits_sh = ps.run(20, 0, [pins[0].ctypes.data, pins[1].ctypes.data], 0, pins[2].ctypes.data, True)
+    hits_sh += ps.run(16, 20, [pins[0].ctypes.data, pins[1].ctypes.data], 0, None, True)
+    assert hits_sh == hits_cpp and ps.db_rows == rows_cpp
+    ps.close()
     # Python loop
     det = detector.LoopDetector(ctx, 1, inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3)
     det.local_index.add(db)
