@@ -1,5 +1,7 @@
 """CPU tests of the oracle itself: restatements agree with each other and with the committed golden vectors
 (tools/gen_golden.py pinned those against the reference's own PyTorch module in the build container)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -161,3 +163,62 @@ def test_mobilenetvlad_oracle_golden(golden):
     y = V.forward(V.synth_weights(), g["images"])
     assert np.allclose(np.linalg.norm(y, axis=1), 1, atol=1e-5)
     assert np.abs(y - g["out"]).max() < 1e-5
+
+
+def _ref_nms2():
+    """oracle/_ref/libref_nms2.so: the REFERENCE'S OWN NMS2() text (superpoint_tensorrt.cpp:232-310) compiled verbatim against stand-in
+    cv::Mat / cv::Point2f types (oracle/Makefile, oracle/ref_build/).  Built where /root/reference exists, travels as a binary otherwise."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "ref"])
+    path = os.path.join(root, "oracle", "_ref", "libref_nms2.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_nms2.so not built (needs /root/reference once)")
+    L = ctypes.CDLL(path)
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.ref_nms2.restype = ctypes.c_int
+    L.ref_nms2.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+
+    def run(prob, thres, max_num, dist=4):
+        """getKeyPoints (:164-189: mask = prob > thres, findNonZero row-major) feeding the compiled NMS2"""
+        ys, xs = np.nonzero(prob > thres)                      # row-major, like cv::findNonZero
+        xy = np.stack([xs, ys], 1).astype(np.float32)
+        conf = np.ascontiguousarray(prob[ys, xs], np.float32)
+        out = np.zeros((max(max_num, 1), 2), np.float32)
+        n = L.ref_nms2(np.ascontiguousarray(xy).ctypes.data_as(fp), conf.ctypes.data_as(fp), len(xy), prob.shape[1], prob.shape[0], dist, max_num,
+                       out.ctypes.data_as(fp))
+        return out[:n].astype(np.int32)
+    return run
+
+
+def test_nms2_restatement_is_pinned_to_the_reference_text():
+    """The literal restatement (oracle_nms2_literal, the checker of every key-point parity test) against the reference's own function compiled
+    from its own source.  Interior-only maps (no candidate within 4 px of the frame: no out-of-bounds access in the reference) must agree
+    exactly with the fixed-spec mode; with candidates at the left / right edge the reference's column wrap-around (contiguous cv::Mat rows)
+    must agree with the restatement's wrap_columns mode -- the documented deviation of the fixed spec.  Confidences are distinct, so the
+    reference's unstable std::sort has one valid result."""
+    ref = _ref_nms2()
+    rng = np.random.default_rng(42)
+    for trial in range(30):
+        H, W = int(rng.integers(24, 70)), int(rng.integers(24, 90))
+        prob = np.zeros((H, W), np.float32)
+        n = int(rng.integers(5, H * W // 6))
+        ys, xs = rng.integers(4, H - 4, n), rng.integers(4, W - 4, n)
+        prob[ys, xs] = rng.permutation(n).astype(np.float32)[: len(ys)] / n * 0.9 + 0.05        # distinct values in (0.05, 0.95]
+        for thr, max_num in ((0.0, 10_000), (0.3, 10_000), (0.1, 12)):
+            xy, conf, _, _ = P.get_keypoints(prob, thr, max_num)
+            got = ref(prob, thr, max_num)
+            assert np.array_equal(got, xy), (trial, thr, max_num)
+    # left / right edges: reference = wrap-around, restated by wrap_columns=True (rows kept 4 px from the top and bottom)
+    diff = 0
+    for trial in range(30):
+        H, W = int(rng.integers(24, 60)), int(rng.integers(12, 40))
+        prob = np.zeros((H, W), np.float32)
+        n = int(rng.integers(20, H * W // 4))
+        ys, xs = rng.integers(4, H - 4, n), rng.integers(0, W, n)
+        prob[ys, xs] = rng.permutation(n).astype(np.float32) / n * 0.9 + 0.05
+        xy_w, _, _, _ = P.get_keypoints(prob, 0.0, 10_000, wrap_columns=True)
+        assert np.array_equal(ref(prob, 0.0, 10_000), xy_w), trial
+        diff += not np.array_equal(xy_w, P.get_keypoints(prob, 0.0, 10_000)[0])
+    assert diff > 0            # the quirk is real (and only reachable at the frame's left / right edge)
