@@ -10,14 +10,21 @@ import numpy as np
 SELF_ID = 1
 
 
-def make_stream(seed=11, n_frames=90, n_places=14, dim=4096, n_dirs=4):
+def make_stream(seed=11, n_frames=90, n_places=14, dim=4096, n_dirs=4, n_drones=3):
+    """n_drones = 3 is the stream the golden fixtures were generated with; n_drones = 5 (self + 4 remote drones, every third frame remote,
+    round robin) is the 5-drone replay of BASELINE configs[2]."""
     rng = np.random.default_rng(seed)
     place = rng.standard_normal((n_places, n_dirs, dim)).astype(np.float32)
     place /= np.linalg.norm(place, axis=-1, keepdims=True)
     frames = []
     pos = {1: 0, 2: 5, 3: 9}
+    for d in range(4, n_drones + 1):
+        pos[d] = (4 * d) % n_places
     for f in range(n_frames):
-        drone = 1 if (f % 3 != 2) else (2 if (f // 3) % 2 == 0 else 3)
+        if n_drones == 3:
+            drone = 1 if (f % 3 != 2) else (2 if (f // 3) % 2 == 0 else 3)
+        else:
+            drone = 1 if (f % 3 != 2) else 2 + (f // 3) % (n_drones - 1)
         step = rng.integers(0, 3)
         pos[drone] = (pos[drone] + step) % n_places if rng.random() < 0.8 else int(rng.integers(0, n_places))
         pl = pos[drone]
@@ -92,3 +99,90 @@ def run_product_batched(frames, ctx, det_mod, batch=4, rows_on_device=False, **k
 def trace(log):
     return np.array([[r["msg_id"], int(r["added"]), int(r["queried"]), r["image_id"], r["old_msg_id"], r["dir_old"],
                       int(r["loop"])] for r in log], np.int64)
+
+
+# ---- fast oracle for long replays: the same LoopDetectorRef, its two indexes answered from score matrices computed by two big float64
+# GEMMs instead of one scalar scan per query (which rows exist when a query runs does not depend on any query result) -----------------------
+class _PlanIndex:
+    def __init__(self, log, name):
+        self.rows, self.log, self.name = [], log, name
+
+    @property
+    def ntotal(self):
+        return len(self.rows)
+
+    def add(self, x):
+        self.rows.append(np.asarray(x, np.float32).reshape(-1))
+
+    def search(self, q, k, use_numpy=False):
+        self.log.append((self.name, np.asarray(q, np.float32).reshape(-1), len(self.rows), k))
+        return np.full((1, k), -3.4028235e38, np.float32), np.full((1, k), -1, np.int64)
+
+
+class _ReplayIndex:
+    def __init__(self, results):
+        self.results, self.n = results, 0
+
+    @property
+    def ntotal(self):
+        return self.n
+
+    def add(self, x):
+        self.n += 1
+
+    def search(self, q, k, use_numpy=False):
+        D, I, n_seen, kk = self.results.pop(0)
+        assert n_seen == self.n and kk == k
+        return D, I
+
+
+def _frames_ref(frames):
+    from oracle import match_ref as M
+    return [M.FisheyeFrameDesc(msg_id=fr["msg_id"], drone_id=fr["drone_id"], landmark_num=fr["landmark_num"], prevent_adding_db=fr["prevent_adding_db"],
+                               images=[M.ImageDesc(drone_id=i["drone_id"], landmark_num=i["landmark_num"], image_desc=i["image_desc"]) for i in fr["images"]])
+            for fr in frames]
+
+
+def run_oracle_fast(frames, params=None):
+    """Decision trace of oracle/match_ref.LoopDetectorRef over a long stream; exact inner products in float64 (torch GEMM), rounded to f32,
+    ties -> lower row.  Returns (log, searches) where searches[i] = (index name, n rows seen, sorted f64 scores of the top candidates)."""
+    import torch
+    from oracle import match_ref as M
+    params = params or PARAMS
+    loop = lambda n, o, dn, do, im: loop_ok(n.msg_id, o.msg_id)
+    plan = []
+    det = M.LoopDetectorRef(SELF_ID, compute_loop=loop, **params)
+    det.local_index, det.remote_index = _PlanIndex(plan, "local"), _PlanIndex(plan, "remote")
+    ref_frames = _frames_ref(frames)
+    for f in ref_frames:
+        det.on_image_recv(f)
+    results = {"local": [], "remote": []}
+    info = []
+    for name, idx in (("local", det.local_index), ("remote", det.remote_index)):
+        qs = [(q, n, k) for (nm, q, n, k) in plan if nm == name]
+        if not qs:
+            continue
+        rows = torch.from_numpy(np.stack(idx.rows)).double() if idx.rows else torch.zeros((0, 4096), dtype=torch.float64)
+        Q = torch.from_numpy(np.stack([q for q, _, _ in qs])).double()
+        for s in range(0, len(qs), 512):                         # blocks of queries: bounded memory
+            S = (Q[s:s + 512] @ rows.T).numpy() if len(rows) else np.zeros((len(qs[s:s + 512]), 0))
+            for j, (q, n, k) in enumerate(qs[s:s + 512]):
+                sc = S[j, :n].astype(np.float32)
+                D = np.full((1, k), -3.4028235e38, np.float32)
+                I = np.full((1, k), -1, np.int64)
+                if n:
+                    kk = min(k, n)
+                    cand = np.argpartition(-sc, kk - 1)[:kk] if n > kk else np.arange(n)
+                    thr = sc[cand].min()
+                    cand = np.nonzero(sc >= thr)[0]               # everything tied with the cut-off takes part in the id-ordered sort
+                    order = cand[np.lexsort((cand, -sc[cand].astype(np.float64)))][:kk]
+                    D[0, :kk], I[0, :kk] = sc[order], order
+                results[name].append((D, I, n, k))
+    for nm, q, n, k in plan:
+        info.append((nm, n))
+    det2 = M.LoopDetectorRef(SELF_ID, compute_loop=loop, **params)
+    det2.local_index, det2.remote_index = _ReplayIndex(results["local"]), _ReplayIndex(results["remote"])
+    for f in ref_frames:
+        det2.on_image_recv(f)
+    assert not results["local"] and not results["remote"]
+    return det2.log

@@ -83,3 +83,20 @@ def test_batched_detector_equals_frame_by_frame(omni, ctx, batch, on_device):
     assert np.array_equal(got, DS.trace(DS.run_oracle(frames)))
     assert (seq[:, 4] != -1).sum() > 10
 
+
+
+def test_c3_replay_10k_keyframes_5_drones_match_ids_equal_oracle(omni, ctx):
+    """BASELINE configs[2] at size: a 10 000-key-frame, 5-drone replay (about 30 000 database rows over the local and the remote index,
+    about 10 000 searches) through the HIP index + host rules -- frame by frame AND through the batched entry point (micro-batches of 8, rows
+    handed over in HBM) -- gives the decision trace (added / queried / image id / matched frame / direction / loop) of the oracle's literal
+    LoopDetector.  The oracle answers its searches from float64 GEMMs (tests/detector_stream.run_oracle_fast, equal to the scalar oracle on
+    the short streams)."""
+    from omni_swarm_amd import detector
+    frames = DS.make_stream(seed=77, n_frames=10000, n_places=800, n_drones=5)
+    ref = DS.trace(DS.run_oracle_fast(frames))
+    got_b = DS.trace(DS.run_product_batched(frames, ctx, detector, batch=8, rows_on_device=True))
+    bad = np.nonzero((got_b != ref).any(1))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], got_b[bad[:3]], ref[bad[:3]])
+    got_s = DS.trace(DS.run_product(frames, ctx, detector))
+    assert np.array_equal(got_s, ref)
+    assert (ref[:, 1] == 1).sum() > 7000 and (ref[:, 4] != -1).sum() > 5000 and len({f["drone_id"] for f in frames}) == 5
