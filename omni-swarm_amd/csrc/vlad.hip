@@ -17,6 +17,8 @@ struct VladFusedBlock {      // one inverted-residual block = [expand] + depthwi
     int cin, hid, cout, stride, expand, res, hin, win, hout, wout;
     const float* bp;
     float* blob;             // device: packed per-chunk weights (see VladBlockArgs)
+    float* mblob;            // device: the same per chunk with the projection padded to cop columns (VladMBlockArgs); null = not available
+    int cop;
     const float *we_t, *be, *wd_t, *bd, *wp_t;   // the layers' own device weights ([cin][hid], [9][hid], [hid][cout]) for the MFMA path
 };
 
@@ -24,11 +26,14 @@ struct omni_vlad {
     omni_ctx* ctx = nullptr;
     bool fused = false;                       // every block has a fused kernel (OMNI_VLAD_UNFUSED=1 forces the layer-by-layer path)
     bool mfma_late = true;                    // low-resolution blocks on the f32-MFMA pointwise path (OMNI_VLAD_MFMA=0 disables)
+    int mblock_max_px = 0;                    // blocks whose INPUT has at most this many pixels per image run on vlad_mblock_kernel (OMNI_VLAD_MBLOCK_PX)
     int mfma_max_px = 2048;                   // ... = blocks whose input has at most this many pixels per image (OMNI_VLAD_MFMA_PX)
     std::vector<VladFusedBlock> blocks;
     int W = 0, H = 0, max_batch = 0, K = 0, Dm = 0, out_dim = 0, hf = 0, wf = 0;
     std::vector<VladLayerDev> layers;
     float *assign_wT = nullptr, *assign_b = nullptr, *clusters = nullptr, *fc_w = nullptr, *fc_b = nullptr;
+    float *fc_wp = nullptr, *fc_part = nullptr;   // FC weights in MFMA B-operand order + K-split partial tiles (vlad_fc_mfma_kernel); null: VALU path
+    bool fc_mfma = false;
     float *buf[3] = {nullptr, nullptr, nullptr};   // rotating activation buffers
     size_t buf_elems = 0;
     float *assign = nullptr, *vlad = nullptr, *out = nullptr;
@@ -507,6 +512,161 @@ static int vlad_pw_mfma(hipStream_t st, const float* in, int64_t P, int cin, int
     return OMNI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused inverted-residual block on the matrix cores (exact f32, v_mfma_f32_32x32x2_f32): expand 1x1 + ReLU6 -> depthwise 3x3 (stride 1|2)
+// + ReLU6 -> project 1x1 (+ residual) in ONE launch for ANY block shape of the layer table.  A workgroup = one 8x8 tile of output pixels of
+// one image; per 32-channel chunk of the hidden layer
+//     expand   h[R][32]  = relu6(xin[R][cin] . We[cin][32] + be)  on the halo region R = ((8-1) s + 3)^2 pixels, M = region pixels (32 per
+//                          MFMA tile, tiles spread over the 4 waves), zero outside the image (the depthwise conv pads the EXPANDED tensor)
+//     depthwise d[64][32] on the VALU (lane = channel)
+//     project  acc[64][cout] += d[64][32] . Wp[32][cout]          (tile pairs (m, n) spread over the waves, accumulators in registers)
+// Operands come from LDS with odd row strides (conflict-free MFMA fragment reads); the chunk's weights are staged per chunk.  The three
+// launches per block of the low-resolution path (pointwise MFMA / depthwise / pointwise MFMA, 10-18 us each at the launch-latency floor,
+// expanded tensor through L2/HBM twice) become one, and the fp32-VALU fused kernel of the high-resolution blocks runs at matrix rate.
+// ---------------------------------------------------------------------------------------------------------------
+struct VladMBlockArgs {
+    const float* in; float* out;
+    const float* blob;         // per 32-channel chunk: [We cin x 32 | be 32 | Wd 9 x 32 | bd 32 | Wp 32 x cop], zero padded
+    const float* bp;           // [cout]
+    int Hi, Wi, Ho, Wo, cin, hid, cout, cop, stride, res, batch;
+};
+__global__ void __launch_bounds__(256)
+vlad_mblock_kernel(VladMBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int s = a.stride, cin = a.cin, cinp = cin + 1, cop = a.cop;
+    const int RW = 7 * s + 3, R = RW * RW, R32 = (R + 31) >> 5, RP = R32 * 32;
+    const int NT = cop >> 5;
+    float* xin = reinterpret_cast<float*>(smem_raw);       // [RP][cinp]
+    float* h = xin + RP * cinp;                             // [RP][33]
+    float* d = h + RP * 33;                                 // [64][33]
+    float* we = d + 64 * 33;                                // [cin][32]
+    float* be = we + cin * 32;                              // [32]
+    float* wd = be + 32;                                    // [9][32]
+    float* bd = wd + 9 * 32;                                // [32]
+    float* wp = bd + 32;                                    // [32][cop]
+    float* msk = wp + 32 * cop;                             // [RP] 1 inside the image, 0 outside
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int tiles_x = (a.Wo + 7) >> 3, tiles_y = (a.Ho + 7) >> 3;
+    const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * 8, ox0 = (tr % tiles_x) * 8;
+    const int iy0 = oy0 * s - 1, ix0 = ox0 * s - 1;        // region origin in the input
+    const float* inb = a.in + (int64_t)b * a.Hi * a.Wi * cin;
+    const int blob = 32 * (cin + 11 + cop), n_chunks = (a.hid + 31) >> 5;
+
+    {   // input region (also the residual source) + in-image mask
+        const int q4 = cin >> 2;
+        for (int e = tid; e < RP * q4; e += 256) {
+            const int r = e / q4, q = e - r * q4;
+            const int gy = iy0 + r / RW, gx = ix0 + r % RW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) v = *reinterpret_cast<const float4*>(inb + ((int64_t)gy * a.Wi + gx) * cin + q * 4);
+            float* x = xin + r * cinp + q * 4;
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        }
+        for (int r = tid; r < RP; r += 256) {
+            const int gy = iy0 + r / RW, gx = ix0 + r % RW;
+            msk[r] = (r < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) ? 1.f : 0.f;
+        }
+    }
+    floatx16v acc[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        __syncthreads();                                    // previous chunk's readers are done with we/wp/h/d (first pass: xin is complete)
+        {   // this chunk's weights.  (Fetching the NEXT chunk's blob into registers meanwhile and parking it after the projection measured
+            // slower -- 49 vs 45 us per block: the extra registers and barriers cost more than the exposed L2 round trip.)
+            const float4* src = reinterpret_cast<const float4*>(a.blob + (int64_t)ci * blob);
+            float4* dst = reinterpret_cast<float4*>(we);
+            for (int e = tid; e < blob / 4; e += 256) dst[e] = src[e];
+        }
+        __syncthreads();
+        // 1. expand on the matrix cores: region tile m (32 pixels) x 32 hidden channels, K = cin
+        for (int m = wave; m < R32; m += 4) {
+            floatx16v e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = 0.f;
+            const float* xa = xin + (m * 32 + i) * cinp + kk;
+            const float* wb = we + kk * 32 + i;
+            for (int t = 0; t < cin; t += 2) e = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t], wb[t * 32], e, 0, 0, 0);
+            const float bias = be[i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;       // C layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), column = lane & 31
+                h[px * 33 + i] = msk[px] != 0.f ? relu6f(e[r] + bias) : 0.f;
+            }
+        }
+        __syncthreads();
+        // 2. depthwise 3x3 + ReLU6: thread = (channel, 8 output pixels)
+        {
+            const int c = tid & 31, g = tid >> 5;
+            float w9[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w9[t] = wd[t * 32 + c];
+            const float bias = bd[c];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int o = g + 8 * q, oy = o >> 3, ox = o & 7;
+                const float* hp = h + ((oy * s) * RW + ox * s) * 33 + c;
+                float t = bias;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) t = fmaf(hp[(dy * RW + dx) * 33], w9[dy * 3 + dx], t);
+                d[o * 33 + c] = relu6f(t);
+            }
+        }
+        __syncthreads();
+        // 3. projection, accumulated over the chunks: tile pairs (m, n) = (output-pixel half, 32 output channels)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int pr = wave + 4 * p;
+            if (pr < 2 * NT) {
+                const int m = pr / NT, n = pr - m * NT;
+                const float* da = d + (m * 32 + i) * 33 + kk;
+                const float* wb = wp + kk * cop + n * 32 + i;
+#pragma unroll
+                for (int t = 0; t < 32; t += 2) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[t], wb[t * cop], acc[p], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int pr = wave + 4 * p;
+        if (pr >= 2 * NT) continue;
+        const int m = pr / NT, n = pr - m * NT;
+        const int ch = n * 32 + i;
+        if (ch >= a.cout) continue;
+        const float bias = a.bp[ch];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, oy = o >> 3, ox = o & 7;
+            if (oy0 + oy < a.Ho && ox0 + ox < a.Wo) {
+                float v = acc[p][r] + bias;
+                if (a.res) v += xin[((oy + 1) * RW + ox + 1) * cinp + ch];      // stride 1, cin == cout
+                a.out[(((int64_t)b * a.Ho + oy0 + oy) * a.Wo + ox0 + ox) * a.cout + ch] = v;
+            }
+        }
+    }
+}
+
+static size_t vlad_mblock_smem(int cin, int cop, int stride) {
+    const int RW = 7 * stride + 3, RP = ((RW * RW + 31) / 32) * 32;
+    return ((size_t)RP * (cin + 1) + (size_t)RP * 33 + 64 * 33 + 32 * (cin + 11 + cop) + RP) * 4;
+}
+static int launch_vlad_mblock(hipStream_t st, const VladMBlockArgs& a) {
+    const size_t smem = vlad_mblock_smem(a.cin, a.cop, a.stride);
+    static size_t attr = 0;
+    if (attr < smem) { OMNI_HIP_TRY(hipFuncSetAttribute((const void*)vlad_mblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = smem; }
+    const int tiles = cdiv(a.Wo, 8) * cdiv(a.Ho, 8);
+    hipLaunchKernelGGL(vlad_mblock_kernel, dim3(tiles * a.batch), dim3(256), smem, st, a);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 // returns OMNI_ERR_INVALID (without setting an error) when no instantiation covers the block's shape
 static bool vlad_block_supported(int cin, int cout) {
     const int cp = cout <= 8 ? 8 : cout <= 16 ? 16 : cout <= 32 ? 32 : cout <= 64 ? 64 : cout <= 128 ? 128 : 0;
@@ -673,6 +833,82 @@ vlad_fc4_kernel(const float* __restrict__ v, int nb, int n_in, const float* __re
                 if (lane == 0) out[(int64_t)b * n_out + j0 + r] = sacc + bias[j0 + r];
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FC 3584 -> 4096 on the matrix cores, exact f32 (v_mfma_f32_32x32x2_f32 = an fmaf chain): out[b][j] = v[b] . W[j] + bias[j] for up to 32
+// images per pass, the 58.7 MB matrix streamed ONCE per pass.  M = images (A = the NetVLAD vectors, L2-resident), N = 32 output rows j
+// (B = W), K split over FCM_KY workgroups x 4 waves; inside a wave the two half-waves take the two halves of its K range, so both operands
+// are 16-byte loads.  W is re-packed at create time as [j tile][k group of 4][32 rows][4]: a half-wave's B load is one contiguous 512 B.
+// The waves of a workgroup are summed through LDS in a fixed order, the FCM_KY partial tiles by vlad_fc_finish_kernel (+ bias + the final
+// L2 normalisation): deterministic.  Replaces 4 passes of vlad_fc4_kernel (33 us each at 8 images per pass) + l2norm_rows_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+#define FCM_KY 8
+__global__ void __launch_bounds__(256)
+vlad_fc_mfma_kernel(const float* __restrict__ v, int nb, int n_in, const float* __restrict__ Wp, int n_out, float* __restrict__ part /*[FCM_KY][32][n_out]*/) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int jt = blockIdx.x, ky = blockIdx.y;
+    const int groups = n_in >> 2;                                  // k groups of 4
+    const int per_wave = groups / (FCM_KY * 4), half = per_wave >> 1;       // create() checks divisibility
+    const int g0 = (ky * 4 + wave) * per_wave + kk * half;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const f32x4v* wp = reinterpret_cast<const f32x4v*>(Wp) + ((int64_t)jt * groups + g0) * 32 + i;
+    const float4* vp = reinterpret_cast<const float4*>(v + (int64_t)(i < nb ? i : nb - 1) * n_in) + g0;     // rows past nb repeat the last image (not written)
+    floatx16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 a0 = vp[0], a1 = a0;
+    f32x4v b0 = __builtin_nontemporal_load(wp), b1 = b0;
+    if (half > 1) { a1 = vp[1]; b1 = __builtin_nontemporal_load(wp + 32); }
+    for (int t = 0; t < half; ++t) {
+        float4 an = a1;
+        f32x4v bn = b1;
+        if (t + 2 < half) { an = vp[t + 2]; bn = __builtin_nontemporal_load(wp + (int64_t)(t + 2) * 32); }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0[3], acc, 0, 0, 0);
+        a0 = a1; b0 = b1; a1 = an; b1 = bn;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
+    const int j = jt * 32 + i;                                      // C layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (b < nb) part[((int64_t)ky * 32 + b) * n_out + j] = acc[r];
+    }
+}
+
+// out[b][:] = normalise(sum_ky part[ky][b][:] + bias); one workgroup per image
+__global__ void __launch_bounds__(256)
+vlad_fc_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias, int n_out, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    float ss = 0.f;
+    for (int j = threadIdx.x; j < n_out; j += 256) {
+        float t = part[(int64_t)b * n_out + j];
+#pragma unroll
+        for (int ky = 1; ky < FCM_KY; ++ky) t += part[((int64_t)ky * 32 + b) * n_out + j];
+        t += bias[j];
+        out[(int64_t)b * n_out + j] = t;
+        ss = fmaf(t, t, ss);
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    const float nrm = sqrtf(red[0]);
+    for (int j = threadIdx.x; j < n_out; j += 256) out[(int64_t)b * n_out + j] = out[(int64_t)b * n_out + j] / nrm;
 }
 
 static int upload(float** dst, const float* src, size_t n, hipStream_t st) {
@@ -843,6 +1079,15 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
     for (size_t bi = first; bi < v->blocks.size(); ++bi) {
         const VladFusedBlock& B = v->blocks[bi];
         const int64_t Pin = (int64_t)batch * B.hin * B.win, Pout = (int64_t)batch * B.hout * B.wout;
+        if (B.mblob && B.hin * B.win <= v->mblock_max_px) {                  // per-image size: batch-independent numerics
+            VladMBlockArgs m;
+            m.in = v->buf[cur]; m.out = v->buf[(cur + 1) % 3]; m.blob = B.mblob; m.bp = B.bp;
+            m.Hi = B.hin; m.Wi = B.win; m.Ho = B.hout; m.Wo = B.wout; m.cin = B.cin; m.hid = B.hid; m.cout = B.cout; m.cop = B.cop;
+            m.stride = B.stride; m.res = B.res; m.batch = batch;
+            if ((rc = launch_vlad_mblock(st, m))) return rc;
+            cur = (cur + 1) % 3;
+            continue;
+        }
         if (B.expand && B.cin % 8 == 0 && B.hid % 8 == 0 && B.hin * B.win <= v->mfma_max_px && v->mfma_late) {     // per-image size: batch-independent numerics
             // low-resolution block: expand / project as f32-MFMA pointwise GEMMs, depthwise in between (three launches; the fused
             // VALU kernel has too few workgroups at these sizes and is latency-bound)
@@ -893,6 +1138,17 @@ static int vlad_forward(omni_vlad* v, const uint8_t* gray_dev, int stride, int b
     const int n_in = v->K * v->Dm;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(batch), dim3(256), 0, st, v->vlad, n_in);
     OMNI_LAUNCH_CHECK();
+    if (v->fc_mfma) {
+        for (int b0 = 0; b0 < batch; b0 += 32) {
+            const int nb = batch - b0 < 32 ? batch - b0 : 32;
+            hipLaunchKernelGGL(vlad_fc_mfma_kernel, dim3(v->out_dim / 32, FCM_KY), dim3(256), 0, st, v->vlad + (int64_t)b0 * n_in, nb, n_in, v->fc_wp,
+                               v->out_dim, v->fc_part);
+            OMNI_LAUNCH_CHECK();
+            hipLaunchKernelGGL(vlad_fc_finish_kernel, dim3(nb), dim3(256), 0, st, v->fc_part, v->fc_b, v->out_dim, v->out + (int64_t)b0 * v->out_dim);
+            OMNI_LAUNCH_CHECK();
+        }
+        return OMNI_OK;
+    }
     for (int b0 = 0; b0 < batch; b0 += FC_MAXB) {
         const int nb = batch - b0 < FC_MAXB ? batch - b0 : FC_MAXB;
         const size_t smem = (size_t)nb * n_in * 4;
@@ -991,6 +1247,21 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
                     for (int co = 0; co < B.cout; ++co) q[(B.cin + 11) * 32 + c * B.cout + co] = Lp.weight[(size_t)co * B.hid + ch];
                 }
                 if (omni::upload(&B.blob, pk.data(), pk.size(), st)) { fusable = false; ok = false; break; }
+                B.mblob = nullptr; B.cop = ((B.cout + 31) / 32) * 32;
+                if (Le && B.cin % 4 == 0 && B.cop <= 128 && omni::vlad_mblock_smem(B.cin, B.cop, B.stride) <= 160 * 1024) {
+                    const int mb = 32 * (B.cin + 11 + B.cop);
+                    std::vector<float> mk((size_t)n_chunks * mb, 0.f);
+                    for (int ch = 0; ch < B.hid; ++ch) {
+                        float* q = mk.data() + (size_t)(ch / 32) * mb;
+                        const int c = ch % 32;
+                        for (int k = 0; k < B.cin; ++k) q[k * 32 + c] = Le->weight[(size_t)ch * B.cin + k];
+                        q[B.cin * 32 + c] = Le->bias[ch];
+                        for (int t = 0; t < 9; ++t) q[(B.cin + 1) * 32 + t * 32 + c] = Ld.weight[(size_t)ch * 9 + t];
+                        q[(B.cin + 10) * 32 + c] = Ld.bias[ch];
+                        for (int co = 0; co < B.cout; ++co) q[(B.cin + 11) * 32 + c * B.cop + co] = Lp.weight[(size_t)co * B.hid + ch];
+                    }
+                    if (omni::upload(&B.mblob, mk.data(), mk.size(), st)) { fusable = false; ok = false; break; }
+                }
             }
             v->blocks.push_back(B);
             i += 2;
@@ -999,6 +1270,14 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
         v->fused = fusable && !(env && env[0] == '1');
         const char* env2 = getenv("OMNI_VLAD_MFMA");
         v->mfma_late = !(env2 && env2[0] == '0');
+        // fused matrix-core block kernel for blocks whose input has at most this many pixels per image (0 disables).  Measured at 32 images
+        // (profiles/r02_vlad32_*): the ten 38x30 / 19x15 blocks take 451 us on it vs 502 us as three launches each; on the 75x60 ... 300x240
+        // blocks it is slower than the fp32-VALU fused kernel (one 8x8 tile per workgroup keeps 47-108 KB of LDS: 1-2 workgroups per CU
+        // and every phase of a chunk is a dependent chain behind a barrier -- waves wait 50 % of their life, MFMA-busy 14-18 %).  A
+        // split-fp16 variant (v_mfma_f32_32x32x16_f16, hi/lo operands: 5x less matrix time) measured SLOWER still (60 us per block): the
+        // matrix pipe is not what bounds these blocks, the per-workgroup latency chain is.
+        const char* env5 = getenv("OMNI_VLAD_MBLOCK_PX");
+        v->mblock_max_px = env5 ? atoi(env5) : 2048;
         const char* env4 = getenv("OMNI_VLAD_MFMA_PX");
         if (env4 && atoi(env4) > 0) v->mfma_max_px = atoi(env4);
     }
@@ -1010,6 +1289,19 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
         ok = !omni::upload(&v->assign_wT, awT.data(), awT.size(), st) && !omni::upload(&v->assign_b, w->assign_b, v->K, st) &&
              !omni::upload(&v->clusters, w->clusters, n_in, st) && !omni::upload(&v->fc_w, w->fc_w, n_in * v->out_dim, st) &&
              !omni::upload(&v->fc_b, w->fc_b, v->out_dim, st);
+        {   // FC on the matrix cores: W [out][n_in] -> [out / 32][n_in / 4][32 rows][4] (vlad_fc_mfma_kernel); OMNI_VLAD_FC_MFMA=0 keeps the VALU kernel
+            const char* ef = getenv("OMNI_VLAD_FC_MFMA");
+            const bool want = !(ef && ef[0] == '0') && v->fused;
+            if (ok && want && v->out_dim % 32 == 0 && n_in % (4 * 2 * FCM_KY * 4) == 0) {
+                const size_t groups = n_in / 4;
+                std::vector<float> pk(n_in * (size_t)v->out_dim);
+                for (int j = 0; j < v->out_dim; ++j)
+                    for (size_t g = 0; g < groups; ++g)
+                        memcpy(&pk[(((size_t)(j / 32) * groups + g) * 32 + (j % 32)) * 4], &w->fc_w[(size_t)j * n_in + g * 4], 16);
+                ok = !omni::upload(&v->fc_wp, pk.data(), pk.size(), st) && hipMalloc((void**)&v->fc_part, (size_t)FCM_KY * 32 * v->out_dim * 4) == hipSuccess;
+                v->fc_mfma = ok;
+            }
+        }
         for (int i = 0; i < 3 && ok; ++i) ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->assign, (size_t)max_batch * h * wd * v->K * 4) == hipSuccess &&
              hipMalloc((void**)&v->vlad, (size_t)max_batch * n_in * 4) == hipSuccess &&
@@ -1026,8 +1318,8 @@ void omni_vlad_destroy(omni_vlad* v) {
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
     for (auto& L : v->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
-    for (auto& B : v->blocks) if (B.blob) (void)hipFree(B.blob);
-    void* ptrs[] = {v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
+    for (auto& B : v->blocks) { if (B.blob) (void)hipFree(B.blob); if (B.mblob) (void)hipFree(B.mblob); }
+    void* ptrs[] = {v->fc_wp, v->fc_part, v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     v->hstage.release();
     delete v;

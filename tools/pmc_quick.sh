@@ -1,12 +1,14 @@
 #!/bin/bash
-# quick single-pass PMC probe of the conv kernels: tools/pmc_quick.sh <tag> [env assignments...]
+# quick single-pass PMC probe: tools/pmc_quick.sh <tag> [env assignments...]   (PMC_CMD = command to profile, PMC_FILTER = kernel-name substring;
+# defaults: a short bench.py run, "conv")
 TAG=$1; shift
 export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-  --kernel-trace --output-format csv -d gpurun_out/q_$TAG -o q -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --match-db-rows 4096 > /dev/null 2> gpurun_out/q_$TAG.err
+  --kernel-trace --output-format csv -d gpurun_out/q_$TAG -o q -- ${PMC_CMD:-python bench.py --steps 4 --warmup 1 --no-cpu-baseline --match-db-rows 4096 --big-db-keyframes 0 --f32-steps 0 --python-steps 0 --geometry-steps 0 --batched-rows 0} > /dev/null 2> gpurun_out/q_$TAG.err
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, os
+FILTER = os.environ.get("PMC_FILTER", "conv")
 d = "gpurun_out/q_$TAG"
 dur = collections.defaultdict(list)
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
@@ -18,7 +20,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         cnt[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
 print("tag $TAG")
 for k in cnt:
-    if "conv" not in k: continue
+    if FILTER not in k: continue
     # split by grid size (layers differ)
     grids = sorted({g for v in cnt[k].values() for _, g in v})
     for g in grids:
