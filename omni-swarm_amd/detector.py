@@ -27,13 +27,34 @@ DEEP_DESC_SIZE = 4096           # loop_defines.h:30
 STEREO_PINHOLE, STEREO_FISHEYE, PINHOLE_DEPTH = 0, 1, 2
 
 
+def _pose():
+    """Pose_t as fromROSPose fills it (loop_cam.cpp:366-368): position xyz + orientation quaternion wxyz."""
+    return np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+
+
 @dataclass
-class ImageDescriptor:           # swarm_msgs::ImageDescriptor_t, fields used on this path (loop_cam.cpp:529-551)
+class ImageDescriptor:
+    """swarm_msgs::ImageDescriptor_t (un-vendored): every field the reference reads or writes on this path -- loop_cam.cpp:529-585 (extractor),
+    :362-374,:434-440 (stereo part), loop_net.cpp:51-79,206-218 (wire split / reassembly), loop_detector.cpp:539-603 (matching).  Same fields
+    as omni::ImageDescriptor (host/omni_swarm.hpp)."""
     drone_id: int = 0
     landmark_num: int = 0
-    image_desc: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
-    feature_descriptor: np.ndarray = field(default_factory=lambda: np.zeros((0, 64), np.float32))
-    landmarks_2d: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
+    image_desc: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))                    # 4096 (empty: direction not received)
+    feature_descriptor: np.ndarray = field(default_factory=lambda: np.zeros((0, 64), np.float32))      # n x 64
+    landmarks_2d: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))             # pixel key points
+    landmarks_2d_norm: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))        # lifted (x/z, y/z), loop_cam.cpp:558-569
+    landmarks_3d: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))             # triangulated, loop_cam.cpp:434-440
+    landmarks_flag: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))                  # 1 = has a 3-D point
+    direction: int = 0
+    msg_id: int = 0
+    frame_id: int = 0
+    timestamp: float = 0.0
+    prevent_adding_db: bool = False
+    pose_drone: np.ndarray = field(default_factory=_pose)
+    camera_extrinsic: np.ndarray = field(default_factory=_pose)
+    image_width: int = 0
+    image_height: int = 0
+    image: bytes = b""                                                                                 # optional JPEG (loop_cam.cpp:49-71), opaque
 
 
 @dataclass
@@ -43,6 +64,9 @@ class FisheyeFrameDescriptor:    # swarm_msgs::FisheyeFrameDescriptor_t
     landmark_num: int = 0
     prevent_adding_db: bool = False
     images: list = field(default_factory=list)
+    image_num: int = 0
+    timestamp: float = 0.0
+    pose_drone: np.ndarray = field(default_factory=_pose)
 
 
 class LoopDetector:

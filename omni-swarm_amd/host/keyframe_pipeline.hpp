@@ -186,7 +186,8 @@ private:
             }
         }
         int hits = 0;
-        for (auto& c : det_.on_images_recv_batch(frames_, lane.rows_dev)) hits += c.found ? 1 : 0;
+        for (auto& c : det_.on_images_recv_batch(std::move(frames_), lane.rows_dev)) hits += c.found ? 1 : 0;
+        frames_.clear();
         return hits;
     }
 

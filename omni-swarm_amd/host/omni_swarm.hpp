@@ -400,6 +400,12 @@ public:
     // (omni_index_search_prefix_dev) -- fetched with one copy, and the decision rules are replayed frame by frame through the unchanged
     // on_image_recv.  rows_dev (optional): the frames' global descriptors, [sum of images][4096] fp32 in frame order, already in HBM
     // (e.g. MobileNetVLAD's output buffer): rows are appended and queried from there, the host copies are not read.
+    // rvalue overload: frames that enter the database are MOVED into it (the const& overload copies them, 270 KB per fisheye key frame)
+    std::vector<LoopCandidate> on_images_recv_batch(std::vector<FisheyeFrameDescriptor>&& frames, const float* rows_dev = nullptr) {
+        movable_ = &frames;
+        try { auto out = on_images_recv_batch(static_cast<const std::vector<FisheyeFrameDescriptor>&>(frames), rows_dev); movable_ = nullptr; return out; }
+        catch (...) { movable_ = nullptr; throw; }
+    }
     std::vector<LoopCandidate> on_images_recv_batch(const std::vector<FisheyeFrameDescriptor>& frames, const float* rows_dev = nullptr) {
         struct Add { IndexFlatIP* index; size_t row; };
         struct Search { IndexFlatIP* index; size_t row; int max_index; int64_t n_limit; };
@@ -510,15 +516,18 @@ public:
         replaying_ = true; sim_local_ = start_local; sim_remote_ = start_remote; next_deferred_ = next_row_id_ = 0;
         std::vector<LoopCandidate> out;
         try {
-            for (auto& f : frames) out.push_back(on_image_recv(f));
+            for (size_t fi = 0; fi < frames.size(); ++fi) { move_src_ = movable_ ? &(*movable_)[fi] : nullptr; out.push_back(on_image_recv(frames[fi])); }
+            move_src_ = nullptr;
         } catch (...) { replaying_ = false; throw; }
         replaying_ = false;
         if (next_deferred_ != deferred_.size() || next_row_id_ != row_ids_.size()) throw std::logic_error("on_images_recv_batch: plan and replay diverged");
         return out;
     }
 
-    LoopCandidate on_image_recv(const FisheyeFrameDescriptor& f) {               // :11-137
+    LoopCandidate on_image_recv(const FisheyeFrameDescriptor& f_in) {            // :11-137
         LoopCandidate r;
+        const FisheyeFrameDescriptor* fp = &f_in;          // re-pointed to the database's copy once the frame has been moved into it
+#define f (*fp)
         if (f.images.empty()) return r;
         const int drone_id = f.drone_id;
         if (drone_id != self_id && database_size() == 0) return r;                // :36-38
@@ -530,7 +539,7 @@ public:
         if (f.landmark_num < MIN_LOOP_NUM) return r;                              // :65
         bool init_mode = false;
         if (drone_id != self_id) init_mode = inter_drone_loop_count[{drone_id, self_id}] < inter_drone_init_frames;   // :67-72
-        if (!f.prevent_adding_db || new_node) { add_to_database(f); r.added = true; }                               // :89-94
+        if (!f.prevent_adding_db || new_node) { fp = add_to_database(f); r.added = true; }                          // :89-94
         if (database_size() > MATCH_INDEX_DIST || init_mode || drone_id != self_id) {                               // :98
             r.queried = true;
             int direction_new = stereo_fisheye ? 1 : 0, direction_old = -1, image_id = -1;
@@ -549,6 +558,7 @@ public:
             }
         }
         return r;
+#undef f
     }
 
     int self_id;
@@ -569,6 +579,8 @@ private:
     size_t next_deferred_ = 0, next_row_id_ = 0;
     char* batch_buf_ = nullptr;
     size_t batch_buf_bytes_ = 0;
+    std::vector<FisheyeFrameDescriptor>* movable_ = nullptr;      // set by the rvalue overload of on_images_recv_batch
+    FisheyeFrameDescriptor* move_src_ = nullptr;
     int add_image(const ImageDescriptor& img) {                                   // :164-173
         if (replaying_) {                                                         // on_images_recv_batch: already appended, in this order
             const int row = row_ids_.at(next_row_id_++);
@@ -579,10 +591,12 @@ private:
         remote_index.add(1, img.image_desc.data());
         return (int)remote_index.ntotal - 1 + REMOTE_MAGIN_NUMBER;
     }
-    void add_to_database(const FisheyeFrameDescriptor& f) {                       // :150-162
+    const FisheyeFrameDescriptor* add_to_database(const FisheyeFrameDescriptor& f) {      // :150-162; returns the stored frame
         for (size_t i = 0; i < f.images.size(); ++i)
             if (f.images[i].landmark_num > 0) { int index = add_image(f.images[i]); imgid2fisheye[index] = f.msg_id; imgid2dir[index] = (int)i; }
-        fisheyeframe_database[f.msg_id] = f;
+        FisheyeFrameDescriptor& slot = fisheyeframe_database[f.msg_id];
+        if (move_src_ && move_src_ == &f) slot = std::move(*move_src_); else slot = f;
+        return &slot;
     }
     int query_index(const ImageDescriptor& img, IndexFlatIP& index, bool remote_db, double thres, int max_index, double& distance) {   // :199-242
         float distances[1000] = {0};

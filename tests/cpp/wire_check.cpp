@@ -1,0 +1,88 @@
+// Exercises host/loop_net_wire.hpp: a key frame of drone 2 is split into header + landmark packets, delivered to drone 1 shuffled and with
+// losses under a fake clock, and reassembled; prints what arrived.  argv[1]: 0 = reference frame key, 1 = group_by_frame_id; argv[2] = seed.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../omni-swarm_amd/host/loop_net_wire.hpp"
+
+using namespace omni;
+
+int main(int argc, char** argv) {
+    const bool group = argc > 1 && std::atoi(argv[1]) != 0;
+    std::mt19937 rng(argc > 2 ? std::atoi(argv[2]) : 1);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    FisheyeFrameDescriptor f;
+    f.msg_id = 4242; f.drone_id = 2; f.timestamp = 12.5;
+    f.pose_drone.position[0] = 1.5; f.pose_drone.quat_wxyz[0] = 0.8; f.pose_drone.quat_wxyz[3] = 0.6;
+    const int n_lm[4] = {40, 25, 0, 60};
+    int flagged_total = 0;
+    for (int d = 0; d < 4; ++d) {
+        ImageDescriptor im;
+        im.drone_id = 2; im.direction = d; im.frame_id = f.msg_id; im.timestamp = f.timestamp; im.pose_drone = f.pose_drone; im.landmark_num = n_lm[d];
+        im.camera_extrinsic.position[2] = 0.05 * d; im.prevent_adding_db = d == 1;
+        im.image_desc.resize(4096);
+        for (auto& v : im.image_desc) v = U(rng);
+        for (int i = 0; i < n_lm[d]; ++i) {
+            im.landmarks_2d.push_back({(float)(10 * i + d), (float)(3 * i)});
+            im.landmarks_2d_norm.push_back({U(rng), U(rng)});
+            const bool fl = (i % 3) != 0;
+            im.landmarks_flag.push_back(fl);
+            im.landmarks_3d.push_back(fl ? Point3f{U(rng), U(rng), 5 + U(rng)} : Point3f{});
+            flagged_total += fl;
+            for (int k = 0; k < 64; ++k) im.feature_descriptor.push_back(U(rng));
+        }
+        f.images.push_back(im);
+        f.landmark_num += n_lm[d];
+    }
+    struct Pkt { std::string ch; std::vector<uint8_t> b; };
+    std::vector<Pkt> pkts;
+    LoopNetWire tx(2), rx(1);
+    tx.publish = [&](const char* ch, const std::vector<uint8_t>& b) { pkts.push_back({ch, b}); };
+    rx.group_by_frame_id = group;
+    std::vector<FisheyeFrameDescriptor> got;
+    rx.frame_desc_callback = [&](const FisheyeFrameDescriptor& fr) { got.push_back(fr); };
+    tx.frame_desc_callback = [&](const FisheyeFrameDescriptor&) { std::printf("SELF_LEAK\n"); };
+    tx.broadcast_fisheye_desc(f);
+    size_t bytes = 0, n_hdr = 0;
+    for (auto& p : pkts) { bytes += p.b.size(); n_hdr += p.ch == wire::CH_HEADER; }
+    std::printf("SENT %zu %zu %zu %d\n", pkts.size(), n_hdr, bytes, flagged_total);
+    // the sender hears its own packets (LCM multicast loops back): all ignored (sent_message, loop_net.cpp:133-136, loop_net.h:85-87)
+    for (auto& p : pkts) tx.on_packet(p.ch.c_str(), p.b.data(), p.b.size(), 0.0);
+    tx.scan_recv_packets(10.0);
+    // shuffled delivery with every 10th landmark packet lost; a corrupt packet is rejected
+    std::vector<Pkt> net = pkts;
+    std::shuffle(net.begin(), net.end(), rng);
+    int lost = 0, k = 0;
+    double t = 100.0;
+    for (auto& p : net) {
+        if (p.ch == wire::CH_LANDMARKS && (++k % 10) == 0) { ++lost; continue; }
+        rx.on_packet(p.ch.c_str(), p.b.data(), p.b.size(), t);
+        t += 0.001;
+    }
+    std::vector<uint8_t> junk(40, 7);
+    std::printf("JUNK %d\n", rx.on_packet(wire::CH_HEADER, junk.data(), junk.size(), t) ? 1 : 0);
+    std::printf("BEFORE_TIMEOUT %zu\n", got.size());
+    rx.scan_recv_packets(t + 0.6);          // images with losses complete by timeout (recv_period 0.5)
+    rx.scan_recv_packets(t + 1.7);          // frames complete by 2 x recv_period
+    std::printf("LOST %d FRAMES %zu\n", lost, got.size());
+    for (auto& fr : got) {
+        std::printf("FRAME %lld %d %d %zu", (long long)fr.msg_id, fr.drone_id, fr.landmark_num, fr.images.size());
+        for (auto& im : fr.images) {
+            // payload check against the sender's copy: every received landmark must match the sent one with the same pixel position
+            int bad = 0;
+            const ImageDescriptor& src = f.images[im.direction];
+            for (size_t i = 0; i < im.landmarks_2d.size(); ++i) {
+                int j = -1;
+                for (size_t q = 0; q < src.landmarks_2d.size(); ++q) if (src.landmarks_2d[q].x == im.landmarks_2d[i].x && src.landmarks_2d[q].y == im.landmarks_2d[i].y) j = (int)q;
+                if (j < 0 || !src.landmarks_flag[j] || std::memcmp(&src.feature_descriptor[(size_t)j * 64], &im.feature_descriptor[i * 64], 256) != 0 ||
+                    src.landmarks_3d[j].z != im.landmarks_3d[i].z || src.landmarks_2d_norm[j].x != im.landmarks_2d_norm[i].x) ++bad;
+            }
+            const bool desc_ok = im.landmark_num == 0 ? im.image_desc.empty() : im.image_desc == src.image_desc;
+            std::printf(" [%d %d %d %d %d]", im.direction, im.landmark_num, bad, desc_ok ? 1 : 0, im.prevent_adding_db ? 1 : 0);
+        }
+        std::printf(" %.3f %.3f\n", fr.pose_drone.position[0], fr.pose_drone.quat_wxyz[3]);
+    }
+    return 0;
+}

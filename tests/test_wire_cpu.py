@@ -1,0 +1,52 @@
+"""LoopNet's wire side (omni-swarm_amd/host/loop_net_wire.hpp; swarm_loop/src/loop_net.cpp:19-120,143-324): header + per-landmark packets,
+LCM-style big-endian encoding, reassembly under shuffling and loss with the reference's time-outs, self-sent filter, corrupt packets rejected.
+CPU only: g++ builds tests/cpp/wire_check.cpp."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("wire") / "wire_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", out, os.path.join(ROOT, "tests", "cpp", "wire_check.cpp")])
+    return out
+
+
+def run(exe, group, seed):
+    r = subprocess.run([exe, str(group), str(seed)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    return [ln.split() for ln in r.stdout.strip().split("\n")]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_split_and_reassemble(exe, seed):
+    for group in (0, 1):
+        out = run(exe, group, seed)
+        tags = [ln[0] for ln in out]
+        assert "SELF_LEAK" not in tags                                  # a drone ignores its own packets
+        sent = next(ln for ln in out if ln[0] == "SENT")
+        n_pkts, n_hdr, n_bytes, flagged = map(int, sent[1:])
+        assert n_hdr == 3 and n_pkts == 3 + flagged                     # one header per non-empty direction, one packet per 3-D landmark
+        assert n_bytes == 3 * (8 + 8 + 4 + 8 + 8 + 4 + 4 + 1 + 2 * 56 + 4 + 4096 * 4) + flagged * (8 + 8 + 8 + 4 + 4 + 4 + 7 * 4 + 4 + 64 * 4)
+        assert next(ln for ln in out if ln[0] == "JUNK")[1] == "0"      # a packet that does not parse is rejected
+        assert next(ln for ln in out if ln[0] == "BEFORE_TIMEOUT")[1] == "0"    # lossy images only complete by time-out
+        lost = int(next(ln for ln in out if ln[0] == "LOST")[1])
+        frames = [ln for ln in out if ln[0] == "FRAME"]
+        # the reference keys frames by the image's msg_id: one frame per direction; group_by_frame_id reunites the key frame
+        assert len(frames) == (1 if group else 3)
+        total = 0
+        for fr in frames:
+            assert fr[1] == "4242" and fr[2] == "2" and fr[4] == "4"
+            total += int(fr[3])
+            imgs = " ".join(fr[5:-2]).replace("[", "").split("]")[:4]
+            for im in imgs:
+                d, n, bad, desc_ok, prevent = map(int, im.split())
+                assert bad == 0 and desc_ok == 1                         # descriptors, 3-D points and global descriptor arrive bit-exact
+                if n:
+                    assert prevent == (1 if d == 1 else 0)
+            assert fr[-2] == "1.500" and fr[-1] == "0.600"
+        assert total == flagged - lost
