@@ -63,6 +63,7 @@ typedef struct omni_vlad omni_vlad;
 typedef struct omni_index omni_index;
 typedef struct omni_cam omni_cam;
 typedef struct omni_shard omni_shard;
+typedef struct omni_flatten omni_flatten;
 
 int         omni_abi_version(void);
 const char* omni_last_error(void);
@@ -236,6 +237,18 @@ int omni_bf_match_batched_dev(omni_ctx* ctx, int n_pairs, int max_n, int dim, in
                               const float* q_dev, int64_t q_stride, const int* nq_dev,
                               const float* t_dev, int64_t t_stride, const int* nt_dev,
                               int* q_idx_dev, int* t_idx_dev, float* dist_dev, int* n_matches_dev);
+
+/* ---- fisheye flattening: FisheyeUndist::undist_all_cuda = cv::cuda::remap(INTER_LINEAR) per virtual pinhole view
+ * (swarm_localization/test/fisheye_undist.hpp:57-90; VINS-Fisheye runs that class in front of swarm_loop).
+ * map_xy[v] = the view's undistortion map [view_h][view_w][2] float (source x, y per output pixel: genOneUndistMap, :188-215; made on the host,
+ * host/fisheye_flatten.hpp).  One launch remaps `batch` fisheye images into all views; image b's views are written back to back at
+ * out_dev + b * omni_flatten_out_bytes(): view v at its running offset, rows packed -- ready for omni_sp_enqueue_dev / omni_cam_enqueue_dev.
+ * Bilinear taps as cv::cuda's LinearFilter, border constant 0, round half to even. */
+omni_flatten* omni_flatten_create(omni_ctx* ctx, int src_width, int src_height, int n_views, const int* view_w, const int* view_h,
+                                  const float* const* map_xy);
+void          omni_flatten_destroy(omni_flatten* f);
+int64_t       omni_flatten_out_bytes(const omni_flatten* f);       /* bytes of all views of ONE source image */
+int           omni_flatten_enqueue_dev(omni_flatten* f, const uint8_t* src_dev, int src_stride, int batch, uint8_t* out_dev);   /* asynchronous */
 
 /* ---- key-frame frontend: the device work of LoopCam::on_flattened_images (swarm_loop/src/loop_cam.cpp:178-229;
  * generate_stereo_image_descriptor :341-523, extractor_img_desc_deepnet :525-585, match_HFNet_local_features :141-174)

@@ -36,7 +36,7 @@ SYMBOLS = [
     "omni_index_save", "omni_index_load",
     "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
     "omni_shard_unique_id", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev",
-    "omni_shard_search",
+    "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
 
 
@@ -147,6 +147,10 @@ def lib():
     sig("omni_cam_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int])
     sig("omni_cam_enqueue_host", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
     sig("omni_cam_wait", C.c_int, [_vp, C.POINTER(_CamResult)])
+    sig("omni_flatten_create", _vp, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(_fp)])
+    sig("omni_flatten_destroy", None, [_vp])
+    sig("omni_flatten_out_bytes", C.c_int64, [_vp])
+    sig("omni_flatten_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp])
     sig("omni_shard_unique_id", C.c_int, [C.c_char_p])
     sig("omni_shard_create", _vp, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p])
     sig("omni_shard_destroy", None, [_vp])
@@ -516,6 +520,61 @@ class IndexFlatIP:
         ms = C.c_float()
         _check(lib().omni_index_last_scan_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+class Flatten:
+    """omni_flatten: FisheyeUndist::undist_all_cuda -- one launch remaps fisheye images into all virtual pinhole views (maps from
+    omni_swarm_amd.flatten.generate_undist_maps or host/fisheye_flatten.hpp)."""
+
+    def __init__(self, ctx: Context, src_width: int, src_height: int, maps):
+        self.ctx = ctx
+        self.maps = [np.ascontiguousarray(m, np.float32) for m in maps]          # [h][w][2]
+        self.shapes = [(m.shape[0], m.shape[1]) for m in self.maps]
+        n = len(self.maps)
+        vw = (C.c_int * n)(*[s[1] for s in self.shapes])
+        vh = (C.c_int * n)(*[s[0] for s in self.shapes])
+        ptrs = (_fp * n)(*[_pf(m) for m in self.maps])
+        self.h = lib().omni_flatten_create(ctx.h, src_width, src_height, n, vw, vh, ptrs)
+        if not self.h:
+            raise OmniError(f"omni_flatten_create failed: {lib().omni_last_error().decode()}")
+        ctx._adopt(self)
+        self.out_bytes = lib().omni_flatten_out_bytes(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().omni_flatten_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enqueue_dev(self, src_dev: int, src_stride: int, batch: int, out_dev: int):
+        _check(lib().omni_flatten_enqueue_dev(self.h, src_dev, src_stride, batch, out_dev))
+
+    def __call__(self, fisheye_u8: np.ndarray):
+        """[H,W] or [B,H,W] uint8 -> list over images of lists of views (host convenience: upload, remap, download)."""
+        g = np.ascontiguousarray(fisheye_u8, np.uint8)
+        if g.ndim == 2:
+            g = g[None]
+        src = self.ctx.to_device(g)
+        out = self.ctx.alloc(self.out_bytes * g.shape[0])
+        try:
+            self.enqueue_dev(src, g.shape[2], g.shape[0], out)
+            raw = self.ctx.from_device(out, (g.shape[0], self.out_bytes), np.uint8)
+        finally:
+            self.ctx.free(src)
+            self.ctx.free(out)
+        res = []
+        for b in range(g.shape[0]):
+            views, o = [], 0
+            for (h, w) in self.shapes:
+                views.append(raw[b, o:o + h * w].reshape(h, w).copy())
+                o += h * w
+            res.append(views)
+        return res
 
 
 SHARD_ID_BYTES = 128

@@ -4,7 +4,9 @@
 #include <cstring>
 #include <string>
 
+#include "fisheye_flatten.hpp"
 #include "keyframe_pipeline.hpp"
+#include "loop_net_wire.hpp"
 
 namespace {
 thread_local std::string g_err;
@@ -72,6 +74,29 @@ int omni_pipeline_geometry_stats(omni_pipeline* h, int* compute_loop_calls, int*
     if (compute_loop_calls) *compute_loop_calls = h->p->geometry_calls();
     if (edges) *edges = (int)h->p->edges().size();
     return 0;
+}
+
+// FisheyeUndist's undistortion maps (host/fisheye_flatten.hpp).  mei = {xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0}.  Call with maps == NULL to get
+// n_views / view_w / view_h (arrays of >= 5), then with maps[v] pointing at view_w[v] * view_h[v] * 2 floats each.
+int omni_fisheye_maps(const double* mei, int img_width, double fov_deg, int cam_id, int* n_views, int* view_w, int* view_h, float* const* maps) {
+    try {
+        omni::MeiCamera c;
+        c.xi = mei[0]; c.k1 = mei[1]; c.k2 = mei[2]; c.p1 = mei[3]; c.p2 = mei[4]; c.gamma1 = mei[5]; c.gamma2 = mei[6]; c.u0 = mei[7]; c.v0 = mei[8];
+        if (!maps) {          // sizes only: no map is generated
+            omni::FlattenMaps m;
+            double side_fov = (fov_deg - 180) * M_PI / 180.0;
+            if (side_fov < 0) side_fov = 0;
+            const int sh = (int)(2 * (img_width / 2.0) * std::tan(side_fov / 2));
+            *n_views = sh > 0 ? 5 : 1;
+            view_w[0] = view_h[0] = img_width;
+            for (int v = 1; v < *n_views; ++v) { view_w[v] = img_width; view_h[v] = sh; }
+            return 0;
+        }
+        const omni::FlattenMaps m = omni::generate_all_undist_maps(c, (unsigned)img_width, fov_deg, cam_id);
+        *n_views = (int)m.w.size();
+        for (size_t v = 0; v < m.w.size(); ++v) { view_w[v] = m.w[v]; view_h[v] = m.h[v]; std::memcpy(maps[v], m.xy[v].data(), m.xy[v].size() * 4); }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
 int omni_pipeline_sync(omni_pipeline* h) {
