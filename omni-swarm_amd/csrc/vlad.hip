@@ -32,6 +32,7 @@ struct omni_vlad {
     int W = 0, H = 0, max_batch = 0, K = 0, Dm = 0, out_dim = 0, hf = 0, wf = 0;
     std::vector<VladLayerDev> layers;
     float *assign_wT = nullptr, *assign_b = nullptr, *clusters = nullptr, *fc_w = nullptr, *fc_b = nullptr;
+    float* mb_partial = nullptr; size_t mb_partial_bytes = 0; int mb_cpw = 1;   // hidden-layer split of vlad_mblock_kernel
     float *fc_wp = nullptr, *fc_part = nullptr;   // FC weights in MFMA B-operand order + K-split partial tiles (vlad_fc_mfma_kernel); null: VALU path
     bool fc_mfma = false;
     float *buf[3] = {nullptr, nullptr, nullptr};   // rotating activation buffers
@@ -529,6 +530,14 @@ struct VladMBlockArgs {
     const float* blob;         // per 32-channel chunk: [We cin x 32 | be 32 | Wd 9 x 32 | bd 32 | Wp 32 x cop], zero padded
     const float* bp;           // [cout]
     int Hi, Wi, Ho, Wo, cin, hid, cout, cop, stride, res, batch;
+    // hidden-layer split: workgroup (tile, g) handles chunks [g * cpw, (g + 1) * cpw) and writes its partial projection tile; a second, tiny
+    // launch (vlad_mblock_reduce_kernel) adds the partials in group order (deterministic), bias and residual.  A block is a chain of short
+    // dependent phases behind barriers: one workgroup walking all 5-11 chunks lives 30-90 us with the CU mostly idle (PMC: waves wait 50 % of
+    // their life, profiles/r02_*); splitting the chain over workgroups turns it into parallel work.  (Reducing inside the kernel -- last
+    // arrival of a tile behind __threadfence + a device-scope counter -- measured 8x SLOWER: an agent-scope release on this part writes the
+    // XCD's L2 back, once per workgroup.)
+    int cpw, n_groups;         // chunks per workgroup, groups per tile (1 = no split: the output is written directly)
+    float* partial;            // [tile][group][64][cop]
 };
 __global__ void __launch_bounds__(256)
 vlad_mblock_kernel(VladMBlockArgs a) {
@@ -552,7 +561,8 @@ vlad_mblock_kernel(VladMBlockArgs a) {
     const int oy0 = (tr / tiles_x) * 8, ox0 = (tr % tiles_x) * 8;
     const int iy0 = oy0 * s - 1, ix0 = ox0 * s - 1;        // region origin in the input
     const float* inb = a.in + (int64_t)b * a.Hi * a.Wi * cin;
-    const int blob = 32 * (cin + 11 + cop), n_chunks = (a.hid + 31) >> 5;
+    const int blob = 32 * (cin + 11 + cop), n_chunks_all = (a.hid + 31) >> 5;
+    const int chunk0 = blockIdx.y * a.cpw, n_chunks = chunk0 + a.cpw < n_chunks_all ? chunk0 + a.cpw : n_chunks_all;
 
     {   // input region (also the residual source) + in-image mask
         const int q4 = cin >> 2;
@@ -575,7 +585,7 @@ vlad_mblock_kernel(VladMBlockArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    for (int ci = 0; ci < n_chunks; ++ci) {
+    for (int ci = chunk0; ci < n_chunks; ++ci) {
         __syncthreads();                                    // previous chunk's readers are done with we/wp/h/d (first pass: xin is complete)
         {   // this chunk's weights.  (Fetching the NEXT chunk's blob into registers meanwhile and parking it after the projection measured
             // slower -- 49 vs 45 us per block: the extra registers and barriers cost more than the exposed L2 round trip.)
@@ -633,6 +643,19 @@ vlad_mblock_kernel(VladMBlockArgs a) {
             }
         }
     }
+    if (a.n_groups > 1) {
+        // partial projection tile of this group -> global scratch (L2), then the last arrival of the tile reduces in group order
+        float* part = a.partial + ((int64_t)blockIdx.x * a.n_groups + blockIdx.y) * 64 * cop;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int pr = wave + 4 * p;
+            if (pr >= 2 * NT) continue;
+            const int m = pr / NT, n = pr - m * NT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * cop + n * 32 + i] = acc[p][r];
+        }
+        return;                                             // vlad_mblock_reduce_kernel adds the groups in order (+ bias, residual)
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int pr = wave + 4 * p;
@@ -653,6 +676,35 @@ vlad_mblock_kernel(VladMBlockArgs a) {
     }
 }
 
+// out[tile pixel][ch] = sum_g partial[tile][g][o][ch] (g ascending) + bias (+ the block input at the same pixel); thread = (pixel, 4 channels)
+__global__ void __launch_bounds__(256)
+vlad_mblock_reduce_kernel(VladMBlockArgs a) {
+    const int cop = a.cop, q4 = cop >> 2;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int tiles_x = (a.Wo + 7) >> 3, tiles_y = (a.Ho + 7) >> 3;
+    const int64_t total = (int64_t)tiles_x * tiles_y * a.batch * 64 * q4;
+    if (e >= total) return;
+    const int c4 = (int)(e % q4) * 4;
+    const int o = (int)((e / q4) & 63);
+    const int64_t tile = e / ((int64_t)q4 * 64);
+    const int b = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (int64_t)b * tiles_x * tiles_y);
+    const int oy = (tr / tiles_x) * 8 + (o >> 3), ox = (tr % tiles_x) * 8 + (o & 7);
+    if (c4 >= a.cout || oy >= a.Ho || ox >= a.Wo) return;
+    const float* p = a.partial + (tile * a.n_groups * 64 + o) * cop + c4;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int g = 1; g < a.n_groups; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)g * 64 * cop);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float4 bs = *reinterpret_cast<const float4*>(a.bp + c4);          // cout % 4 == 0
+    v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+    if (a.res) {                                                             // stride 1, cin == cout
+        const float4 r = *reinterpret_cast<const float4*>(a.in + (((int64_t)b * a.Hi + oy) * a.Wi + ox) * a.cin + c4);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4*>(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.cout + c4) = v;
+}
+
 static size_t vlad_mblock_smem(int cin, int cop, int stride) {
     const int RW = 7 * stride + 3, RP = ((RW * RW + 31) / 32) * 32;
     return ((size_t)RP * (cin + 1) + (size_t)RP * 33 + 64 * 33 + 32 * (cin + 11 + cop) + RP) * 4;
@@ -662,8 +714,13 @@ static int launch_vlad_mblock(hipStream_t st, const VladMBlockArgs& a) {
     static size_t attr = 0;
     if (attr < smem) { OMNI_HIP_TRY(hipFuncSetAttribute((const void*)vlad_mblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = smem; }
     const int tiles = cdiv(a.Wo, 8) * cdiv(a.Ho, 8);
-    hipLaunchKernelGGL(vlad_mblock_kernel, dim3(tiles * a.batch), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(vlad_mblock_kernel, dim3(tiles * a.batch, a.n_groups), dim3(256), smem, st, a);
     OMNI_LAUNCH_CHECK();
+    if (a.n_groups > 1) {
+        const int64_t total = (int64_t)tiles * a.batch * 64 * (a.cop / 4);
+        hipLaunchKernelGGL(vlad_mblock_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+        OMNI_LAUNCH_CHECK();
+    }
     return OMNI_OK;
 }
 
@@ -1084,6 +1141,10 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
             m.in = v->buf[cur]; m.out = v->buf[(cur + 1) % 3]; m.blob = B.mblob; m.bp = B.bp;
             m.Hi = B.hin; m.Wi = B.win; m.Ho = B.hout; m.Wo = B.wout; m.cin = B.cin; m.hid = B.hid; m.cout = B.cout; m.cop = B.cop;
             m.stride = B.stride; m.res = B.res; m.batch = batch;
+            const int n_chunks = (B.hid + 31) / 32, tiles = cdiv(B.wout, 8) * cdiv(B.hout, 8) * batch;
+            m.cpw = v->mb_cpw > 0 ? v->mb_cpw : n_chunks; m.n_groups = cdiv(n_chunks, m.cpw);
+            if ((size_t)tiles * m.n_groups * 64 * B.cop * 4 > v->mb_partial_bytes) { m.cpw = n_chunks; m.n_groups = 1; }      // scratch too small: no split
+            m.partial = v->mb_partial;
             if ((rc = launch_vlad_mblock(st, m))) return rc;
             cur = (cur + 1) % 3;
             continue;
@@ -1302,6 +1363,23 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
                 v->fc_mfma = ok;
             }
         }
+        {   // scratch of the hidden-layer split (OMNI_VLAD_MBLOCK_CPW = chunks per workgroup; 0 = no split)
+            const char* ec = getenv("OMNI_VLAD_MBLOCK_CPW");
+            v->mb_cpw = ec ? atoi(ec) : 1;
+            size_t need = 0, max_tiles = 0;
+            for (auto& B : v->blocks) {
+                if (!B.mblob || B.hin * B.win > v->mblock_max_px) continue;
+                const size_t tiles = (size_t)omni::cdiv(B.wout, 8) * omni::cdiv(B.hout, 8) * max_batch;
+                const int n_chunks = (B.hid + 31) / 32, cpw = v->mb_cpw > 0 ? v->mb_cpw : n_chunks;
+                need = std::max(need, tiles * omni::cdiv(n_chunks, cpw) * 64 * B.cop * 4);
+                max_tiles = std::max(max_tiles, tiles);
+            }
+            if (ok && need && need <= ((size_t)1 << 30)) {
+                (void)max_tiles;
+                ok = hipMalloc((void**)&v->mb_partial, need) == hipSuccess;
+                v->mb_partial_bytes = ok ? need : 0;
+            }
+        }
         for (int i = 0; i < 3 && ok; ++i) ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->assign, (size_t)max_batch * h * wd * v->K * 4) == hipSuccess &&
              hipMalloc((void**)&v->vlad, (size_t)max_batch * n_in * 4) == hipSuccess &&
@@ -1319,7 +1397,7 @@ void omni_vlad_destroy(omni_vlad* v) {
     (void)hipStreamSynchronize(v->ctx->stream);
     for (auto& L : v->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
     for (auto& B : v->blocks) { if (B.blob) (void)hipFree(B.blob); if (B.mblob) (void)hipFree(B.mblob); }
-    void* ptrs[] = {v->fc_wp, v->fc_part, v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
+    void* ptrs[] = {v->mb_partial, v->fc_wp, v->fc_part, v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     v->hstage.release();
     delete v;

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (gpurun_out/<tag>_pmc3, _pmc4): HBM bytes per
+launch of the kernels bench.py quotes a `traffic` for.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE (KiB) counts half of a wide
+coalesced streaming read -> bytes = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024.
+
+    python tools/make_traffic.py r02k 64 > profiles/r02k_traffic.json        (64 = images per SuperPoint launch in that run)
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def mean_by(dirname, counter, match, grid=None):
+    vals = []
+    for f in glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and match(r["Kernel_Name"]) and (grid is None or int(r["Grid_Size"]) == grid):
+                vals.append(float(r["Counter_Value"]))
+    return vals
+
+
+def main(tag, images):
+    out = {"source": f"gpurun_out/{tag}_pmc3 (FETCH_SIZE) and {tag}_pmc4 (WRITE_SIZE): separate rocprofv3 --pmc passes of tools/profile_gpu.sh at HEAD, "
+                     f"micro-batches of {images // 8} key frames = {images} images per SuperPoint launch",
+           "correction": "gfx950: FETCH_SIZE counts 1/2 of a wide coalesced read (MI355X_MICROARCH.md, HBM): bytes = FETCH_SIZE_KiB*1024*2 + WRITE_SIZE_KiB*1024"}
+    kernels = {
+        "conv3x3_c64_pp_kernel<POOL,FUSE1A>": lambda n: "conv3x3_c64_pp_kernelILb1ELi0ELb1" in n,
+        "conv3x3_c128_rs_kernel<POOL>": lambda n: "conv3x3_c128_rs_kernelILb1" in n,
+        "conv3x3_c128_rs_kernel": lambda n: "conv3x3_c128_rs_kernelILb0" in n,
+        "ip_scan_mq_kernel": lambda n: "ip_scan_mq_kernel" in n,
+        "vlad_mblock_kernel": lambda n: "vlad_mblock_kernel" in n,
+        "vlad_fc_mfma_kernel": lambda n: "vlad_fc_mfma_kernel" in n,
+    }
+    for key, m in kernels.items():
+        rd = mean_by(f"gpurun_out/{tag}_pmc3", "FETCH_SIZE", m)
+        wr = mean_by(f"gpurun_out/{tag}_pmc4", "WRITE_SIZE", m)
+        if rd and wr:
+            r, w = sum(rd) / len(rd) * 1024 * 2, sum(wr) / len(wr) * 1024
+            out[key] = {"read_bytes": round(r), "write_bytes": round(w), "bytes_per_launch": round(r + w), "dispatches": len(rd)}
+            if "conv" in key:
+                out[key]["images_per_launch"] = images
+    # the 100k-row single-query scans: the largest FETCH_SIZE cluster of ip_scan_kernel<float,1>
+    rd = sorted(mean_by(f"gpurun_out/{tag}_pmc3", "FETCH_SIZE", lambda n: "ip_scan_kernel<float, 1>" in n))
+    if rd:
+        big = [x for x in rd if x > 0.8 * rd[-1]]
+        out["ip_scan_kernel<float,1>"] = {"bytes_per_launch": round(sum(big) / len(big) * 1024 * 2), "dispatches": len(big),
+                                          "note": "largest-database launches only (the p50 legs: 100k and 400k rows); algorithmic = rows x 16384 B"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 64)

@@ -7,8 +7,9 @@ TAG=${1:-r01x}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 40 --warmup 4 --no-cpu-baseline"
-BENCH_PMC="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --match-db-rows 100000"
+LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-db-keyframes 0"
+BENCH="python bench.py --steps 40 --warmup 8 --min-time 0 $LEGS"
+BENCH_PMC="python bench.py --steps 8 --warmup 8 --min-time 0 --match-db-rows 100000 $LEGS"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ${TAG} -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.err
 python tools/rocprof_summary.py $(ls $OUT/${TAG}_trace/*_results.db $OUT/${TAG}_trace/*/*_results.db 2>/dev/null | head -1) "(${TAG}; $BENCH; f16; 1x MI355X)" > $OUT/${TAG}_kernel_stats.md 2>> $OUT/${TAG}_trace.err
 i=0
