@@ -272,7 +272,12 @@ struct VladBlockArgs {
 // Weights reach the lanes through LDS: the next chunk's blob is fetched into registers while the current chunk computes and
 // written to the alternate LDS buffer afterwards, so only the first chunk pays a global-memory round trip (a workgroup per
 // CU with nothing else resident cannot hide one per weight matrix per chunk).
-template <int CIN, int CP, int TILE>
+// STRIDE is a template parameter so that the region geometry (RW, RH, R) is a compile-time constant: with a run-time stride every
+// "pixel -> (row, column)" of the in-image test was a 32-bit integer division by a run-time value (~40 VALU instructions each), executed
+// per region pixel per lane per chunk -- 1900 of the ~2300 instructions a wave issued per tile of the 300x240 block (the kernels are
+// VALU-issue bound: PMC SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES 0.38-0.46 with 4 waves per SIMD).  The test itself is now done once per
+// tile into an LDS mask that every chunk reuses.
+template <int CIN, int CP, int TILE, int STRIDE>
 __global__ void __launch_bounds__(256)
 vlad_block_kernel(VladBlockArgs a) {
     constexpr int TW = TILE >= 128 ? 16 : 8, TH = TILE / TW;
@@ -280,13 +285,18 @@ vlad_block_kernel(VladBlockArgs a) {
     constexpr int NLD = (32 * (CIN + 11 + CP) / 4 + 255) / 256;      // float4 per thread that cover the largest blob
     static_assert(NACC >= 1, "tile too small for this cout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int s = a.stride;
-    const int RW = TW * s + 2, RH = TH * s + 2, R = RW * RH;
+    constexpr int s = STRIDE;
+    constexpr int RW = TW * s + 2, RH = TH * s + 2, R = RW * RH;
+    // stride 1: region rows padded to the expand loop's step (no bounds tests inside it).  Stride 2 keeps the exact row count and the tests:
+    // measured at 32 images, padded vs exact -- b2 110 -> 104 us, b4/b5 67 -> 61 us, but b1 198 -> 239 us, b6 43 -> 62 us
+    constexpr bool PAD = STRIDE == 1;
+    constexpr int RP = PAD ? (R + 31) / 32 * 32 : R;
     const int blob = 32 * (CIN + 11 + a.cout), blob4 = blob / 4;     // cout % 4 == 0
-    float* xin = reinterpret_cast<float*>(smem_raw);       // [R][CIN]
-    float* h = xin + R * CIN;                               // [R][32]
-    float* d = h + R * 32;                                  // [TILE][32]
+    float* xin = reinterpret_cast<float*>(smem_raw);       // [RP][CIN], rows >= R zero
+    float* h = xin + RP * CIN;                              // [RP][32]
+    float* d = h + RP * 32;                                 // [TILE][32]
     float* wbuf = d + TILE * 32;                            // [2][blob]
+    float* msk = wbuf + 2 * blob;                           // [RP] 1 inside the image, 0 outside (the depthwise conv pads the EXPANDED tensor)
     const int tid = threadIdx.x;
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
     const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
@@ -296,12 +306,16 @@ vlad_block_kernel(VladBlockArgs a) {
     const int n_chunks = (a.hid + 31) / 32;
 
     for (int i = tid; i < blob4; i += 256) reinterpret_cast<float4*>(wbuf)[i] = reinterpret_cast<const float4*>(a.blob)[i];
-    for (int i = tid; i < R * (CIN / 4); i += 256) {
+    for (int i = tid; i < RP * (CIN / 4); i += 256) {
         const int r = i / (CIN / 4), q = i - r * (CIN / 4);
         const int gy = iy0 + r / RW, gx = ix0 + r % RW;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) v = *reinterpret_cast<const float4*>(inb + ((int64_t)gy * a.Wi + gx) * CIN + q * 4);
+        if (r < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) v = *reinterpret_cast<const float4*>(inb + ((int64_t)gy * a.Wi + gx) * CIN + q * 4);
         *reinterpret_cast<float4*>(xin + r * CIN + q * 4) = v;
+    }
+    for (int r = tid; r < RP; r += 256) {
+        const int gy = iy0 + r / RW, gx = ix0 + r % RW;
+        msk[r] = (r < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) ? 1.f : 0.f;
     }
     float acc[NACC];
 #pragma unroll
@@ -333,21 +347,16 @@ vlad_block_kernel(VladBlockArgs a) {
             // U region pixels at a time: U independent FMA chains (a 256-thread workgroup per CU has no other wave to hide
             // the latency of one dependent chain of CIN FMAs behind)
             constexpr int U = CIN >= 48 ? 2 : 4;
-            for (int r0 = rg; r0 < R; r0 += 8 * U) {
+            static_assert(!PAD || RP % (8 * U) == 0, "padded region rows must be a multiple of the expand step");
+            for (int r0 = rg; r0 < RP; r0 += 8 * U) {
                 float t[U];
-                bool inb[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int r = r0 + 8 * u;
-                    const int gy = iy0 + r / RW, gx = ix0 + r % RW;
-                    inb[u] = r < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
-                    t[u] = be;
-                }
+                for (int u = 0; u < U; ++u) t[u] = be;
 #pragma unroll
                 for (int k4 = 0; k4 < CIN / 4; ++k4) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const int r = (r0 + 8 * u) < R ? (r0 + 8 * u) : rg;
+                        const int r = (PAD || (r0 + 8 * u) < RP) ? (r0 + 8 * u) : rg;
                         const float4 x = *reinterpret_cast<const float4*>(xin + r * CIN + k4 * 4);
                         t[u] = fmaf(x.x, we[k4 * 4 + 0], t[u]); t[u] = fmaf(x.y, we[k4 * 4 + 1], t[u]);
                         t[u] = fmaf(x.z, we[k4 * 4 + 2], t[u]); t[u] = fmaf(x.w, we[k4 * 4 + 3], t[u]);
@@ -356,12 +365,12 @@ vlad_block_kernel(VladBlockArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int r = r0 + 8 * u;
-                    if (r < R) h[r * 32 + c] = inb[u] ? relu6f(t[u]) : 0.f;
+                    if (PAD || r < RP) h[r * 32 + c] = msk[r] != 0.f ? relu6f(t[u]) : 0.f;      // padded rows: mask 0
                 }
             }
         } else {
             const int cc = ci * 32 + c;
-            for (int r = rg; r < R; r += 8) h[r * 32 + c] = (cc < CIN) ? xin[r * CIN + cc] : 0.f;
+            for (int r = rg; r < RP; r += 8) h[r * 32 + c] = (cc < CIN) ? xin[r * CIN + cc] : 0.f;
         }
         __syncthreads();
         // 2. depthwise 3x3 + ReLU6
@@ -415,17 +424,21 @@ vlad_block_kernel(VladBlockArgs a) {
     }
 }
 
-template <int CIN, int CP, int TILE>
-static int launch_vlad_block(hipStream_t st, const VladBlockArgs& a) {
+template <int CIN, int CP, int TILE, int STRIDE>
+static int launch_vlad_block_s(hipStream_t st, const VladBlockArgs& a) {
     constexpr int TW = TILE >= 128 ? 16 : 8, TH = TILE / TW;
-    const int RW = TW * a.stride + 2, RH = TH * a.stride + 2;
-    const size_t smem = ((size_t)RW * RH * (CIN + 32) + TILE * 32 + 2 * 32 * (CIN + 11 + a.cout)) * 4;
-    auto kfn = vlad_block_kernel<CIN, CP, TILE>;
+    constexpr int RW = TW * STRIDE + 2, RH = TH * STRIDE + 2, RP = STRIDE == 1 ? (RW * RH + 31) / 32 * 32 : RW * RH;
+    const size_t smem = ((size_t)RP * (CIN + 32 + 1) + TILE * 32 + 2 * 32 * (CIN + 11 + a.cout)) * 4;
+    auto kfn = vlad_block_kernel<CIN, CP, TILE, STRIDE>;
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int tiles = cdiv(a.Wo, TW) * cdiv(a.Ho, TH);
     hipLaunchKernelGGL(kfn, dim3(tiles * a.batch), dim3(256), smem, st, a);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
+}
+template <int CIN, int CP, int TILE>
+static int launch_vlad_block(hipStream_t st, const VladBlockArgs& a) {
+    return a.stride == 2 ? launch_vlad_block_s<CIN, CP, TILE, 2>(st, a) : launch_vlad_block_s<CIN, CP, TILE, 1>(st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1365,7 +1378,7 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
         }
         {   // scratch of the hidden-layer split (OMNI_VLAD_MBLOCK_CPW = chunks per workgroup; 0 = no split)
             const char* ec = getenv("OMNI_VLAD_MBLOCK_CPW");
-            v->mb_cpw = ec ? atoi(ec) : 1;
+            v->mb_cpw = ec ? atoi(ec) : 0;             // measured: splitting does not pay (same total issue-bound work + a reduce launch per block)
             size_t need = 0, max_tiles = 0;
             for (auto& B : v->blocks) {
                 if (!B.mblob || B.hin * B.win > v->mblock_max_px) continue;
