@@ -222,3 +222,38 @@ def test_nms2_restatement_is_pinned_to_the_reference_text():
         assert np.array_equal(ref(prob, 0.0, 10_000), xy_w), trial
         diff += not np.array_equal(xy_w, P.get_keypoints(prob, 0.0, 10_000)[0])
     assert diff > 0            # the quirk is real (and only reachable at the frame's left / right edge)
+
+
+def test_mobilenetvlad_backbone_matches_an_independent_mobilenetv2():
+    """The reference ships no MobileNetVLAD graph (parity unpinned, assumed architecture).  What CAN be checked offline: the assumed backbone --
+    MobileNetV2 at width 0.35 up to the 112-channel block -- against an INDEPENDENT implementation of that architecture (Hugging Face
+    `transformers.MobileNetV2Model`, written after TF-slim's definition): same layer table (channels, strides, groups of all 51 convolutions)
+    and, with the oracle's seeded weights loaded into it (batch norm set to identity + the conv bias), the same feature map.  A wrong row in
+    omni-swarm_amd/weights.py:VLAD_BLOCKS, a wrong padding or a misplaced residual would show up here."""
+    import torch
+    transformers = pytest.importorskip("transformers")
+    from transformers import MobileNetV2Config, MobileNetV2Model
+    cfg = MobileNetV2Config(num_channels=3, depth_multiplier=0.35, min_depth=8, depth_divisible_by=8, expand_ratio=6, output_stride=32,
+                            first_layer_is_expansion=True, finegrained_output=True, tf_padding=False, hidden_act="relu6")
+    hf = MobileNetV2Model(cfg, add_pooling_layer=False).eval()
+    convs = [(n, m) for n, m in hf.named_modules() if isinstance(m, torch.nn.Conv2d) and not n.startswith("conv_1x1")]
+    specs = V.layer_specs()
+    assert len(convs) == len(specs) == 51
+    w = V.synth_weights()
+    with torch.no_grad():
+        for (hname, conv), (name, kind, cin, cout, stride) in zip(convs, specs):
+            groups = cin if kind == "dw3x3_relu6" else 1
+            assert (conv.in_channels, conv.out_channels, conv.stride[0], conv.groups) == (cin, cout, stride, groups), (hname, name)
+            assert conv.kernel_size[0] == (1 if kind.startswith("pw") else 3)
+            conv.weight.copy_(torch.from_numpy(w[name + ".weight"]))
+            bn = dict(hf.named_modules())[hname.rsplit(".", 1)[0] + ".normalization"]
+            bn.weight.fill_(1.0); bn.running_mean.zero_(); bn.eps = 1e-12; bn.running_var.fill_(1.0 - 1e-12)      # identity up to 1 ulp
+            bn.bias.copy_(torch.from_numpy(w[name + ".bias"]))
+        img = synth.image_u8(321, 96, 128, n_shapes=60)
+        _, feat, _ = V.forward(w, img, return_features=True)
+        x = ((torch.from_numpy(img).float() - 128.0) / 128.0)[None, None].repeat(1, 3, 1, 1)
+        h = hf.conv_stem(x)
+        for layer in hf.layer:
+            h = layer(h)
+    assert h.shape == feat.shape == (1, 112, 3, 4)
+    assert np.abs(h.numpy() - feat).max() < 1e-4 * max(1.0, np.abs(feat).max())
