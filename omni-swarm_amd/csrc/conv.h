@@ -62,6 +62,9 @@ int detector_head(hipStream_t stream, int precision, const void* in, int in_stri
 
 // Same on the matrix cores (v_mfma_f32_32x32x2_f32 for the 64 kept channels, VALU for the dustbin); weights packed on the host.
 void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*[16384]*/, float* wdust /*[256]*/);
+void detector_pack_weights16(const float* wT /*[256][65]*/, uint16_t* wA16 /*[32768]: split-fp16 A fragments*/);
+int detector_head_mfma16(hipStream_t stream, const void* in_f16, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
+                         const float* bias, float* semi, int n_cu);
 int detector_head_mfma(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                        const float* wA, const float* wdust, const float* bias, float* semi, int n_cu);
 

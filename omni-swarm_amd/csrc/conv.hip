@@ -1606,6 +1606,122 @@ int detector_head_mfma(hipStream_t st, int precision, const void* in, int in_str
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same head for fp16 activations on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the K rate of the f32 form): the activations ARE
+// fp16 (exact operands); only the f32 weights are split, w = hi + lo with hi = fp16(w), lo = fp16(w - hi), and both products are
+// accumulated in f32 (a fp16 x fp16 product is exact in f32): fp32-class logits -- the weight is represented to 2^-22 -- at 4 MFMAs of 32
+// cycles per 16 input channels instead of 16 MFMAs of 64 cycles.  B operand = 16 bytes of the cell's channels straight from HBM (no
+// conversion); the dustbin logit stays a VALU dot product over the same registers.  Epilogue (softmax over 65, depth-to-space) unchanged.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DETM_THREADS)
+detector_head_mfma16_kernel(const _Float16* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
+                            const uint4* __restrict__ wA16 /*[hl 2][m 2][s 16][lane 64] x 8 halfs*/, const float* __restrict__ wdust /*[256]*/,
+                            const float* __restrict__ bias /*[65]*/, float* __restrict__ semi) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* wl = reinterpret_cast<uint4*>(smem_raw);            // 4096 x 16 B = 64 KB
+    float* wd = reinterpret_cast<float*>(wl + 4096);           // [256]
+    float* bl = wd + 256;                                      // [65]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < 4096; i += DETM_THREADS) wl[i] = wA16[i];
+    wd[tid] = wdust[tid];
+    if (tid < 65) bl[tid] = bias[tid];
+    __syncthreads();
+    const float dust_bias = bl[64];
+    const int n_frag = (n_cells + 31) >> 5;
+    for (int f = blockIdx.x * 4 + wave; f < n_frag; f += gridDim.x * 4) {
+        const int cell = f * 32 + n;
+        const bool valid = cell < n_cells;
+        const _Float16* ip = in + (int64_t)(valid ? cell : n_cells - 1) * in_stride + in_off + hh * 8;     // k-step s: channels [16 s + 8 hh, + 8)
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        float dust = 0.f;
+        half8_t xr[8], xn[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const half8_t*>(ip + i * 16);
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {                      // two halves of 8 k-steps; the second half's loads fly during the first
+            if (hf == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xn[i] = *reinterpret_cast<const half8_t*>(ip + (8 + i) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int sidx = hf * 8 + t;
+                const half8_t a0h = __builtin_bit_cast(half8_t, wl[((0 * 2 + 0) * 16 + sidx) * 64 + lane]);
+                const half8_t a1h = __builtin_bit_cast(half8_t, wl[((0 * 2 + 1) * 16 + sidx) * 64 + lane]);
+                const half8_t a0l = __builtin_bit_cast(half8_t, wl[((1 * 2 + 0) * 16 + sidx) * 64 + lane]);
+                const half8_t a1l = __builtin_bit_cast(half8_t, wl[((1 * 2 + 1) * 16 + sidx) * 64 + lane]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, xr[t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, xr[t], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, xr[t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, xr[t], acc1, 0, 0, 0);
+                const float4 d0 = *reinterpret_cast<const float4*>(wd + sidx * 16 + hh * 8), d1 = *reinterpret_cast<const float4*>(wd + sidx * 16 + hh * 8 + 4);
+                dust = fmaf((float)xr[t][0], d0.x, dust); dust = fmaf((float)xr[t][1], d0.y, dust);
+                dust = fmaf((float)xr[t][2], d0.z, dust); dust = fmaf((float)xr[t][3], d0.w, dust);
+                dust = fmaf((float)xr[t][4], d1.x, dust); dust = fmaf((float)xr[t][5], d1.y, dust);
+                dust = fmaf((float)xr[t][6], d1.z, dust); dust = fmaf((float)xr[t][7], d1.w, dust);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xr[i] = xn[i];
+        }
+        dust = dust + __shfl_xor(dust, 32, 64) + dust_bias;
+        float l0[16], l1[16], mx = dust;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            l0[r] = acc0[r] + bl[c]; l1[r] = acc1[r] + bl[32 + c];
+            mx = fmaxf(mx, fmaxf(l0[r], l1[r]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { l0[r] = expf(l0[r] - mx); l1[r] = expf(l1[r] - mx); sum += l0[r] + l1[r]; }
+        sum = sum + __shfl_xor(sum, 32, 64) + expf(dust - mx);
+        if (valid) {
+            const int wx = cell % Wc;
+            const int hy = (cell / Wc) % Hc;
+            const int b = cell / (Wc * Hc);
+            float* o = semi + ((int64_t)b * Hc * 8 + hy * 8) * (Wc * 8) + wx * 8 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(o + (int64_t)g * (Wc * 8)) =
+                    make_float4(l0[4 * g + 0] / sum, l0[4 * g + 1] / sum, l0[4 * g + 2] / sum, l0[4 * g + 3] / sum);
+                *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) =
+                    make_float4(l1[4 * g + 0] / sum, l1[4 * g + 1] / sum, l1[4 * g + 2] / sum, l1[4 * g + 3] / sum);
+            }
+        }
+    }
+}
+
+// host: [256][65] transposed weights -> split-fp16 A fragments [hl][m][s][lane][e] = split(W[32 m + (lane & 31)][16 s + 8 (lane >> 5) + e])
+void detector_pack_weights16(const float* wT /*[256][65]*/, uint16_t* wA16 /*2*2*16*64*8*/) {
+    for (int m = 0; m < 2; ++m)
+        for (int sx = 0; sx < 16; ++sx)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const float w = wT[(size_t)(16 * sx + 8 * (lane >> 5) + e) * 65 + 32 * m + (lane & 31)];
+                    const uint16_t hi = f2h_bits(w);
+                    const uint16_t lo = f2h_bits(w - h2f(hi));
+                    wA16[((((size_t)0 * 2 + m) * 16 + sx) * 64 + lane) * 8 + e] = hi;
+                    wA16[((((size_t)1 * 2 + m) * 16 + sx) * 64 + lane) * 8 + e] = lo;
+                }
+}
+
+int detector_head_mfma16(hipStream_t st, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
+                         const float* bias, float* semi, int n_cu) {
+    const int n_cells = batch * Hc * Wc;
+    const size_t smem = (size_t)4096 * 16 + (256 + 80) * 4;
+    int grid = cdiv(cdiv(n_cells, 32), 4);
+    if (n_cu > 0 && grid > 2 * n_cu) grid = 2 * n_cu;         // 66 KB of LDS: two workgroups per CU
+    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(detector_head_mfma16_kernel, dim3(grid), dim3(DETM_THREADS), smem, st, (const _Float16*)in, in_stride, in_off, n_cells, Hc, Wc,
+                       (const uint4*)wA16, wdust, bias, semi);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // convDb (1x1, 256 -> 256, f32 out) + the descriptor L2 normalisation over the 256 channels in ONE pass (fp16 path).  The pair is
 // HBM bound (0.59 GFLOP but 2.3 MB read + 4.6 MB written per image); run separately the f32 map made a second round trip
 // (write 4.6, read 4.6, write 4.6 MB).  A workgroup = 8 waves, wave w owns output channels 32w..32w+31 with their A fragments

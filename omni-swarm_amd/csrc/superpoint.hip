@@ -35,6 +35,8 @@ struct omni_sp {
     float* w1a = nullptr;                    // [64][9]
     float* wPbT = nullptr;                   // [256][65]
     float *wPbA = nullptr, *wPbDust = nullptr; // convPb in MFMA A-fragment order + the dustbin row
+    void* wPbA16 = nullptr;                    // convPb as split-fp16 A fragments (detector_head_mfma16_kernel); OMNI_DET16=0 keeps the f32 MFMA head
+    bool det16 = true;
     void* wDbFrag = nullptr;                    // convDb as register-resident fp16 A fragments (fused convDb + L2 norm, fp16 path)
     float* bias_heads = nullptr;             // [512]
     float* lut = nullptr;
@@ -81,6 +83,11 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         detector_pack_weights(t.data(), wa.data(), wdst.data());
         if ((rc = dev_upload((void**)&s->wPbA, wa.data(), wa.size() * 4, st))) return rc;
         if ((rc = dev_upload((void**)&s->wPbDust, wdst.data(), wdst.size() * 4, st))) return rc;
+        std::vector<uint16_t> w16(2 * 2 * 16 * 64 * 8);
+        detector_pack_weights16(t.data(), w16.data());
+        if ((rc = dev_upload(&s->wPbA16, w16.data(), w16.size() * 2, st))) return rc;
+        const char* e16 = getenv("OMNI_DET16");
+        s->det16 = !(e16 && e16[0] == '0');
     }
     {
         std::vector<float> bh(512);
@@ -220,8 +227,10 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
     if (s->conv_variant == 1) { if ((rc = detector_head(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
-    else if ((rc = detector_head_mfma(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
-                                      s->ctx->prop.multiProcessorCount))) return rc;
+    else if (P == OMNI_PREC_F16 && s->det16) {
+        if ((rc = detector_head_mfma16(st, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount))) return rc;
+    } else if ((rc = detector_head_mfma(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
+                                        s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
     if (s->precision == OMNI_PREC_F16 && s->conv_variant == 0) {
         // convDb + descriptor L2 norm in one HBM pass (channels [256,512) = cDa of the fused heads buffer, pixel stride 512)
@@ -310,7 +319,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
-    void* ptrs[] = {s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
+    void* ptrs[] = {s->wPbA16, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
                     s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
