@@ -281,10 +281,11 @@ def main():
                 self.swarm = None
             else:
                 self.det = None
-                if one_gpu:       # bring-up on one GPU: torch/gloo collectives over host copies
-                    self.swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, coll_dev)
-                else:             # the exchange inside libomni_hip.so: ncclAllGather on device buffers (csrc/shard.hip)
+                self.native = not one_gpu and args.host == "python"
+                if self.native:   # the exchange inside libomni_hip.so: ncclAllGather on device buffers (csrc/shard.hip)
                     self.swarm = shard.NativeSwarmIndex(ictx, capi.IndexFlatIP(ictx, 4096), rank, world, shard_uid())
+                else:             # torch.distributed collectives over host copies (gloo bring-up on one GPU, or the fallback)
+                    self.swarm = shard.SwarmIndex(capi.IndexFlatIP(ictx, 4096), rank, world, dist, coll_dev)
                 per_rank = 4 * args.db_keyframes // world
                 self.swarm.preload_local(RowFactory(7 + rank).rows(per_rank), per_rank * world)
 
@@ -311,11 +312,11 @@ def main():
             else:
                 # the micro-batch's mb steps (each: add world*4 rows, query direction 1) in two collectives + one index sync
                 base = self.swarm.ntotal
-                if one_gpu:
+                if self.native:   # rows and queries straight from MobileNetVLAD's output buffer in HBM ([mb][4][4096])
+                    results = self.swarm.step_batch_dev(mb, 4, cam.vlad.dev_output(), 1, K_SEARCH)
+                else:
                     rows = np.stack([np.stack([i["image_desc"] for i in out["images"][4 * m:4 * m + 4]]) for m in range(mb)])
                     results = self.swarm.step_batch(rows, query_row=1, k=K_SEARCH)
-                else:             # rows and queries straight from MobileNetVLAD's output buffer in HBM ([mb][4][4096])
-                    results = self.swarm.step_batch_dev(mb, 4, cam.vlad.dev_output(), 1, K_SEARCH)
                 for m, (D, I) in enumerate(results):
                     nt = base + (m + 1) * world * 4                                 # ntotal as of this key frame's step
                     ok = (I[0] >= 0) & (I[0] <= nt - MATCH_INDEX_DIST) & (D[0] > QUERY_THRES)
@@ -350,6 +351,18 @@ def main():
 
     hits = 0
     pyloop = None
+    if cpp_host and world > 1:
+        # the sharded C++ loop needs RCCL inside libomni_hip.so (dlopen) and one GPU per rank: probe it collectively, and if ANY rank cannot
+        # set it up every rank takes the torch.distributed path instead (still GPU compute; the line's host_loop field says which ran)
+        ok = 1.0
+        try:
+            capi.shard_unique_id()
+        except Exception as e:                                # noqa: BLE001
+            print(f"[bench] rank {rank}: omni_shard unavailable ({e}); falling back to the torch.distributed exchange", file=sys.stderr)
+            ok = 0.0
+        t = torch.tensor([ok], device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        cpp_host = bool(t.item() > 0.5)
     if cpp_host:
         main_leg = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, args.steps, args.warmup, args.min_time)
         hits = main_leg["loop_candidates_found"]
@@ -422,7 +435,8 @@ def main():
             for s in range(0, rows_here, 32768):
                 midx.add(gen.rows(min(32768, rows_here - s)))
         mq = RowFactory(99).rows(1)
-        if world > 1 and one_gpu:
+        native_p50 = world > 1 and not one_gpu and cpp_host
+        if world > 1 and not native_p50:
             big = shard.ShardedIndex(midx, rank, world, dist, coll_dev)
             for s in range(0, rows_here, 32768):
                 midx.add(gen.rows(min(32768, rows_here - s)))
@@ -444,7 +458,7 @@ def main():
             scan.append(midx.last_scan_ms())
         p50 = reduce_max(float(np.median(lat[10:])))
         scan_ms = float(np.median(scan[10:]))
-        if world > 1 and not one_gpu:
+        if world > 1 and native_p50:
             big.close()
         midx.close()
         return p50, scan_ms, rows_here
@@ -502,7 +516,8 @@ def main():
                                    "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query + results to host; "
                                    f"{args.db_keyframes}-keyframe DB ({4 * args.db_keyframes} rows); seeded synthetic weights",
                        "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": args.pipelines,
-                       "keyframes_per_microbatch": MB, "host_loop": "c++ (host/keyframe_pipeline.hpp)" if cpp_host else "python",
+                       "keyframes_per_microbatch": MB, "host_loop": ("c++ (host/keyframe_pipeline.hpp)" + (" + omni_shard (RCCL inside libomni_hip.so)" if world > 1 else "")) if cpp_host else
+                                    "python" + (" + torch.distributed exchange" if world > 1 else ""),
                        "image_upload": "inside the timed region (pinned host -> HBM, one async copy per micro-batch)",
                        "parallelism": f"dp{world} keyframes + {world}-way row-sharded index" if world > 1 else "single GPU",
                        "device": info["name"], "n_cu": info["n_cu"]},

@@ -191,3 +191,30 @@ def test_cpp_host_loop_equals_python_host_loop(omni, ctx, tmp_path):
     assert hits_cpp == hits_py and hits_py >= 16             # the second pass over blocks 0/1 revisits every key frame of the first
     for p in pins:
         ctx.host_free(p)
+
+
+def test_cam_enqueue_host_with_a_row_stride(omni, ctx):
+    """omni_cam_enqueue_host from a host block whose rows are padded (stride > width: a cv::Mat ROI / aligned buffer): the 2-D upload packs
+    the rows, results equal the packed upload."""
+    import ctypes as C
+    c = omni.capi
+    from omni_swarm_amd import frontend
+    weights, vw = S.synth_weights(0), V.synth_weights()
+    comp, mean = synth.pca()
+    w, h, stride = 128, 96, 160
+    imgs = np.stack([synth.image_u8(1200 + i, h, w, n_shapes=60) for i in range(8)])
+    cam = frontend.LoopCam(ctx, weights, comp, mean, vw, V.layer_specs(), (V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM), w, h, 0.015, 150, c.PREC_F16, n_dirs=4)
+    packed = ctx.host_alloc(imgs.shape, np.uint8)
+    packed[:] = imgs
+    cam.enqueue_host(packed)
+    ref = cam.fetch()
+    padded = ctx.host_alloc((8, h, stride), np.uint8)
+    padded[:] = 255
+    padded[:, :, :w] = imgs
+    omni.capi._check(c.lib().omni_cam_enqueue_host(cam.cam.h, padded.ctypes.data_as(C.c_void_p), stride, w, h, 1))
+    got = cam.fetch()
+    for a, b in zip(ref["images"], got["images"]):
+        assert np.array_equal(a["landmarks_2d"], b["landmarks_2d"]) and np.array_equal(a["feature_descriptor"], b["feature_descriptor"])
+        assert np.array_equal(a["image_desc"], b["image_desc"]) and np.array_equal(a["ids_up"], b["ids_up"])
+    ctx.host_free(packed); ctx.host_free(padded)
+    cam.close()
