@@ -159,6 +159,9 @@ typedef struct omni_vlad_weights {
 /* MobileNetVLADTensorRT(engine, width, height) (mobilenetvlad_tensorrt.h:10-19) */
 omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width, int height, int max_batch);
 void       omni_vlad_destroy(omni_vlad* v);
+/* OMNI_PREC_F32 (default): exact-f32 kernels, the parity mode.  OMNI_PREC_F16: the inverted-residual blocks run with fp16 matrix-core
+ * operands and fp32 accumulation / residual stream -- the reference's engine is an fp16 TensorRT plan (launch/realsense.launch:10-11) */
+int        omni_vlad_set_precision(omni_vlad* v, int precision);
 /* std::vector<float> MobileNetVLADTensorRT::inference(const cv::Mat&) (mobilenetvlad_tensorrt.cpp:4-14):
  * u8 -> f32 with NO scaling feeds the net; out [batch][out_dim] */
 int omni_vlad_infer(omni_vlad* v, const uint8_t* gray_host, int stride, int batch, int fisheye_mask, float* out);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
-    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy",
+    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision",
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset", "omni_index_truncate",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
@@ -119,6 +119,7 @@ def lib():
     sig("omni_sp_stage_flops", C.c_double, [_vp, C.c_int])
     sig("omni_vlad_create", _vp, [_vp, C.POINTER(_VladWeights), C.c_int, C.c_int, C.c_int])
     sig("omni_vlad_destroy", None, [_vp])
+    sig("omni_vlad_set_precision", C.c_int, [_vp, C.c_int])
     sig("omni_vlad_infer", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _fp])
     sig("omni_vlad_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int])
     sig("omni_vlad_fetch", C.c_int, [_vp, C.c_int, _fp])
@@ -397,6 +398,10 @@ class MobileNetVLAD:
             self.close()
         except Exception:
             pass
+
+    def set_precision(self, precision: int):
+        """PREC_F32 (default, parity mode) or PREC_F16 (fp16 matrix-core operands in the inverted-residual blocks)."""
+        _check(lib().omni_vlad_set_precision(self.h, int(precision)))
 
     def inference(self, gray_u8: np.ndarray, fisheye_mask: bool = False) -> np.ndarray:
         g = np.ascontiguousarray(gray_u8, np.uint8)

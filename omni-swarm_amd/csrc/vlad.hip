@@ -10,6 +10,7 @@
 // pointwise (1x1) conv, a depthwise 3x3, a stem conv, the NetVLAD aggregation and an HBM-bound FC that reads the
 // 58.7 MB weight matrix once per batch.
 #include "common.h"
+#include "vlad_h.h"
 
 struct VladLayerDev { int kind, cin, cout, stride, hin, win, hout, wout; float* w; float* b; };
 
@@ -18,12 +19,14 @@ struct VladFusedBlock {      // one inverted-residual block = [expand] + depthwi
     const float* bp;
     float* blob;             // device: packed per-chunk weights (see VladBlockArgs)
     float* mblob;            // device: the same per chunk with the projection padded to cop columns (VladMBlockArgs); null = not available
+    void* hblob;             // device: fp16 fragment-order weights of vlad_hblock_kernel (vlad_h.hip); null = not available
     int cop;
     const float *we_t, *be, *wd_t, *bd, *wp_t;   // the layers' own device weights ([cin][hid], [9][hid], [hid][cout]) for the MFMA path
 };
 
 struct omni_vlad {
     omni_ctx* ctx = nullptr;
+    int prec = OMNI_PREC_F32;                 // OMNI_PREC_F16: blocks with an hblob run on vlad_hblock_kernel (omni_vlad_set_precision)
     bool fused = false;                       // every block has a fused kernel (OMNI_VLAD_UNFUSED=1 forces the layer-by-layer path)
     bool mfma_late = true;                    // low-resolution blocks on the f32-MFMA pointwise path (OMNI_VLAD_MFMA=0 disables)
     int mblock_max_px = 0;                    // blocks whose INPUT has at most this many pixels per image run on vlad_mblock_kernel (OMNI_VLAD_MBLOCK_PX)
@@ -1149,6 +1152,14 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
     for (size_t bi = first; bi < v->blocks.size(); ++bi) {
         const VladFusedBlock& B = v->blocks[bi];
         const int64_t Pin = (int64_t)batch * B.hin * B.win, Pout = (int64_t)batch * B.hout * B.wout;
+        if (v->prec == OMNI_PREC_F16 && B.hblob) {
+            VladHBlockArgs ha;
+            ha.in = v->buf[cur]; ha.out = v->buf[(cur + 1) % 3]; ha.blob = B.hblob; ha.bp = B.bp;
+            ha.Hi = B.hin; ha.Wi = B.win; ha.Ho = B.hout; ha.Wo = B.wout; ha.cin = B.cin; ha.hid = B.hid; ha.cout = B.cout; ha.res = B.res; ha.batch = batch;
+            if ((rc = launch_vlad_hblock(st, ha, B.stride))) return rc;
+            cur = (cur + 1) % 3;
+            continue;
+        }
         if (B.mblob && B.hin * B.win <= v->mblock_max_px) {                  // per-image size: batch-independent numerics
             VladMBlockArgs m;
             m.in = v->buf[cur]; m.out = v->buf[(cur + 1) % 3]; m.blob = B.mblob; m.bp = B.bp;
@@ -1336,6 +1347,14 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
                     }
                     if (omni::upload(&B.mblob, mk.data(), mk.size(), st)) { fusable = false; ok = false; break; }
                 }
+                B.hblob = nullptr;
+                if (Le && omni::vlad_hblock_supported(B.cin, B.hid, B.cout, B.stride)) {
+                    std::vector<char> hk(omni::vlad_hblock_blob_bytes(B.cin, B.hid, B.cout));
+                    omni::vlad_hblock_pack(B.cin, B.hid, B.cout, Le->weight, Le->bias, Ld.weight, Ld.bias, Lp.weight, hk.data());
+                    if (hipMalloc(&B.hblob, hk.size()) != hipSuccess || hipMemcpy(B.hblob, hk.data(), hk.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                        omni::set_error("device allocation failed"); fusable = false; ok = false; break;
+                    }
+                }
             }
             v->blocks.push_back(B);
             i += 2;
@@ -1409,11 +1428,25 @@ void omni_vlad_destroy(omni_vlad* v) {
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
     for (auto& L : v->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
-    for (auto& B : v->blocks) { if (B.blob) (void)hipFree(B.blob); if (B.mblob) (void)hipFree(B.mblob); }
+    for (auto& B : v->blocks) { if (B.blob) (void)hipFree(B.blob); if (B.mblob) (void)hipFree(B.mblob); if (B.hblob) (void)hipFree(B.hblob); }
     void* ptrs[] = {v->mb_partial, v->fc_wp, v->fc_part, v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     v->hstage.release();
     delete v;
+}
+
+int omni_vlad_set_precision(omni_vlad* v, int precision) {
+    OMNI_REQUIRE(v, OMNI_ERR_INVALID, "null handle");
+    OMNI_REQUIRE(precision == OMNI_PREC_F32 || precision == OMNI_PREC_F16, OMNI_ERR_INVALID, "precision %d", precision);
+    if (precision == OMNI_PREC_F16) {
+        OMNI_REQUIRE(v->fused, OMNI_ERR_INVALID, "OMNI_PREC_F16 needs the fused block path (layer table not groupable into inverted-residual blocks)");
+        int n = 0;
+        for (auto& B : v->blocks) n += B.hblob != nullptr;
+        OMNI_REQUIRE(n > 0, OMNI_ERR_INVALID, "OMNI_PREC_F16: no block of this layer table has an fp16 kernel");
+    }
+    std::lock_guard<std::mutex> lk(v->mu);
+    v->prec = precision;
+    return OMNI_OK;
 }
 
 int omni_vlad_enqueue_dev(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {

@@ -10,6 +10,8 @@ from omni_swarm_amd import capi, synth, weights
 B = int(os.environ.get("BATCH", 32))
 ctx = capi.Context(0)
 net = capi.MobileNetVLAD(ctx, weights.mobilenetvlad_synth_weights(), weights.mobilenetvlad_layer_specs(), 32, 112, 4096, 600, 480, B)
+if os.environ.get("PREC", "f32") == "f16":
+    net.set_precision(capi.PREC_F16)
 dev = ctx.to_device(np.stack([synth.image_u8(i, 480, 600) for i in range(B)]))
 for _ in range(3):
     net.enqueue_dev(dev, 600, B, True)
