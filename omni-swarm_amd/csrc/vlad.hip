@@ -20,12 +20,14 @@ struct VladFusedBlock {      // one inverted-residual block = [expand] + depthwi
     float* blob;             // device: packed per-chunk weights (see VladBlockArgs)
     float* mblob;            // device: the same per chunk with the projection padded to cop columns (VladMBlockArgs); null = not available
     void* hblob;             // device: fp16 fragment-order weights of vlad_hblock_kernel (vlad_h.hip); null = not available
+    void* sblob;             // device: split-fp16 fragment-order weights of vlad_sblock_kernel (vlad_s.hip); null = not available
     int cop;
     const float *we_t, *be, *wd_t, *bd, *wp_t;   // the layers' own device weights ([cin][hid], [9][hid], [hid][cout]) for the MFMA path
 };
 
 struct omni_vlad {
     omni_ctx* ctx = nullptr;
+    bool sblock = true;                       // blocks with an sblob run on vlad_sblock_kernel (OMNI_VLAD_SBLOCK=0 disables: A/B and parity tests)
     int prec = OMNI_PREC_F32;                 // OMNI_PREC_F16: blocks with an hblob run on vlad_hblock_kernel (omni_vlad_set_precision)
     bool fused = false;                       // every block has a fused kernel (OMNI_VLAD_UNFUSED=1 forces the layer-by-layer path)
     bool mfma_late = true;                    // low-resolution blocks on the f32-MFMA pointwise path (OMNI_VLAD_MFMA=0 disables)
@@ -1160,6 +1162,15 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
             cur = (cur + 1) % 3;
             continue;
         }
+        if (v->sblock && B.sblob) {
+            VladSBlockArgs sa;
+            sa.in = v->buf[cur]; sa.out = v->buf[(cur + 1) % 3]; sa.blob = B.sblob; sa.bp = B.bp;
+            sa.Hi = B.hin; sa.Wi = B.win; sa.Ho = B.hout; sa.Wo = B.wout; sa.cin = B.cin; sa.hid = B.hid; sa.cout = B.cout; sa.res = B.res; sa.batch = batch;
+            sa.n_cu = v->ctx->prop.multiProcessorCount > 0 ? v->ctx->prop.multiProcessorCount : 256; sa.trace = nullptr;
+            if ((rc = launch_vlad_sblock(st, sa, B.stride))) return rc;
+            cur = (cur + 1) % 3;
+            continue;
+        }
         if (B.mblob && B.hin * B.win <= v->mblock_max_px) {                  // per-image size: batch-independent numerics
             VladMBlockArgs m;
             m.in = v->buf[cur]; m.out = v->buf[(cur + 1) % 3]; m.blob = B.mblob; m.bp = B.bp;
@@ -1347,6 +1358,14 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
                     }
                     if (omni::upload(&B.mblob, mk.data(), mk.size(), st)) { fusable = false; ok = false; break; }
                 }
+                B.sblob = nullptr;
+                if (Le && omni::vlad_sblock_supported(B.cin, B.hid, B.cout, B.stride)) {
+                    std::vector<char> sk(omni::vlad_sblock_blob_bytes(B.cin, B.hid, B.cout));
+                    omni::vlad_sblock_pack(B.cin, B.hid, B.cout, Le->weight, Le->bias, Ld.weight, Ld.bias, Lp.weight, sk.data());
+                    if (hipMalloc(&B.sblob, sk.size()) != hipSuccess || hipMemcpy(B.sblob, sk.data(), sk.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                        omni::set_error("device allocation failed"); fusable = false; ok = false; break;
+                    }
+                }
                 B.hblob = nullptr;
                 if (Le && omni::vlad_hblock_supported(B.cin, B.hid, B.cout, B.stride)) {
                     std::vector<char> hk(omni::vlad_hblock_blob_bytes(B.cin, B.hid, B.cout));
@@ -1369,6 +1388,8 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
         // and every phase of a chunk is a dependent chain behind a barrier -- waves wait 50 % of their life, MFMA-busy 14-18 %).  A
         // split-fp16 variant (v_mfma_f32_32x32x16_f16, hi/lo operands: 5x less matrix time) measured SLOWER still (60 us per block): the
         // matrix pipe is not what bounds these blocks, the per-workgroup latency chain is.
+        const char* env6 = getenv("OMNI_VLAD_SBLOCK");
+        v->sblock = !(env6 && env6[0] == '0');
         const char* env5 = getenv("OMNI_VLAD_MBLOCK_PX");
         v->mblock_max_px = env5 ? atoi(env5) : 2048;
         const char* env4 = getenv("OMNI_VLAD_MFMA_PX");
@@ -1428,7 +1449,7 @@ void omni_vlad_destroy(omni_vlad* v) {
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
     for (auto& L : v->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
-    for (auto& B : v->blocks) { if (B.blob) (void)hipFree(B.blob); if (B.mblob) (void)hipFree(B.mblob); if (B.hblob) (void)hipFree(B.hblob); }
+    for (auto& B : v->blocks) { if (B.blob) (void)hipFree(B.blob); if (B.mblob) (void)hipFree(B.mblob); if (B.hblob) (void)hipFree(B.hblob); if (B.sblob) (void)hipFree(B.sblob); }
     void* ptrs[] = {v->mb_partial, v->fc_wp, v->fc_part, v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     v->hstage.release();

@@ -19,3 +19,20 @@ void vlad_hblock_pack(int cin, int hid, int cout, const float* we, const float* 
 int launch_vlad_hblock(hipStream_t st, const VladHBlockArgs& a, int stride);
 
 }  // namespace omni
+
+// ---- split-operand variant (vlad_sblock_kernel): fp16 matrix-core operands carried as (hi, lo) pairs, fp32-class results ----
+namespace omni {
+struct VladSBlockArgs {
+    const float* in; float* out;     // fp32 NHWC block input / output
+    const void* blob;                // vlad_sblock_pack(): [dw taps + bias, all chunks][per chunk: expand fragments | projection fragments]
+    const float* bp;                 // [cout] projection bias
+    int Hi, Wi, Ho, Wo, cin, hid, cout, res, batch;
+    int n_cu;                        // compute units of the device (persistent grid)
+    unsigned m_img, m_tx;            // ceil(2^32 / tiles per image), ceil(2^32 / tiles per row): set by the launcher
+    unsigned long long* trace;       // OMNI_VLAD_SB_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
+};
+bool vlad_sblock_supported(int cin, int hid, int cout, int stride);
+size_t vlad_sblock_blob_bytes(int cin, int hid, int cout);
+void vlad_sblock_pack(int cin, int hid, int cout, const float* we, const float* be, const float* wd, const float* bd, const float* wp, void* out);
+int launch_vlad_sblock(hipStream_t st, const VladSBlockArgs& a, int stride);
+}  // namespace omni

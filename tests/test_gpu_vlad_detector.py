@@ -51,6 +51,57 @@ def test_fused_stem_block0_is_bit_identical(omni, ctx, monkeypatch):
         assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("size", [(96, 128, 2, False), (104, 136, 1, True), (150, 210, 3, False), (480, 600, 2, True)])
+def test_split_fp16_blocks_are_fp32_class(omni, ctx, monkeypatch, size):
+    """vlad_sblock_kernel (fp16 matrix cores, every operand carried as hi + lo, fp32 everywhere else) against the exact-f32 kernels it
+    replaces and against the oracle: 1e-4 relative on the descriptor (measured 2e-6, as the f32 kernels), odd sizes (partial tiles on every
+    edge, borders inside a tile), the fisheye mask, persistent and one-tile-per-workgroup launches bit-identical, batch-1 == batch-n."""
+    h, w, nb, mask = size
+    vw = V.synth_weights()
+    imgs = np.stack([synth.image_u8(900 + i, h, w, n_shapes=80) for i in range(nb)])
+    outs = {}
+    for key, env in (("split", {"OMNI_VLAD_SBLOCK": "1", "OMNI_VLAD_SB_PERSIST": "1"}), ("split_np", {"OMNI_VLAD_SBLOCK": "1", "OMNI_VLAD_SB_PERSIST": "0"}),
+                     ("f32", {"OMNI_VLAD_SBLOCK": "0", "OMNI_VLAD_SB_PERSIST": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = omni.capi.MobileNetVLAD(ctx, vw, V.layer_specs(), V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM, w, h, nb)
+        outs[key] = net.inference(imgs, fisheye_mask=mask)
+        if key == "split":
+            one = net.inference(imgs[nb - 1], fisheye_mask=mask)
+            assert np.array_equal(one[0], outs[key][nb - 1])
+        net.close()
+    assert np.array_equal(outs["split"], outs["split_np"])
+    masked = imgs.copy()
+    if mask:
+        masked[:, h * 3 // 4:] = 0
+    ref = V.forward(vw, masked)
+    for key in ("split", "f32"):
+        rel = np.linalg.norm(outs[key] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert rel.max() < 1e-4, (key, rel)
+    rel = np.linalg.norm(outs["split"] - outs["f32"], axis=1) / np.linalg.norm(outs["f32"], axis=1)
+    assert rel.max() < 1e-4, rel
+
+
+def test_fp16_operand_mode_error_and_batch_invariance(omni, ctx):
+    """omni_vlad_set_precision(OMNI_PREC_F16): plain fp16 operands in the inverted-residual blocks (what the reference's fp16 TensorRT plan
+    does, launch/realsense.launch:10-11), fp32 accumulation and residual stream.  Gate: 1e-2 relative on the descriptor (measured 4e-3, cosine
+    to the fp32 descriptor >= 0.9999), every image bit-identical to its batch-1 result; switching back restores the fp32 result bit for bit."""
+    c = omni.capi
+    imgs = np.stack([synth.image_u8(40 + i, 480, 600) for i in range(4)])
+    net = _vlad(omni, ctx, 600, 480, 4)
+    y32 = net.inference(imgs, fisheye_mask=True)
+    net.set_precision(c.PREC_F16)
+    y16 = net.inference(imgs, fisheye_mask=True)
+    rel = np.linalg.norm(y16 - y32, axis=1) / np.linalg.norm(y32, axis=1)
+    assert 1e-4 < rel.max() < 1e-2, rel
+    assert (y16 * y32).sum(1).min() > 0.9999
+    assert np.array_equal(net.inference(imgs[1], fisheye_mask=True)[0], y16[1])
+    net.set_precision(c.PREC_F32)
+    assert np.array_equal(net.inference(imgs, fisheye_mask=True), y32)
+    with pytest.raises(c.OmniError):
+        net.set_precision(7)
+
+
 def test_loop_detector_trace_equals_oracle(omni, ctx, golden):
     from omni_swarm_amd import detector
     frames = DS.make_stream(seed=11)
