@@ -992,10 +992,15 @@ __device__ __forceinline__ void rs_steps(uint32_t row_base, int n, int hh, const
     }
 }
 
-template <bool POOL>
+// TRN: transposed tiles -- the 32-pixel fragments run along y, the six fragment rows along x (the LDS image, the k order and every MFMA are
+// those of the plain kernel; only the pixel <-> address maps differ).  A 60x75 layer is 2 x 13 tiles of 32x6 instead of 3 x 10 of 6x32:
+// 0.90 instead of 0.78 of the computed pixels are real (the 75-pixel rows wasted 22 % of every 32-pixel fragment).  Same products, summed
+// tap-column-major instead of tap-row-major (fp32 accumulation order): equal to the plain kernel to fp32 rounding, batch-independent as before.
+template <bool POOL, bool TRN = false>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
                        const float* __restrict__ bias, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu,
+                       const char* __restrict__ zero_page /* >= 16 zero bytes: DMA source of the halo pixels outside the image */,
                        unsigned long long* trace /* OMNI_RS_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
@@ -1015,7 +1020,8 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
         const _Float16* wbase = wp + (int64_t)(g32 >> 1) * 2 * 9 * 4096 + (g32 & 1) * 512 + lane * 8;
 #pragma unroll
         for (int s2 = 0; s2 < 72; ++s2) {
-            const int tap = s2 >> 3, ch = (s2 >> 2) & 1, kg4 = s2 & 3;
+            const int tk = s2 >> 3, ch = (s2 >> 2) & 1, kg4 = s2 & 3;
+            const int tap = TRN ? (tk % 3) * 3 + tk / 3 : tk;          // transposed tiles: the kernel's (row, column) shifts are the image's (column, row)
             wreg[s2] = *reinterpret_cast<const half8_t*>(wbase + ((ch * 9 + tap) * 4 + kg4) * 1024);
         }
     }
@@ -1025,22 +1031,24 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
     auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
         b = t / tiles_per_img;
         const int r = t - b * tiles_per_img;
-        ty0 = (r / tiles_x) * RS_TH; tx0 = (r % tiles_x) * RS_TW;
+        ty0 = (r / tiles_x) * (TRN ? RS_TW : RS_TH); tx0 = (r % tiles_x) * (TRN ? RS_TH : RS_TW);
     };
+    constexpr int ITY = TRN ? RS_ITW : RS_ITH, ITX = TRN ? RS_ITH : RS_ITW;      // halo extent in image rows / columns
     // DMA: 68 wave-instructions of 1 KiB per tile, wave w issues pieces 17 w .. 17 w + 16 into buffer `which`
     uint32_t goff[17];                        // interior tiles: byte offset of this lane's chunk of piece j relative to the halo origin
 #pragma unroll
     for (int j = 0; j < 17; ++j) {
         const int idx = (wave * 17 + j) * 64 + lane;
         const int pix = idx >> 4, phys = idx & 15;
-        const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
+        const int iv = pix / RS_ITW, iu = pix - iv * RS_ITW;
+        const int iy = TRN ? iu : iv, ix = TRN ? iv : iu;
         goff[j] = (uint32_t)((iy * W + ix) * 256 + ((phys ^ (pix & 15)) << 4));
     }
     auto issue = [&](int t, int which) {
         int b, ty0, tx0;
         tile_origin(t, b, ty0, tx0);
         const int y0 = ty0 - 1, x0 = tx0 - 1;
-        if (y0 >= 0 && y0 + RS_ITH <= H && x0 >= 0 && x0 + RS_ITW <= W) {       // interior (wave-uniform): base + 32-bit lane offset
+        if (y0 >= 0 && y0 + ITY <= H && x0 >= 0 && x0 + ITX <= W) {             // interior (wave-uniform): base + 32-bit lane offset
             const char* org = reinterpret_cast<const char*>(in + ((int64_t)b * H * W + (int64_t)y0 * W + x0) * 128);
             char* base = smem_raw + which * RS_BUF_BYTES + wave * 17 * 1024;
 #pragma unroll
@@ -1049,7 +1057,8 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
                                                  (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
             return;
         }
-        // border tile: clamp per piece (addresses stay valid, the halo pixels outside the image are zeroed after landing).  Unrolled:
+        // border tile: halo pixels outside the image are DMA'd from a page of zeros (the conv's zero padding lands in LDS with the data: no
+        // fix-up pass, no extra barrier -- the former clamp + zero-fix cost 1.8-2.4 k cycles on 73 % of the tiles of a 60x75 layer).  Unrolled:
         // halo pixel of this lane's chunk = 4 (17 wave + j) + (lane >> 4); the per-lane term is re-blinded per tile so that the 17
         // coordinate pairs are recomputed (a few VALU each) rather than hoisted into registers the kernel does not have
         int lq = lane >> 4;
@@ -1059,45 +1068,17 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
 #pragma unroll
         for (int j = 0; j < 17; ++j) {
             const int pix = (wave * 17 + j) * 4 + lq;
-            const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
-            int gy = y0 + iy, gx = x0 + ix;
-            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
-            gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const int iv = pix / RS_ITW, iu = pix - iv * RS_ITW;
+            const int gy = y0 + (TRN ? iu : iv), gx = x0 + (TRN ? iv : iu);
             const uint32_t off = (uint32_t)(gy * W + gx) * 256u + (uint32_t)(((lane & 15) ^ (pix & 15)) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + off),
+            const char* src = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img + off : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
         }
     };
-    // Border tiles: halo pixels outside the image were loaded from a clamped address and are zeroed after landing.  Thread = halo pixel
-    // (its 16 chunks are 256 contiguous bytes whatever the swizzle), which needs every wave's DMA to have landed first: one extra
-    // workgroup barrier on border tiles -- measured (s_memtime): 4 500 cycles for the former per-piece loop over each wave's own chunks
-    // vs 350 for an interior tile, on 73 % of the tiles of a 60x75 layer.
-    auto is_border = [&](int t) {
-        int b, ty0, tx0;
-        tile_origin(t, b, ty0, tx0);
-        const int y0 = ty0 - 1, x0 = tx0 - 1;
-        return !(y0 >= 0 && y0 + RS_ITH <= H && x0 >= 0 && x0 + RS_ITW <= W);
-    };
-    auto zero_fix = [&](int t, int which) {
-        int b, ty0, tx0;
-        tile_origin(t, b, ty0, tx0);
-        const int y0 = ty0 - 1, x0 = tx0 - 1;
-        char* base = smem_raw + which * RS_BUF_BYTES;
-        for (int pix = tid; pix < RS_PIX; pix += 256) {
-            const int iy = pix / RS_ITW, ix = pix - iy * RS_ITW;
-            const int gy = y0 + iy, gx = x0 + ix;
-            if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
-                uint4* p = reinterpret_cast<uint4*>(base + pix * 256);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) p[(c + lane) & 15] = make_uint4(0u, 0u, 0u, 0u);   // rotated: pixels are 256 B apart = one bank group
-            }
-        }
-    };
-
     int t = wg;
     if (t < total) issue(t, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t < total && is_border(t)) { __syncthreads(); zero_fix(t, 0); }
     __syncthreads();
 
     int cur = 0;
@@ -1145,33 +1126,43 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
             } else {
 #pragma unroll
                 for (int f = 0; f < RS_TH; ++f) {
-                    const int oy = ty0 + f;
+                    const int oy = TRN ? ty0 + n : ty0 + f, oxx = TRN ? tx0 + f : ox;
                     float v[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = acc[f][i];
-                    _Float16* o = out + (((int64_t)b * H + oy) * W + ox) * cout + g32 * 32;
-                    store_frag16<false>(v, bs, o, hh, relu, (oy < H) && (ox < W));
+                    _Float16* o = out + (((int64_t)b * H + oy) * W + oxx) * cout + g32 * 32;
+                    store_frag16<false>(v, bs, o, hh, relu, (oy < H) && (oxx < W));
                 }
             }
         }
         if (tr && tk < 8) trace[tk * 8 + 3] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile landed (and this tile's stores retired)
         if (tr && tk < 8) trace[tk * 8 + 4] = __builtin_amdgcn_s_memtime();
-        if (tn < total && is_border(tn)) { __syncthreads(); zero_fix(tn, cur ^ 1); }
         __syncthreads();
         if (tr && tk < 8) { trace[tk * 8 + 5] = __builtin_amdgcn_s_memtime(); ++tk; }
     }
 }
 
-template <bool POOL>
+template <bool POOL, bool TRN = false>
 static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
-    auto kfn = conv3x3_c128_rs_kernel<POOL>;
+    if constexpr (!POOL && !TRN) {
+        // the tile orientation with fewer tiles (OMNI_RS_TRN=0/1 forces one: A/B hook; results do not depend on it)
+        static const int force = [] { const char* e = getenv("OMNI_RS_TRN"); return e ? atoi(e) : -1; }();
+        const int plain = cdiv(a.W, RS_TW) * cdiv(a.H, RS_TH), trn = cdiv(a.W, RS_TH) * cdiv(a.H, RS_TW);
+        if (force == 1 || (force < 0 && trn < plain)) return launch_conv_rs<false, true>(st, a, n_cu);
+    }
+    auto kfn = conv3x3_c128_rs_kernel<POOL, TRN>;
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_SMEM));
-    const int tiles_x = cdiv(a.W, RS_TW), tiles_y = cdiv(a.H, RS_TH), n_cg = a.cout / 128;
+    const int tiles_x = cdiv(a.W, TRN ? RS_TH : RS_TW), tiles_y = cdiv(a.H, TRN ? RS_TW : RS_TH), n_cg = a.cout / 128;
     const int total = a.batch * tiles_x * tiles_y;
     int per_cg = n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
     if (per_cg > total) per_cg = total;
+    static char* zero_page = nullptr;                   // 256 zero bytes: the DMA source of out-of-image halo pixels (never written again)
+    if (!zero_page) {
+        OMNI_HIP_TRY(hipMalloc((void**)&zero_page, 256));
+        OMNI_HIP_TRY(hipMemset(zero_page, 0, 256));
+    }
     static const bool want_trace = [] { const char* e = getenv("OMNI_RS_TRACE"); return e && e[0] == '1'; }();
     static unsigned long long* trace_dev = nullptr;
     if (want_trace) {
@@ -1180,7 +1171,7 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     }
     hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), RS_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_cg,
-                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, want_trace ? trace_dev : nullptr);
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, zero_page, want_trace ? trace_dev : nullptr);
     OMNI_LAUNCH_CHECK();
     if (want_trace) {
         unsigned long long h[64];
