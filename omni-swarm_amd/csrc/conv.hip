@@ -561,6 +561,7 @@ struct Fuse1aArgs {
     const float* bias1a;          // [64]
     const uint32_t* lut_hl;       // [256] half(x) | half(x - half(x)) << 16,  x = float(double(i) * (1.0 / 255.0))
     unsigned long long* trace;    // OMNI_PP_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
+    const char* zero_page;        // >= 16 zero bytes: DMA source of the halo pixels outside the image (set by the launcher)
 };
 
 template <bool POOL, int ABL, bool FUSE1A>
@@ -635,37 +636,16 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 idx = idx < C64_CHUNKS ? idx : C64_CHUNKS - 1;
                 const int pix = idx >> 3, phys = idx & 7;
                 const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
-                int gy = y0 + iy, gx = x0 + ix;
-                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);     // clamped to a valid address, zero-fixed after landing
-                gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+                const int gy = y0 + iy, gx = x0 + ix;
                 const int logical = phys ^ ((pix >> 1) & 7);
-                const _Float16* g = img + ((int64_t)gy * W + gx) * 64 + logical * 8;
+                // halo pixels outside the image come from a page of zeros: the zero padding lands with the data, no fix-up pass
+                const char* g = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? reinterpret_cast<const char*>(img + ((int64_t)gy * W + gx) * 64 + logical * 8)
+                                                                         : fz.zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(buf + wi * 1024), 16, 0, 0);
             }
         }
     };
-    // zero the out-of-image halo pixels of tile t: every wave fixes exactly the chunks its OWN DMA instructions wrote, after
-    // its own vmcnt(0) -- no cross-wave dependency, so no barrier between DMA and fix
-    auto zero_fix = [&](int t) {
-        int b, ty0, tx0;
-        tile_origin(t, b, ty0, tx0);
-        const int y0 = ty0 - 1, x0 = tx0 - 1;
-        if (y0 >= 0 && y0 + C64_ITH <= H && x0 >= 0 && x0 + C64_ITW <= W) return;      // interior tile (wave-uniform)
-#pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const int wi = wl * 11 + j;
-            if (wi < 43) {
-                const int idx = wi * 64 + lane;
-                const int pix = idx >> 3;
-                const int iy = pix / C64_ITW, ix = pix - iy * C64_ITW;
-                const int gy = y0 + iy, gx = x0 + ix;
-                if (idx < C64_CHUNKS && (gy < 0 || gy >= H || gx < 0 || gx >= W))
-                    *reinterpret_cast<uint4*>(buf + idx * 16) = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-    };
-
     // bias lives in LDS behind the halo buffers (256 B): holding it in registers (32 VGPRs) spills next to 64 accumulators,
     // 48 fragment registers and the DMA / fragment address tables
     float* const bias_lds = reinterpret_cast<float*>(smem_raw + C64_W_BYTES + 2 * BUFB);
@@ -797,7 +777,6 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         } else {
             issue(wg + k_load * nwg);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            zero_fix(wg + k_load * nwg);
         }
         k_load += 2;
     }
@@ -902,12 +881,11 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                zero_fix(wg + k_load * nwg);
                 k_load += 2;
             }
         }
         if (dbg & 32) __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes (zero-fix) done; global stores may stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS traffic done; global stores may stay in flight
         __builtin_amdgcn_s_barrier();
     }
 }
@@ -923,9 +901,16 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
     int per_ct = n_cu / n_ct;
     if (per_ct < 1) per_ct = 1;
     if (per_ct > cdiv(total, 2)) per_ct = cdiv(total, 2);      // at least two tiles per workgroup: one per wave group
+    static char* zero_page = nullptr;                   // 256 zero bytes, never written again
+    if (!zero_page) {
+        OMNI_HIP_TRY(hipMalloc((void**)&zero_page, 256));
+        OMNI_HIP_TRY(hipMemset(zero_page, 0, 256));
+    }
+    Fuse1aArgs fzz = fz;
+    fzz.zero_page = zero_page;
     hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), smem_bytes, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
-                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg, fz);
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg, fzz);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
