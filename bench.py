@@ -467,7 +467,7 @@ def main():
     gbs = rows_here * 4096 * 4 / (scan_ms * 1e-3) / 1e9
     roofline_knn = {"bound": "hbm", "kernel": "ip_scan_kernel<float,1>", "achieved": round(gbs, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    **traffic_fields("ip_scan_kernel<float,1>", rows_here == 100_000), "bytes_per_launch": rows_here * 16384,
+                    **traffic_fields(f"ip_scan_kernel<float,1>@{rows_here}"), "bytes_per_launch": rows_here * 16384,
                     "launch_ms": round(scan_ms, 4), "rows_per_gpu": rows_here}
     loop_match = {"p50_ms": round(p50, 4), "db_rows_node": args.match_db_rows, "db_rows_per_gpu": rows_here, "k": K_SEARCH,
                   "includes": "H2D query, scan, top-k, D2H result" + (", all_gather + merge" if world > 1 else "")}

@@ -41,12 +41,20 @@ def main(tag, images):
             out[key] = {"read_bytes": round(r), "write_bytes": round(w), "bytes_per_launch": round(r + w), "dispatches": len(rd)}
             if "conv" in key:
                 out[key]["images_per_launch"] = images
-    # the 100k-row single-query scans: the largest FETCH_SIZE cluster of ip_scan_kernel<float,1>
+    # single-query scans: one entry per database size seen in the pass (launches clustered by FETCH_SIZE; rows = bytes / 16 384 rounded to 1 000)
     rd = sorted(mean_by(f"gpurun_out/{tag}_pmc3", "FETCH_SIZE", lambda n: "ip_scan_kernel<float, 1>" in n))
-    if rd:
-        big = [x for x in rd if x > 0.8 * rd[-1]]
-        out["ip_scan_kernel<float,1>"] = {"bytes_per_launch": round(sum(big) / len(big) * 1024 * 2), "dispatches": len(big),
-                                          "note": "largest-database launches only (the p50 legs: 100k and 400k rows); algorithmic = rows x 16384 B"}
+    clusters = []
+    for x in rd:
+        if clusters and x < 1.1 * clusters[-1][0]:
+            clusters[-1].append(x)
+        else:
+            clusters.append([x])
+    for c in clusters:
+        b = sum(c) / len(c) * 1024 * 2
+        rows = int(round(b / 16384 / 1000.0)) * 1000
+        if rows >= 50000 and len(c) >= 5:
+            out[f"ip_scan_kernel<float,1>@{rows}"] = {"bytes_per_launch": round(b), "dispatches": len(c), "rows": rows,
+                                                      "note": "algorithmic = rows x 16384 B (no write traffic to speak of: 8 B per row)"}
     print(json.dumps(out, indent=1))
 
 
