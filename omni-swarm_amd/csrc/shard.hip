@@ -11,12 +11,13 @@
 //     ncclAllGather(per-shard top-k)  k*(8+4) B per query per rank: latency-bound on xGMI
 //     D2H of the gathered lists + host merge of THIS rank's queries          (omni_topk_merge: score desc, global id asc)
 // Everything runs on the shard's stream (the local index's context stream): no host bounce before the final D2H, no torch.
-// RCCL is resolved at run time (dlopen of librccl.so.1, i.e. the copy already in the process when torch.distributed loaded one): the
+// RCCL is resolved at run time (dlopen of the librccl next to the HIP runtime this library is linked into the process with): the
 // single-GPU paths of libomni_hip.so do not depend on it; omni_shard_* fails with a message when it is missing.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <climits>
+#include <string>
 
 #include "common.h"
 
@@ -36,8 +37,26 @@ RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) { api.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.so) break; }
+        // The RCCL copy must sit on the SAME ROCm stack as the HIP runtime this library runs on: a process can hold two (PyTorch wheels
+        // bundle their own libamdhip64 / libhsa-runtime64 / librccl next to /opt/rocm's), and an RCCL whose HSA runtime is not the initialised
+        // one fails ncclCommInitRank with "no ROCm-capable device is detected".  So: first the librccl in the directory the loaded
+        // libamdhip64 came from, then the default search.
+        Dl_info hip_info;
+        if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &hip_info) && hip_info.dli_fname) {
+            std::string dir(hip_info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* n : {"librccl.so.1", "librccl.so"}) {
+                    api.so = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_GLOBAL);
+                    if (api.so) break;
+                }
+            }
+        }
+        if (!api.so) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) { api.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.so) break; }
+        }
         if (!api.so) return;
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.so, "ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.so, "ncclCommInitRank"));
