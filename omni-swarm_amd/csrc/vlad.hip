@@ -1166,7 +1166,7 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
             VladSBlockArgs sa;
             sa.in = v->buf[cur]; sa.out = v->buf[(cur + 1) % 3]; sa.blob = B.sblob; sa.bp = B.bp;
             sa.Hi = B.hin; sa.Wi = B.win; sa.Ho = B.hout; sa.Wo = B.wout; sa.cin = B.cin; sa.hid = B.hid; sa.cout = B.cout; sa.res = B.res; sa.batch = batch;
-            sa.n_cu = v->ctx->prop.multiProcessorCount > 0 ? v->ctx->prop.multiProcessorCount : 256; sa.trace = nullptr;
+            sa.n_cu = v->ctx->prop.multiProcessorCount > 0 ? v->ctx->prop.multiProcessorCount : 256; sa.trace = nullptr; sa.dbg = 0;
             if ((rc = launch_vlad_sblock(st, sa, B.stride))) return rc;
             cur = (cur + 1) % 3;
             continue;

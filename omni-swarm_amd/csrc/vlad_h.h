@@ -29,6 +29,7 @@ struct VladSBlockArgs {
     int Hi, Wi, Ho, Wo, cin, hid, cout, res, batch;
     int n_cu;                        // compute units of the device (persistent grid)
     unsigned m_img, m_tx;            // ceil(2^32 / tiles per image), ceil(2^32 / tiles per row): set by the launcher
+    int dbg;                         // OMNI_VLAD_SB_DBG (timing ablations only, WRONG results): bit 0 no result stores, bit 1 no input prefetch
     unsigned long long* trace;       // OMNI_VLAD_SB_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
 };
 bool vlad_sblock_supported(int cin, int hid, int cout, int stride);

@@ -150,7 +150,7 @@ vlad_sblock_kernel(VladSBlockArgs a) {
             }
     };
     auto store_out = [&]() {
-        if (!out_ok) return;
+        if (!out_ok || (a.dbg & 1)) return;
 #pragma unroll
         for (int q = 0; q < MQ; ++q)
 #pragma unroll
@@ -228,7 +228,7 @@ vlad_sblock_kernel(VladSBlockArgs a) {
             out_ok = out_pixel(tile, out_off, off_res);
             fetch_res(out_ok, off_res);
         }
-        if (tile + (int)gridDim.x < tiles_total) fetch_x(tile + gridDim.x);
+        if (tile + (int)gridDim.x < tiles_total && !(a.dbg & 2)) fetch_x(tile + gridDim.x);
 #pragma unroll
         for (int p = 0; p < MQ; ++p)
 #pragma unroll
@@ -421,6 +421,8 @@ static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
     static unsigned long long* trace_dev = nullptr;
     VladSBlockArgs at = a;
     at.trace = nullptr;
+    static const int dbg = [] { const char* e = getenv("OMNI_VLAD_SB_DBG"); return e ? atoi(e) : 0; }();
+    at.dbg = dbg;
     {   // sb_div()'s reciprocals
         const unsigned d_img = (unsigned)(cdiv(a.Wo, 8) * cdiv(a.Ho, C::TH)), d_tx = (unsigned)cdiv(a.Wo, 8);
         at.m_img = d_img > 1 ? (unsigned)(((1ull << 32) + d_img - 1) / d_img) : 0u;
