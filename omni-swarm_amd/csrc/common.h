@@ -39,6 +39,19 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what was set per (kernel instantiation, device)
+// instead of per process, so that a process driving several GPUs through several omni_ctx stays correct.  One static State per call site.
+struct DynSmemState { size_t set[16] = {0}; };
+static inline hipError_t ensure_dyn_smem(DynSmemState& st, const void* kfn, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16 && st.set[dev] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 16) st.set[dev] = bytes;
+    return e;
+}
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grow-only device scratch buffer.
@@ -75,15 +88,27 @@ struct HostBuf {
 
 }  // namespace omni
 
+#define OMNI_ZERO_PAGE_BYTES 65536
+
 struct omni_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop;
     std::mutex mu;
+    // 64 KB of zeros in HBM, never written after creation: the LDS-DMA source of convolution halo pixels outside the image.  A lane reads the
+    // 16 bytes at (its would-be image offset mod 64 KB), so the requests spread over the L2 channels: with ONE shared line the rate depended
+    // on where the allocator happened to put it (7 % of the whole pipeline between two placements)
+    void* zero_page = nullptr;
     omni::DevBuf scratch;     // generic per-call scratch (bf match, host-entry staging)
     omni::DevBuf scratch2;
     omni::HostBuf hstage;
+    int ensure_zero_page() {
+        if (zero_page) return OMNI_OK;
+        OMNI_HIP_TRY(hipMalloc(&zero_page, OMNI_ZERO_PAGE_BYTES));
+        OMNI_HIP_TRY(hipMemsetAsync(zero_page, 0, OMNI_ZERO_PAGE_BYTES, stream));
+        return OMNI_OK;
+    }
 };
 
 // ---- 64-bit sortable keys -------------------------------------------------------------------------------------

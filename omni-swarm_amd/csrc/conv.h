@@ -36,6 +36,7 @@ struct ConvArgs {
     bool relu, pool;
     bool out_f32;          // write fp32 regardless of the compute precision (final 1x1 descriptor conv)
     int n_cu = 0;          // CUs on the device (> 0 enables the persistent cin=64 fp16 kernel)
+    const void* zero_page = nullptr;   // omni_ctx::zero_page (the persistent LDS-DMA kernels need it; null = generic kernels only)
     int variant = 0;       // test hook (OMNI_CONV_V1): 0 = best kernel per layer, 1 = generic kernel everywhere, 2 = v2 persistent kernel,
                            // 3 = v3 ping-pong kernel without the conv1a fusion
 };

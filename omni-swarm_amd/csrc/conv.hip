@@ -561,7 +561,7 @@ struct Fuse1aArgs {
     const float* bias1a;          // [64]
     const uint32_t* lut_hl;       // [256] half(x) | half(x - half(x)) << 16,  x = float(double(i) * (1.0 / 255.0))
     unsigned long long* trace;    // OMNI_PP_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
-    const char* zero_page;        // >= 16 zero bytes: DMA source of the halo pixels outside the image (set by the launcher)
+    const char* zero_page;        // OMNI_ZERO_PAGE_BYTES of zeros: DMA source of the halo pixels outside the image (set by the launcher)
 };
 
 template <bool POOL, int ABL, bool FUSE1A>
@@ -640,7 +640,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 const int logical = phys ^ ((pix >> 1) & 7);
                 // halo pixels outside the image come from a page of zeros: the zero padding lands with the data, no fix-up pass
                 const char* g = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? reinterpret_cast<const char*>(img + ((int64_t)gy * W + gx) * 64 + logical * 8)
-                                                                         : fz.zero_page;
+                                                                         : fz.zero_page + ((uint32_t)(idx * 16) & (OMNI_ZERO_PAGE_BYTES - 16));
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(buf + wi * 1024), 16, 0, 0);
             }
@@ -901,13 +901,9 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
     int per_ct = n_cu / n_ct;
     if (per_ct < 1) per_ct = 1;
     if (per_ct > cdiv(total, 2)) per_ct = cdiv(total, 2);      // at least two tiles per workgroup: one per wave group
-    static char* zero_page = nullptr;                   // 256 zero bytes, never written again
-    if (!zero_page) {
-        OMNI_HIP_TRY(hipMalloc((void**)&zero_page, 256));
-        OMNI_HIP_TRY(hipMemset(zero_page, 0, 256));
-    }
+    OMNI_REQUIRE(a.zero_page, OMNI_ERR_INVALID, "conv: ConvArgs.zero_page is not set");
     Fuse1aArgs fzz = fz;
-    fzz.zero_page = zero_page;
+    fzz.zero_page = reinterpret_cast<const char*>(a.zero_page);
     hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), smem_bytes, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
                        tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg, fzz);
@@ -985,7 +981,7 @@ template <bool POOL, bool TRN = false>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
                        const float* __restrict__ bias, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu,
-                       const char* __restrict__ zero_page /* >= 16 zero bytes: DMA source of the halo pixels outside the image */,
+                       const char* __restrict__ zero_page /* OMNI_ZERO_PAGE_BYTES of zeros: DMA source of the halo pixels outside the image */,
                        unsigned long long* trace /* OMNI_RS_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
@@ -1056,7 +1052,7 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
             const int iv = pix / RS_ITW, iu = pix - iv * RS_ITW;
             const int gy = y0 + (TRN ? iu : iv), gx = x0 + (TRN ? iv : iu);
             const uint32_t off = (uint32_t)(gy * W + gx) * 256u + (uint32_t)(((lane & 15) ^ (pix & 15)) << 4);
-            const char* src = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img + off : zero_page;
+            const char* src = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img + off : zero_page + (off & (OMNI_ZERO_PAGE_BYTES - 16));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
         }
@@ -1143,11 +1139,8 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     int per_cg = n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
     if (per_cg > total) per_cg = total;
-    static char* zero_page = nullptr;                   // 256 zero bytes: the DMA source of out-of-image halo pixels (never written again)
-    if (!zero_page) {
-        OMNI_HIP_TRY(hipMalloc((void**)&zero_page, 256));
-        OMNI_HIP_TRY(hipMemset(zero_page, 0, 256));
-    }
+    OMNI_REQUIRE(a.zero_page, OMNI_ERR_INVALID, "conv: ConvArgs.zero_page is not set");
+    const char* zero_page = reinterpret_cast<const char*>(a.zero_page);
     static const bool want_trace = [] { const char* e = getenv("OMNI_RS_TRACE"); return e && e[0] == '1'; }();
     static unsigned long long* trace_dev = nullptr;
     if (want_trace) {
@@ -1252,14 +1245,14 @@ int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {
     OMNI_REQUIRE(a.ksize == 1 || a.ksize == 3, OMNI_ERR_INVALID, "conv_mfma: ksize=%d", a.ksize);
     OMNI_REQUIRE(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), OMNI_ERR_INVALID, "pooling needs even H, W");
     OMNI_REQUIRE(!(a.pool && a.ksize == 1), OMNI_ERR_INVALID, "1x1 + pool not instantiated");
-    if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 64 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 64) && a.n_cu > 0 &&
+    if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 64 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 64) && a.n_cu > 0 && a.zero_page &&
         a.variant != 1) {
         if (a.variant == 2) return a.pool ? launch_conv_c64<true>(st, a, a.n_cu) : launch_conv_c64<false>(st, a, a.n_cu);
         return a.pool ? launch_conv_pp<true>(st, a, a.n_cu) : launch_conv_pp<false>(st, a, a.n_cu);
     }
     static const bool no_rs = [] { const char* e = getenv("OMNI_CONV_RS"); return e && e[0] == '0'; }();     // A/B hook
     if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 128 && a.cout % 128 == 0 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 128) &&
-        a.n_cu > 0 && a.variant == 0 && !no_rs && (!a.pool || a.H % 2 == 0))
+        a.n_cu > 0 && a.zero_page && a.variant == 0 && !no_rs && (!a.pool || a.H % 2 == 0))
         return a.pool ? launch_conv_rs<true>(st, a, a.n_cu) : launch_conv_rs<false>(st, a, a.n_cu);
     if (precision == OMNI_PREC_F16) {
         if (a.ksize == 3) return a.pool ? launch_conv<_Float16, 3, true>(st, a) : launch_conv<_Float16, 3, false>(st, a);

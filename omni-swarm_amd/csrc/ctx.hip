@@ -31,7 +31,8 @@ omni_ctx* omni_ctx_create(int device_id) {
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&c->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || c->ensure_zero_page() != OMNI_OK ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
         omni::set_error("failed to initialise HIP context on device %d", device_id);
         delete c;
         return nullptr;
@@ -44,6 +45,7 @@ void omni_ctx_destroy(omni_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->scratch.release(); c->scratch2.release(); c->hstage.release();
+    if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

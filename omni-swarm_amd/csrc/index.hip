@@ -525,8 +525,8 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, 
 #define OMNI_ROWS_CASE(QB)                                                                                              \
     case QB: {                                                                                                          \
         auto kf = ip_scan_rows_kernel<QB, R>;                                                                           \
-        static size_t attr = 0;                                                                                         \
-        if (attr < smem) { OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = smem; } \
+        static DynSmemState attr;                                                                                       \
+        OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)kf, smem));                                                     \
         hipLaunchKernelGGL(kf, dim3(grid_g), dim3(SCAN_THREADS), smem, st, reinterpret_cast<const float*>(ix->db), n, ix->dim, q_dev, keys,  \
                            key_stride, lim);                                                                            \
         break; }
@@ -563,11 +563,8 @@ static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, con
     ScanLimits<MQ_NQ> lim;
     for (int q = 0; q < MQ_NQ; ++q) lim.v[q] = limits && q < nq ? limits[q] : INT64_MAX;
     auto kfn = ip_scan_mq_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
-        OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MQ_SMEM));
-        attr_set = true;
-    }
+    static DynSmemState attr;
+    OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)kfn, MQ_SMEM));
     const int slices = ix->dim / MQ_KS;
     int rc;
     if ((rc = ix->mq_q.ensure((size_t)slices * MQ_SLICE_BYTES))) return rc;

@@ -192,13 +192,14 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     hipStream_t st = s->ctx->stream;
     const int H = s->H, W = s->W, P = s->precision;
     int rc, stage = 0;
+    if ((rc = s->ctx->ensure_zero_page())) return rc;
     auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
     auto conv = [&](int l, const void* in, void* out, const float* bias, int h, int w, int cin, int cout, int ks, bool relu,
                     bool pool, bool out_f32) -> int {
         ConvArgs a;
         a.in = in; a.out = out; a.w_packed = s->wpk[l]; a.bias = bias; a.batch = batch; a.H = h; a.W = w; a.cin = cin;
         a.cout = cout; a.ksize = ks; a.relu = relu; a.pool = pool; a.out_f32 = out_f32;
-        a.n_cu = s->ctx->prop.multiProcessorCount; a.variant = s->conv_variant;
+        a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page; a.variant = s->conv_variant;
         return conv_mfma(st, P, a);
     };
     if ((rc = mark())) return rc;
@@ -208,7 +209,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (s->fuse1a) {   // conv1a is computed inside conv1b's kernel: the conv1a activation tensor is never materialised
         ConvArgs a;
         a.in = nullptr; a.out = s->a1b; a.w_packed = s->wpk[L1B]; a.bias = s->bias[L1B]; a.batch = batch; a.H = H; a.W = W; a.cin = 64;
-        a.cout = 64; a.ksize = 3; a.relu = true; a.pool = true; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount;
+        a.cout = 64; a.ksize = 3; a.relu = true; a.pool = true; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page;
         if ((rc = conv1ab_fused(st, a, gray_dev, stride, fisheye_mask, reinterpret_cast<const _Float16*>(s->w1a_frag), s->bias[L1A], s->lut_hl))) return rc;
     } else if ((rc = conv(L1B, s->a1a, s->a1b, s->bias[L1B], H, W, 64, 64, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;

@@ -729,8 +729,8 @@ static size_t vlad_mblock_smem(int cin, int cop, int stride) {
 }
 static int launch_vlad_mblock(hipStream_t st, const VladMBlockArgs& a) {
     const size_t smem = vlad_mblock_smem(a.cin, a.cop, a.stride);
-    static size_t attr = 0;
-    if (attr < smem) { OMNI_HIP_TRY(hipFuncSetAttribute((const void*)vlad_mblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = smem; }
+    static DynSmemState attr;
+    OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)vlad_mblock_kernel, smem));
     const int tiles = cdiv(a.Wo, 8) * cdiv(a.Ho, 8);
     hipLaunchKernelGGL(vlad_mblock_kernel, dim3(tiles * a.batch, a.n_groups), dim3(256), smem, st, a);
     OMNI_LAUNCH_CHECK();

@@ -242,8 +242,8 @@ static int launch_hb(hipStream_t st, const VladHBlockArgs& a) {
     constexpr int RW = 7 * STRIDE + 3, RP = ((RW * RW + 31) / 32) * 32;
     constexpr size_t smem = (size_t)RP * (KS * 32 + 16) + (size_t)RP * HB_HS + 64 * HB_HS;
     auto kfn = vlad_hblock_kernel<STRIDE, KS, NT>;
-    static bool attr = false;
-    if (!attr) { OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; }
+    static DynSmemState attr;
+    OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)kfn, smem));
     hipLaunchKernelGGL(kfn, dim3(cdiv(a.Wo, 8) * cdiv(a.Ho, 8) * a.batch), dim3(256), smem, st, a);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;

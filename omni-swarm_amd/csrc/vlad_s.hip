@@ -405,8 +405,8 @@ static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
     const size_t smem = C::smem(a.hid) + pad;
     OMNI_REQUIRE(smem <= 160 * 1024, OMNI_ERR_CAPACITY, "vlad_sblock: %zu B of LDS for hid=%d", smem, a.hid);
     auto kfn = vlad_sblock_kernel<STRIDE, CIN, NT>;
-    static size_t attr = 0;
-    if (attr < smem) { OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = smem; }
+    static DynSmemState attr;
+    OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)kfn, smem));
     // persistent workgroups: as many as fit the CUs' LDS at once, each walking tiles blockIdx.x, + gridDim.x, ... with the next tile's input in flight
     const int tiles = cdiv(a.Wo, 8) * cdiv(a.Ho, C::TH) * a.batch;
     OMNI_REQUIRE((int64_t)a.batch * a.Hi * a.Wi * a.cin < (1ll << 31) && (int64_t)a.batch * a.Ho * a.Wo * a.cout < (1ll << 31) && tiles < (1 << 20),
