@@ -817,6 +817,8 @@ vlad_aggregate8_kernel(const float* __restrict__ feat, const float* __restrict__
     float v = 0.f;
     if (dd < Dm) {
         const float c = clusters[k * Dm + dd];
+        // same fmaf chain, loads of nine positions in flight (36 dependent L2 round trips per thread were most of this kernel's 26 us)
+#pragma unroll 9
         for (int p = pt; p < n_pos; p += AGG_PARTS) v = fmaf(a[p * K + k], c - f[(int64_t)p * Dm + dd], v);
     }
     part[pt][dd] = v;
@@ -919,6 +921,7 @@ vlad_fc4_kernel(const float* __restrict__ v, int nb, int n_in, const float* __re
 // L2 normalisation): deterministic.  Replaces 4 passes of vlad_fc4_kernel (33 us each at 8 images per pass) + l2norm_rows_kernel.
 // ---------------------------------------------------------------------------------------------------------------
 #define FCM_KY 8
+#define FCM_DEPTH 14
 __global__ void __launch_bounds__(256)
 vlad_fc_mfma_kernel(const float* __restrict__ v, int nb, int n_in, const float* __restrict__ Wp, int n_out, float* __restrict__ part /*[FCM_KY][32][n_out]*/) {
     __shared__ float red[3][16][64];
@@ -934,18 +937,26 @@ vlad_fc_mfma_kernel(const float* __restrict__ v, int nb, int n_in, const float* 
     floatx16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 a0 = vp[0], a1 = a0;
-    f32x4v b0 = __builtin_nontemporal_load(wp), b1 = b0;
-    if (half > 1) { a1 = vp[1]; b1 = __builtin_nontemporal_load(wp + 32); }
-    for (int t = 0; t < half; ++t) {
-        float4 an = a1;
-        f32x4v bn = b1;
-        if (t + 2 < half) { an = vp[t + 2]; bn = __builtin_nontemporal_load(wp + (int64_t)(t + 2) * 32); }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0[3], acc, 0, 0, 0);
-        a0 = a1; b0 = b1; a1 = an; b1 = bn;
+    // the wave's whole K range goes in flight at once (<= FCM_DEPTH 16-byte loads of W and of v per lane, groups of FCM_DEPTH): with two
+    // loads ahead the 14 dependent 1 KiB loads of a wave were the bound (1.8 TB/s), not the matrix pipe
+    for (int t0 = 0; t0 < half; t0 += FCM_DEPTH) {
+        float4 av[FCM_DEPTH];
+        f32x4v bv[FCM_DEPTH];
+#pragma unroll
+        for (int u = 0; u < FCM_DEPTH; ++u) {
+            const int t = t0 + u < half ? t0 + u : half - 1;            // tail: harmless re-read, not used
+            av[u] = vp[t];
+            bv[u] = __builtin_nontemporal_load(wp + (int64_t)t * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < FCM_DEPTH; ++u) {
+            if (t0 + u < half) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u][3], acc, 0, 0, 0);
+            }
+        }
     }
     if (wave > 0) {
 #pragma unroll
