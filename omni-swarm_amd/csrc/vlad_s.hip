@@ -415,8 +415,10 @@ static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
     const int wave_cap = 32 / (C::THREADS / 64);                 // 8 waves per SIMD
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
-    static const int persist = [] { const char* e = getenv("OMNI_VLAD_SB_PERSIST"); return e ? atoi(e) : 1; }();   // A/B hook: 0 = one tile per workgroup
-    const int grid = (!persist || tiles < a.n_cu * per_cu) ? tiles : a.n_cu * per_cu;
+    // OMNI_VLAD_SB_PERSIST (A/B hook): 0 = one tile per workgroup, N >= 1 = N x (CUs x resident workgroups per CU) workgroups
+    static const int persist = [] { const char* e = getenv("OMNI_VLAD_SB_PERSIST"); return e ? atoi(e) : 1; }();
+    const int64_t cap = (int64_t)a.n_cu * per_cu * (persist > 0 ? persist : 1);
+    const int grid = (!persist || tiles < cap) ? tiles : (int)cap;
     static const bool want_trace = [] { const char* e = getenv("OMNI_VLAD_SB_TRACE"); return e && e[0] == '1'; }();
     static unsigned long long* trace_dev = nullptr;
     VladSBlockArgs at = a;
