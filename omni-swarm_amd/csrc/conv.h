@@ -77,6 +77,11 @@ void convdb_pack_weights(const float* w /*[256][256]*/, uint16_t* frag /*[65536]
 int convdb_l2norm(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, int in_cstride, const void* wfrag, const float* bias,
                   float* out, int64_t n_pixels);
 
+// convDb + L2 norm + bilinear sampling at the four coarse cells around every key point only (the dense map is not produced): raw_desc
+// [batch][max_num][256], bit-identical to convdb_l2norm followed by sp_sample_kernel; after sp_nms_kernel on the same stream
+int convdb_sparse_sample(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, int in_cstride, const void* wfrag, const float* bias, int W,
+                         int H, int max_num, const float* kps_xy, const int* n_kps, float* raw_desc, int batch);
+
 // test hook: NHWC (fp16 or fp32) -> NCHW fp32
 int nhwc_any_to_nchw_f32(hipStream_t stream, int precision_of_in, const void* in, float* out, int batch, int C, int HW);
 

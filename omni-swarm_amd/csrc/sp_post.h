@@ -33,9 +33,18 @@ struct SpPostBuffers {      // all device pointers, sized for max_batch images
     const float* pca_mean;  // [256]
 };
 
-// semi: [B][H][W] f32 probability map; desc_nhwc: [B][H/8][W/8][256] f32 (channel-normalised coarse descriptors)
+// descriptors sampled without the dense map (fp16 path): convDb + L2 norm only at the cells around the key points (conv.h: convdb_sparse_sample)
+struct SpSparseDesc {
+    const omni_ctx* ctx = nullptr;
+    const void* in_f16 = nullptr;   // cDa: NHWC fp16, already offset to the 256 input channels; null = sample the dense map instead
+    int in_cstride = 0;
+    const void* wfrag = nullptr;    // convdb_pack_weights
+    const float* bias = nullptr;
+};
+
+// semi: [B][H][W] f32 probability map; desc_nhwc: [B][H/8][W/8][256] f32 (channel-normalised coarse descriptors; unused when sparse.in_f16 is set)
 int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffers& b, const float* semi,
-                   const float* desc_nhwc, int batch);
+                   const float* desc_nhwc, int batch, const SpSparseDesc& sparse = SpSparseDesc{});
 
 // layout helpers between the reference's NCHW binding layout and the internal NHWC
 int nchw_to_nhwc(hipStream_t stream, const float* in, float* out, int batch, int C, int HW);

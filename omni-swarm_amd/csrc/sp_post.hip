@@ -13,6 +13,7 @@
 // by radix-selecting the cut-off confidence and ranking the few keys above it: final order = confidence desc, index asc
 // (the fixed spec; the reference's std::sort leaves ties unspecified).
 #include "sp_post.h"
+#include "conv.h"
 #include "topk.h"
 
 namespace omni {
@@ -421,7 +422,7 @@ int nhwc_to_nchw(hipStream_t stream, const float* in, float* out, int batch, int
 }
 
 int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffers& b, const float* semi,
-                   const float* desc_nhwc, int batch) {
+                   const float* desc_nhwc, int batch, const SpSparseDesc& sparse) {
     const int hw = p.width * p.height;
     const int state_words = cdiv(hw, 16);
     size_t smem = (size_t)state_words * 4;
@@ -439,9 +440,15 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
     hipLaunchKernelGGL(sp_nms_kernel, dim3(batch), dim3(NMS_THREADS), smem, stream, semi, p.width, p.height, p.max_num, b.cand,
                        b.cand_masks, b.counters, b.surv_keys, b.kps_xy, b.scores, b.n_kps, state_words, smem_main);
     OMNI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(p.max_num, SAMPLE_KPB), batch), dim3(256), 0, stream, desc_nhwc, p.width, p.height,
-                       p.max_num, b.kps_xy, b.n_kps, b.raw_desc);
-    OMNI_LAUNCH_CHECK();
+    if (sparse.in_f16) {
+        int rc = convdb_sparse_sample(stream, sparse.ctx, sparse.in_f16, sparse.in_cstride, sparse.wfrag, sparse.bias, p.width, p.height, p.max_num,
+                                      b.kps_xy, b.n_kps, b.raw_desc, batch);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(p.max_num, SAMPLE_KPB), batch), dim3(256), 0, stream, desc_nhwc, p.width, p.height,
+                           p.max_num, b.kps_xy, b.n_kps, b.raw_desc);
+        OMNI_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(sp_chan_sumsq_kernel, dim3(NORM_SEGS, batch), dim3(256), 0, stream, p.max_num, b.n_kps, b.raw_desc, b.norm_partial);
     OMNI_LAUNCH_CHECK();
     if (p.pca_dim > 0) {

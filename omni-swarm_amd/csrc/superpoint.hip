@@ -37,6 +37,11 @@ struct omni_sp {
     float *wPbA = nullptr, *wPbDust = nullptr; // convPb in MFMA A-fragment order + the dustbin row
     void* wPbA16 = nullptr;                    // convPb as split-fp16 A fragments (detector_head_mfma16_kernel); OMNI_DET16=0 keeps the f32 MFMA head
     bool det16 = true;
+    // fp16 path: descriptors are computed only at the four coarse cells around each key point (convdb_sparse_sample) and the dense map `draw`
+    // is produced on demand (omni_sp_get_dense) -- OMNI_SP_SPARSE_DESC=0 keeps the dense map in every forward pass (A/B, parity tests)
+    bool sparse_desc = true;
+    bool dense_valid = false, dense_possible = false;   // `draw` holds / `heads` can still produce the dense map of the last forward pass
+    int last_batch = 0;
     void* wDbFrag = nullptr;                    // convDb as register-resident fp16 A fragments (fused convDb + L2 norm, fp16 path)
     float* bias_heads = nullptr;             // [512]
     float* lut = nullptr;
@@ -88,6 +93,8 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         if ((rc = dev_upload(&s->wPbA16, w16.data(), w16.size() * 2, st))) return rc;
         const char* e16 = getenv("OMNI_DET16");
         s->det16 = !(e16 && e16[0] == '0');
+        const char* esd = getenv("OMNI_SP_SPARSE_DESC");
+        s->sparse_desc = !(esd && esd[0] == '0');
     }
     {
         std::vector<float> bh(512);
@@ -233,7 +240,11 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     } else if ((rc = detector_head_mfma(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
                                         s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
-    if (s->precision == OMNI_PREC_F16 && s->conv_variant == 0) {
+    const bool sparse = s->precision == OMNI_PREC_F16 && s->conv_variant == 0 && s->sparse_desc && run_post;
+    s->dense_valid = !sparse; s->dense_possible = true; s->last_batch = batch;
+    if (sparse) {
+        // nothing here: convDb runs inside the post-processing, at the key points only
+    } else if (s->precision == OMNI_PREC_F16 && s->conv_variant == 0) {
         // convDb + descriptor L2 norm in one HBM pass (channels [256,512) = cDa of the fused heads buffer, pixel stride 512)
         if ((rc = convdb_l2norm(st, s->ctx, (const char*)s->heads + (size_t)256 * s->esz, 512, s->wDbFrag, s->bias[LDB], s->draw,
                                 (int64_t)batch * s->Hc * s->Wc))) return rc;
@@ -249,7 +260,9 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     }
     if ((rc = mark())) return rc;
     if (run_post) {
-        if ((rc = sp_postprocess(st, post_params(s), s->pb, s->semi, s->draw, batch))) return rc;
+        SpSparseDesc sd;
+        if (sparse) { sd.ctx = s->ctx; sd.in_f16 = (const char*)s->heads + (size_t)256 * s->esz; sd.in_cstride = 512; sd.wfrag = s->wDbFrag; sd.bias = s->bias[LDB]; }
+        if ((rc = sp_postprocess(st, post_params(s), s->pb, s->semi, s->draw, batch, sd))) return rc;
     }
     if ((rc = mark())) return rc;
     return OMNI_OK;
@@ -379,6 +392,13 @@ int omni_sp_get_dense(omni_sp* s, int batch, float* semi_host, float* desc_host)
     int rc;
     if (semi_host) OMNI_HIP_TRY(hipMemcpyAsync(semi_host, s->semi, (size_t)batch * s->H * s->W * 4, hipMemcpyDeviceToHost, st));
     if (desc_host) {
+        if (!s->dense_valid) {
+            // the last forward pass sampled its descriptors without the dense map: produce it now from the head activations still in HBM
+            OMNI_REQUIRE(s->dense_possible && batch <= s->last_batch, OMNI_ERR_INVALID, "no forward pass of >= %d images to take the dense descriptors from", batch);
+            if ((rc = omni::convdb_l2norm(st, s->ctx, (const char*)s->heads + (size_t)256 * s->esz, 512, s->wDbFrag, s->bias[LDB], s->draw,
+                                          (int64_t)s->last_batch * s->Hc * s->Wc))) return rc;
+            s->dense_valid = true;
+        }
         const size_t n = (size_t)batch * 256 * s->Hc * s->Wc;
         if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
         if ((rc = omni::nhwc_to_nchw(st, s->draw, s->dense_tmp.as<float>(), batch, 256, s->Hc * s->Wc))) return rc;
@@ -401,6 +421,7 @@ int omni_sp_postprocess_dense(omni_sp* s, const float* semi_host, const float* d
     OMNI_HIP_TRY(hipMemcpyAsync(s->semi, semi_host, (size_t)batch * s->H * s->W * 4, hipMemcpyHostToDevice, st));
     OMNI_HIP_TRY(hipMemcpyAsync(s->dense_tmp.p, desc_host, n * 4, hipMemcpyHostToDevice, st));
     if ((rc = omni::nchw_to_nhwc(st, s->dense_tmp.as<float>(), s->draw, batch, 256, s->Hc * s->Wc))) return rc;
+    s->dense_valid = true; s->dense_possible = false; s->last_batch = batch;          // `draw` / `semi` now hold the caller's maps
     if ((rc = omni::sp_postprocess(st, omni::post_params(s), s->pb, s->semi, s->draw, batch))) return rc;
     return omni::sp_fetch_locked(s, batch, kps_xy, n_kps, desc, scores);
 }
