@@ -79,8 +79,13 @@ int convdb_l2norm(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, i
 
 // convDb + L2 norm + bilinear sampling at the four coarse cells around every key point only (the dense map is not produced): raw_desc
 // [batch][max_num][256], bit-identical to convdb_l2norm followed by sp_sample_kernel; after sp_nms_kernel on the same stream
+// compact: in_f16 = [image][key point][corner][in_cstride] (conv_c128_sparse's output) instead of the coarse map
 int convdb_sparse_sample(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, int in_cstride, const void* wfrag, const float* bias, int W,
-                         int H, int max_num, const float* kps_xy, const int* n_kps, float* raw_desc, int batch);
+                         int H, int max_num, const float* kps_xy, const int* n_kps, float* raw_desc, int batch, bool compact);
+// 3x3 conv (128 input channels, ReLU, fp16) at the coarse cells around the key points only: output channels [32 g32_first, + 256) of the packed
+// layer w_packed / bias, written compactly as [image][key point][corner][out_cstride]; bit-identical to the dense layer at those cells
+int conv_c128_sparse(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, const void* w_packed, const float* bias, int Hc, int Wc,
+                     int g32_first, int W, int H, int max_num, const float* kps_xy, const int* n_kps, void* out_f16, int out_cstride, int batch);
 
 // test hook: NHWC (fp16 or fp32) -> NCHW fp32
 int nhwc_any_to_nchw_f32(hipStream_t stream, int precision_of_in, const void* in, float* out, int batch, int C, int HW);

@@ -936,6 +936,8 @@ static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
 //     each feeds up to three MFMAs (the three ky that map the row onto an output row): 432 MFMAs per tile per wave,
 //     0.44 LDS reads per MFMA.
 // ---------------------------------------------------------------------------------------------------------------
+#define CSP_KP 8                                  // key points per tile of the sparse descriptor kernels (32 corner cells)
+bool conv_rs_transposed(int H, int W);
 #define RS_TH 6
 #define RS_TW 32
 #define RS_ITH (RS_TH + 2)
@@ -1128,9 +1130,7 @@ template <bool POOL, bool TRN = false>
 static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     if constexpr (!POOL && !TRN) {
         // the tile orientation with fewer tiles (OMNI_RS_TRN=0/1 forces one: A/B hook; results do not depend on it)
-        static const int force = [] { const char* e = getenv("OMNI_RS_TRN"); return e ? atoi(e) : -1; }();
-        const int plain = cdiv(a.W, RS_TW) * cdiv(a.H, RS_TH), trn = cdiv(a.W, RS_TH) * cdiv(a.H, RS_TW);
-        if (force == 1 || (force < 0 && trn < plain)) return launch_conv_rs<false, true>(st, a, n_cu);
+        if (conv_rs_transposed(a.H, a.W)) return launch_conv_rs<false, true>(st, a, n_cu);
     }
     auto kfn = conv3x3_c128_rs_kernel<POOL, TRN>;
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_SMEM));
@@ -1164,6 +1164,170 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
                         h[k * 8 + 5] - h[k * 8 + 4], h[k * 8 + 5] - h[k * 8]);
     }
     return OMNI_OK;
+}
+
+// the tile orientation launch_conv_rs picks for a non-pooled H x W layer (it fixes the order the taps are summed in)
+bool conv_rs_transposed(int H, int W) {
+    static const int force = [] { const char* e = getenv("OMNI_RS_TRN"); return e ? atoi(e) : -1; }();
+    const int plain = cdiv(W, RS_TW) * cdiv(H, RS_TH), trn = cdiv(W, RS_TH) * cdiv(H, RS_TW);
+    return force == 1 || (force < 0 && trn < plain);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 conv, 128 input channels, ONLY at the coarse cells around the key points (convDa, superpoint.ipynb:183: its output is read by
+// computeDescriptors at the four cells around each key point and nowhere else -- <= 800 of 4 500 cells).  Weights as in the register-stationary
+// kernel above (wave = 32 output channels, all K = 9 x 128 in 288 registers, the same packed array), but a "pixel tile" is the 32 corner
+// cells of 8 key points: their 3x3 x 128-channel neighbourhoods are gathered into LDS (thread = (cell, eighth): 18 16-byte pieces, fetched
+// into registers one tile ahead), one accumulator fragment per wave, 72 MFMAs per tile in EXACTLY the order the dense kernel sums the taps
+// in for this layer shape (TRN), bias + ReLU + fp16 as store_frag16: the values are bit-identical to the dense layer's at those cells.
+// out: compact [image][key point][corner][256] fp16 (+ cout_off); cells outside the map / beyond n_kps are not written.
+// ---------------------------------------------------------------------------------------------------------------
+// k-step S (dense order) of the sparse kernel: B fragment of step S + 2 issued, step S waited for, one MFMA (the rs_steps pattern: a single
+// wave per SIMD has nobody to hide an LDS round trip behind, and left to itself hipcc waited lgkmcnt(0) in front of every MFMA)
+template <int S, bool TRN>
+__device__ __forceinline__ void spc_steps(uint32_t base, const half8_t (&wreg)[72], floatx16& acc, half8_t (&fb)[3]) {
+    if constexpr (S < 72) {
+        constexpr int o = S / 8, kg = S % 8, tap = TRN ? o : (o % 3) * 3 + o / 3;
+        if constexpr (S + 2 < 72) {
+            constexpr int o2 = (S + 2) / 8, kg2 = (S + 2) % 8, tap2 = TRN ? o2 : (o2 % 3) * 3 + o2 / 3;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[(S + 2) % 3]) : "v"(base), "i"(tap2 * 256 + kg2 * 32));
+        }
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fb[S % 3]) : "i"((S + 2 < 72) ? 2 : (S + 1 < 72 ? 1 : 0)));
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap * 8 + kg], fb[S % 3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        spc_steps<S + 1, TRN>(base, wreg, acc, fb);
+    }
+}
+
+#define SPC_CELL_BYTES 2320                       // 9 taps x 256 B + 16: an odd number of 16-byte slots, conflict-free B-fragment reads
+#define SPC_BUF_BYTES (32 * SPC_CELL_BYTES)       // 74 240
+#define SPC_SMEM (2 * SPC_BUF_BYTES)
+template <bool TRN>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_c128_sparse_kernel(const _Float16* __restrict__ in /*[B][Hc][Wc][128]*/, const _Float16* __restrict__ wp, const float* __restrict__ bias,
+                           int Hc, int Wc, int g32_first, int W, int H, int max_num, const float* __restrict__ kps_xy,
+                           const int* __restrict__ n_kps, _Float16* __restrict__ out, int out_cstride, int tiles_per_img, int n_tiles,
+                           const char* __restrict__ zero_page /* omni_ctx::zero_page: what out-of-map taps and missing cells read */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hh = lane >> 5;
+    const int half = blockIdx.x & 1, wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;      // 128 output channels per workgroup, two halves
+    const int g32 = g32_first + half * 4 + wave;
+    half8_t wreg[72];                              // wreg[tap * 8 + kg], tap = ky * 3 + kx of the IMAGE
+    {
+        const _Float16* wbase = wp + (int64_t)(g32 >> 1) * 2 * 9 * 4096 + (g32 & 1) * 512 + lane * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 72; ++s2) {
+            const int tap = s2 >> 3, ch = (s2 >> 2) & 1, kg4 = s2 & 3;
+            wreg[s2] = *reinterpret_cast<const half8_t*>(wbase + ((ch * 9 + tap) * 4 + kg4) * 1024);
+        }
+    }
+    float4 bs[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const float4*>(bias + g32 * 32 + 8 * g + 4 * hh);
+    const float fW = (float)W, fH = (float)H, fWc = (float)Wc, fHc = (float)Hc;
+    // corner cell `slot` of tile t -> (image, key point, cell x, cell y); false: no such key point (sp_sample_kernel's arithmetic)
+    auto cell_of = [&](int t, int slot, int& b, int& kp, int& cx, int& cy) __attribute__((always_inline)) -> bool {
+        b = t / tiles_per_img;
+        kp = (t - b * tiles_per_img) * CSP_KP + (slot >> 2);
+        cx = cy = -4;
+        if (kp >= n_kps[b]) return false;
+        const float kx = kps_xy[((int64_t)b * max_num + kp) * 2 + 0], ky = kps_xy[((int64_t)b * max_num + kp) * 2 + 1];
+        const float gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, kx), fW), 1.0f);
+        const float gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, ky), fH), 1.0f);
+        const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), fWc), 1.0f), 2.0f);
+        const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), fHc), 1.0f), 2.0f);
+        cx = (int)floorf(ix) + (slot & 1); cy = (int)floorf(iy) + ((slot >> 1) & 1);
+        return cx >= 0 && cx < Wc && cy >= 0 && cy < Hc;
+    };
+    // gather: thread = (cell tid >> 3, eighth tid & 7): pieces j * 8 + eighth, j < 18, of the cell's 144 16-byte pieces (tap = j >> 1).  The 18
+    // staging registers are named scalars and the nine taps are spelled out: as an array indexed inside unrolled loops hipcc kept them in scratch
+    // memory (a store per load, the gather serialised: 214 us per launch instead of 20)
+    const int gcell = tid >> 3, gpart = tid & 7;
+    uint4 sa0, sb0, sa1, sb1, sa2, sb2, sa3, sb3, sa4, sb4, sa5, sb5, sa6, sb6, sa7, sb7, sa8, sb8;
+    int fb, fkp, fcx, fcy; bool fok; const char* fimg;
+#define SPC_FETCH_TAP(T)                                                                                                     \
+    {                                                                                                                        \
+        const int y = fcy + (T) / 3 - 1, x = fcx + (T) % 3 - 1;                                                              \
+        const bool inside = fok && y >= 0 && y < Hc && x >= 0 && x < Wc;                                                     \
+        const char* src = inside ? fimg + ((int64_t)y * Wc + x) * 256 + gpart * 16 : zero_page + (tid & 255) * 32;           \
+        sa##T = *reinterpret_cast<const uint4*>(src);                                                                        \
+        sb##T = *reinterpret_cast<const uint4*>(inside ? src + 128 : src + 16);                                              \
+    }
+#define SPC_FETCH(TILE)                                                                                                      \
+    {                                                                                                                        \
+        fok = cell_of((TILE), gcell, fb, fkp, fcx, fcy);                                                                     \
+        fimg = reinterpret_cast<const char*>(in + (int64_t)fb * Hc * Wc * 128);                                              \
+        SPC_FETCH_TAP(0) SPC_FETCH_TAP(1) SPC_FETCH_TAP(2) SPC_FETCH_TAP(3) SPC_FETCH_TAP(4) SPC_FETCH_TAP(5) SPC_FETCH_TAP(6) SPC_FETCH_TAP(7) SPC_FETCH_TAP(8) \
+    }
+#define SPC_PARK_TAP(T) *reinterpret_cast<uint4*>(pdst + (T) * 256) = sa##T; *reinterpret_cast<uint4*>(pdst + (T) * 256 + 128) = sb##T;
+#define SPC_PARK(WHICH)                                                                                                      \
+    {                                                                                                                        \
+        char* pdst = smem_raw + (WHICH) * SPC_BUF_BYTES + gcell * SPC_CELL_BYTES + gpart * 16;                               \
+        SPC_PARK_TAP(0) SPC_PARK_TAP(1) SPC_PARK_TAP(2) SPC_PARK_TAP(3) SPC_PARK_TAP(4) SPC_PARK_TAP(5) SPC_PARK_TAP(6) SPC_PARK_TAP(7) SPC_PARK_TAP(8) \
+    }
+    int t = wg;
+    if (t < n_tiles) { SPC_FETCH(t) SPC_PARK(0) }
+    __syncthreads();
+    int cur = 0;
+    for (; t < n_tiles; t += nwg, cur ^= 1) {
+        const int tn = t + nwg;
+        if (tn < n_tiles) SPC_FETCH(tn)                                // in flight behind the MFMA loop
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {   // the dense kernel's order: plain tiles sum kx outer / ky inner, transposed tiles ky outer / kx inner (spc_steps)
+            const uint32_t base = lds0 + cur * SPC_BUF_BYTES + n * SPC_CELL_BYTES + hh * 16;
+            half8_t fb[3];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // nothing of ours in flight on the LDS counter but the reads below
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0]) : "v"(base), "i"(0));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1]) : "v"(base), "i"(32));
+            __builtin_amdgcn_sched_barrier(0);
+            spc_steps<0, TRN>(base, wreg, acc, fb);
+        }
+        {   // bias + ReLU + fp16 (store_frag16<false>): lane = cell n, channels 32 g32 + 8 g + 4 hh + (0..3)
+            int b, kp, cx, cy;
+            const bool ok = cell_of(t, n, b, kp, cx, cy);
+            if (ok) {
+                _Float16* op = out + (((int64_t)b * max_num + kp) * 4 + (n & 3)) * out_cstride + (g32 - g32_first) * 32 + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t d0 = pack_relu_f16<false>(acc[4 * g + 0] + bs[g].x, acc[4 * g + 1] + bs[g].y, 1);
+                    const uint32_t d1 = pack_relu_f16<false>(acc[4 * g + 2] + bs[g].z, acc[4 * g + 3] + bs[g].w, 1);
+                    *reinterpret_cast<uint2*>(op + 8 * g) = make_uint2(d0, d1);
+                }
+            }
+        }
+        if (tn < n_tiles) SPC_PARK(cur ^ 1)
+        __syncthreads();
+    }
+#undef SPC_FETCH_TAP
+#undef SPC_FETCH
+#undef SPC_PARK_TAP
+#undef SPC_PARK
+}
+
+int conv_c128_sparse(hipStream_t st, const omni_ctx* ctx, const void* in_f16, const void* w_packed, const float* bias, int Hc, int Wc, int g32_first,
+                     int W, int H, int max_num, const float* kps_xy, const int* n_kps, void* out_f16, int out_cstride, int batch) {
+    const int tiles_per_img = cdiv(max_num, CSP_KP), n_tiles = tiles_per_img * batch;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int pairs = cus / 2;                                                 // two workgroups (channel halves) per tile stream
+    if (pairs > n_tiles) pairs = n_tiles;
+    if (pairs < 1) pairs = 1;
+    const bool trn = conv_rs_transposed(Hc, Wc);
+    OMNI_REQUIRE(ctx->zero_page, OMNI_ERR_INVALID, "conv_c128_sparse: the context has no zero block");
+    auto launch = [&](auto kfn) -> int {
+        static DynSmemState attr;
+        OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)kfn, SPC_SMEM));
+        hipLaunchKernelGGL(kfn, dim3(2 * pairs), dim3(256), SPC_SMEM, st, (const _Float16*)in_f16, (const _Float16*)w_packed, bias, Hc, Wc, g32_first, W, H,
+                           max_num, kps_xy, n_kps, (_Float16*)out_f16, out_cstride, tiles_per_img, n_tiles, (const char*)ctx->zero_page);
+        OMNI_LAUNCH_CHECK();
+        return OMNI_OK;
+    };
+    return trn ? launch(conv3x3_c128_sparse_kernel<true>) : launch(conv3x3_c128_sparse_kernel<false>);
 }
 
 template <typename T, int KS, bool POOL>
@@ -1802,7 +1966,6 @@ int convdb_l2norm(hipStream_t st, const omni_ctx* ctx, const void* in_f16, int i
 // sp_sample_kernel on the dense map, the 4.6 MB/image fp32 map is never written, 5.6x fewer cells are computed.
 // raw_desc[b][i][256] for i < n_kps[b]; runs after sp_nms_kernel on the same stream.
 // ---------------------------------------------------------------------------------------------------------------
-#define CSP_KP 8
 // value of lane (lane & ~3) + J in every lane of the quad (v_mov_b32 with a quad_perm DPP control: no LDS)
 template <int J>
 __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, J * 85, 0xF, 0xF, false); }
@@ -1812,7 +1975,7 @@ __device__ __forceinline__ float quad_bcast(float v) { return __builtin_bit_cast
 __global__ void __launch_bounds__(64 * CDB_WAVES)
 convdb_sparse_kernel(const _Float16* __restrict__ in, int in_cstride, const _Float16* __restrict__ wfrag, const float* __restrict__ bias,
                      int W, int H, int max_num, const float* __restrict__ kps_xy, const int* __restrict__ n_kps, float* __restrict__ raw_desc,
-                     int tiles_per_img, int n_tiles) {
+                     int tiles_per_img, int n_tiles, int compact /* in = [image][key point][corner][in_cstride] instead of the coarse map */) {
     __shared__ __attribute__((aligned(16))) char tile[2][CDB_PX * 512];
     __shared__ float part[2][CDB_WAVES][CDB_PX];
     __shared__ float sbias[256];
@@ -1842,7 +2005,7 @@ convdb_sparse_kernel(const _Float16* __restrict__ in, int in_cstride, const _Flo
         const float wx = (slot & 1) ? ix - fx0 : (fx0 + 1.f) - ix, wy = (slot & 2) ? iy - fy0 : (fy0 + 1.f) - iy;
         wgt = __fmul_rn(wx, wy);
         if (cx < 0 || cx >= Wc || cy < 0 || cy >= Hc) return -1;
-        return ((int64_t)b * Hc + cy) * Wc + cx;
+        return compact ? ((int64_t)b * max_num + kp) * 4 + (slot & 3) : ((int64_t)b * Hc + cy) * Wc + cx;
     };
     // staging: thread -> 2 of the tile's 1024 16-byte chunks (cell tid >> 5 and + 16, chunk tid & 31)
     const int spx0 = tid >> 5, spx1 = spx0 + 16, sc = tid & 31;
@@ -1914,12 +2077,12 @@ convdb_sparse_kernel(const _Float16* __restrict__ in, int in_cstride, const _Flo
 }
 
 int convdb_sparse_sample(hipStream_t st, const omni_ctx* ctx, const void* in_f16, int in_cstride, const void* wfrag, const float* bias, int W, int H,
-                         int max_num, const float* kps_xy, const int* n_kps, float* raw_desc, int batch) {
+                         int max_num, const float* kps_xy, const int* n_kps, float* raw_desc, int batch, bool compact) {
     const int tiles_per_img = cdiv(max_num, CSP_KP), n_tiles = tiles_per_img * batch;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const int grid = n_tiles < cus ? n_tiles : cus;
     hipLaunchKernelGGL(convdb_sparse_kernel, dim3((unsigned)grid), dim3(64 * CDB_WAVES), 0, st, (const _Float16*)in_f16, in_cstride,
-                       (const _Float16*)wfrag, bias, W, H, max_num, kps_xy, n_kps, raw_desc, tiles_per_img, n_tiles);
+                       (const _Float16*)wfrag, bias, W, H, max_num, kps_xy, n_kps, raw_desc, tiles_per_img, n_tiles, compact ? 1 : 0);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }

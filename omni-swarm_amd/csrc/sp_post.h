@@ -40,6 +40,10 @@ struct SpSparseDesc {
     int in_cstride = 0;
     const void* wfrag = nullptr;    // convdb_pack_weights
     const float* bias = nullptr;
+    // convDa itself only around the key points (conv_c128_sparse): a4b -> da_compact [B][max_num][4][256] fp16, which then replaces in_f16
+    const void* a4b = nullptr;      // [B][Hc][Wc][128] fp16; null = in_f16 is the dense cDa map
+    const void* da_w = nullptr; const float* da_bias = nullptr; int da_g32_first = 0;
+    void* da_compact = nullptr;
 };
 
 // semi: [B][H][W] f32 probability map; desc_nhwc: [B][H/8][W/8][256] f32 (channel-normalised coarse descriptors; unused when sparse.in_f16 is set)

@@ -440,9 +440,16 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
     hipLaunchKernelGGL(sp_nms_kernel, dim3(batch), dim3(NMS_THREADS), smem, stream, semi, p.width, p.height, p.max_num, b.cand,
                        b.cand_masks, b.counters, b.surv_keys, b.kps_xy, b.scores, b.n_kps, state_words, smem_main);
     OMNI_LAUNCH_CHECK();
-    if (sparse.in_f16) {
+    if (sparse.a4b) {
+        int rc = conv_c128_sparse(stream, sparse.ctx, sparse.a4b, sparse.da_w, sparse.da_bias, p.height / 8, p.width / 8, sparse.da_g32_first, p.width, p.height,
+                                  p.max_num, b.kps_xy, b.n_kps, sparse.da_compact, 256, batch);
+        if (rc) return rc;
+        rc = convdb_sparse_sample(stream, sparse.ctx, sparse.da_compact, 256, sparse.wfrag, sparse.bias, p.width, p.height, p.max_num, b.kps_xy, b.n_kps,
+                                  b.raw_desc, batch, true);
+        if (rc) return rc;
+    } else if (sparse.in_f16) {
         int rc = convdb_sparse_sample(stream, sparse.ctx, sparse.in_f16, sparse.in_cstride, sparse.wfrag, sparse.bias, p.width, p.height, p.max_num,
-                                      b.kps_xy, b.n_kps, b.raw_desc, batch);
+                                      b.kps_xy, b.n_kps, b.raw_desc, batch, false);
         if (rc) return rc;
     } else {
         hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(p.max_num, SAMPLE_KPB), batch), dim3(256), 0, stream, desc_nhwc, p.width, p.height,

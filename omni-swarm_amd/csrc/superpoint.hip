@@ -40,6 +40,9 @@ struct omni_sp {
     // fp16 path: descriptors are computed only at the four coarse cells around each key point (convdb_sparse_sample) and the dense map `draw`
     // is produced on demand (omni_sp_get_dense) -- OMNI_SP_SPARSE_DESC=0 keeps the dense map in every forward pass (A/B, parity tests)
     bool sparse_desc = true;
+    bool sparse_da = true;                   // ... and convDa itself only there too (conv_c128_sparse); OMNI_SP_SPARSE_DA=0: convDa stays dense
+    void* headsP = nullptr;                  // [B][Hc][Wc][256] cPa alone (sparse_da passes)
+    void* da_compact = nullptr;              // [B][max_num][4][256] fp16: cDa at the corner cells of the key points
     bool dense_valid = false, dense_possible = false;   // `draw` holds / `heads` can still produce the dense map of the last forward pass
     int last_batch = 0;
     void* wDbFrag = nullptr;                    // convDb as register-resident fp16 A fragments (fused convDb + L2 norm, fp16 path)
@@ -95,6 +98,8 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         s->det16 = !(e16 && e16[0] == '0');
         const char* esd = getenv("OMNI_SP_SPARSE_DESC");
         s->sparse_desc = !(esd && esd[0] == '0');
+        const char* esa = getenv("OMNI_SP_SPARSE_DA");
+        s->sparse_da = s->sparse_desc && !(esa && esa[0] == '0');
     }
     {
         std::vector<float> bh(512);
@@ -159,6 +164,10 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     OMNI_HIP_TRY(hipMalloc(&s->a4a, B * (H / 8) * (W / 8) * 128 * e));
     OMNI_HIP_TRY(hipMalloc(&s->a4b, B * (H / 8) * (W / 8) * 128 * e));
     OMNI_HIP_TRY(hipMalloc(&s->heads, B * (H / 8) * (W / 8) * 512 * e));
+    if (s->precision == OMNI_PREC_F16) {
+        OMNI_HIP_TRY(hipMalloc(&s->headsP, B * (H / 8) * (W / 8) * 256 * e));
+        OMNI_HIP_TRY(hipMalloc(&s->da_compact, B * (size_t)s->max_num * 4 * 256 * 2));
+    }
     OMNI_HIP_TRY(hipMalloc((void**)&s->draw, B * (H / 8) * (W / 8) * 256 * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->semi, B * H * W * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->gray_stage, B * H * W));
@@ -232,15 +241,20 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if ((rc = mark())) return rc;
     if ((rc = conv(L4B, s->a4a, s->a4b, s->bias[L4B], H / 8, W / 8, 128, 128, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
-    if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, false))) return rc;
+    const bool sparse = s->precision == OMNI_PREC_F16 && s->conv_variant == 0 && s->sparse_desc && run_post;
+    const bool sparse_da = sparse && s->sparse_da && s->headsP;
+    // the detector branch needs cPa everywhere; cDa (output channels 256-511 of the fused heads layer) is only read around the key points
+    const void* cpa = sparse_da ? s->headsP : s->heads;
+    const int cpa_stride = sparse_da ? 256 : 512;
+    if (sparse_da) { if ((rc = conv(LPA, s->a4b, s->headsP, s->bias_heads, H / 8, W / 8, 128, 256, 3, true, false, false))) return rc; }
+    else if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
     if (s->conv_variant == 1) { if ((rc = detector_head(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
     else if (P == OMNI_PREC_F16 && s->det16) {
-        if ((rc = detector_head_mfma16(st, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount))) return rc;
-    } else if ((rc = detector_head_mfma(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
+        if ((rc = detector_head_mfma16(st, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount))) return rc;
+    } else if ((rc = detector_head_mfma(st, P, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
                                         s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
-    const bool sparse = s->precision == OMNI_PREC_F16 && s->conv_variant == 0 && s->sparse_desc && run_post;
     s->dense_valid = !sparse; s->dense_possible = true; s->last_batch = batch;
     if (sparse) {
         // nothing here: convDb runs inside the post-processing, at the key points only
@@ -262,9 +276,26 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (run_post) {
         SpSparseDesc sd;
         if (sparse) { sd.ctx = s->ctx; sd.in_f16 = (const char*)s->heads + (size_t)256 * s->esz; sd.in_cstride = 512; sd.wfrag = s->wDbFrag; sd.bias = s->bias[LDB]; }
+        if (sparse_da) { sd.a4b = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_compact = s->da_compact; }
         if ((rc = sp_postprocess(st, post_params(s), s->pb, s->semi, s->draw, batch, sd))) return rc;
     }
     if ((rc = mark())) return rc;
+    return OMNI_OK;
+}
+
+// the dense head activations and descriptor map of the LAST forward pass, when it sampled its descriptors sparsely: the fused heads layer over
+// every cell (conv4b's output is still in HBM) + convDb + L2 norm
+static int sp_make_dense(omni_sp* s) {
+    hipStream_t st = s->ctx->stream;
+    int rc;
+    ConvArgs a;
+    a.in = s->a4b; a.out = s->heads; a.w_packed = s->wpk[LPA]; a.bias = s->bias_heads; a.batch = s->last_batch; a.H = s->Hc; a.W = s->Wc; a.cin = 128;
+    a.cout = 512; a.ksize = 3; a.relu = true; a.pool = false; a.out_f32 = false;
+    a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page; a.variant = s->conv_variant;
+    if ((rc = conv_mfma(st, s->precision, a))) return rc;
+    if ((rc = convdb_l2norm(st, s->ctx, (const char*)s->heads + (size_t)256 * s->esz, 512, s->wDbFrag, s->bias[LDB], s->draw,
+                            (int64_t)s->last_batch * s->Hc * s->Wc))) return rc;
+    s->dense_valid = true;
     return OMNI_OK;
 }
 
@@ -334,7 +365,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
     void* ptrs[] = {s->wPbA16, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
-                    s->a4a, s->a4b, s->heads, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
+                    s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     s->hstage.release(); s->dense_tmp.release();
@@ -395,9 +426,7 @@ int omni_sp_get_dense(omni_sp* s, int batch, float* semi_host, float* desc_host)
         if (!s->dense_valid) {
             // the last forward pass sampled its descriptors without the dense map: produce it now from the head activations still in HBM
             OMNI_REQUIRE(s->dense_possible && batch <= s->last_batch, OMNI_ERR_INVALID, "no forward pass of >= %d images to take the dense descriptors from", batch);
-            if ((rc = omni::convdb_l2norm(st, s->ctx, (const char*)s->heads + (size_t)256 * s->esz, 512, s->wDbFrag, s->bias[LDB], s->draw,
-                                          (int64_t)s->last_batch * s->Hc * s->Wc))) return rc;
-            s->dense_valid = true;
+            if ((rc = omni::sp_make_dense(s))) return rc;
         }
         const size_t n = (size_t)batch * 256 * s->Hc * s->Wc;
         if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
@@ -438,6 +467,13 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
     for (const Ent& e : tab) {
         if (strcmp(e.n, name) != 0) continue;
         if (e.p == s->a1a && s->fuse1a) { omni::set_error("conv1a is fused into conv1b on this path and not materialised (OMNI_CONV_V1=3 keeps it)"); return OMNI_ERR_INVALID; }
+        if ((e.p == s->heads || e.p == s->draw) && !s->dense_valid) {
+            OMNI_REQUIRE(s->dense_possible && batch <= s->last_batch, OMNI_ERR_INVALID, "no forward pass of >= %d images to take layer %s from", batch, name);
+            std::lock_guard<std::mutex> lk(s->mu);
+            (void)hipSetDevice(s->ctx->device);
+            int rc = omni::sp_make_dense(s);
+            if (rc) return rc;
+        }
         const int h = s->H / e.div, w = s->W / e.div;
         if (C) *C = e.c;
         if (Hl) *Hl = h;

@@ -129,8 +129,9 @@ def test_f16_path_tolerances(omni, ctx):
 
 
 def test_f16_sparse_descriptors_are_bit_identical_to_the_dense_map_path(omni, ctx, monkeypatch):
-    """fp16 path: convDb + L2 norm + bilinear sampling only at the four coarse cells around each key point (convdb_sparse_kernel; the
-    4.6 MB/image dense map is not written) against the dense map + sp_sample_kernel (OMNI_SP_SPARSE_DESC=0): same key points, same descriptors
+    """fp16 path: convDa (conv3x3_c128_sparse_kernel) and convDb + L2 norm + bilinear sampling (convdb_sparse_kernel) only at the four coarse
+    cells around each key point -- the dense cDa half of the heads layer and the 4.6 MB/image descriptor map are not computed -- against the
+    dense layers + sp_sample_kernel (OMNI_SP_SPARSE_DESC=0), also with only convDb sparse (OMNI_SP_SPARSE_DA=0): same key points, same descriptors
     BIT FOR BIT -- with and without PCA, odd sizes (key points on the map's border rows / columns: corner cells outside the map), few and many
     key points (partial key-point tiles), several images per launch; omni_sp_get_dense after a sparse pass == the dense pass's map."""
     weights = S.synth_weights(0)
@@ -139,20 +140,22 @@ def test_f16_sparse_descriptors_are_bit_identical_to_the_dense_map_path(omni, ct
                                        (64, 96, 2, 0.001, 1000, True)):
         imgs = np.stack([synth.image_u8(310 + i, h, w, n_shapes=60) for i in range(nb)])
         res = {}
-        for flag in ("1", "0"):
-            monkeypatch.setenv("OMNI_SP_SPARSE_DESC", flag)
+        for flag, (desc_flag, da_flag) in {"sparse": ("1", "1"), "sparse_db_only": ("1", "0"), "dense": ("0", "0")}.items():
+            monkeypatch.setenv("OMNI_SP_SPARSE_DESC", desc_flag)
+            monkeypatch.setenv("OMNI_SP_SPARSE_DA", da_flag)
             sp = omni.capi.SuperPoint(ctx, weights, comp if pca else None, mean if pca else None, w, h, thr, maxn, omni.capi.PREC_F16, nb)
             out = sp.inference(imgs, fisheye_mask=(h == 480))
             dense = sp.get_dense(nb)
             one = sp.inference(imgs[nb - 1], fisheye_mask=(h == 480))
             res[flag] = (out, dense, one)
             sp.close()
-        for b in range(nb):
-            (k1, d1, s1), (k0, d0, s0) = res["1"][0][b], res["0"][0][b]
-            assert len(k1) > 0 and np.array_equal(k1, k0) and np.array_equal(s1, s0)
-            assert np.array_equal(d1, d0), (h, w, b, np.abs(d1 - d0).max())
-        assert np.array_equal(res["1"][1][0], res["0"][1][0]) and np.array_equal(res["1"][1][1], res["0"][1][1])
-        assert np.array_equal(res["1"][2][0][1], res["1"][0][nb - 1][1])          # batch 1 == batch n, sparse path
+        for flag in ("sparse", "sparse_db_only"):
+            for b in range(nb):
+                (k1, d1, s1), (k0, d0, s0) = res[flag][0][b], res["dense"][0][b]
+                assert len(k1) > 0 and np.array_equal(k1, k0) and np.array_equal(s1, s0)
+                assert np.array_equal(d1, d0), (flag, h, w, b, np.abs(d1 - d0).max())
+            assert np.array_equal(res[flag][1][0], res["dense"][1][0]) and np.array_equal(res[flag][1][1], res["dense"][1][1])
+            assert np.array_equal(res[flag][2][0][1], res[flag][0][nb - 1][1])          # batch 1 == batch n, sparse paths
 
 
 def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, monkeypatch):
