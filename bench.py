@@ -36,8 +36,24 @@ sys.path.insert(0, ROOT)
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
 PEAK_F32_TFLOPS = 157.3       # f32-input MFMA = vector peak
 PEAK_HBM_GBS = 8000.0         # HBM3E spec peak (6.29 TB/s measured achievable)
-SP_FLOP_PER_IMAGE = 48.85e9   # SURVEY.md 2.3 @600x480
-KF_IMAGES = 8                 # reference-faithful key frame: 8 SuperPoint + 4 MobileNetVLAD
+SP_FLOP_PER_IMAGE = 48.85e9   # SURVEY.md 2.3 @600x480: the dense network
+# fp16 path: convDa (128 -> 256, 3x3) and convDb (256 -> 256, 1x1) run only at the <= 4 * max_num coarse cells around the key points instead of all
+# 75 x 60 = 4500 (conv3x3_c128_sparse_kernel, convdb_sparse_kernel): FLOP actually executed per image
+SP_DA_FLOP_PER_CELL, SP_DB_FLOP_PER_CELL, SP_CELLS = 2.0 * 9 * 128 * 256, 2.0 * 256 * 256, 4500
+
+
+def sp_flop_executed(precision, max_num, conv_stages_only=False):
+    """FLOP per image actually executed (conv_stages_only: by the stages named conv*, i.e. without the sparse descriptor kernels, which run inside the
+    post-processing stage)."""
+    sparse_db = precision == "f16" and os.environ.get("OMNI_SP_SPARSE_DESC", "1") != "0"
+    sparse_da = sparse_db and os.environ.get("OMNI_SP_SPARSE_DA", "1") != "0"
+    cells = 0 if conv_stages_only else min(4 * max_num, SP_CELLS)
+    f = SP_FLOP_PER_IMAGE
+    if sparse_db:
+        f -= SP_DB_FLOP_PER_CELL * (SP_CELLS - cells)
+    if sparse_da:
+        f -= SP_DA_FLOP_PER_CELL * (SP_CELLS - cells)
+    return f
 
 
 def traffic_fields(key, enabled=True, images_per_launch=None):
@@ -422,7 +438,9 @@ def main():
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 **traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", args.precision == "f16", n_img),
                 "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
-                "conv_stack_tflops": round(SP_FLOP_PER_IMAGE * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
+                "conv_stack_tflops": round(sp_flop_executed(args.precision, MAXN, True) * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
+                "conv_stack_note": "FLOP executed by the stages named conv* (fp16 path: without convDa / convDb, which run only at the cells around the key points "
+                                   "inside the post-processing stage) / their time",
                 "stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof}, "superpoint_ms_per_keyframe": round(sp_ms, 3)}
     ictx.free(pool_dev)
 
@@ -522,8 +540,9 @@ def main():
                        "parallelism": f"dp{world} keyframes + {world}-way row-sharded index" if world > 1 else "single GPU",
                        "device": info["name"], "n_cu": info["n_cu"]},
             "loop_candidates_found": hits,
-            "gflop_per_keyframe_superpoint": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
-            "achieved_tflops_end_to_end": round(kfps * SP_FLOP_PER_IMAGE * KF_IMAGES / 1e12 / world, 1),
+            "gflop_per_keyframe_superpoint": round(sp_flop_executed(args.precision, MAXN) * KF_IMAGES / 1e9, 1),
+            "gflop_per_keyframe_superpoint_dense": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
+            "achieved_tflops_end_to_end": round(kfps * sp_flop_executed(args.precision, MAXN) * KF_IMAGES / 1e12 / world, 1),
             "roofline": roofline, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
             "db100k": db100k, "with_geometry": with_geometry, "value_f32": value_f32, "python_host": python_host, "parity": parity, "cpu_baseline": cpu,
         }
