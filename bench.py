@@ -37,6 +37,7 @@ PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROAR
 PEAK_F32_TFLOPS = 157.3       # f32-input MFMA = vector peak
 PEAK_HBM_GBS = 8000.0         # HBM3E spec peak (6.29 TB/s measured achievable)
 SP_FLOP_PER_IMAGE = 48.85e9   # SURVEY.md 2.3 @600x480: the dense network
+KF_IMAGES = 8                 # reference-faithful key frame: 8 SuperPoint + 4 MobileNetVLAD
 # fp16 path: convDa (128 -> 256, 3x3) and convDb (256 -> 256, 1x1) run only at the <= 4 * max_num coarse cells around the key points instead of all
 # 75 x 60 = 4500 (conv3x3_c128_sparse_kernel, convdb_sparse_kernel): FLOP actually executed per image
 SP_DA_FLOP_PER_CELL, SP_DB_FLOP_PER_CELL, SP_CELLS = 2.0 * 9 * 128 * 256, 2.0 * 256 * 256, 4500
