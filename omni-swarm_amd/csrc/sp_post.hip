@@ -39,20 +39,17 @@ namespace omni {
 #define NEG_SENTINEL (-3.0e38f)
 __global__ void __launch_bounds__(256)
 sp_cand_kernel(const float* __restrict__ semi, int W, int H, float thres, int* __restrict__ cand, uint64_t* __restrict__ masks,
-               int* __restrict__ counters, int tiles_per_img, int n_tiles) {
+               int* __restrict__ counters) {
     __shared__ float tile[CT_H + 8][CT_W + 8 + 1];
     __shared__ int s_wave_cnt[4];
     __shared__ int s_base;
     __shared__ unsigned short s_list[CT_W * CT_H];
+    const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (W + CT_W - 1) / CT_W;
+    const int ty0 = (blockIdx.x / tiles_x) * CT_H, tx0 = (blockIdx.x % tiles_x) * CT_W;
     const int hw = W * H;
-  // persistent workgroups walk the (image, tile) list: 19 200 one-tile workgroups per 64 images were bound by the dispatch rate, not by the work
-  for (int tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
-    const int b = tix / tiles_per_img, tin = tix - b * tiles_per_img;
-    const int ty0 = (tin / tiles_x) * CT_H, tx0 = (tin % tiles_x) * CT_W;
     const float* sm = semi + (int64_t)b * hw;
-    __syncthreads();                                                   // the previous tile's readers are done with the shared arrays
     for (int i = tid; i < (CT_H + 8) * (CT_W + 8); i += 256) {
         const int iy = i / (CT_W + 8), ix = i - iy * (CT_W + 8);
         const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
@@ -73,7 +70,7 @@ sp_cand_kernel(const float* __restrict__ semi, int W, int H, float thres, int* _
     if (lane == 63) s_wave_cnt[wave] = incl;
     __syncthreads();
     const int total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
-    if (total == 0) continue;
+    if (total == 0) return;
     if (tid == 0) s_base = atomicAdd(&counters[b * 4 + 0], total);     // ONE global atomic per workgroup
     {
         int pos = incl - mine;
@@ -102,7 +99,6 @@ sp_cand_kernel(const float* __restrict__ semi, int W, int H, float thres, int* _
             mo[2 * (int64_t)pos + 1] = m1;
         }
     }
-  }
 }
 
 __device__ __forceinline__ unsigned st_get(const unsigned* st, int p) { return (st[p >> 4] >> ((p & 15) * 2)) & 3u; }
@@ -437,12 +433,8 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
     OMNI_REQUIRE(p.max_num >= 1 && p.max_num <= 1024, OMNI_ERR_CAPACITY, "max_num=%d outside [1,1024]", p.max_num);
     OMNI_REQUIRE(p.dist_thresh == 4, OMNI_ERR_INVALID, "NMS radius %d: the window masks are built for 4 (superpoint_tensorrt.cpp:183)", p.dist_thresh);
     OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
-    {
-        const int tiles_per_img = cdiv(p.width, CT_W) * cdiv(p.height, CT_H), n_tiles = tiles_per_img * batch;
-        const int grid = n_tiles < 2048 ? n_tiles : 2048;                    // 8 workgroups of 9 KB LDS per CU
-        hipLaunchKernelGGL(sp_cand_kernel, dim3(grid), dim3(256), 0, stream, semi, p.width, p.height, p.thres, b.cand, b.cand_masks, b.counters,
-                           tiles_per_img, n_tiles);
-    }
+    hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(p.width, CT_W) * cdiv(p.height, CT_H), batch), dim3(256), 0, stream, semi, p.width, p.height,
+                       p.thres, b.cand, b.cand_masks, b.counters);
     OMNI_LAUNCH_CHECK();
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(sp_nms_kernel, dim3(batch), dim3(NMS_THREADS), smem, stream, semi, p.width, p.height, p.max_num, b.cand,
