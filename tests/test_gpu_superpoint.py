@@ -137,7 +137,7 @@ def test_f16_sparse_descriptors_are_bit_identical_to_the_dense_map_path(omni, ct
     weights = S.synth_weights(0)
     comp, mean = synth.pca()
     for (h, w, nb, thr, maxn, pca) in ((480, 600, 3, 0.015, 200, True), (96, 128, 2, 0.015, 37, False), (104, 136, 1, 0.2, 200, True),
-                                       (64, 96, 2, 0.001, 1000, True)):
+                                       (64, 96, 2, 0.001, 1000, True), (64, 96, 2, 0.999, 50, True)):      # the last one: no key point at all
         imgs = np.stack([synth.image_u8(310 + i, h, w, n_shapes=60) for i in range(nb)])
         res = {}
         for flag, (desc_flag, da_flag) in {"sparse": ("1", "1"), "sparse_db_only": ("1", "0"), "dense": ("0", "0")}.items():
@@ -152,7 +152,7 @@ def test_f16_sparse_descriptors_are_bit_identical_to_the_dense_map_path(omni, ct
         for flag in ("sparse", "sparse_db_only"):
             for b in range(nb):
                 (k1, d1, s1), (k0, d0, s0) = res[flag][0][b], res["dense"][0][b]
-                assert len(k1) > 0 and np.array_equal(k1, k0) and np.array_equal(s1, s0)
+                assert (len(k1) > 0 or thr > 0.9) and np.array_equal(k1, k0) and np.array_equal(s1, s0)
                 assert np.array_equal(d1, d0), (flag, h, w, b, np.abs(d1 - d0).max())
             assert np.array_equal(res[flag][1][0], res["dense"][1][0]) and np.array_equal(res[flag][1][1], res["dense"][1][1])
             assert np.array_equal(res[flag][2][0][1], res[flag][0][nb - 1][1])          # batch 1 == batch n, sparse paths
