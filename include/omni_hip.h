@@ -121,7 +121,9 @@ int omni_sp_fetch(omni_sp* sp, int batch, float* kps_xy, int* n_kps, float* desc
 int omni_sp_dev_outputs(omni_sp* sp, const float** kps_xy_dev, const int** n_kps_dev, const float** desc_dev,
                         const float** scores_dev);
 /* the engine's raw outputs in the reference's binding layout (tensorrt_generic.cpp:62-73):
- * semi [batch][H][W] f32 and desc [batch][256][H/8][W/8] f32 (NCHW).  For parity tests. */
+ * semi [batch][H][W] f32 and desc [batch][256][H/8][W/8] f32 (NCHW).  For parity tests.  On the OMNI_PREC_F16 path a forward pass only
+ * evaluates the descriptor head at the coarse cells around its key points (the key-point descriptors are bit-identical to sampling the
+ * dense map); the dense `desc` is computed here, on demand, from the activations of the LAST forward pass (batch <= that pass's batch). */
 int omni_sp_get_dense(omni_sp* sp, int batch, float* semi_host, float* desc_host);
 /* run only the post-processing (getKeyPoints + NMS2 + computeDescriptors, superpoint_tensorrt.cpp:164-310) on
  * caller-supplied engine outputs in the layout above -- isolates the detector from conv rounding in tests */
