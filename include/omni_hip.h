@@ -164,6 +164,13 @@ void       omni_vlad_destroy(omni_vlad* v);
 /* OMNI_PREC_F32 (default): exact-f32 kernels, the parity mode.  OMNI_PREC_F16: the inverted-residual blocks run with fp16 matrix-core
  * operands and fp32 accumulation / residual stream -- the reference's engine is an fp16 TensorRT plan (launch/realsense.launch:10-11) */
 int        omni_vlad_set_precision(omni_vlad* v, int precision);
+/* test hook (host only, no device needed): the weight blob of one inverted-residual block as the split-fp16 matrix-core kernel reads it
+ * (expand [hid][cin] + bias, depthwise [hid][9] + bias, projection [cout][hid], the layer table's OIHW order).  Returns the blob size in
+ * bytes (out == NULL: size query), -1 when no kernel instantiation covers the shape, -2 on bad arguments.  Layout (vlad_s.hip): per 48-channel
+ * chunk [10][48] fp32 depthwise taps + bias for all chunks, then per chunk the expand A fragments ([x_hi | x_lo | 1 1] pass with
+ * We_hi, We_hi, be_hi, be_lo; x_hi pass with We_lo) and the projection A fragments (hi, lo per k-step), each fragment [64 lanes][8 halfs]. */
+int64_t    omni_vlad_pack_block(int cin, int hid, int cout, int stride, const float* we, const float* be, const float* wd, const float* bd,
+                                const float* wp, void* out, int64_t out_bytes);
 /* std::vector<float> MobileNetVLADTensorRT::inference(const cv::Mat&) (mobilenetvlad_tensorrt.cpp:4-14):
  * u8 -> f32 with NO scaling feeds the net; out [batch][out_dim] */
 int omni_vlad_infer(omni_vlad* v, const uint8_t* gray_host, int stride, int batch, int fisheye_mask, float* out);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
-    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision",
+    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block",
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset", "omni_index_truncate",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
@@ -120,6 +120,7 @@ def lib():
     sig("omni_vlad_create", _vp, [_vp, C.POINTER(_VladWeights), C.c_int, C.c_int, C.c_int])
     sig("omni_vlad_destroy", None, [_vp])
     sig("omni_vlad_set_precision", C.c_int, [_vp, C.c_int])
+    sig("omni_vlad_pack_block", C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _vp, C.c_int64])
     sig("omni_vlad_infer", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _fp])
     sig("omni_vlad_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int])
     sig("omni_vlad_fetch", C.c_int, [_vp, C.c_int, _fp])
@@ -423,6 +424,19 @@ class MobileNetVLAD:
         p = _vp()
         _check(lib().omni_vlad_dev_output(self.h, C.byref(p)))
         return p.value
+
+
+def vlad_pack_block(cin, hid, cout, stride, we, be, wd, bd, wp):
+    """Host-only test hook: the split-fp16 weight blob of one inverted-residual block (bytes), or None when no kernel covers the shape."""
+    we, be, wd, bd, wp = (_f32(x) for x in (we, be, wd, bd, wp))
+    need = lib().omni_vlad_pack_block(cin, hid, cout, stride, None, None, None, None, None, None, 0)
+    if need < 0:
+        return None
+    out = np.zeros(need, np.uint8)
+    got = lib().omni_vlad_pack_block(cin, hid, cout, stride, _pf(we), _pf(be), _pf(wd), _pf(bd), _pf(wp), out.ctypes.data_as(_vp), need)
+    if got != need:
+        raise OmniError(f"omni_vlad_pack_block failed: {lib().omni_last_error().decode()}")
+    return out
 
 
 class IndexFlatIP:

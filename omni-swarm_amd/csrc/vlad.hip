@@ -1467,6 +1467,16 @@ void omni_vlad_destroy(omni_vlad* v) {
     delete v;
 }
 
+int64_t omni_vlad_pack_block(int cin, int hid, int cout, int stride, const float* we, const float* be, const float* wd, const float* bd,
+                             const float* wp, void* out, int64_t out_bytes) {
+    if (!omni::vlad_sblock_supported(cin, hid, cout, stride)) return -1;
+    const int64_t need = (int64_t)omni::vlad_sblock_blob_bytes(cin, hid, cout);
+    if (!out) return need;
+    if (!we || !be || !wd || !bd || !wp || out_bytes < need) { omni::set_error("omni_vlad_pack_block: null weights or %lld < %lld bytes", (long long)out_bytes, (long long)need); return -2; }
+    omni::vlad_sblock_pack(cin, hid, cout, we, be, wd, bd, wp, out);
+    return need;
+}
+
 int omni_vlad_set_precision(omni_vlad* v, int precision) {
     OMNI_REQUIRE(v, OMNI_ERR_INVALID, "null handle");
     OMNI_REQUIRE(precision == OMNI_PREC_F32 || precision == OMNI_PREC_F16, OMNI_ERR_INVALID, "precision %d", precision);

@@ -60,3 +60,47 @@ def test_topk_merge_host(omni):
     # short shards: padding entries are ignored
     D2, I2 = omni.capi.topk_merge(np.full((2, 1, 3), -3.4e38, np.float32), np.full((2, 1, 3), -1, np.int64), 3)
     assert (I2 == -1).all()
+
+
+def test_vlad_split_fp16_weight_blob_layout_and_exactness(omni):
+    """omni_vlad_pack_block (host only): the blob vlad_sblock_kernel reads.  Decoded here with the documented layout: every weight of the two
+    pointwise convolutions comes back as hi + lo within 2^-21 relative, the expand bias sits in the two constant K slots, padded rows / K slots
+    are zero, the depthwise taps and bias are the fp32 values themselves; unsupported shapes report -1."""
+    c = omni.capi
+    rng = np.random.default_rng(5)
+    assert c.vlad_pack_block(8, 50, 8, 1, *(np.zeros(1, np.float32),) * 5) is None            # hidden width not a multiple of 48
+    for cin, hid, cout, stride in ((8, 48, 8, 2), (24, 144, 32, 1), (56, 336, 112, 1)):
+        we, be = rng.standard_normal((hid, cin)).astype(np.float32), rng.standard_normal(hid).astype(np.float32)
+        wd, bd = rng.standard_normal((hid, 9)).astype(np.float32), rng.standard_normal(hid).astype(np.float32)
+        wp = rng.standard_normal((cout, hid)).astype(np.float32)
+        blob = c.vlad_pack_block(cin, hid, cout, stride, we, be, wd, bd, wp)
+        n_chunks, S1, S2, NT = hid // 48, (2 * cin + 2 + 15) // 16, (cin + 15) // 16, {1: 1, 2: 2, 3: 4, 4: 4}[(cout + 31) // 32]
+        CB = (S1 + S2) * 2048 + NT * 6144
+        assert blob.size == n_chunks * (480 * 4 + CB)
+        taps = blob[:n_chunks * 1920].view(np.float32).reshape(n_chunks, 10, 48)
+        assert np.array_equal(taps[:, :9].transpose(0, 2, 1).reshape(hid, 9), wd) and np.array_equal(taps[:, 9].reshape(hid), bd)
+        frag = blob[n_chunks * 1920:].reshape(n_chunks, CB)
+
+        def a_frag(ch, off):                      # [64 lanes][8] halfs -> [32 rows][16 k]: row = lane & 31, k = 8 (lane >> 5) + e
+            f = frag[ch, off:off + 1024].view(np.float16).astype(np.float64).reshape(2, 32, 8)
+            return np.concatenate([f[0], f[1]], axis=1)
+
+        for ch in range(n_chunks):
+            K1 = np.concatenate([np.concatenate([a_frag(ch, (ks * 2 + m) * 1024) for m in range(2)], axis=0) for ks in range(S1)], axis=1)      # [64][S1*16]
+            K2 = np.concatenate([np.concatenate([a_frag(ch, ((S1 + ks) * 2 + m) * 1024) for m in range(2)], axis=0) for ks in range(S2)], axis=1)
+            W = we[ch * 48:(ch + 1) * 48].astype(np.float64)
+            assert np.array_equal(K1[:48, :cin], K1[:48, cin:2 * cin])                                    # We_hi twice (x_hi and x_lo slots)
+            rec = K1[:48, :cin] + K2[:48, :cin]
+            assert np.abs(rec - W).max() <= 2.0 ** -21 * np.abs(W).max()
+            b = be[ch * 48:(ch + 1) * 48].astype(np.float64)
+            assert np.abs(K1[:48, 2 * cin] + K1[:48, 2 * cin + 1] - b).max() <= 2.0 ** -21 * np.abs(b).max()
+            assert not K1[48:].any() and not K2[48:].any() and not K1[:, 2 * cin + 2:].any() and not K2[:, cin:].any()
+            base = (S1 + S2) * 2048
+            for m in range(NT):
+                hi = np.concatenate([a_frag(ch, base + ((m * 3 + ks) * 2 + 0) * 1024) for ks in range(3)], axis=1)          # [32 cout][48 hidden]
+                lo = np.concatenate([a_frag(ch, base + ((m * 3 + ks) * 2 + 1) * 1024) for ks in range(3)], axis=1)
+                rows = min(32, max(0, cout - 32 * m))
+                ref = wp[32 * m:32 * m + rows, ch * 48:(ch + 1) * 48].astype(np.float64)
+                if rows:
+                    assert np.abs(hi[:rows] + lo[:rows] - ref).max() <= 2.0 ** -21 * np.abs(ref).max()
+                assert not hi[rows:].any() and not lo[rows:].any()
