@@ -243,6 +243,10 @@ int         omni_shard_search(omni_shard* s, int nq, const float* q_host, int k,
  * out arrays sized >= nq; matches ordered by query index; *n_matches = count.  dim <= 256. */
 int omni_bf_match(omni_ctx* ctx, const float* q_host, int nq, const float* t_host, int nt, int dim, int mode,
                   int* q_idx, int* t_idx, float* dist, int* n_matches);
+/* several pairs from host pointers in ONE upload / launch pair / download (the geometric verification matches up to four direction pairs per
+ * loop candidate, loop_detector.cpp:431-537): outputs [n_pairs][max_n], n_matches [n_pairs]; nq[p], nt[p] <= max_n; n_pairs <= 64. */
+int omni_bf_match_multi(omni_ctx* ctx, int n_pairs, const float* const* q_host, const int* nq, const float* const* t_host, const int* nt, int dim,
+                        int mode, int max_n, int* q_idx, int* t_idx, float* dist, int* n_matches);
 /* batched, HBM-resident: pair p uses q = q_dev + p*q_stride (floats), nq = nq_dev[p], likewise t.
  * outputs (device): q_idx/t_idx/dist [n_pairs][max_n], n_matches [n_pairs]. */
 int omni_bf_match_batched_dev(omni_ctx* ctx, int n_pairs, int max_n, int dim, int mode,

@@ -34,7 +34,7 @@ SYMBOLS = [
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_reset", "omni_index_truncate",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
-    "omni_bf_match", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
+    "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
     "omni_shard_unique_id", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev",
     "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
@@ -142,6 +142,7 @@ def lib():
     sig("omni_index_save", C.c_int, [_vp, C.c_char_p])
     sig("omni_index_load", C.c_int, [_vp, C.c_char_p])
     sig("omni_bf_match", C.c_int, [_vp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _ip, _ip, _fp, _ip])
+    sig("omni_bf_match_multi", C.c_int, [_vp, C.c_int, C.POINTER(_fp), _ip, C.POINTER(_fp), _ip, C.c_int, C.c_int, C.c_int, _ip, _ip, _fp, _ip])
     sig("omni_bf_match_batched_dev", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, C.c_int64,
                                                _vp, _vp, _vp, _vp, _vp])
     sig("omni_cam_create", _vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
@@ -671,6 +672,22 @@ def bf_match(ctx: Context, q: np.ndarray, t: np.ndarray, mode: int = BF_OPENCV):
     _check(lib().omni_bf_match(ctx.h, _pf(q), nq, _pf(t), nt, dim, mode, qi.ctypes.data_as(_ip), ti.ctypes.data_as(_ip),
                                _pf(dd), C.byref(n)))
     return qi[:n.value].copy(), ti[:n.value].copy(), dd[:n.value].copy()
+
+
+def bf_match_multi(ctx: Context, pairs, mode: int = BF_OPENCV):
+    """[(q, t), ...] -> [(query_idx, train_idx, distance), ...]: bf_match of every pair in one GPU round trip."""
+    P = len(pairs)
+    qs, ts = [_f32(q) for q, _ in pairs], [_f32(t) for _, t in pairs]
+    dim = next((a.shape[1] for a in qs + ts if a.ndim == 2 and a.shape[0]), 64)
+    nq = np.array([q.shape[0] for q in qs], np.int32)
+    nt = np.array([t.shape[0] for t in ts], np.int32)
+    max_n = int(max(1, nq.max(), nt.max()))
+    qp = (_fp * P)(*[_pf(q) if q.shape[0] else None for q in qs])
+    tp = (_fp * P)(*[_pf(t) if t.shape[0] else None for t in ts])
+    qi, ti, dd, n = np.zeros((P, max_n), np.int32), np.zeros((P, max_n), np.int32), np.zeros((P, max_n), np.float32), np.zeros(P, np.int32)
+    _check(lib().omni_bf_match_multi(ctx.h, P, qp, nq.ctypes.data_as(_ip), tp, nt.ctypes.data_as(_ip), dim, mode, max_n, qi.ctypes.data_as(_ip),
+                                     ti.ctypes.data_as(_ip), _pf(dd), n.ctypes.data_as(_ip)))
+    return [(qi[p, :n[p]].copy(), ti[p, :n[p]].copy(), dd[p, :n[p]].copy()) for p in range(P)]
 
 
 def bf_match_batched_dev(ctx: Context, n_pairs, max_n, dim, mode, q_dev, q_stride, nq_dev, t_dev, t_stride, nt_dev,

@@ -249,4 +249,48 @@ int omni_bf_match(omni_ctx* ctx, const float* q_host, int nq, const float* t_hos
     return OMNI_OK;
 }
 
+int omni_bf_match_multi(omni_ctx* ctx, int n_pairs, const float* const* q_host, const int* nq, const float* const* t_host, const int* nt, int dim,
+                        int mode, int max_n, int* q_idx, int* t_idx, float* dist, int* n_matches) {
+    OMNI_REQUIRE(ctx && q_host && t_host && nq && nt && q_idx && t_idx && dist && n_matches, OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(n_pairs >= 1 && n_pairs <= 64, OMNI_ERR_CAPACITY, "n_pairs=%d outside [1,64]", n_pairs);
+    OMNI_REQUIRE(max_n >= 1 && max_n <= BF_MAX_N && dim >= 4 && dim <= BF_MAX_DIM, OMNI_ERR_CAPACITY, "max_n=%d dim=%d", max_n, dim);
+    for (int p = 0; p < n_pairs; ++p) {
+        OMNI_REQUIRE(nq[p] >= 0 && nt[p] >= 0 && nq[p] <= max_n && nt[p] <= max_n, OMNI_ERR_CAPACITY, "pair %d: nq=%d nt=%d outside [0,%d]", p, nq[p], nt[p], max_n);
+        OMNI_REQUIRE((nq[p] == 0 || q_host[p]) && (nt[p] == 0 || t_host[p]), OMNI_ERR_INVALID, "pair %d: null descriptors", p);
+        n_matches[p] = 0;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    // device scratch layout: q [P][max_n][dim] | t [P][max_n][dim] | nq [P] nt [P] | oq | ot | od [P][max_n] | on [P]
+    const size_t slab = (size_t)max_n * dim * 4, fq = (((size_t)n_pairs * slab) + 255) & ~(size_t)255;
+    const size_t off_t = fq, off_n = off_t + fq, off_oq = off_n + 512;
+    const size_t fo = (((size_t)n_pairs * max_n * 4) + 255) & ~(size_t)255;
+    const size_t off_ot = off_oq + fo, off_od = off_ot + fo, off_on = off_od + fo, total = off_on + 256;
+    int rc;
+    if ((rc = ctx->scratch.ensure(total))) return rc;
+    if ((rc = ctx->hstage.ensure(total))) return rc;
+    char* d = ctx->scratch.as<char>();
+    char* h = ctx->hstage.as<char>();
+    for (int p = 0; p < n_pairs; ++p) {
+        if (nq[p]) memcpy(h + (size_t)p * slab, q_host[p], (size_t)nq[p] * dim * 4);
+        if (nt[p]) memcpy(h + off_t + (size_t)p * slab, t_host[p], (size_t)nt[p] * dim * 4);
+        ((int*)(h + off_n))[p] = nq[p];
+        ((int*)(h + off_n))[64 + p] = nt[p];
+    }
+    OMNI_HIP_TRY(hipMemcpyAsync(d, h, off_n + 512, hipMemcpyHostToDevice, ctx->stream));
+    rc = omni::bf_launch(ctx, n_pairs, max_n, dim, mode, (const float*)d, (int64_t)max_n * dim, (const int*)(d + off_n), (const float*)(d + off_t),
+                         (int64_t)max_n * dim, (const int*)(d + off_n) + 64, (int*)(d + off_oq), (int*)(d + off_ot), (float*)(d + off_od), (int*)(d + off_on));
+    if (rc) return rc;
+    OMNI_HIP_TRY(hipMemcpyAsync(h + off_oq, d + off_oq, total - off_oq, hipMemcpyDeviceToHost, ctx->stream));
+    OMNI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < n_pairs; ++p) {
+        const int n = (nq[p] && nt[p]) ? ((int*)(h + off_on))[p] : 0;     // BFMatcher on an empty set returns no matches
+        memcpy(q_idx + (size_t)p * max_n, h + off_oq + (size_t)p * max_n * 4, (size_t)n * 4);
+        memcpy(t_idx + (size_t)p * max_n, h + off_ot + (size_t)p * max_n * 4, (size_t)n * 4);
+        memcpy(dist + (size_t)p * max_n, h + off_od + (size_t)p * max_n * 4, (size_t)n * 4);
+        n_matches[p] = n;
+    }
+    return OMNI_OK;
+}
+
 }  // extern "C"

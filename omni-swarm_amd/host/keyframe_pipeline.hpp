@@ -36,9 +36,37 @@ public:
         for (int p = 0; p < c.pipelines; ++p) lanes_.push_back(std::make_unique<Lane>(c, c.microbatch));
         if (c.geometry) {
             geo_.self_id = c.self_id; geo_.MIN_LOOP_NUM = c.min_loop_num; geo_.MIN_DIRECTION_LOOP = c.min_direction_loop;
-            geo_.match = [this](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) { bf_.match(q, nq, t, nt, dim, out); };
+            // compute_correspond_features matches up to four direction pairs per candidate (loop_detector.cpp:431-537): all of them in ONE GPU
+            // round trip, issued before the geometry runs; its per-pair match() calls are then served from that result (same matches: the
+            // matcher is a pure function of its two descriptor sets), anything else falls through to the single-pair call
+            geo_.match = [this](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) {
+                for (size_t p = 0; p < pre_pairs_.size(); ++p)
+                    if (pre_pairs_[p].query == q && pre_pairs_[p].train == t && pre_pairs_[p].nq == nq && pre_pairs_[p].nt == nt && pre_dim_ == dim) { out = pre_out_[p]; return; }
+                bf_.match(q, nq, t, nt, dim, out);
+            };
             auto inner = geo_.as_callback([this](const LoopEdge& e) { edges_.push_back(e); });
-            det_.compute_loop = [this, inner](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) { ++geometry_calls_; return inner(a, b, da, db, im); };
+            det_.compute_loop = [this, inner](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) {
+                ++geometry_calls_;
+                pre_pairs_.clear(); pre_out_.clear(); pre_dim_ = 0;
+                const int nd = geo_.MAX_DIRS;
+                for (int d = da; d < da + nd; ++d) {                   // the pairing rule of compute_correspond_features (frame pair)
+                    const int dn = d % nd, dold = ((db - da + nd) % nd + d) % nd;
+                    if (dn < (int)a.images.size() && dold < (int)b.images.size() && b.images[dold].landmark_num > 0 && a.images[dn].landmark_num > 0) {
+                        const ImageDescriptor &x = a.images[dn], &y = b.images[dold];
+                        const int nx = (int)x.landmarks_2d.size(), ny = (int)y.landmarks_2d.size();
+                        if (nx > 0 && ny > 0 && x.feature_descriptor.size() % nx == 0) {
+                            const int dim = (int)(x.feature_descriptor.size() / nx);
+                            if (pre_dim_ == 0) pre_dim_ = dim;
+                            if (dim == pre_dim_ && (int)y.feature_descriptor.size() == ny * dim)
+                                pre_pairs_.push_back({x.feature_descriptor.data(), nx, y.feature_descriptor.data(), ny});
+                        }
+                    }
+                }
+                if (pre_pairs_.size() > 1) bf_.match_multi(pre_pairs_, pre_dim_, pre_out_); else pre_pairs_.clear();
+                const bool ok = inner(a, b, da, db, im);
+                pre_pairs_.clear(); pre_out_.clear();
+                return ok;
+            };
         }
     }
     int geometry_calls() const { return geometry_calls_; }
@@ -196,6 +224,9 @@ private:
     LoopDetectorCore det_;
     BFMatcherL2X bf_{index_ctx_};
     LoopGeometry geo_;
+    std::vector<BFMatcherL2X::Pair> pre_pairs_;            // descriptor pairs of the candidate being verified, matched ahead in one call
+    std::vector<std::vector<DMatch>> pre_out_;
+    int pre_dim_ = 0;
     std::vector<LoopEdge> edges_;
     int geometry_calls_ = 0;
     std::vector<std::unique_ptr<Lane>> lanes_;

@@ -334,6 +334,25 @@ public:
         check(omni_bf_match(ctx_.get(), query, nq, train, nt, dim, mode_, qi.data(), ti.data(), dd.data(), &n), "BFMatcherL2X::match");
         for (int i = 0; i < n; ++i) matches.push_back({qi[i], ti[i], dd[i]});
     }
+    // several (query, train) pairs in one GPU round trip; out[p] as match() would return it
+    struct Pair { const float* query; int nq; const float* train; int nt; };
+    void match_multi(const std::vector<Pair>& pairs, int dim, std::vector<std::vector<DMatch>>& out) {
+        out.assign(pairs.size(), {});
+        if (pairs.empty()) return;
+        int max_n = 1;
+        std::vector<const float*> q(pairs.size()), t(pairs.size());
+        std::vector<int> nq(pairs.size()), nt(pairs.size()), n(pairs.size());
+        for (size_t p = 0; p < pairs.size(); ++p) {
+            q[p] = pairs[p].query; t[p] = pairs[p].train; nq[p] = pairs[p].nq; nt[p] = pairs[p].nt;
+            max_n = std::max(max_n, std::max(nq[p], nt[p]));
+        }
+        std::vector<int> qi(pairs.size() * max_n), ti(pairs.size() * max_n);
+        std::vector<float> dd(pairs.size() * max_n);
+        check(omni_bf_match_multi(ctx_.get(), (int)pairs.size(), q.data(), nq.data(), t.data(), nt.data(), dim, mode_, max_n, qi.data(), ti.data(), dd.data(),
+                                  n.data()), "BFMatcherL2X::match_multi");
+        for (size_t p = 0; p < pairs.size(); ++p)
+            for (int i = 0; i < n[p]; ++i) out[p].push_back({qi[p * max_n + i], ti[p * max_n + i], dd[p * max_n + i]});
+    }
 #ifdef OMNI_WITH_OPENCV
     void match(const cv::Mat& query, const cv::Mat& train, std::vector<cv::DMatch>& matches) {
         std::vector<DMatch> m;

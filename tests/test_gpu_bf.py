@@ -58,3 +58,24 @@ def test_ties_first_minimum_wins_and_empty(omni, ctx):
     dup2 = np.concatenate([dup, dup[:10]])              # exact duplicates in the train set
     for mode in (0, 1):
         _same(omni, ctx, dup, dup2, mode)
+
+
+def test_multi_pair_call_equals_single_pair_calls(omni, ctx):
+    """omni_bf_match_multi (one upload / launch pair / download for several descriptor pairs: the geometric verification's four direction
+    pairs) == omni_bf_match pair by pair, ragged sizes and empty sets included."""
+    rng = np.random.default_rng(11)
+    sizes = [(200, 200), (37, 190), (200, 1), (0, 50), (120, 0), (64, 64)]
+    pairs = []
+    for nq, nt in sizes:
+        q = rng.standard_normal((nq, 64)).astype(np.float32)
+        t = rng.standard_normal((nt, 64)).astype(np.float32)
+        if nq and nt:
+            t[: min(nq, nt) // 2] = q[: min(nq, nt) // 2] + 0.01 * rng.standard_normal((min(nq, nt) // 2, 64)).astype(np.float32)
+        pairs.append((q, t))
+    for mode in (omni.capi.BF_OPENCV, omni.capi.BF_MUTUAL):
+        multi = omni.capi.bf_match_multi(ctx, pairs, mode)
+        for (q, t), got in zip(pairs, multi):
+            ref = omni.capi.bf_match(ctx, q, t, mode)
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    one = omni.capi.bf_match_multi(ctx, pairs[:1])
+    assert all(np.array_equal(a, b) for a, b in zip(one[0], omni.capi.bf_match(ctx, *pairs[0])))
