@@ -49,8 +49,11 @@ enum {
 };
 
 enum { OMNI_PREC_F32 = 0,   /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations: the parity mode */
-       OMNI_PREC_F16 = 1 }; /* fp16 storage + v_mfma_f32_32x32x16_f16, fp32 accumulate: the reference's engines
+       OMNI_PREC_F16 = 1,   /* fp16 storage + v_mfma_f32_32x32x16_f16, fp32 accumulate: the reference's engines
                                are fp16 TensorRT (launch/realsense.launch:10-11) */
+       OMNI_PREC_SPLIT = 2 }; /* omni_sp only: fp32-class on the fp16 matrix cores -- every operand of the 3x3 convolutions is a
+                               (hi, lo) pair of halfs, three MFMA terms per product, heads in exact f32: meets north_star's
+                               tolerance (key points identical to the fp32 graph, descriptors <= 1e-3) at ~1/3 of the fp16 rate */
 
 enum { OMNI_STORE_F32 = 0, OMNI_STORE_F16 = 1 };   /* global-descriptor DB storage */
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMNI_LIB") or os.path.join(_HERE, "lib", "libomni_hip.so")   # OMNI_LIB: A/B a second build of the same ABI
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = 0, 1, 2, 3, 4
-PREC_F32, PREC_F16 = 0, 1
+PREC_F32, PREC_F16, PREC_SPLIT = 0, 1, 2
 STORE_F32, STORE_F16 = 0, 1
 BF_OPENCV, BF_MUTUAL = 0, 1
 SP_NUM_LAYERS = 12

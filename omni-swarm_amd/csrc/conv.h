@@ -37,10 +37,22 @@ struct ConvArgs {
     bool out_f32;          // write fp32 regardless of the compute precision (final 1x1 descriptor conv)
     int n_cu = 0;          // CUs on the device (> 0 enables the persistent cin=64 fp16 kernel)
     const void* zero_page = nullptr;   // omni_ctx::zero_page (the persistent LDS-DMA kernels need it; null = generic kernels only)
+    float split_inv = 0.f; // OMNI_PREC_SPLIT: 2^-k of conv_pack_weights_split (the epilogue's factor)
     int variant = 0;       // test hook (OMNI_CONV_V1): 0 = best kernel per layer, 1 = generic kernel everywhere, 2 = v2 persistent kernel,
                            // 3 = v3 ping-pong kernel without the conv1a fusion
 };
 int conv_mfma(hipStream_t stream, int precision, const ConvArgs& a);
+
+// OMNI_PREC_SPLIT (conv_split.hip): 3x3 conv, cin 64 / 128, on the fp16 matrix cores with every operand split into hi + lo halfs (fp32-class).
+// Activations are "split-64" NHWC: per pixel and block of 64 channels [hi x 64 | lo x 64] halfs, values x conv_split_act_scale().
+// a.w_packed / a.split_inv from conv_pack_weights_split (cin * cout * 9 * 2 halfs); a.bias = out_f32 ? bias : act_scale * bias;
+// a.out = out_f32 ? NHWC fp32 (true values) : split-64.
+float conv_pack_weights_split(const float* w_oihw, int cin, int cout, uint16_t* out);
+float conv_split_act_scale();
+int conv_split(hipStream_t stream, const ConvArgs& a);
+int conv1a_split(hipStream_t stream, const uint8_t* gray, int stride, int batch, int H, int W, int fisheye_mask, const float* w, const float* bias,
+                 const float* u8_lut, void* out_split);
+int split_to_nchw_f32(hipStream_t stream, const void* in_split, float* out, int batch, int C, int HW);   // test hook
 
 // conv1a + conv1b + ReLU + 2x2 max-pool fused (fp16 path): conv1a runs on the matrix cores inside conv1b's ping-pong kernel
 // with split fp16 operands (conv.hip); a = the conv1b layer (a.in unused).  Host-side packers for its constant inputs.

@@ -32,6 +32,8 @@ struct omni_sp {
     // weights
     void* wpk[OMNI_SP_NUM_LAYERS] = {};     // packed MFMA weights (L1B..L4B, LDB) ; heads_a fused in wpk[LPA]
     float* bias[OMNI_SP_NUM_LAYERS] = {};
+    float* bias_s[OMNI_SP_NUM_LAYERS] = {};  // OMNI_PREC_SPLIT: conv_split_act_scale() * bias (the split layers write scaled activations)
+    float winv[OMNI_SP_NUM_LAYERS] = {};     // OMNI_PREC_SPLIT: 2^-k of the layer's weight scaling
     float* w1a = nullptr;                    // [64][9]
     float* wPbT = nullptr;                   // [256][65]
     float *wPbA = nullptr, *wPbDust = nullptr; // convPb in MFMA A-fragment order + the dustbin row
@@ -128,6 +130,11 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     // packed MFMA weights
     auto pack_upload = [&](int l, const float* w_oihw, int cin, int cout, int ks) -> int {
         const size_t n = conv_packed_elems(cin, cout, ks);
+        if (s->precision == OMNI_PREC_SPLIT && ks == 3) {
+            std::vector<uint16_t> p(n * 2);
+            s->winv[l] = conv_pack_weights_split(w_oihw, cin, cout, p.data());
+            return dev_upload(&s->wpk[l], p.data(), n * 4, st);
+        }
         if (s->precision == OMNI_PREC_F16) {
             std::vector<__half> p(n);
             conv_pack_weights_f16(w_oihw, cin, cout, ks, p.data());
@@ -145,6 +152,14 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         memcpy(wh.data(), w->weight[LPA], per * 4);
         memcpy(wh.data() + per, w->weight[LDA], per * 4);
         if ((rc = pack_upload(LPA, wh.data(), 128, 512, 3))) return rc;
+    }
+    if (s->precision == OMNI_PREC_SPLIT) {
+        const float S = conv_split_act_scale();
+        for (int l : {L1B, L2A, L2B, L3A, L3B, L4A, L4B}) {
+            std::vector<float> b(kLayers[l].cout);
+            for (int c = 0; c < kLayers[l].cout; ++c) b[c] = S * w->bias[l][c];
+            if ((rc = dev_upload((void**)&s->bias_s[l], b.data(), b.size() * 4, st))) return rc;
+        }
     }
     if (pca_comp) {
         std::vector<float> t((size_t)256 * s->pca_dim);
@@ -216,11 +231,18 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         a.in = in; a.out = out; a.w_packed = s->wpk[l]; a.bias = bias; a.batch = batch; a.H = h; a.W = w; a.cin = cin;
         a.cout = cout; a.ksize = ks; a.relu = relu; a.pool = pool; a.out_f32 = out_f32;
         a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page; a.variant = s->conv_variant;
+        if (P == OMNI_PREC_SPLIT) {     // split-64 activations in and (unless out_f32) out; the scaled bias goes with scaled outputs
+            a.split_inv = s->winv[l];
+            if (!out_f32) a.bias = s->bias_s[l];
+            return conv_split(st, a);
+        }
         return conv_mfma(st, P, a);
     };
+    const int PH = P == OMNI_PREC_SPLIT ? OMNI_PREC_F32 : P;      // the heads' tails: OMNI_PREC_SPLIT hands them fp32 activations
     if ((rc = mark())) return rc;
     s->fuse1a = (P == OMNI_PREC_F16 && s->conv_variant == 0 && stride % 4 == 0 && ((uintptr_t)gray_dev & 3) == 0);   // else: separate conv1a
-    if (!s->fuse1a) { if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
+    if (P == OMNI_PREC_SPLIT) { if ((rc = conv1a_split(st, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
+    else if (!s->fuse1a) { if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
     if ((rc = mark())) return rc;
     if (s->fuse1a) {   // conv1a is computed inside conv1b's kernel: the conv1a activation tensor is never materialised
         ConvArgs a;
@@ -247,12 +269,12 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const void* cpa = sparse_da ? s->headsP : s->heads;
     const int cpa_stride = sparse_da ? 256 : 512;
     if (sparse_da) { if ((rc = conv(LPA, s->a4b, s->headsP, s->bias_heads, H / 8, W / 8, 128, 256, 3, true, false, false))) return rc; }
-    else if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, false))) return rc;
+    else if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, P == OMNI_PREC_SPLIT))) return rc;
     if ((rc = mark())) return rc;
-    if (s->conv_variant == 1) { if ((rc = detector_head(st, P, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
+    if (s->conv_variant == 1) { if ((rc = detector_head(st, PH, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
     else if (P == OMNI_PREC_F16 && s->det16) {
         if ((rc = detector_head_mfma16(st, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount))) return rc;
-    } else if ((rc = detector_head_mfma(st, P, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
+    } else if ((rc = detector_head_mfma(st, PH, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
                                         s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
     s->dense_valid = !sparse; s->dense_possible = true; s->last_batch = batch;
@@ -269,7 +291,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         a.in = (const char*)s->heads + (size_t)256 * s->esz; a.out = s->draw; a.w_packed = s->wpk[LDB]; a.bias = s->bias[LDB];
         a.batch = batch; a.H = s->Hc; a.W = s->Wc; a.cin = 256; a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false;
         a.out_f32 = true; a.in_cstride = 512;
-        if ((rc = conv_mfma(st, P, a))) return rc;
+        if ((rc = conv_mfma(st, PH, a))) return rc;
         if ((rc = l2norm_channels(st, s->draw, (int64_t)batch * s->Hc * s->Wc))) return rc;
     }
     if ((rc = mark())) return rc;
@@ -345,7 +367,7 @@ omni_sp* omni_sp_create(omni_ctx* ctx, const omni_sp_weights* w, const float* pc
         omni::set_error("width=%d height=%d must be positive multiples of 8 (the reference asserts the engine size, superpoint_tensorrt.cpp:122)", width, height);
         return nullptr;
     }
-    if (precision != OMNI_PREC_F32 && precision != OMNI_PREC_F16) { omni::set_error("bad precision %d", precision); return nullptr; }
+    if (precision != OMNI_PREC_F32 && precision != OMNI_PREC_F16 && precision != OMNI_PREC_SPLIT) { omni::set_error("bad precision %d", precision); return nullptr; }
     if (max_num < 1 || max_num > 1024 || max_batch < 1 || max_batch > 256) { omni::set_error("max_num=%d (1..1024) / max_batch=%d (1..256) out of range", max_num, max_batch); return nullptr; }
     if (pca_comp && (!pca_mean || pca_dim < 1 || pca_dim > 256)) { omni::set_error("bad PCA arguments"); return nullptr; }
     if ((size_t)width * height / 16 * 4 + 16 > 160 * 1024) { omni::set_error("image %dx%d exceeds the in-LDS NMS plane", width, height); return nullptr; }
@@ -363,7 +385,7 @@ void omni_sp_destroy(omni_sp* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); }
+    for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); if (s->bias_s[l]) (void)hipFree(s->bias_s[l]); }
     void* ptrs[] = {s->wPbA16, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
                     s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
@@ -462,7 +484,7 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
     const int P = s->precision;
     const Ent tab[] = {{"conv1a", s->a1a, 64, 1, P},   {"conv1b", s->a1b, 64, 2, P},   {"conv2a", s->a2a, 64, 2, P},
                        {"conv2b", s->a2b, 64, 4, P},   {"conv3a", s->a3a, 128, 4, P},  {"conv3b", s->a3b, 128, 8, P},
-                       {"conv4a", s->a4a, 128, 8, P},  {"conv4b", s->a4b, 128, 8, P},  {"heads", s->heads, 512, 8, P},
+                       {"conv4a", s->a4a, 128, 8, P},  {"conv4b", s->a4b, 128, 8, P},  {"heads", s->heads, 512, 8, P == OMNI_PREC_SPLIT ? OMNI_PREC_F32 : P},
                        {"desc", s->draw, 256, 8, OMNI_PREC_F32}};
     for (const Ent& e : tab) {
         if (strcmp(e.n, name) != 0) continue;
@@ -484,7 +506,8 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
         const size_t n = (size_t)batch * e.c * h * w;
         int rc;
         if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
-        if ((rc = omni::nhwc_any_to_nchw_f32(s->ctx->stream, e.prec, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc;
+        if (e.prec == OMNI_PREC_SPLIT) { if ((rc = omni::split_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc; }
+        else if ((rc = omni::nhwc_any_to_nchw_f32(s->ctx->stream, e.prec, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc;
         OMNI_HIP_TRY(hipMemcpyAsync(out_nchw_host, s->dense_tmp.p, n * 4, hipMemcpyDeviceToHost, s->ctx->stream));
         OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
         return OMNI_OK;

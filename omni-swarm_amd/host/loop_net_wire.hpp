@@ -109,6 +109,9 @@ inline bool decode(const uint8_t* p, size_t n, LandmarkDescriptor& l) {
 class LoopNetWire {
 public:
     static constexpr int FEATURE_DESC_SIZE = 64;         // loop_defines.h:67
+    static constexpr size_t IMAGE_DESC_SIZE = 4096;      // MobileNetVLAD's output (loop_defines.h)
+    static constexpr int MAX_FEATURES = 4096;            // sanity bound on a header's feature_num (the reference sends <= 200)
+    double orphan_timeout = 10.0;                        // landmarks whose header never arrives are forgotten after this many seconds
     double recv_period = 0.5;                            // loop_net.h:33
     int MIN_DIRECTION_LOOP = 3;
     bool SEND_ALL_FEATURES = false;
@@ -150,9 +153,24 @@ public:
     }
 
     // lcm.subscribe handlers (:9-13): returns false for packets that do not parse
+    // Array lengths come from the network: a landmark must carry exactly FEATURE_DESC_SIZE floats and a header a 4096-float global descriptor
+    // (or none) -- LoopDetector reads that many from image_desc / feature_descriptor without looking at the vector's size -- and the direction
+    // must index the 4 images of a frame.  Packets of any other shape (another version, corruption that kept the framing) are dropped.
     bool on_packet(const char* channel, const uint8_t* data, size_t n, double now) {
-        if (std::strcmp(channel, wire::CH_HEADER) == 0) { wire::ImageDescriptorHeader h; if (!wire::decode(data, n, h)) return false; on_header(h, now); return true; }
-        if (std::strcmp(channel, wire::CH_LANDMARKS) == 0) { wire::LandmarkDescriptor l; if (!wire::decode(data, n, l)) return false; on_landmark(l, now); return true; }
+        if (std::strcmp(channel, wire::CH_HEADER) == 0) {
+            wire::ImageDescriptorHeader h;
+            if (!wire::decode(data, n, h)) return false;
+            if (!(h.image_desc.size() == IMAGE_DESC_SIZE || h.image_desc.empty()) || h.feature_num < 0 || h.feature_num > MAX_FEATURES || h.direction < 0 || h.direction >= 4) return false;
+            on_header(h, now);
+            return true;
+        }
+        if (std::strcmp(channel, wire::CH_LANDMARKS) == 0) {
+            wire::LandmarkDescriptor l;
+            if (!wire::decode(data, n, l)) return false;
+            if (l.feature_descriptor.size() != (size_t)FEATURE_DESC_SIZE) return false;
+            on_landmark(l, now);
+            return true;
+        }
         return false;
     }
 
@@ -174,6 +192,14 @@ public:
             im.landmark_num = (int)im.landmarks_2d.size();
             if (!im.landmarks_2d.empty()) image_desc_callback(im);
             received_images.erase(id);
+            msg_header_recv_time.erase(id);
+            orphan_first_seen.erase(id);
+        }
+        // entries created by landmarks whose header never came (lost, rejected, or sent by somebody else's bug) must not pile up
+        for (auto it = orphan_first_seen.begin(); it != orphan_first_seen.end();) {
+            if (msg_header_recv_time.count(it->first)) { it = orphan_first_seen.erase(it); continue; }      // the header arrived meanwhile
+            if (tnow - it->second > orphan_timeout) { received_images.erase(it->first); blacklist.insert(it->first); it = orphan_first_seen.erase(it); continue; }
+            ++it;
         }
         std::vector<int64_t> finish_frames;
         for (int64_t hash : active_receving_frames) {
@@ -188,6 +214,7 @@ public:
             for (auto& im : f.images) f.landmark_num += im.landmark_num;
             if (frame_desc_callback) frame_desc_callback(f);
             received_frames.erase(hash);
+            frame_header_recv_time.erase(hash);
         }
     }
 
@@ -208,6 +235,7 @@ private:
     // :300-324
     void on_landmark(const wire::LandmarkDescriptor& m, double now) {
         if (msg_blocked(m.header_id)) return;
+        if (!received_images.count(m.header_id)) orphan_first_seen.emplace(m.header_id, now);
         ImageDescriptor& t = received_images[m.header_id];          // a landmark may overtake its header: the entry is created here (:308-311)
         t.landmarks_2d_norm.push_back(m.landmark_2d_norm); t.landmarks_2d.push_back(m.landmark_2d); t.landmarks_3d.push_back(m.landmark_3d);
         t.landmarks_flag.push_back((uint8_t)m.landmark_flag);
@@ -240,7 +268,7 @@ private:
     std::set<int64_t> sent_message, blacklist, active_receving_msg, active_receving_frames;
     std::map<int64_t, ImageDescriptor> received_images;
     std::map<int64_t, FisheyeFrameDescriptor> received_frames;
-    std::map<int64_t, double> msg_header_recv_time, frame_header_recv_time;
+    std::map<int64_t, double> msg_header_recv_time, frame_header_recv_time, orphan_first_seen;
 };
 
 }  // namespace omni
