@@ -106,6 +106,7 @@ omni_sp* omni_sp_create(omni_ctx* ctx, const omni_sp_weights* w, const float* pc
                         int pca_dim, int width, int height, float thres, int max_num, int precision, int max_batch);
 void     omni_sp_destroy(omni_sp* sp);
 int      omni_sp_desc_dim(const omni_sp* sp);              /* pca_dim, or 256 without PCA */
+int      omni_sp_image_size(const omni_sp* sp, int* width, int* height);   /* the size the handle was created for (:122 asserts it per call) */
 
 /* SuperPointTensorRT::inference(const cv::Mat&, std::vector<cv::Point2f>&, std::vector<float>&)
  * (superpoint_tensorrt.cpp:117-162) for `batch` images.
@@ -187,6 +188,7 @@ void        omni_index_destroy(omni_index* idx);
 int         omni_index_add(omni_index* idx, int64_t n, const float* x_host);       /* IndexFlatIP::add(n, x) */
 int         omni_index_add_dev(omni_index* idx, int64_t n, const float* x_dev);
 int64_t     omni_index_ntotal(const omni_index* idx);                              /* .ntotal */
+int         omni_index_dim(const omni_index* idx);                                 /* .d */
 int         omni_index_reset(omni_index* idx);
 /* drop the rows appended last so that ntotal == n_rows again (undo of appends enqueued ahead by a batched caller that failed) */
 int         omni_index_truncate(omni_index* idx, int64_t n_rows);

@@ -14,7 +14,7 @@ struct omni_cam {
     omni_sp* sp = nullptr;
     omni_vlad* vlad = nullptr;
     omni_ctx *c1 = nullptr, *c2 = nullptr;
-    int n = 0, M = 0, D = 0, out_dim = 0, bf_mode = 0;
+    int n = 0, M = 0, D = 0, out_dim = 0, bf_mode = 0, W = 0, H = 0;   // W x H: the size the SuperPoint handle (and MobileNetVLAD) was created for
     int *d_qidx = nullptr, *d_tidx = nullptr, *d_nm = nullptr;
     float* d_dist = nullptr;
     const float *kps_dev = nullptr, *desc_dev = nullptr, *sc_dev = nullptr, *g_dev = nullptr;
@@ -39,6 +39,7 @@ omni_cam* omni_cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omn
     omni_cam* c = new omni_cam();
     c->sp = sp; c->vlad = vlad; c->c1 = sp_ctx; c->c2 = vlad_ctx; c->n = n_dirs; c->M = max_num; c->D = omni_sp_desc_dim(sp);
     c->out_dim = global_dim; c->bf_mode = bf_mode;
+    (void)omni_sp_image_size(sp, &c->W, &c->H);
     const size_t n = n_dirs, M = max_num, D = c->D;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
@@ -91,6 +92,8 @@ int omni_cam_enqueue_dev(omni_cam* c, const uint8_t* gray_dev, int stride, int f
 int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask) {
     OMNI_REQUIRE(c && gray_host, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(width > 0 && height > 0 && stride >= width, OMNI_ERR_INVALID, "bad image geometry %dx%d stride %d", width, height, stride);
+    // the networks read 2n images of THEIR size from the staging buffer: any other size would run them past its end
+    OMNI_REQUIRE(width == c->W && height == c->H, OMNI_ERR_INVALID, "omni_cam_enqueue_host: images are %dx%d but the networks were created for %dx%d", width, height, c->W, c->H);
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->c1->device);
     const size_t need = (size_t)2 * c->n * width * height;

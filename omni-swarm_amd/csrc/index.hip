@@ -697,6 +697,7 @@ void omni_index_destroy(omni_index* ix) {
 }
 
 int64_t omni_index_ntotal(const omni_index* ix) { return ix ? ix->ntotal : -1; }
+int omni_index_dim(const omni_index* ix) { return ix ? ix->dim : -1; }
 
 int omni_index_reset(omni_index* ix) {
     OMNI_REQUIRE(ix, OMNI_ERR_INVALID, "null index");

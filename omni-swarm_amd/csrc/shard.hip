@@ -31,6 +31,7 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string err;           // why the library could not be used (dlerror() is consumed by the first read: kept here)
 };
 
 RcclApi& rccl() {
@@ -41,8 +42,15 @@ RcclApi& rccl() {
         // bundle their own libamdhip64 / libhsa-runtime64 / librccl next to /opt/rocm's), and an RCCL whose HSA runtime is not the initialised
         // one fails ncclCommInitRank with "no ROCm-capable device is detected".  So: first the librccl in the directory the loaded
         // libamdhip64 came from, then the default search.
+        // OMNI_RCCL_LIB: an explicit library path first (tests point it at tests/stub_rccl, which lets several ranks share one GPU)
+        if (const char* forced = getenv("OMNI_RCCL_LIB")) {
+            if (forced[0]) {
+                api.so = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+                if (!api.so) { const char* e = dlerror(); api.err = std::string("OMNI_RCCL_LIB=") + forced + ": " + (e ? e : "dlopen failed"); return; }
+            }
+        }
         Dl_info hip_info;
-        if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &hip_info) && hip_info.dli_fname) {
+        if (!api.so && dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &hip_info) && hip_info.dli_fname) {
             std::string dir(hip_info.dli_fname);
             const size_t slash = dir.rfind('/');
             if (slash != std::string::npos) {
@@ -57,13 +65,14 @@ RcclApi& rccl() {
             const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
             for (const char* n : names) { api.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.so) break; }
         }
-        if (!api.so) return;
+        if (!api.so) { const char* e = dlerror(); api.err = e ? e : "librccl.so.1 not found"; return; }
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.so, "ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.so, "ncclCommInitRank"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.so, "ncclCommDestroy"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.so, "ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.so, "ncclGetErrorString"));
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+        if (!api.ok) api.err = "ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString missing from the library";
     });
     return api;
 }
@@ -103,7 +112,7 @@ extern "C" {
 
 int omni_shard_unique_id(char* id_out) {
     OMNI_REQUIRE(id_out, OMNI_ERR_INVALID, "null argument");
-    OMNI_REQUIRE(rccl().ok, OMNI_ERR_HIP, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    OMNI_REQUIRE(rccl().ok, OMNI_ERR_HIP, "RCCL (librccl.so.1) could not be loaded: %s", rccl().err.c_str());
     ncclUniqueId id;
     OMNI_RCCL_TRY(rccl().GetUniqueId(&id));
     memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
@@ -112,7 +121,8 @@ int omni_shard_unique_id(char* id_out) {
 
 omni_shard* omni_shard_create(omni_ctx* ctx, omni_index* local, int dim, int rank, int world, const char* unique_id) {
     if (!ctx || !local || !unique_id || world < 1 || rank < 0 || rank >= world) { omni::set_error("bad argument"); return nullptr; }
-    if (!rccl().ok) { omni::set_error("RCCL (librccl.so.1) could not be loaded"); return nullptr; }
+    if (!rccl().ok) { omni::set_error("RCCL (librccl.so.1) could not be loaded: %s", rccl().err.c_str()); return nullptr; }
+    if (omni_index_dim(local) != dim) { omni::set_error("dim=%d but the local index holds %d-d rows", dim, omni_index_dim(local)); return nullptr; }
     if (omni_index_ntotal(local) != 0) { omni::set_error("the local shard must be empty"); return nullptr; }
     if (omni_index_set_shard(local, rank, world) != OMNI_OK) return nullptr;
     (void)hipSetDevice(ctx->device);
@@ -187,26 +197,34 @@ int omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev
     // 2. append the rows this rank owns, in global-id order
     hipLaunchKernelGGL(shard_pick_rows_kernel, dim3(F * m), dim3(256), 0, st, s->all_rows.as<float>(), W, F, m, dim, s->rank, s->owned.as<float>());
     OMNI_LAUNCH_CHECK();
+    const int64_t local_before = omni_index_ntotal(s->local);
     if ((rc = omni_index_add_dev(s->local, (int64_t)F * m, s->owned.as<float>()))) return rc;
-    // 3. the F*world queries (step f of rank r = row query_row of block [r][f]) in one pass, each over the rows of its turn
-    std::vector<int64_t> idx(nq), lim(nq);
-    for (int f = 0; f < F; ++f)
-        for (int r = 0; r < W; ++r) {
-            idx[f * W + r] = ((int64_t)r * F + f) * m + query_row;
-            lim[f * W + r] = (s->ntotal + (int64_t)(f + 1) * W * m - s->rank + W - 1) / W;      // local rows with global id < ntotal after step f
+    // from here on a failure must take the appended rows out again: s->ntotal only moves on success, and a shard that kept the rows would
+    // hand every later step wrong per-query limits and wrong global ids
+    rc = [&]() -> int {
+        int rc;
+        // 3. the F*world queries (step f of rank r = row query_row of block [r][f]) in one pass, each over the rows of its turn
+        std::vector<int64_t> idx(nq), lim(nq);
+        for (int f = 0; f < F; ++f)
+            for (int r = 0; r < W; ++r) {
+                idx[f * W + r] = ((int64_t)r * F + f) * m + query_row;
+                lim[f * W + r] = (s->ntotal + (int64_t)(f + 1) * W * m - s->rank + W - 1) / W;      // local rows with global id < ntotal after step f
+            }
+        char* sb = s->send.as<char>();
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int n = nq - q0 < 64 ? nq - q0 : 64;
+            if ((rc = omni_index_search_batch_prefix_dev(s->local, n, s->all_rows.as<float>(), idx.data() + q0, k, lim.data() + q0,
+                                                         reinterpret_cast<float*>(sb + (size_t)nq * k * 8) + (size_t)q0 * k,
+                                                         reinterpret_cast<int64_t*>(sb) + (size_t)q0 * k)))
+                return rc;
         }
-    char* sb = s->send.as<char>();
-    for (int q0 = 0; q0 < nq; q0 += 64) {
-        const int n = nq - q0 < 64 ? nq - q0 : 64;
-        if ((rc = omni_index_search_batch_prefix_dev(s->local, n, s->all_rows.as<float>(), idx.data() + q0, k, lim.data() + q0,
-                                                     reinterpret_cast<float*>(sb + (size_t)nq * k * 8) + (size_t)q0 * k,
-                                                     reinterpret_cast<int64_t*>(sb) + (size_t)q0 * k)))
-            return rc;
-    }
-    // 4. the per-shard lists of every query, to everybody
-    OMNI_RCCL_TRY(rccl().AllGather(s->send.p, s->recv.p, list_bytes, ncclInt8, s->comm, st));
-    OMNI_HIP_TRY(hipMemcpyAsync(s->hrecv.p, s->recv.p, list_bytes * W, hipMemcpyDeviceToHost, st));
-    OMNI_HIP_TRY(hipStreamSynchronize(st));
+        // 4. the per-shard lists of every query, to everybody
+        OMNI_RCCL_TRY(rccl().AllGather(s->send.p, s->recv.p, list_bytes, ncclInt8, s->comm, st));
+        OMNI_HIP_TRY(hipMemcpyAsync(s->hrecv.p, s->recv.p, list_bytes * W, hipMemcpyDeviceToHost, st));
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
+        return OMNI_OK;
+    }();
+    if (rc) { (void)omni_index_truncate(s->local, local_before); return rc; }
     s->ntotal += (int64_t)F * W * m;
     // 5. merge the lists of MY queries (query f*W + rank)
     std::vector<int> which(F);

@@ -397,6 +397,13 @@ void omni_sp_destroy(omni_sp* s) {
 
 int omni_sp_desc_dim(const omni_sp* s) { return s ? s->desc_dim : -1; }
 
+int omni_sp_image_size(const omni_sp* s, int* width, int* height) {
+    OMNI_REQUIRE(s, OMNI_ERR_INVALID, "null handle");
+    if (width) *width = s->W;
+    if (height) *height = s->H;
+    return OMNI_OK;
+}
+
 int omni_sp_enqueue_dev(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {
     OMNI_REQUIRE(s && gray_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);

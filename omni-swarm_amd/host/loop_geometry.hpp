@@ -148,7 +148,11 @@ public:
         DP_old_to_new = geom::Pose::DeltaPose(p_drone_old_in_new, drone_pose_now, is_4dof);
         const double rperr = geom::rp_error(p_drone_old_in_new, drone_pose_old, drone_pose_now);
         inlier_num = (int)inliers.size();
-        return geom::pnp_result_verify(true, init_mode, inlier_num, rperr, DP_old_to_new, verify) ? 1 : 0;
+        // the reference has ONE MIN_LOOP_NUM / INIT_MODE_MIN_LOOP_NUM (launch parameters, swarm_loop.cpp:221-226) for the feature-count gates
+        // and for the inlier gate of pnp_result_verify (loop_detector.cpp:317-334): the members of this class are the single source
+        geom::VerifyParams vp = verify;
+        vp.min_loop_num = MIN_LOOP_NUM; vp.init_mode_min_loop_num = INIT_MODE_MIN_LOOP_NUM;
+        return geom::pnp_result_verify(true, init_mode, inlier_num, rperr, DP_old_to_new, vp) ? 1 : 0;
     }
 
     // :295-315

@@ -219,6 +219,7 @@ public:
     }
 
     bool msg_blocked(int64_t id) const { return blacklist.count(id) || sent_message.count(id); }     // loop_net.h:85-87
+    int pending_images() const { return (int)received_images.size(); }
 
 private:
     // :187-229

@@ -425,7 +425,16 @@ public:
         try { auto out = on_images_recv_batch(static_cast<const std::vector<FisheyeFrameDescriptor>&>(frames), rows_dev); movable_ = nullptr; return out; }
         catch (...) { movable_ = nullptr; throw; }
     }
-    std::vector<LoopCandidate> on_images_recv_batch(const std::vector<FisheyeFrameDescriptor>& frames, const float* rows_dev = nullptr) {
+    std::vector<LoopCandidate> on_images_recv_batch(const std::vector<FisheyeFrameDescriptor>& frames_in, const float* rows_dev = nullptr) {
+        // host rows are read as 4096 floats each: an image whose global descriptor has another length (a malformed or other-version packet
+        // that got past LoopNet) counts as an image without landmarks -- the reference would read past the vector (loop_detector.cpp:166-170)
+        std::vector<FisheyeFrameDescriptor> cleaned;
+        if (!rows_dev) {
+            bool bad = false;
+            for (auto& f : frames_in) bad = bad || malformed(f);
+            if (bad) { cleaned = frames_in; for (auto& f : cleaned) sanitise(f); movable_ = nullptr; }
+        }
+        const std::vector<FisheyeFrameDescriptor>& frames = cleaned.empty() ? frames_in : cleaned;
         struct Add { IndexFlatIP* index; size_t row; };
         struct Search { IndexFlatIP* index; size_t row; int max_index; int64_t n_limit; };
         std::vector<Add> adds; std::vector<Search> searches;
@@ -472,6 +481,9 @@ public:
             rows_dev = own_rows;
         }
         const int64_t start_local = local_index.ntotal, start_remote = remote_index.ntotal;
+        std::vector<char> raw;
+        std::vector<std::pair<size_t, size_t>> where(searches.size(), {SIZE_MAX, SIZE_MAX});     // byte offsets of I and D per search
+        try {
         for (size_t a = 0; a < adds.size();) {                                    // consecutive rows of one index go in as one append
             size_t b = a + 1;
             while (b < adds.size() && adds[b].index == adds[a].index && adds[b].row == adds[b - 1].row + 1) ++b;
@@ -494,8 +506,7 @@ public:
             c->js.push_back(j);
         }
         for (auto& c : chunks) { c.off_i = need; c.off_d = need + c.js.size() * c.k * 8; need += c.js.size() * c.k * 12; }
-        std::vector<char> raw(need);
-        std::vector<std::pair<size_t, size_t>> where(searches.size(), {SIZE_MAX, SIZE_MAX});     // byte offsets of I and D per search
+        raw.resize(need);
         if (need) {
             if (batch_buf_bytes_ < need) {
                 if (batch_buf_) omni_dev_free(ctx_.get(), batch_buf_);
@@ -517,6 +528,17 @@ public:
             check(omni_memcpy_d2h(ctx_.get(), raw.data(), batch_buf_, need), "on_images_recv_batch fetch");   // the only synchronisation
         } else if (!adds.empty()) {
             check(omni_ctx_sync(ctx_.get()), "omni_ctx_sync");
+        }
+        } catch (...) {
+            // a failed append / search / copy: take the rows of this batch out again so that row ids, the id maps and the recency rule of every
+            // later frame stay what they were (the Python twin's _rollback)
+            (void)omni_index_truncate(local_index.handle(), start_local);
+            (void)omni_index_truncate(remote_index.handle(), start_remote);
+            local_index.ntotal = omni_index_ntotal(local_index.handle());
+            remote_index.ntotal = omni_index_ntotal(remote_index.handle());
+            if (own_rows) omni_dev_free(ctx_.get(), own_rows);
+            row_ids_.clear(); deferred_.clear();
+            throw;
         }
         deferred_.clear();
         for (size_t j = 0; j < searches.size(); ++j) {
@@ -544,26 +566,28 @@ public:
     }
 
     LoopCandidate on_image_recv(const FisheyeFrameDescriptor& f_in) {            // :11-137
+        if (!replaying_ && malformed(f_in)) { FisheyeFrameDescriptor c = f_in; sanitise(c); return on_image_recv(c); }
         LoopCandidate r;
-        const FisheyeFrameDescriptor* fp = &f_in;          // re-pointed to the database's copy once the frame has been moved into it
-#define f (*fp)
-        if (f.images.empty()) return r;
-        const int drone_id = f.drone_id;
+        if (f_in.images.empty()) return r;
+        const int drone_id = f_in.drone_id;
         if (drone_id != self_id && database_size() == 0) return r;                // :36-38
         const bool new_node = all_nodes.find(drone_id) == all_nodes.end();
         all_nodes.insert(drone_id);
         int dir_count = 0;
-        for (auto& img : f.images) if (img.landmark_num > 0) ++dir_count;
+        for (auto& img : f_in.images) if (img.landmark_num > 0) ++dir_count;
         if (dir_count < MIN_DIRECTION_LOOP) return r;                             // :60-63
-        if (f.landmark_num < MIN_LOOP_NUM) return r;                              // :65
+        if (f_in.landmark_num < MIN_LOOP_NUM) return r;                           // :65
         bool init_mode = false;
         if (drone_id != self_id) init_mode = inter_drone_loop_count[{drone_id, self_id}] < inter_drone_init_frames;   // :67-72
-        if (!f.prevent_adding_db || new_node) { fp = add_to_database(f); r.added = true; }                          // :89-94
+        const bool nonkeyframe = f_in.prevent_adding_db;
+        const FisheyeFrameDescriptor* fp = &f_in;          // re-pointed to the database's copy: the frame may have been MOVED into it
+        if (!nonkeyframe || new_node) { fp = add_to_database(f_in); r.added = true; }                               // :89-94
+        const FisheyeFrameDescriptor& f = *fp;
         if (database_size() > MATCH_INDEX_DIST || init_mode || drone_id != self_id) {                               // :98
             r.queried = true;
             int direction_new = stereo_fisheye ? 1 : 0, direction_old = -1, image_id = -1;
             double distance = -1;
-            const FisheyeFrameDescriptor* old = query_fisheyeframe_from_database(f, init_mode, f.prevent_adding_db, direction_new, direction_old, image_id, distance);
+            const FisheyeFrameDescriptor* old = query_fisheyeframe_from_database(f, init_mode, nonkeyframe, direction_new, direction_old, image_id, distance);
             if (direction_old >= 0 && old) {
                 r.found = true; r.old_msg_id = old->msg_id; r.image_id = image_id; r.direction_new = direction_new; r.direction_old = direction_old; r.distance = distance;
                 bool success = false;
@@ -577,7 +601,15 @@ public:
             }
         }
         return r;
-#undef f
+    }
+
+    // an image that claims landmarks but whose global descriptor is not 4096 floats long
+    static bool malformed(const FisheyeFrameDescriptor& f) {
+        for (auto& img : f.images) if (img.landmark_num > 0 && img.image_desc.size() != 4096) return true;
+        return false;
+    }
+    static void sanitise(FisheyeFrameDescriptor& f) {
+        for (auto& img : f.images) if (img.landmark_num > 0 && img.image_desc.size() != 4096) { f.landmark_num -= img.landmark_num; img.landmark_num = 0; }
     }
 
     int self_id;

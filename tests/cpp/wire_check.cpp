@@ -63,6 +63,26 @@ int main(int argc, char** argv) {
     }
     std::vector<uint8_t> junk(40, 7);
     std::printf("JUNK %d\n", rx.on_packet(wire::CH_HEADER, junk.data(), junk.size(), t) ? 1 : 0);
+    {   // well-framed packets of the wrong shape are dropped: a 10-float landmark, a 100-float global descriptor, a direction outside the frame
+        wire::LandmarkDescriptor lb; lb.header_id = 777; lb.feature_descriptor.assign(10, 1.f);
+        const auto b1 = wire::encode(lb);
+        wire::ImageDescriptorHeader hb; hb.msg_id = 778; hb.image_desc.assign(100, 1.f);
+        const auto b2 = wire::encode(hb);
+        wire::ImageDescriptorHeader hd; hd.msg_id = 779; hd.image_desc.assign(4096, 1.f); hd.direction = 7;
+        const auto b3 = wire::encode(hd);
+        std::printf("MALFORMED %d %d %d\n", rx.on_packet(wire::CH_LANDMARKS, b1.data(), b1.size(), t) ? 1 : 0, rx.on_packet(wire::CH_HEADER, b2.data(), b2.size(), t) ? 1 : 0,
+                    rx.on_packet(wire::CH_HEADER, b3.data(), b3.size(), t) ? 1 : 0);
+        // a landmark whose header never arrives: kept for orphan_timeout seconds, then forgotten (and its id black-listed)
+        wire::LandmarkDescriptor lo; lo.header_id = 999; lo.feature_descriptor.assign(64, 2.f);
+        const auto b4 = wire::encode(lo);
+        const int acc = rx.on_packet(wire::CH_LANDMARKS, b4.data(), b4.size(), t) ? 1 : 0;
+        const int held = rx.pending_images();
+        LoopNetWire probe(3);
+        probe.on_packet(wire::CH_LANDMARKS, b4.data(), b4.size(), 0.0);
+        const int before = probe.pending_images();
+        probe.scan_recv_packets(100.0);
+        std::printf("ORPHAN %d %d %d %d %d\n", acc, held > 0 ? 1 : 0, before, probe.pending_images(), probe.msg_blocked(999) ? 1 : 0);
+    }
     std::printf("BEFORE_TIMEOUT %zu\n", got.size());
     rx.scan_recv_packets(t + 0.6);          // images with losses complete by timeout (recv_period 0.5)
     rx.scan_recv_packets(t + 1.7);          // frames complete by 2 x recv_period

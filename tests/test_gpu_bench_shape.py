@@ -70,6 +70,37 @@ def test_superpoint_64_images_f16_bit_identical_to_batch1_and_within_gate_of_ora
     big.close(); one.close()
 
 
+def test_superpoint_64_images_split_precision_meets_the_north_star_bar(omni, ctx, batch64):
+    """OMNI_PREC_SPLIT at the benchmarked launch shape (64 images, threshold 0.02, fisheye mask): the gates ARE north_star's bar -- key points
+    identical to the fp32 oracle (set, and order up to confidence ties below the fp32 summation noise: the rule of the exact-f32 path), dense
+    and 64-d descriptors <= 1e-3 relative at p99 (measured ~1e-6) -- and every image is bit-identical to the same image run alone."""
+    from tests.test_gpu_superpoint import assert_same_keypoints
+    c = omni.capi
+    weights = S.synth_weights(0)
+    comp, mean = synth.pca()
+    big = c.SuperPoint(ctx, weights, comp, mean, W, H, THR, MAXN, c.PREC_SPLIT, 64)
+    one = c.SuperPoint(ctx, weights, comp, mean, W, H, THR, MAXN, c.PREC_SPLIT, 1)
+    res = big.inference(batch64, fisheye_mask=True)
+    semi64, desc64 = big.get_dense(64)
+    for b in range(64):
+        (k1, d1, s1), = one.inference(batch64[b], fisheye_mask=True)
+        assert np.array_equal(res[b][0], k1) and np.array_equal(res[b][1], d1) and np.array_equal(res[b][2], s1), b
+    assert min(len(r[0]) for r in res) == MAXN
+    for b in (0, 9, 31, 40, 63):
+        semi_r, desc_r = S.forward(weights, S.preprocess_u8(batch64[b], True))
+        rel = np.linalg.norm(desc64[b] - desc_r[0], axis=0) / np.linalg.norm(desc_r[0], axis=0)
+        assert np.percentile(rel, 99) <= 1e-3, (b, np.percentile(rel, 99))
+        xy, conf, _, _ = P.get_keypoints(semi_r[0], THR, MAXN)
+        assert_same_keypoints(res[b][0], res[b][2], xy, conf)                  # overlap 1.0, order up to the 2e-5 tie rule
+        d_r, _ = P.compute_descriptors(desc_r[0], xy, W, H, comp, mean)
+        order = [{tuple(p): j for j, p in enumerate(xy.tolist())}[tuple(p)] for p in res[b][0].astype(np.int32).tolist()]
+        e = np.linalg.norm(res[b][1] - d_r[order], axis=1) / np.linalg.norm(d_r[order], axis=1)
+        assert np.percentile(e, 99) <= 1e-3, (b, np.percentile(e, 99))
+        xys, confs, _, _ = P.get_keypoints(semi64[b], THR, MAXN)               # the post-processing is exact on the net's own heat map
+        assert np.array_equal(res[b][0].astype(np.int32), xys) and np.array_equal(res[b][2], confs)
+    big.close(); one.close()
+
+
 def test_mobilenetvlad_32_images_bit_identical_to_batch1_and_within_1e3_of_oracle(omni, ctx, batch64):
     c = omni.capi
     vw = V.synth_weights()

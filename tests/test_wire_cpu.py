@@ -33,6 +33,8 @@ def test_split_and_reassemble(exe, seed):
         assert n_hdr == 3 and n_pkts == 3 + flagged                     # one header per non-empty direction, one packet per 3-D landmark
         assert n_bytes == 3 * (8 + 8 + 4 + 8 + 8 + 4 + 4 + 1 + 2 * 56 + 4 + 4096 * 4) + flagged * (8 + 8 + 8 + 4 + 4 + 4 + 7 * 4 + 4 + 64 * 4)
         assert next(ln for ln in out if ln[0] == "JUNK")[1] == "0"      # a packet that does not parse is rejected
+        assert next(ln for ln in out if ln[0] == "MALFORMED")[1:] == ["0", "0", "0"]     # right framing, wrong array lengths / direction: dropped
+        assert next(ln for ln in out if ln[0] == "ORPHAN")[1:] == ["1", "1", "1", "0", "1"]   # header-less landmarks expire, their id is black-listed
         assert next(ln for ln in out if ln[0] == "BEFORE_TIMEOUT")[1] == "0"    # lossy images only complete by time-out
         lost = int(next(ln for ln in out if ln[0] == "LOST")[1])
         frames = [ln for ln in out if ln[0] == "FRAME"]
