@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 import omni_loader  # noqa: E402
 
+omni_loader.load()          # registers omni-swarm_amd/ as `omni_swarm_amd` so that test modules can import its data generators at collection time
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

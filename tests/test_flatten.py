@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import flatten_ref as F
-from oracle import synth
+from omni_swarm_amd import synth          # seeded synthetic inputs (data generators; shared by bench.py)
 
 MEI = (1.8, -0.2, 0.05, 0.001, -0.002, 1100.0, 1098.0, 640.0, 512.0)       # a DJI-class fisheye in camodocal's MEI parametrisation
 

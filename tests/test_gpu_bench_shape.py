@@ -16,7 +16,7 @@ from oracle import match_ref as M
 from oracle import mobilenetvlad_ref as V
 from oracle import postproc_ref as P
 from oracle import superpoint_ref as S
-from oracle import synth
+from omni_swarm_amd import synth          # seeded synthetic inputs (data generators; shared by bench.py)
 
 pytestmark = pytest.mark.gpu
 W, H, THR, MAXN, MB = 600, 480, 0.02, 200, 8

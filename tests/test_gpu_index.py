@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import match_ref as M
-from oracle import synth
+from omni_swarm_amd import synth          # seeded synthetic inputs (data generators; shared by bench.py)
 
 pytestmark = pytest.mark.gpu
 DIM = 4096

@@ -18,7 +18,7 @@ import pytest
 
 from oracle import postproc_ref as P
 from oracle import superpoint_ref as S
-from oracle import synth
+from omni_swarm_amd import synth          # seeded synthetic inputs (data generators; shared by bench.py)
 
 pytestmark = pytest.mark.gpu
 LAYERS = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"]

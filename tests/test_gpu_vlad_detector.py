@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import mobilenetvlad_ref as V
-from oracle import synth
+from omni_swarm_amd import synth          # seeded synthetic inputs (data generators; shared by bench.py)
 from tests import detector_stream as DS
 
 pytestmark = pytest.mark.gpu

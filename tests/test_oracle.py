@@ -9,7 +9,7 @@ from oracle import match_ref as M
 from oracle import mobilenetvlad_ref as V
 from oracle import postproc_ref as P
 from oracle import superpoint_ref as S
-from oracle import synth
+from omni_swarm_amd import synth          # seeded synthetic inputs (data generators; shared by bench.py)
 from tests import detector_stream as DS
 
 
@@ -156,6 +156,145 @@ def test_detector_fall_through_quirk_is_restated():
     rec = det.on_image_recv(frame(60, 1, target * np.float32(0.999)))
     assert rec["queried"] and rec["image_id"] >= 0 and rec["image_id"] < M.REMOTE_MAGIN_NUMBER
     assert rec["distance"] > 0.9                 # the remote hit's score, attached to a local label
+
+
+class _RefDetector:
+    """oracle/_ref/libref_detector.so: the REFERENCE'S OWN text of LoopDetector::on_image_recv (loop_detector.cpp:11-137), add_to_database (x2),
+    query_from_database (x2), query_fisheyeframe_from_database and database_size (:150-292), compiled verbatim against the stand-ins of
+    oracle/ref_build/detector_shim.h (faiss::IndexFlatIP = oracle_ip_search, the geometry stage = a callback).  Built where /root/reference
+    exists (oracle/Makefile), travels as a binary otherwise."""
+
+    def __init__(self, self_id, verdict, *, inner_product_thres=0.6, init_mode_product_thres=0.3, match_index_dist=10, min_loop_num=15,
+                 min_direction_loop=3, inter_drone_init_frames=50, camera_configuration=M.STEREO_FISHEYE):
+        import ctypes
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "ref"])
+        path = os.path.join(root, "oracle", "_ref", "libref_detector.so")
+        if not os.path.exists(path):
+            pytest.skip("oracle/_ref/libref_detector.so not built (needs /root/reference once)")
+        self.C = ctypes
+        L = self.L = ctypes.CDLL(path)
+        self._cb_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int64, ctypes.c_int64)
+        self._cb = self._cb_t(lambda a, b: int(bool(verdict(a, b))))
+        L.ref_det_create.restype = ctypes.c_void_p
+        L.ref_det_create.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, self._cb_t]
+        L.ref_det_destroy.argtypes = [ctypes.c_void_p]
+        ip, fp, lp, dp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
+        L.ref_det_on_image_recv.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip, fp, lp]
+        L.ref_det_query_index.argtypes = [ctypes.c_void_p, ctypes.c_int, fp, ctypes.c_double, ctypes.c_int, dp]
+        L.ref_det_query_image.argtypes = [ctypes.c_void_p, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, dp]
+        L.ref_det_database_size.argtypes = [ctypes.c_void_p]
+        L.ref_det_inter_drone_loop_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        self.h = L.ref_det_create(self_id, inner_product_thres, init_mode_product_thres, match_index_dist, min_loop_num, min_direction_loop,
+                                  inter_drone_init_frames, camera_configuration, self._cb)
+
+    def close(self):
+        if self.h:
+            self.L.ref_det_destroy(self.h)
+            self.h = None
+
+    def on_image_recv(self, fr):
+        """fr: a tests/detector_stream frame dict -> [added, queried, image_id, old_msg_id, dir_old, loop, database_size, compute_loop calls]"""
+        C = self.C
+        n = len(fr["images"])
+        lm = np.array([i["landmark_num"] for i in fr["images"]], np.int32)
+        did = np.array([i["drone_id"] for i in fr["images"]], np.int32)
+        desc = np.ascontiguousarray(np.stack([i["image_desc"] for i in fr["images"]]), np.float32) if n else np.zeros((1, 4096), np.float32)
+        out = np.zeros(8, np.int64)
+        self.L.ref_det_on_image_recv(self.h, int(fr["msg_id"]), int(fr["drone_id"]), int(fr["landmark_num"]), int(fr["prevent_adding_db"]), n,
+                                     lm.ctypes.data_as(C.POINTER(C.c_int)), did.ctypes.data_as(C.POINTER(C.c_int)),
+                                     desc.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_int64)))
+        return out
+
+    def query_index(self, remote_db, vec, thres, max_index, distance):
+        C = self.C
+        d = C.c_double(distance)
+        v = np.ascontiguousarray(vec, np.float32)
+        r = self.L.ref_det_query_index(self.h, int(remote_db), v.ctypes.data_as(C.POINTER(C.c_float)), float(thres), int(max_index), C.byref(d))
+        return r, d.value
+
+    def query_image(self, drone_id, vec, init_mode, nonkeyframe, distance=-1.0):
+        C = self.C
+        d = C.c_double(distance)
+        v = np.ascontiguousarray(vec, np.float32)
+        r = self.L.ref_det_query_image(self.h, int(drone_id), v.ctypes.data_as(C.POINTER(C.c_float)), int(init_mode), int(nonkeyframe), C.byref(d))
+        return r, d.value
+
+
+@pytest.mark.parametrize("seed,n_drones,n_frames", [(11, 3, 90), (5, 5, 240), (23, 5, 240), (7, 3, 150)])
+def test_detector_restatement_is_pinned_to_the_reference_text(seed, n_drones, n_frames):
+    """oracle/match_ref.LoopDetectorRef -- what every detector parity test (Python product, C++ product, batched, GPU, the 10k-frame replay)
+    is compared with -- against the reference's own on_image_recv / add_to_database / query_* text on multi-drone streams that exercise
+    every branch (remote frames on an empty database, too few directions / landmarks, non-keyframes of known and new nodes, init mode ending
+    after inter_drone_init_frames loops, remote and local hits, candidates whose old frame is remote): the same frames are added, the same
+    frames query, the same candidate (row id, frame, direction) comes back, the same loops are accepted, the database has the same size."""
+    frames = DS.make_stream(seed=seed, n_frames=n_frames, n_drones=n_drones)
+    ref = _RefDetector(DS.SELF_ID, DS.loop_ok, **DS.PARAMS)
+    tr = DS.trace(DS.run_oracle(frames))
+    got = np.array([ref.on_image_recv(fr) for fr in frames])
+    assert np.array_equal(got[:, :6], tr[:, 1:7]), np.nonzero((got[:, :6] != tr[:, 1:7]).any(1))[0][:10]
+    det = M.LoopDetectorRef(DS.SELF_ID, compute_loop=lambda n, o, dn, do, im: DS.loop_ok(n.msg_id, o.msg_id), **DS.PARAMS)
+    for fr, g in zip(DS._frames_ref(frames), got):
+        det.on_image_recv(fr)
+        assert det.database_size() == g[6]
+    for (a, b), c in det.inter_drone_loop_count.items():
+        assert ref.L.ref_det_inter_drone_loop_count(ref.h, a, b) == c
+    assert (tr[:, 4] >= 0).sum() > 15 and tr[:, 6].sum() > 3
+    ref.close()
+
+
+def test_query_rule_is_pinned_to_the_reference_text_on_random_index_states():
+    """query_from_database, both overloads (loop_detector.cpp:176-242), on 1000 random states of the two indexes: return value AND the in/out
+    `distance` -- including the :241 fall-through (returns the last examined label, `distance` untouched) and the `distance` shared by the
+    remote and the local query of a self frame (:184-186)."""
+    rng = np.random.default_rng(99)
+    n_fall, n_leak = 0, 0
+    for trial in range(40):
+        mid = int(rng.integers(1, 8))
+        ref = _RefDetector(1, lambda a, b: 0, match_index_dist=mid, min_loop_num=1, min_direction_loop=1, inner_product_thres=0.5, init_mode_product_thres=0.25)
+        det = M.LoopDetectorRef(1, match_index_dist=mid, min_loop_num=1, min_direction_loop=1, inner_product_thres=0.5, init_mode_product_thres=0.25)
+        places = rng.standard_normal((6, 4096)).astype(np.float32)
+        places /= np.linalg.norm(places, axis=1, keepdims=True)
+
+        def vec(p):
+            c = rng.uniform(0.3, 0.95)
+            nz = rng.standard_normal(4096).astype(np.float32)
+            v = c * places[p] + np.sqrt(1 - c * c) * nz / np.linalg.norm(nz)
+            return (v / np.linalg.norm(v)).astype(np.float32)
+        for f in range(int(rng.integers(0, 14))):               # fill both indexes through the front door
+            drone = 1 if rng.random() < 0.6 else 2
+            imgs = [{"drone_id": drone, "landmark_num": int(rng.integers(0, 3) > 0) * 50, "image_desc": vec(int(rng.integers(0, 6)))} for _ in range(4)]
+            fr = {"msg_id": 100 + f, "drone_id": drone, "landmark_num": 200, "prevent_adding_db": False, "images": imgs}
+            ref.on_image_recv(fr)
+            det.on_image_recv(DS._frames_ref([fr])[0])
+        for _ in range(25):
+            q = vec(int(rng.integers(0, 6)))
+            img = M.ImageDesc(drone_id=1, landmark_num=50, image_desc=q)
+            thres, max_index, d0 = float(rng.uniform(0.1, 0.9)), int(rng.integers(1, 9)), float(rng.choice([-1.0, 0.77]))
+            for remote in (0, 1):
+                dist = [d0]
+                r = det._query_index(img, det.remote_index if remote else det.local_index, bool(remote), thres, max_index, dist)
+                rr, dd = ref.query_index(remote, q, thres, max_index, d0)
+                assert (r, dist[0]) == (rr, dd), (trial, remote, r, rr, dist[0], dd)
+                n_fall += int(r != -1 and dist[0] == d0)
+            for drone, init_mode, nonkey in ((1, 0, 0), (1, 0, 1), (1, 1, 0), (2, 1, 0), (2, 0, 1)):
+                dist = [-1.0]
+                r = det.query_from_database(M.ImageDesc(drone_id=drone, landmark_num=50, image_desc=q), bool(init_mode), bool(nonkey), dist)
+                rr, dd = ref.query_image(drone, q, init_mode, nonkey)
+                assert (r, dist[0]) == (rr, dd), (trial, drone, init_mode, nonkey, r, rr, dist[0], dd)
+                n_leak += int(drone == 1 and not nonkey and r != -1 and r < M.REMOTE_MAGIN_NUMBER and dist[0] > -1)
+        ref.close()
+    assert n_fall > 20 and n_leak > 20          # the quirks were exercised
+
+
+def test_product_architecture_tables_equal_the_oracles_own():
+    """The oracle states the two architectures itself (superpoint.ipynb:143-160; MobileNetV2 table at width 0.35 + NetVLAD head, assumed); the
+    product's tables (omni-swarm_amd/weights.py, what the HIP side is built from) must say the same."""
+    from omni_swarm_amd import weights as W
+    assert S.LAYERS == W.SUPERPOINT_LAYERS
+    assert V.BLOCKS == list(W.VLAD_BLOCKS) and V.layer_specs() == W.mobilenetvlad_layer_specs()
+    assert (V.N_CLUSTERS, V.OUT_DIM, V.STEM_OUT, V.FEAT_DIM, V.VLAD_DIM) == (W.VLAD_N_CLUSTERS, W.VLAD_OUT_DIM, W.VLAD_STEM_OUT, W.VLAD_FEAT_DIM, W.VLAD_DIM)
 
 
 def test_mobilenetvlad_oracle_golden(golden):

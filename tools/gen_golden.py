@@ -27,7 +27,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import match_ref, mobilenetvlad_ref, postproc_ref, superpoint_ref, synth  # noqa: E402
+from oracle import match_ref, mobilenetvlad_ref, postproc_ref, superpoint_ref  # noqa: E402
+import omni_loader  # noqa: E402
+
+omni_loader.load()
+from omni_swarm_amd import synth  # noqa: E402  (seeded synthetic inputs: data, shared with bench.py)
 
 REF_NB = "/root/reference/swarm_loop/superpoint.ipynb"
 OUT = os.path.join(ROOT, "tests", "golden")

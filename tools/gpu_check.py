@@ -11,9 +11,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import omni_loader  # noqa: E402
-from oracle import match_ref, mobilenetvlad_ref, postproc_ref, superpoint_ref, synth  # noqa: E402
+from oracle import match_ref, mobilenetvlad_ref, postproc_ref, superpoint_ref  # noqa: E402
 
 omni = omni_loader.load()
+from omni_swarm_amd import synth  # noqa: E402
 c = omni.capi
 RESULTS = []
 

@@ -10,9 +10,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import omni_loader  # noqa: E402
-from oracle import postproc_ref as P, superpoint_ref as S, synth  # noqa: E402
+from oracle import postproc_ref as P, superpoint_ref as S  # noqa: E402
 
 omni = omni_loader.load()
+from omni_swarm_amd import synth  # noqa: E402
 c = omni.capi
 ctx = c.Context(0)
 print("device:", ctx.device_info(), flush=True)
