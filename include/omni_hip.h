@@ -192,6 +192,11 @@ int         omni_index_dim(const omni_index* idx);                              
 int         omni_index_reset(omni_index* idx);
 /* drop the rows appended last so that ntotal == n_rows again (undo of appends enqueued ahead by a batched caller that failed) */
 int         omni_index_truncate(omni_index* idx, int64_t n_rows);
+/* OMNI_STORE_F32 shards keep an fp16 mirror of their rows (+50 % HBM; OMNI_INDEX_MIRROR=0 disables it): a batch of >= 4 queries is scored
+ * against the mirror in one matrix-core pass, the best k+24 candidates per query are re-scored exactly against the fp32 rows, and a per-query
+ * certificate proves the result is the exact fp32 top-k (scores bit-identical to the single-query path); uncertified queries are re-run with
+ * the exact scan.  Counters since creation: queries answered through the mirror / of those, the ones that needed the exact re-run. */
+int         omni_index_cert_stats(omni_index* idx, int64_t* searches, int64_t* fallbacks);
 /* IndexFlatIP::search(nq, q, k, D, I): exact inner product, k best descending, ties -> lower row id,
  * missing results padded with I = -1, D = -FLT_MAX.  k <= 1024 (the reference caps at 1000, loop_detector.cpp:200). */
 int         omni_index_search(omni_index* idx, int nq, const float* q_host, int k, float* D, int64_t* I);

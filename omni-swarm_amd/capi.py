@@ -31,7 +31,7 @@ SYMBOLS = [
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
     "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block",
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
-    "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate",
+    "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
     "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
@@ -132,6 +132,9 @@ def lib():
     sig("omni_index_ntotal", C.c_int64, [_vp])
     sig("omni_index_reset", C.c_int, [_vp])
     sig("omni_index_truncate", C.c_int, [_vp, C.c_int64])
+    sig("omni_index_cert_stats", C.c_int, [_vp, _i64p, _i64p])
+    sig("omni_index_dim", C.c_int, [_vp])
+    sig("omni_sp_image_size", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
     sig("omni_index_search", C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp, _i64p])
     sig("omni_index_search_dev", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp])
     sig("omni_index_search_prefix_dev", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp])
@@ -475,6 +478,12 @@ class IndexFlatIP:
 
     def reset(self):
         _check(lib().omni_index_reset(self.h))
+
+    def cert_stats(self):
+        """(queries answered through the fp16 mirror + exact refinement, of those the ones re-run with the exact scan)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _check(lib().omni_index_cert_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def truncate(self, n_rows: int):
         _check(lib().omni_index_truncate(self.h, n_rows))

@@ -25,8 +25,16 @@ struct omni_index {
     int64_t ntotal = 0;
     int rank = 0, world = 1;
     void* db = nullptr;
-    omni::DevBuf qbuf, keys_a, keys_b, out_d, out_i, stage, mq_q, mq_inv;
-    omni::HostBuf hq, hout;
+    // fp32 shards keep an fp16 MIRROR of the rows in the T16 layout (+50 % memory): a batch of queries is first scored against the mirror in ONE
+    // pass on the matrix cores (8 KB per row instead of 16, every query of the batch at once), the best K' candidates per query are re-scored
+    // EXACTLY against the fp32 rows, and a per-query certificate (the K'-th mirror score plus the fp16 rounding bound is below the k-th exact
+    // score) proves that the result is the exact fp32 top-k -- scores bit-identical to the single-query kernel; a query whose certificate
+    // fails is searched again by the exact multi-pass scan.  OMNI_INDEX_MIRROR=0 switches the mirror off.
+    void* db16 = nullptr;
+    uint32_t* norm_max = nullptr;          // device: bits of the largest squared row norm seen (atomicMax on the bit pattern of a float >= 0)
+    omni::DevBuf qbuf, keys_a, keys_b, out_d, out_i, stage, mq_q, mq_inv, cert_keys, cert_flags;
+    omni::HostBuf hq, hout, hflags;
+    int64_t cert_searches = 0, cert_fallbacks = 0;      // statistics: queries answered through the mirror / of those, re-run exactly
     hipEvent_t scan0 = nullptr, scan1 = nullptr;
     bool scan_timed = false;
     std::mutex mu;
@@ -506,6 +514,95 @@ ip_scan_t16_kernel(const __half* __restrict__ db, int64_t n_rows, int dim, const
     }
 }
 
+// largest squared norm of rows [0, n) of `rows` (row-major fp32), folded into *norm_max (bit pattern of a non-negative float: unsigned order)
+__global__ void __launch_bounds__(256)
+row_norm_max_kernel(const float* __restrict__ rows, int64_t n, int dim, uint32_t* __restrict__ norm_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* rp = rows + row * dim;
+    float a = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(rp + c);
+        a = fmaf(x.x, x.x, a); a = fmaf(x.y, x.y, a); a = fmaf(x.z, x.z, a); a = fmaf(x.w, x.w, a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) atomicMax(norm_max, __float_as_uint(a == a ? a : __builtin_inff()));       // NaN rows poison the certificate (-> exact path)
+}
+
+// exact re-scoring of the mirror pass's candidates: one wave per (query, candidate), the lane-local fmaf chain and the wave reduction of
+// ip_scan_kernel<float, 1> -- the score is bit-identical to the single-query scan's
+__global__ void __launch_bounds__(256)
+cert_refine_kernel(const float* __restrict__ db, int dim, const float* __restrict__ queries, const uint64_t* __restrict__ cand /*[nq][kp]*/, int nq, int kp,
+                   uint64_t* __restrict__ out /*[nq][kp]*/) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (int64_t)nq * kp) return;
+    const int q = (int)(w / kp);
+    const uint64_t key = cand[w];
+    if (key == OMNI_KEY_EMPTY) { if (lane == 0) out[w] = OMNI_KEY_EMPTY; return; }
+    const uint32_t row = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    const float* rp = db + (int64_t)row * dim;
+    const float* qp = queries + (int64_t)q * dim;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    float acc = 0.f;
+#pragma unroll 4
+    for (int c = lane * 4; c < dim; c += 64 * 4) {
+        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(rp + c);
+        const float4 qq = *reinterpret_cast<const float4*>(qp + c);
+        acc = fmaf(x[0], qq.x, acc); acc = fmaf(x[1], qq.y, acc); acc = fmaf(x[2], qq.z, acc); acc = fmaf(x[3], qq.w, acc);
+    }
+    const float sc = wave_sum(acc);
+    if (lane == 0) out[w] = omni_make_key(sc, row);
+}
+
+// per query (one wave): rank the kp <= 64 exact keys, write the best k (as decode_topk_kernel would) and the certificate:
+//   every row NOT among the candidates has a mirror score <= m = the kp-th mirror score, hence an exact score <= m + eps with
+//   eps = 2^-11 |q| max|row|  (fp16 rounding of the row, element-wise relative 2^-11, Cauchy-Schwarz)  +  slack for the mirror pass's own
+//   fp32-class arithmetic and for fp16 subnormals;  if the k-th exact score is above that, no other row can enter the top k.
+__global__ void __launch_bounds__(64)
+cert_select_kernel(const uint64_t* __restrict__ exact /*[nq][kp]*/, const uint64_t* __restrict__ mirror /*[nq][kp]*/, int kp, int k, const float* __restrict__ queries,
+                   int dim, const uint32_t* __restrict__ norm_max, int rank, int world, float* __restrict__ D, int64_t* __restrict__ I, int* __restrict__ flags) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    __shared__ uint64_t s[64];
+    __shared__ uint64_t kth_key;
+    if (lane == 0) kth_key = OMNI_KEY_EMPTY;
+    const uint64_t mine = lane < kp ? exact[(int64_t)q * kp + lane] : OMNI_KEY_EMPTY;
+    s[lane] = mine;
+    float qn = 0.f, q1 = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float v = queries[(int64_t)q * dim + c]; qn = fmaf(v, v, qn); q1 += fabsf(v); }
+    qn = wave_sum(qn); q1 = wave_sum(q1);
+    __syncthreads();
+    int r = 0;
+    for (int j = 0; j < 64; ++j) r += (s[j] > mine);
+    if (mine == OMNI_KEY_EMPTY) r = 64;                                   // all empties share rank >= number of valid keys
+    if (r < k) {
+        D[(int64_t)q * k + r] = omni_orderable_f32((uint32_t)(mine >> 32));
+        I[(int64_t)q * k + r] = (int64_t)(0xFFFFFFFFu - (uint32_t)(mine & 0xFFFFFFFFull)) * world + rank;
+    }
+    int valid = 0;
+    for (int j = 0; j < 64; ++j) valid += (s[j] != OMNI_KEY_EMPTY);
+    for (int i = valid + lane; i < k; i += 64) { D[(int64_t)q * k + i] = -3.402823466e+38f; I[(int64_t)q * k + i] = -1; }
+    // certificate
+    if (r == k - 1) kth_key = mine;
+    __syncthreads();
+    if (lane == 0) {
+        const uint64_t last = mirror[(int64_t)q * kp + kp - 1];           // sorted descending: the smallest retained mirror key
+        int need = 0;
+        if (last != OMNI_KEY_EMPTY) {                                     // otherwise every row of the prefix was a candidate: exact by construction
+            if (valid < k) need = 1;
+            else {
+                const float kth = omni_orderable_f32((uint32_t)(kth_key >> 32));
+                const float m = omni_orderable_f32((uint32_t)(last >> 32));
+                const float rn = sqrtf(__uint_as_float(*norm_max)), qnorm = sqrtf(qn);
+                const float eps = 4.8829e-4f * 1.0001f * qnorm * rn + 6.0e-8f * q1 + 4.0e-6f * qnorm * rn;
+                need = !(kth > m + eps) || !(rn < 6.0e4f);                // NaN / inf / fp16-overflowing rows: not certifiable
+            }
+        }
+        flags[q] = need;
+    }
+}
+
 static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, const float* q_dev, uint64_t* keys, int64_t key_stride,
                        const int64_t* limits) {
     ScanLimits<SCAN_MAX_QB> lim;
@@ -559,7 +656,7 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, 
 
 // up to MQ_NQ queries in one pass over an fp16 shard (ip_scan_mq_kernel)
 static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, const float* q_dev, uint64_t* keys, int64_t key_stride,
-                          const int64_t* limits) {
+                          const int64_t* limits, const void* db_t16 = nullptr) {
     ScanLimits<MQ_NQ> lim;
     for (int q = 0; q < MQ_NQ; ++q) lim.v[q] = limits && q < nq ? limits[q] : INT64_MAX;
     auto kfn = ip_scan_mq_kernel;
@@ -577,7 +674,7 @@ static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, con
     const int64_t blocks = cdiv64(tiles, MQ_WAVES * MQ_RT);
     const int64_t grid = blocks < cus ? blocks : cus;
     static const int rotate = getenv("OMNI_MQ_ROT") ? atoi(getenv("OMNI_MQ_ROT")) : 1;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(MQ_THREADS), MQ_SMEM, st, reinterpret_cast<const _Float16*>(ix->db),
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(MQ_THREADS), MQ_SMEM, st, reinterpret_cast<const _Float16*>(db_t16 ? db_t16 : ix->db),
                        n, ix->dim, ix->mq_q.as<char>(), ix->mq_inv.as<float>(), nq, keys, key_stride, rotate, lim);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
@@ -600,10 +697,30 @@ static int ensure_capacity(omni_index* ix, int64_t rows) {
     if (ix->db && ix->ntotal > 0)
         OMNI_HIP_TRY(hipMemcpyAsync(nd, ix->db, (size_t)((ix->ntotal + 15) & ~(int64_t)15) * ix->dim * ix->elem(), hipMemcpyDeviceToDevice,
                                     ix->ctx->stream));
+    void* nm = nullptr;
+    if (ix->norm_max) {                                              // fp32 shard with an fp16 mirror
+        if (hipMalloc(&nm, (size_t)cap * ix->dim * 2) != hipSuccess) { (void)hipFree(nd); set_error("hipMalloc of the fp16 mirror (%zu bytes) failed", (size_t)cap * ix->dim * 2); return OMNI_ERR_NOMEM; }
+        if (ix->db16 && ix->ntotal > 0)
+            OMNI_HIP_TRY(hipMemcpyAsync(nm, ix->db16, (size_t)((ix->ntotal + 15) & ~(int64_t)15) * ix->dim * 2, hipMemcpyDeviceToDevice, ix->ctx->stream));
+    }
     OMNI_HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
     if (ix->db) (void)hipFree(ix->db);
+    if (ix->db16) (void)hipFree(ix->db16);
     ix->db = nd;
+    ix->db16 = nm;
     ix->capacity = cap;
+    return OMNI_OK;
+}
+
+// rows [row0, row0 + n) of an fp32 shard were just written (stream order): bring the fp16 mirror and the norm bound up to date
+static int mirror_rows(omni_index* ix, int64_t row0, int64_t n) {
+    if (!ix->db16 || n <= 0) return OMNI_OK;
+    hipStream_t st = ix->ctx->stream;
+    const float* rows = (const float*)ix->db + row0 * ix->dim;
+    hipLaunchKernelGGL(f32_to_t16_kernel, dim3((unsigned)cdiv64(n * ix->dim / 8, 256)), dim3(256), 0, st, rows, (__half*)ix->db16, row0, n, ix->dim);
+    OMNI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, rows, n, ix->dim, ix->norm_max);
+    OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
 
@@ -617,6 +734,7 @@ static int append_dev(omni_index* ix, int64_t n, const float* x_dev) {
     if (ix->storage == OMNI_STORE_F32) {
         OMNI_HIP_TRY(hipMemcpyAsync((float*)ix->db + ix->ntotal * ix->dim, x_dev, (size_t)cnt * 4,
                                     hipMemcpyDeviceToDevice, st));
+        if ((rc = mirror_rows(ix, ix->ntotal, n))) return rc;
     } else {
         hipLaunchKernelGGL(f32_to_t16_kernel, dim3((unsigned)cdiv64(cnt / 8, 256)), dim3(256), 0, st, x_dev, (__half*)ix->db, ix->ntotal, n,
                            ix->dim);
@@ -638,6 +756,43 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
     if ((rc = ix->keys_b.ensure((size_t)nq * per_q * 8))) return rc;
     uint64_t* ka = ix->keys_a.as<uint64_t>();
     uint64_t* kb = ix->keys_b.as<uint64_t>();
+    // fp32 shard, a batch of queries: mirror pass + exact refinement + certificate (see omni_index::db16)
+    const int kp = k + 24 > 2 * k ? k + 24 : 2 * k;                 // candidates per query
+    if (n > 0 && ix->storage == OMNI_STORE_F32 && ix->db16 && nq >= mq_min_queries() && nq <= MQ_NQ && kp <= TOPK_SEL_MAX_K) {
+        if ((rc = ix->cert_keys.ensure((size_t)nq * kp * 8))) return rc;
+        if ((rc = ix->cert_flags.ensure((size_t)MQ_NQ * 4))) return rc;
+        if ((rc = ix->hflags.ensure((size_t)MQ_NQ * 4))) return rc;
+        OMNI_HIP_TRY(hipEventRecord(ix->scan0, st));
+        if ((rc = launch_scan_mq(st, ix, n, nq, q_dev, ka, n, limits, ix->db16))) return rc;
+        OMNI_HIP_TRY(hipEventRecord(ix->scan1, st));
+        ix->scan_timed = true;
+        uint64_t* cand = nullptr;
+        if ((rc = topk_keys(st, ka, kb, nq, n, kp, &cand))) return rc;
+        hipLaunchKernelGGL(cert_refine_kernel, dim3((unsigned)cdiv64((int64_t)nq * kp, 4)), dim3(256), 0, st, reinterpret_cast<const float*>(ix->db), ix->dim, q_dev,
+                           cand, nq, kp, ix->cert_keys.as<uint64_t>());
+        OMNI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cert_select_kernel, dim3(nq), dim3(64), 0, st, ix->cert_keys.as<uint64_t>(), cand, kp, k, q_dev, ix->dim, ix->norm_max, ix->rank, ix->world,
+                           D_dev, I_dev, ix->cert_flags.as<int>());
+        OMNI_LAUNCH_CHECK();
+        // the certificate is checked on the host: one small copy + a wait for this search (its callers fetch the results right afterwards);
+        // a query that is not certified is searched again with the exact scan -- results identical either way
+        OMNI_HIP_TRY(hipMemcpyAsync(ix->hflags.p, ix->cert_flags.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
+        ix->cert_searches += nq;
+        const int* fl = ix->hflags.as<int>();
+        static const bool force_fallback = [] { const char* e = getenv("OMNI_INDEX_CERT_FAIL"); return e && e[0] == '1'; }();      // test hook
+        for (int q = 0; q < nq; ++q) {
+            if (!fl[q] && !force_fallback) continue;
+            ++ix->cert_fallbacks;
+            const int64_t lq = limits ? limits[q] : INT64_MAX;
+            if ((rc = launch_scan(st, ix, n, 1, q_dev + (int64_t)q * ix->dim, ka, n, &lq))) return rc;
+            uint64_t* r1 = nullptr;
+            if ((rc = topk_keys(st, ka, kb, 1, n, k, &r1))) return rc;
+            hipLaunchKernelGGL(decode_topk_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, r1, 1, k, ix->rank, ix->world, D_dev + (int64_t)q * k, I_dev + (int64_t)q * k);
+            OMNI_LAUNCH_CHECK();
+        }
+        return OMNI_OK;
+    }
     if (n > 0) {
         OMNI_HIP_TRY(hipEventRecord(ix->scan0, st));
         const bool mq = ix->storage == OMNI_STORE_F16 && nq >= mq_min_queries();
@@ -680,7 +835,13 @@ omni_index* omni_index_create(omni_ctx* ctx, int dim, int storage, int64_t initi
     if (hipEventCreate(&ix->scan0) != hipSuccess || hipEventCreate(&ix->scan1) != hipSuccess) {
         omni::set_error("hipEventCreate failed"); delete ix; return nullptr;
     }
-    if (initial_capacity_rows > 0 && omni::ensure_capacity(ix, initial_capacity_rows) != OMNI_OK) { delete ix; return nullptr; }
+    static const bool mirror_on = [] { const char* e = getenv("OMNI_INDEX_MIRROR"); return !(e && e[0] == '0'); }();
+    if (storage == OMNI_STORE_F32 && mirror_on) {
+        if (hipMalloc((void**)&ix->norm_max, 4) != hipSuccess || hipMemsetAsync(ix->norm_max, 0, 4, ctx->stream) != hipSuccess) {
+            omni::set_error("hipMalloc failed"); omni_index_destroy(ix); return nullptr;
+        }
+    }
+    if (initial_capacity_rows > 0 && omni::ensure_capacity(ix, initial_capacity_rows) != OMNI_OK) { omni_index_destroy(ix); return nullptr; }
     return ix;
 }
 
@@ -689,6 +850,9 @@ void omni_index_destroy(omni_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     if (ix->db) (void)hipFree(ix->db);
+    if (ix->db16) (void)hipFree(ix->db16);
+    if (ix->norm_max) (void)hipFree(ix->norm_max);
+    ix->cert_keys.release(); ix->cert_flags.release(); ix->hflags.release();
     ix->qbuf.release(); ix->keys_a.release(); ix->keys_b.release(); ix->out_d.release(); ix->out_i.release();
     ix->stage.release(); ix->mq_q.release(); ix->mq_inv.release(); ix->hq.release(); ix->hout.release();
     if (ix->scan0) (void)hipEventDestroy(ix->scan0);
@@ -745,6 +909,7 @@ int omni_index_add(omni_index* ix, int64_t n, const float* x_host) {
             if ((rc = omni::ensure_capacity(ix, ix->ntotal + m))) return rc;
             OMNI_HIP_TRY(hipMemcpyAsync((float*)ix->db + ix->ntotal * ix->dim, x_host + s * ix->dim, bytes,
                                         hipMemcpyHostToDevice, ix->ctx->stream));
+            if ((rc = omni::mirror_rows(ix, ix->ntotal, m))) return rc;
             ix->ntotal += m;
         } else {
             if ((rc = ix->stage.ensure(bytes))) return rc;
@@ -910,7 +1075,22 @@ int omni_index_load(omni_index* ix, const char* path) {
     if (rc) { if (nd) (void)hipFree(nd); return rc; }
     (void)hipStreamSynchronize(ix->ctx->stream);
     if (ix->db) (void)hipFree(ix->db);
+    if (ix->db16) { (void)hipFree(ix->db16); ix->db16 = nullptr; }
     ix->db = nd; ix->capacity = cap; ix->ntotal = h.ntotal;
+    if (ix->norm_max) {                                              // rebuild the fp16 mirror of the loaded rows
+        if (hipMalloc(&ix->db16, (size_t)cap * ix->dim * 2) != hipSuccess) { ix->db16 = nullptr; omni::set_error("hipMalloc of the fp16 mirror failed"); return OMNI_ERR_NOMEM; }
+        OMNI_HIP_TRY(hipMemsetAsync(ix->norm_max, 0, 4, ix->ctx->stream));
+        if ((rc = omni::mirror_rows(ix, 0, h.ntotal))) return rc;
+        OMNI_HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    }
+    return OMNI_OK;
+}
+
+int omni_index_cert_stats(omni_index* ix, int64_t* searches, int64_t* fallbacks) {
+    OMNI_REQUIRE(ix, OMNI_ERR_INVALID, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (searches) *searches = ix->cert_searches;
+    if (fallbacks) *fallbacks = ix->cert_fallbacks;
     return OMNI_OK;
 }
 

@@ -288,7 +288,7 @@ def test_full_size_properties_100k_rows(omni, ctx):
     assert idx.last_scan_ms() > 0
 
 
-@pytest.mark.parametrize("storage,nq", [("f32", 8), ("f32", 3), ("f16", 8), ("f16", 2), ("f16", 40)])
+@pytest.mark.parametrize("storage,nq", [("f32", 8), ("f32", 3), ("f32", 40), ("f32", 64), ("f16", 8), ("f16", 2), ("f16", 40)])
 def test_batch_prefix_search_equals_one_prefix_search_per_query(omni, ctx, storage, nq):
     """omni_index_search_batch_prefix_dev (one pass over the shard for a micro-batch of key frames, per-query row limits, queries gathered
     out of a row buffer) == nq separate omni_index_search_prefix_dev calls == the oracle on the truncated database -- including empty
@@ -324,12 +324,69 @@ def test_batch_prefix_search_equals_one_prefix_search_per_query(omni, ctx, stora
             continue
         idx.search_prefix_dev(1, rows_dev + row_idx[j] * DIM * 4, k, lim, one + k * 8, one)
         r1 = ctx.from_device(one, (k * 12,), np.uint8)
-        if storage == "f32" or nq < 4:                 # same scan kernel family: same bits
+        if storage == "f32":                           # fp32 rows: batches go through the fp16 mirror + EXACT re-scoring: the single-query scan's bits
+            assert np.array_equal(I[j], r1[:k * 8].view(np.int64)) and np.array_equal(D[j], r1[k * 8:].view(np.float32))
+        elif nq < 4:                                   # same scan kernel family: same bits
             assert np.array_equal(I[j], r1[:k * 8].view(np.int64)) and np.allclose(D[j], r1[k * 8:].view(np.float32), rtol=1e-6, atol=1e-7)
         Dr, Ir = M.ip_search(ref_db[:lim], rows[row_idx[j]][None], k)
         assert np.array_equal(I[j], Ir[0]) and np.allclose(D[j], Dr[0], rtol=1e-5, atol=2e-6)
+    if storage == "f32" and nq >= 4:
+        served, fallbacks = idx.cert_stats()
+        assert served == nq and fallbacks <= 1, (served, fallbacks)        # random rows: the certificate holds (the empty prefix is trivially exact)
     for p in (rows_dev, buf, one):
         ctx.free(p)
+
+
+def test_fp32_batch_search_certificate_falls_back_to_the_exact_scan_on_near_ties(omni, ctx, tmp_path):
+    """fp32 shard, batched search = fp16 mirror pass + exact re-scoring of the k + 24 best + a certificate that nothing else can enter the top k.
+    A cluster of 120 rows within 1e-4 of each other defeats the certificate (more near-ties than candidates): those queries must be re-run by
+    the exact scan and still return the oracle's ids -- ties resolved to the lower row id -- while queries elsewhere stay certified.  Also:
+    truncate + re-add, and a snapshot load, keep the mirror in step with the fp32 rows."""
+    c = omni.capi
+    rng = np.random.default_rng(123)
+    n, k = 3000, 10
+    db = rng.standard_normal((n, DIM)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    centre = db[100].copy()
+    cluster = rng.choice(np.arange(200, n), 120, replace=False)
+    db[cluster] = centre + 1e-4 * rng.standard_normal((120, DIM)).astype(np.float32)      # score spread 1e-4: far above fp32 summation noise, below the fp16 bound
+    db[cluster[:7]] = centre                                   # exact duplicates: equal scores, lower row id first
+    idx = c.IndexFlatIP(ctx, DIM, c.STORE_F32)
+    idx.add(db)
+    q = np.stack([centre, db[5], centre * 0.5, db[2222], db[17], centre + 0.01 * db[3]]).astype(np.float32)
+
+    def batch(index, limits):
+        rows_dev = ctx.to_device(q)
+        buf = ctx.alloc(len(q) * k * 12)
+        index.search_batch_prefix_dev(rows_dev, None, k, limits, buf + len(q) * k * 8, buf)
+        raw = ctx.from_device(buf, (len(q) * k * 12,), np.uint8)
+        ctx.free(rows_dev); ctx.free(buf)
+        return raw[len(q) * k * 8:].view(np.float32).reshape(len(q), k), raw[:len(q) * k * 8].view(np.int64).reshape(len(q), k)
+
+    D, I = batch(idx, [n] * len(q))
+    Dr, Ir = M.ip_search(db, q, k)
+    assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=2e-6)
+    served, fallbacks = idx.cert_stats()
+    assert served == len(q) and 3 <= fallbacks <= 4, (served, fallbacks)     # the three queries on the cluster (the 4th sits 0.01 away)
+    D1, I1 = idx.search(q[:1], k)                                            # the single-query scan: same ids, same score bits
+    assert np.array_equal(I1[0], I[0]) and np.array_equal(D1[0], D[0])
+    # truncate, append other rows, search again: the mirror follows
+    idx.truncate(1500)
+    extra = rng.standard_normal((40, DIM)).astype(np.float32)
+    extra /= np.linalg.norm(extra, axis=1, keepdims=True)
+    idx.add(extra)
+    db2 = np.concatenate([db[:1500], extra])
+    q[1] = extra[7]
+    D, I = batch(idx, [len(db2)] * len(q))
+    Dr, Ir = M.ip_search(db2, q, k)
+    assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=2e-6) and I[1, 0] == 1507
+    path = str(tmp_path / "m.omnx")
+    idx.save(path)
+    idx2 = c.IndexFlatIP(ctx, DIM, c.STORE_F32)
+    idx2.load(path)
+    D2, I2 = batch(idx2, [len(db2)] * len(q))
+    assert np.array_equal(I2, I) and np.array_equal(D2, D)
+    idx.close(); idx2.close()
 
 
 def test_truncate_and_corrupt_snapshot(omni, ctx, tmp_path):

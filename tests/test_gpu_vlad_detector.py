@@ -151,3 +151,17 @@ def test_c3_replay_10k_keyframes_5_drones_match_ids_equal_oracle(omni, ctx):
     got_s = DS.trace(DS.run_product(frames, ctx, detector))
     assert np.array_equal(got_s, ref)
     assert (ref[:, 1] == 1).sum() > 7000 and (ref[:, 4] != -1).sum() > 5000 and len({f["drone_id"] for f in frames}) == 5
+
+
+def test_c3_replay_with_fp16_rows_counts_the_decisions_that_differ_from_fp32_rows(omni, ctx):
+    """The same 10 000-key-frame replay with the database stored as fp16 rows (OMNI_STORE_F16: half the HBM bytes per search, what
+    `db100k.f16_rows` times) against the fp32-row trace: row scores move by ~1e-4 relative, so a candidate within that of the acceptance
+    threshold (`INNER_PRODUCT_THRES`, loop_detector.cpp:232) or of its runner-up can flip.  Counted here and bounded: the storage format is not
+    allowed to change more than 1 decision in 1 000."""
+    from omni_swarm_amd import detector
+    frames = DS.make_stream(seed=77, n_frames=10000, n_places=800, n_drones=5)
+    ref = DS.trace(DS.run_oracle_fast(frames))
+    got16 = DS.trace(DS.run_product_batched(frames, ctx, detector, batch=8, rows_on_device=True, storage=omni.capi.STORE_F16))
+    differ = int((got16 != ref).any(1).sum())
+    print(f"fp16 rows: {differ} of {len(ref)} key-frame decisions differ from fp32 rows")
+    assert differ <= len(ref) // 1000, differ
