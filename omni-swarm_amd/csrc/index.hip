@@ -434,6 +434,18 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, GatherIdx idx,
     for (int i = threadIdx.x; i < dim / 4; i += blockDim.x) d[i] = s[i];
 }
 
+// decode_topk_kernel for a subset of the queries: result row i goes to query slot dst.v[i]
+__global__ void decode_topk_scatter_kernel(const uint64_t* __restrict__ keys, int nq, int k, int rank, int world, GatherIdx dst, float* __restrict__ D,
+                                           int64_t* __restrict__ I) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * k) return;
+    const int64_t o = dst.v[i / k] * k + (i % k);
+    const uint64_t key = keys[i];
+    if (key == OMNI_KEY_EMPTY) { D[o] = -3.402823466e+38f; I[o] = -1; return; }
+    D[o] = omni_orderable_f32((uint32_t)(key >> 32));
+    I[o] = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) * world + rank;
+}
+
 // half index of (row, 16-byte chunk) in the T16 layout
 __device__ __forceinline__ int64_t t16_chunk(int64_t row, int chunk, int dim) {
     return (row >> 4) * 16 * (int64_t)dim + ((int64_t)chunk * 16 + (row & 15)) * 8;
@@ -758,7 +770,10 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
     uint64_t* kb = ix->keys_b.as<uint64_t>();
     // fp32 shard, a batch of queries: mirror pass + exact refinement + certificate (see omni_index::db16)
     const int kp = k + 24 > 2 * k ? k + 24 : 2 * k;                 // candidates per query
-    if (n > 0 && ix->storage == OMNI_STORE_F32 && ix->db16 && nq >= mq_min_queries() && nq <= MQ_NQ && kp <= TOPK_SEL_MAX_K) {
+    // (small databases stay on the exact kernels: their scans are launch-bound, the mirror's extra launches and its host check would cost more
+    // than the halved HBM traffic saves -- OMNI_INDEX_MIRROR_MIN_ROWS, default 32768)
+    static const int64_t mirror_min_rows = [] { const char* e = getenv("OMNI_INDEX_MIRROR_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)32768; }();
+    if (n >= mirror_min_rows && n > 0 && ix->storage == OMNI_STORE_F32 && ix->db16 && nq >= mq_min_queries() && nq <= MQ_NQ && kp <= TOPK_SEL_MAX_K) {
         if ((rc = ix->cert_keys.ensure((size_t)nq * kp * 8))) return rc;
         if ((rc = ix->cert_flags.ensure((size_t)MQ_NQ * 4))) return rc;
         if ((rc = ix->hflags.ensure((size_t)MQ_NQ * 4))) return rc;
@@ -781,16 +796,29 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
         ix->cert_searches += nq;
         const int* fl = ix->hflags.as<int>();
         static const bool force_fallback = [] { const char* e = getenv("OMNI_INDEX_CERT_FAIL"); return e && e[0] == '1'; }();      // test hook
-        for (int q = 0; q < nq; ++q) {
-            if (!fl[q] && !force_fallback) continue;
-            ++ix->cert_fallbacks;
-            const int64_t lq = limits ? limits[q] : INT64_MAX;
-            if ((rc = launch_scan(st, ix, n, 1, q_dev + (int64_t)q * ix->dim, ka, n, &lq))) return rc;
-            uint64_t* r1 = nullptr;
-            if ((rc = topk_keys(st, ka, kb, 1, n, k, &r1))) return rc;
-            hipLaunchKernelGGL(decode_topk_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, r1, 1, k, ix->rank, ix->world, D_dev + (int64_t)q * k, I_dev + (int64_t)q * k);
-            OMNI_LAUNCH_CHECK();
+        // the uncertified queries, together, through the exact scan (blocks of <= 8 queries per pass over the fp32 rows: what every batch
+        // cost before the mirror existed)
+        GatherIdx gi;
+        int64_t lim_f[MQ_NQ];
+        int nfl = 0;
+        for (int q = 0; q < nq; ++q)
+            if (fl[q] || force_fallback) { gi.v[nfl] = q; lim_f[nfl] = limits ? limits[q] : INT64_MAX; ++nfl; }
+        if (nfl == 0) return OMNI_OK;
+        ix->cert_fallbacks += nfl;
+        for (int i = nfl; i < MQ_NQ; ++i) gi.v[i] = 0;
+        if ((rc = ix->stage.ensure((size_t)nfl * ix->dim * 4))) return rc;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(nfl), dim3(256), 0, st, q_dev, gi, ix->dim, ix->stage.as<float>());
+        OMNI_LAUNCH_CHECK();
+        int max_qb = (int)(131072 / ((size_t)ix->dim * 4));
+        max_qb = max_qb > SCAN_MAX_QB ? SCAN_MAX_QB : (max_qb < 1 ? 1 : max_qb);
+        for (int q0 = 0; q0 < nfl; q0 += max_qb) {
+            const int qb = nfl - q0 < max_qb ? nfl - q0 : max_qb;
+            if ((rc = launch_scan(st, ix, n, qb, ix->stage.as<float>() + (int64_t)q0 * ix->dim, ka + (int64_t)q0 * n, n, lim_f + q0))) return rc;
         }
+        uint64_t* r1 = nullptr;
+        if ((rc = topk_keys(st, ka, kb, nfl, n, k, &r1))) return rc;
+        hipLaunchKernelGGL(decode_topk_scatter_kernel, dim3(cdiv(nfl * k, 256)), dim3(256), 0, st, r1, nfl, k, ix->rank, ix->world, gi, D_dev, I_dev);
+        OMNI_LAUNCH_CHECK();
         return OMNI_OK;
     }
     if (n > 0) {

@@ -89,3 +89,31 @@ def local_descriptors(n: int, dim: int = 64, seed: int = 5, pair_noise: float | 
     b = a[perm] + rng.normal(0, pair_noise, (n, dim)).astype(np.float32)
     b /= np.linalg.norm(b, axis=1, keepdims=True)
     return a, b.astype(np.float32), perm
+
+
+# ---- key frames of a rendered scene: a stereo fisheye rig (up / down cameras, 4 flattened 90-degree pinhole views each) in a room --------
+ROOM_DISPARITY = 16          # pixels between the up and the down view of a wall point (a multiple of the network's 8-pixel cell)
+
+
+def room_wall_depth(width: int = 600, baseline: float = 0.10) -> float:
+    """Distance of the four walls from the rig: focal length (width / 2: 90-degree horizontal field of view) * baseline / ROOM_DISPARITY."""
+    return (width / 2.0) * baseline / ROOM_DISPARITY
+
+
+def room_keyframe(place: int, height: int = 480, width: int = 600, revisit: int = 0, noise_sigma: float = 0.0) -> np.ndarray:
+    """The 8 images [up d0..d3, down d0..d3] a stereo rig at the centre of a square room sees: direction d looks straight at wall d
+    (fronto-parallel, at room_wall_depth()), walls carry seeded textures at one texel per pixel, and the up / down cameras sit
+    +- baseline / 2 along the vertical axis -- so the down view is the up view moved by exactly ROOM_DISPARITY rows and every wall point
+    triangulates to the wall's depth.  The room is tall enough that the views never see floor or ceiling (vertical field of view 77 degrees).
+    Rendering a fronto-parallel plane through a pinhole at one texel per pixel is a crop: up = texture rows [0, H), down = rows
+    [ROOM_DISPARITY, ROOM_DISPARITY + H).  `revisit` > 0 with `noise_sigma` > 0 adds per-camera sensor noise seeded by (place, revisit):
+    the same place seen again."""
+    out = np.empty((8, height, width), np.uint8)
+    for d in range(4):
+        tex = image_u8(50_000 + 8 * place + d, height + ROOM_DISPARITY, width, n_shapes=260)
+        out[d] = tex[:height]
+        out[4 + d] = tex[ROOM_DISPARITY:ROOM_DISPARITY + height]
+    if revisit > 0 and noise_sigma > 0:
+        rng = np.random.default_rng(BASE_SEED + 7_000_000 + 1000 * place + revisit)
+        out = np.clip(np.rint(out.astype(np.float32) + rng.normal(0, noise_sigma, out.shape)), 0, 255).astype(np.uint8)
+    return out

@@ -11,6 +11,10 @@ import omni_loader  # noqa: E402
 
 omni_loader.load()          # registers omni-swarm_amd/ as `omni_swarm_amd` so that test modules can import its data generators at collection time
 
+# fp32 shards answer batched searches through their fp16 mirror only from 32768 rows on (below, the exact kernels are as fast); the tests want
+# that path -- mirror pass, exact re-scoring, certificate, fallback -- on their small databases too (read once by libomni_hip.so)
+os.environ.setdefault("OMNI_INDEX_MIRROR_MIN_ROWS", "0")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
