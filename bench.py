@@ -247,7 +247,22 @@ def main():
                 "ms_per_step_minmax": [round(min(dts) / steps * 1e3, 4), round(max(dts) / steps * 1e3, 4)]}
 
     # ---- the C++ host loop (N = 1) ------------------------------------------------------------------------------------------------
-    def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False):
+    def room_pool():
+        """pool of RENDERED key frames (synth.room_keyframe: a stereo rig in textured rooms, the down view = the up view 16 rows further): cycling
+        it revisits every place again and again -- the geometry stage then has real loops to close (stereo landmarks, PnP, LoopEdges)"""
+        out = []
+        for p in range(POOL):
+            key = ("room", p)
+            if key not in img_cache:
+                a = ictx.host_alloc((KF_IMAGES * MB, H, W), np.uint8)
+                kf = [synth.room_keyframe(100 * rank + MB * p + m, H, W) for m in range(MB)]
+                a[:] = np.stack([kf[m][i] for m in range(MB) for i in range(4)] + [kf[m][4 + i] for m in range(MB) for i in range(4)])
+                img_cache[key] = a
+            out.append(img_cache[key])
+        return out
+
+    def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False, ptrs=None):
+        ptrs = ptrs or pool_ptrs
         pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, MB,
                                        args.pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
         gen = RowFactory(7 + rank)
@@ -265,7 +280,7 @@ def main():
 
         def run(n):
             t = tail if n == steps else wtail
-            state["hits"] += pl.run(n, state["id"], pool_ptrs, state["slot"], None if t is None else t.ctypes.data, True)
+            state["hits"] += pl.run(n, state["id"], ptrs, state["slot"], None if t is None else t.ctypes.data, True)
             state["id"] += n
             state["slot"] += n // MB
         dts = timed_regions(run, pl.sync, steps, warmup, min_time)
@@ -396,9 +411,11 @@ def main():
     if world == 1:
         if cpp_host and args.geometry_steps > 0:
             n = max(MB, args.geometry_steps // MB * MB)
-            with_geometry = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, n, MB * args.pipelines, min(args.min_time, 0.5), geometry=True)
+            with_geometry = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, n, MB * args.pipelines, min(args.min_time, 0.5), geometry=True,
+                                    ptrs=[a.ctypes.data for a in room_pool()])
             with_geometry.update(steps=n, note="same loop + the host geometry stage per candidate (lifting, up/down triangulation, BF + homography-RANSAC "
-                                               "mask, PnP-RANSAC; f64 on one host thread).  The synthetic images share no 3-D scene: candidates are rejected")
+                                               "mask, PnP-RANSAC; f64, host) on key frames of a RENDERED scene (synth.room_keyframe: a stereo rig in textured "
+                                               f"rooms, {POOL * MB} places revisited cyclically): every revisit is a real loop -- stereo landmarks, PnP, an accepted LoopEdge")
         if cpp_host and args.python_steps > 0:
             pyloop = PythonLoop(prec)
             n = max(MB, args.python_steps // MB * MB)

@@ -76,6 +76,31 @@ int omni_pipeline_geometry_stats(omni_pipeline* h, int* compute_loop_calls, int*
     return 0;
 }
 
+// odometry poses of the key frames msg_id = first_msg_id .. first_msg_id + n - 1: poses7[i] = position xyz + quaternion wxyz
+int omni_pipeline_set_poses(omni_pipeline* h, int64_t first_msg_id, int64_t n, const double* poses7) {
+    try { h->p->set_poses(first_msg_id, poses7, n); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// loop candidates so far, [i][4] = {new key frame, old key frame, direction_new, direction_old}; returns how many exist (writes <= max)
+int omni_pipeline_get_candidates(omni_pipeline* h, int64_t* out, int max) {
+    const auto& c = h->p->candidates();
+    for (int i = 0; i < (int)c.size() && i < max; ++i) { out[4 * i] = c[i].new_msg_id; out[4 * i + 1] = c[i].old_msg_id; out[4 * i + 2] = c[i].dir_new; out[4 * i + 3] = c[i].dir_old; }
+    return (int)c.size();
+}
+
+// accepted loop edges so far (swarm_msgs::LoopEdge as compute_loop fills it, loop_detector.cpp:789-811), [i][12] = {keyframe_id_a, keyframe_id_b,
+// drone_id_a, drone_id_b, pnp_inlier_num, relative position xyz, relative attitude quaternion wxyz}; returns how many exist (writes <= max)
+int omni_pipeline_get_edges(omni_pipeline* h, double* out, int max) {
+    const auto& e = h->p->edges();
+    for (int i = 0; i < (int)e.size() && i < max; ++i) {
+        double* o = out + 12 * i;
+        o[0] = (double)e[i].keyframe_id_a; o[1] = (double)e[i].keyframe_id_b; o[2] = e[i].drone_id_a; o[3] = e[i].drone_id_b; o[4] = e[i].pnp_inlier_num;
+        o[5] = e[i].relative_pose.pos.x; o[6] = e[i].relative_pose.pos.y; o[7] = e[i].relative_pose.pos.z;
+        o[8] = e[i].relative_pose.att.w; o[9] = e[i].relative_pose.att.x; o[10] = e[i].relative_pose.att.y; o[11] = e[i].relative_pose.att.z;
+    }
+    return (int)e.size();
+}
+
 // FisheyeUndist's undistortion maps (host/fisheye_flatten.hpp).  mei = {xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0}.  Call with maps == NULL to get
 // n_views / view_w / view_h (arrays of >= 5), then with maps[v] pointing at view_w[v] * view_h[v] * 2 floats each.
 int omni_fisheye_maps(const double* mei, int img_width, double fov_deg, int cam_id, int* n_views, int* view_w, int* view_h, float* const* maps) {

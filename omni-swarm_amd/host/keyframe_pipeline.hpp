@@ -71,6 +71,21 @@ public:
     }
     int geometry_calls() const { return geometry_calls_; }
     const std::vector<LoopEdge>& edges() const { return edges_; }
+    // every loop candidate the detector returned (query_fisheyeframe_from_database found an old frame), in key-frame order
+    struct Candidate { int64_t new_msg_id, old_msg_id; int dir_new, dir_old; };
+    const std::vector<Candidate>& candidates() const { return candidates_; }
+    // odometry poses of the key frames (VIO's pose_drone, swarm_loop.cpp:140-170 takes it from the key-frame message): key frame msg_id gets
+    // poses7[msg_id - first_msg_id] = position xyz + quaternion wxyz; key frames outside the range keep the identity
+    void set_poses(int64_t first_msg_id, const double* poses7, int64_t n) {
+        pose_base_ = first_msg_id;
+        poses_.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            PoseMsg m;
+            for (int k = 0; k < 3; ++k) m.position[k] = poses7[i * 7 + k];
+            for (int k = 0; k < 4; ++k) m.quat_wxyz[k] = poses7[i * 7 + 3 + k];
+            poses_[(size_t)i] = m;
+        }
+    }
     // extrinsics of the virtual pinhole views of the stacked fisheye pair: direction d looks along the body x axis rotated by 90 deg * d,
     // the up / down cameras sit +- baseline/2 along body z (camera axes: x right, y down, z forward)
     geom::Pose view_extrinsic(int direction, bool up) const {
@@ -185,6 +200,8 @@ private:
         for (int m = 0; m < lane.mb; ++m) {
             FisheyeFrameDescriptor& f = frames_[m];
             f.msg_id = first_id + m; f.drone_id = cfg_.self_id; f.prevent_adding_db = false; f.landmark_num = 0;
+            f.timestamp = (double)f.msg_id;
+            f.pose_drone = (f.msg_id >= pose_base_ && f.msg_id < pose_base_ + (int64_t)poses_.size()) ? poses_[(size_t)(f.msg_id - pose_base_)] : PoseMsg{};
             f.images.resize(4);
             for (int d = 0; d < 4; ++d) {
                 const int i = 4 * m + d;                                            // image i of the up cameras
@@ -213,8 +230,11 @@ private:
                 }
             }
         }
-        int hits = 0;
-        for (auto& c : det_.on_images_recv_batch(std::move(frames_), lane.rows_dev)) hits += c.found ? 1 : 0;
+        int hits = 0, fi = 0;
+        for (auto& c : det_.on_images_recv_batch(std::move(frames_), lane.rows_dev)) {
+            if (c.found) { ++hits; candidates_.push_back({first_id + fi, c.old_msg_id, c.direction_new, c.direction_old}); }
+            ++fi;
+        }
         frames_.clear();
         return hits;
     }
@@ -228,6 +248,9 @@ private:
     std::vector<std::vector<DMatch>> pre_out_;
     int pre_dim_ = 0;
     std::vector<LoopEdge> edges_;
+    std::vector<Candidate> candidates_;
+    std::vector<PoseMsg> poses_;
+    int64_t pose_base_ = 0;
     int geometry_calls_ = 0;
     std::vector<std::unique_ptr<Lane>> lanes_;
     std::map<int, std::unique_ptr<Lane>> tail_lanes_;

@@ -16,7 +16,8 @@ from . import capi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
-           "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync"]
+           "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync",
+           "omni_pipeline_set_poses", "omni_pipeline_get_candidates", "omni_pipeline_get_edges"]
 _lib = None
 
 
@@ -42,6 +43,9 @@ def lib():
         L.omni_pipeline_sync.argtypes = [C.c_void_p]
         L.omni_pipeline_attach_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
         L.omni_pipeline_prepare.argtypes = [C.c_void_p, C.c_int]
+        L.omni_pipeline_set_poses.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]
+        L.omni_pipeline_get_candidates.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+        L.omni_pipeline_get_edges.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         _lib = L
     return _lib
 
@@ -104,6 +108,26 @@ class KeyframePipeline:
         a, b = C.c_int(0), C.c_int(0)
         lib().omni_pipeline_geometry_stats(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def set_poses(self, first_msg_id: int, poses7: np.ndarray):
+        """odometry poses [n][7] = position xyz + quaternion wxyz of key frames first_msg_id .. first_msg_id + n - 1"""
+        p = np.ascontiguousarray(poses7, np.float64).reshape(-1, 7)
+        if lib().omni_pipeline_set_poses(self.h, first_msg_id, len(p), p.ctypes.data_as(C.POINTER(C.c_double))):
+            raise _err("omni_pipeline_set_poses")
+
+    def candidates(self) -> np.ndarray:
+        """[n][4] = (new key frame, old key frame, direction_new, direction_old) of every loop candidate so far"""
+        n = lib().omni_pipeline_get_candidates(self.h, None, 0)
+        out = np.zeros((max(n, 1), 4), np.int64)
+        lib().omni_pipeline_get_candidates(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), n)
+        return out[:n]
+
+    def edges(self) -> np.ndarray:
+        """[n][12] = (keyframe_id_a, keyframe_id_b, drone_id_a, drone_id_b, pnp inliers, relative position xyz, relative quaternion wxyz)"""
+        n = lib().omni_pipeline_get_edges(self.h, None, 0)
+        out = np.zeros((max(n, 1), 12), np.float64)
+        lib().omni_pipeline_get_edges(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return out[:n]
 
     def sync(self):
         if lib().omni_pipeline_sync(self.h):
