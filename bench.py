@@ -100,6 +100,7 @@ def parse():
     ap.add_argument("--big-db-keyframes", type=int, default=100_000, help="key frames (x4 rows) of the big-database throughput legs; 0 = skip")
     ap.add_argument("--big-db-steps", type=int, default=64, help="key frames per timed region of the big-database legs")
     ap.add_argument("--f32-steps", type=int, default=16, help="key frames of the f32-precision leg (value_f32); 0 = skip")
+    ap.add_argument("--c5-rows", type=int, default=500_000, help="rows of the fp16 shard of the configs[4] leg (c5_shard); 0 = skip")
     ap.add_argument("--parity-steps", type=int, default=64, help="key frames per region of the OMNI_PREC_SPLIT leg (value_parity: the mode that meets north_star's tolerance); 0 = skip")
     ap.add_argument("--geometry-steps", type=int, default=64, help="key frames of the leg with the geometric verification stage on (with_geometry); 0 = skip")
     ap.add_argument("--python-steps", type=int, default=64, help="key frames of the Python-host leg (python_host); 0 = skip")
@@ -261,10 +262,12 @@ def main():
             out.append(img_cache[key])
         return out
 
-    def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False, ptrs=None):
-        ptrs = ptrs or pool_ptrs
-        pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, MB,
-                                       args.pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
+    def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False, ptrs=None, mb=None, pipelines=None):
+        mb = mb or MB
+        pipelines = pipelines or args.pipelines
+        ptrs = ptrs or (pool_ptrs if mb == MB else [pinned_batch(1000 * rank + 50_000 + 8 * mb * p, mb).ctypes.data for p in range(2)])
+        pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, mb,
+                                       pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
         gen = RowFactory(7 + rank)
         if world > 1:
             pl.attach_shard(rank, world, shard_uid())
@@ -272,20 +275,30 @@ def main():
         else:
             for s in range(0, db_rows, 32768):
                 pl.preload(gen.rows(min(32768, db_rows - s)))
-        tail, _ = tail_for(steps)
-        wtail, _ = tail_for(warmup)
+        assert mb == MB or (steps % mb == 0 and warmup % mb == 0)
+        tail, _ = tail_for(steps) if mb == MB else (None, 0)
+        wtail, _ = tail_for(warmup) if mb == MB else (None, 0)
         pl.prepare(steps)
         pl.prepare(warmup)
-        state = {"id": 0, "slot": 0, "hits": 0}
+        state = {"id": 0, "slot": 0, "hits": 0, "calls": 0}
 
         def run(n):
+            if state["calls"] == (1 if warmup > 0 else 0):
+                pl.latencies_ms(reset=True)                    # the warm-up's micro-batches do not count
+            state["calls"] += 1
             t = tail if n == steps else wtail
             state["hits"] += pl.run(n, state["id"], ptrs, state["slot"], None if t is None else t.ctypes.data, True)
             state["id"] += n
-            state["slot"] += n // MB
+            state["slot"] += n // mb
         dts = timed_regions(run, pl.sync, steps, warmup, min_time)
         out = summarize(dts, steps)
+        lat = pl.latencies_ms()
         out.update(db_rows_start=db_rows, db_rows_end=int(pl.db_rows), loop_candidates_found=state["hits"])
+        if len(lat):
+            out["keyframe_latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
+                                          "micro_batches": int(len(lat)), "keyframes_in_flight": mb * pipelines,
+                                          "definition": "start of a micro-batch's upload -> its key frames' detector (+ geometry) step done; the reference is "
+                                                        "batch-1 and serial (tensorrt_generic.cpp:58-75)"}
         if geometry:
             calls, edges = pl.geometry_stats()
             out.update(compute_loop_calls=calls, loop_edges=edges)
@@ -407,7 +420,7 @@ def main():
     kfps = main_leg["value"]
 
     # ---- comparison legs (N = 1 only; bounded) ----------------------------------------------------------------------------------------
-    python_host = value_f32 = value_parity = db100k = with_geometry = None
+    python_host = value_f32 = value_parity = db100k = with_geometry = c5_shard = None
     if world == 1:
         if cpp_host and args.geometry_steps > 0:
             n = max(MB, args.geometry_steps // MB * MB)
@@ -437,6 +450,15 @@ def main():
                                      "accuracy (every operand a (hi, lo) pair of halfs, three MFMA terms per product; heads in exact f32; MobileNetVLAD is "
                                      "fp32-class in every mode): key points identical to the fp32 oracle, descriptors ~1e-6 -- `parity_split` below; "
                                      "gates: tests/test_gpu_bench_shape.py::test_superpoint_64_images_split_precision_meets_the_north_star_bar")
+        if args.c5_rows > 0 and cpp_host:
+            # BASELINE configs[4] as one GPU of eight sees it: 64 key frames in flight (micro-batches of 16 x 4 pipelines: 128 SuperPoint + 64
+            # MobileNetVLAD images per launch sequence), every micro-batch's 16 queries in ONE matrix-core pass over an fp16 shard
+            c5_mb, c5_pipes = 16, 4
+            n = c5_mb * c5_pipes * 2
+            c5_shard = cpp_leg(prec, capi.STORE_F16, args.c5_rows, n, c5_mb * c5_pipes, min(args.min_time, 0.5), mb=c5_mb, pipelines=c5_pipes)
+            c5_shard.update(steps=n, shard_rows=args.c5_rows, keyframes_per_microbatch=c5_mb, pipelines=c5_pipes,
+                            note="configs[4] end to end on ONE GPU's share: 64 concurrent key frames against a 500k-row fp16 shard (1/8 of the 4M rows of a "
+                                 "1M-key-frame database), the batched search inside the timed loop; the 8-GPU exchange itself is the driver's run")
         if args.big_db_keyframes > 0 and cpp_host:
             n = max(MB, args.big_db_steps // MB * MB)
             db100k = {"db_keyframes": args.big_db_keyframes, "db_rows": 4 * args.big_db_keyframes, "steps": n,
@@ -559,6 +581,7 @@ def main():
             "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f16": "f16", "f32": "f32", "split": "f16 x3 (split operands)"}[args.precision], "data": "synthetic",
             "repeats": main_leg["repeats"], "ms_per_step_minmax": main_leg["ms_per_step_minmax"],
+            "keyframe_latency_ms": main_leg.get("keyframe_latency_ms"),
             "config": {"workload": "configs[1]: reference-faithful fisheye key frame = upload of 8 images + 8 SuperPoint + 4 MobileNetVLAD(assumed arch) "
                                    "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query + results to host; "
                                    f"{args.db_keyframes}-keyframe DB ({4 * args.db_keyframes} rows); seeded synthetic weights",
@@ -573,7 +596,7 @@ def main():
             "gflop_per_keyframe_superpoint_dense": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
             "achieved_tflops_end_to_end": round(kfps * sp_flop_executed(args.precision, MAXN) * KF_IMAGES / 1e12 / world, 1),
             "roofline": roofline, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
-            "db100k": db100k, "with_geometry": with_geometry, "value_f32": value_f32, "value_parity": value_parity,
+            "db100k": db100k, "with_geometry": with_geometry, "value_f32": value_f32, "value_parity": value_parity, "c5_shard": c5_shard,
             "python_host": python_host, "parity": parity, "parity_split": parity_split, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

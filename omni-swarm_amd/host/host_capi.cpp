@@ -101,6 +101,15 @@ int omni_pipeline_get_edges(omni_pipeline* h, double* out, int max) {
     return (int)e.size();
 }
 
+// per-micro-batch latencies (ms, upload start -> detector / geometry done) recorded since the last call with reset != 0; returns how many exist
+int omni_pipeline_get_latencies(omni_pipeline* h, double* out, int max, int reset) {
+    const auto& l = h->p->latencies_ms();
+    const int n = (int)l.size();
+    for (int i = 0; i < n && i < max; ++i) out[i] = l[i];
+    if (reset) h->p->clear_latencies();
+    return n;
+}
+
 // FisheyeUndist's undistortion maps (host/fisheye_flatten.hpp).  mei = {xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0}.  Call with maps == NULL to get
 // n_views / view_w / view_h (arrays of >= 5), then with maps[v] pointing at view_w[v] * view_h[v] * 2 floats each.
 int omni_fisheye_maps(const double* mei, int img_width, double fov_deg, int cam_id, int* n_views, int* view_w, int* view_h, float* const* maps) {

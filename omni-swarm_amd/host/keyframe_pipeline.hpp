@@ -6,13 +6,57 @@
 // serially, one blocking engine call at a time.  This is the host loop bench.py times (through host_capi.cpp); Python only
 // prepares the synthetic inputs and brackets the run with the barrier.
 #pragma once
+#include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <future>
 #include <memory>
+#include <thread>
 
 #include "loop_geometry.hpp"
 #include "omni_swarm.hpp"
 
 namespace omni {
+
+// fixed pool of host threads for the geometry stage (one candidate per task)
+class TaskPool {
+public:
+    explicit TaskPool(int n) {
+        for (int i = 0; i < n; ++i)
+            workers_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [this] { return stop_ || !jobs_.empty(); });
+                        if (stop_ && jobs_.empty()) return;
+                        job = std::move(jobs_.front());
+                        jobs_.pop_front();
+                    }
+                    job();
+                }
+            });
+    }
+    ~TaskPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    template <typename F> auto submit(F&& f) -> std::future<decltype(f())> {
+        auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::forward<F>(f));
+        auto fut = task->get_future();
+        { std::lock_guard<std::mutex> lk(mu_); jobs_.emplace_back([task] { (*task)(); }); }
+        cv_.notify_one();
+        return fut;
+    }
+    int size() const { return (int)workers_.size(); }
+private:
+    std::vector<std::thread> workers_;
+    std::deque<std::function<void()>> jobs_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
 
 class KeyframePipeline {
 public:
@@ -36,18 +80,23 @@ public:
         for (int p = 0; p < c.pipelines; ++p) lanes_.push_back(std::make_unique<Lane>(c, c.microbatch));
         if (c.geometry) {
             geo_.self_id = c.self_id; geo_.MIN_LOOP_NUM = c.min_loop_num; geo_.MIN_DIRECTION_LOOP = c.min_direction_loop;
-            // compute_correspond_features matches up to four direction pairs per candidate (loop_detector.cpp:431-537): all of them in ONE GPU
-            // round trip, issued before the geometry runs; its per-pair match() calls are then served from that result (same matches: the
-            // matcher is a pure function of its two descriptor sets), anything else falls through to the single-pair call
-            geo_.match = [this](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) {
-                for (size_t p = 0; p < pre_pairs_.size(); ++p)
-                    if (pre_pairs_[p].query == q && pre_pairs_[p].train == t && pre_pairs_[p].nq == nq && pre_pairs_[p].nt == nt && pre_dim_ == dim) { out = pre_out_[p]; return; }
-                bf_.match(q, nq, t, nt, dim, out);
-            };
-            auto inner = geo_.as_callback([this](const LoopEdge& e) { edges_.push_back(e); });
-            det_.compute_loop = [this, inner](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) {
+            // Per candidate: (1) on this thread, the up to four direction pairs of compute_correspond_features (loop_detector.cpp:431-537) are
+            // matched in ONE GPU round trip (the matcher is a pure function of its two descriptor sets); (2) the rest of compute_loop -- flag
+            // filter, homography-RANSAC mask, PnP-RANSAC + refit, verification: f64, milliseconds -- runs as a task on a pool of host threads,
+            // its per-pair match() calls served from (1).  Tasks of one micro-batch run side by side; finish() collects them IN CANDIDATE ORDER,
+            // so edges, their ids and the on_loop order are those of the serial flow.  The detector itself only needs compute_loop's verdict for
+            // the init-mode counters of REMOTE drones (inter_drone_loop_count, loop_detector.cpp:66-72,826-827): candidates between two frames
+            // of the self drone are deferred, anything else is verified on the spot.
+            {
+                const char* e = getenv("OMNI_GEOMETRY_THREADS");
+                int nt = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+                if (nt > 0) pool_ = std::make_unique<TaskPool>(nt);
+            }
+            det_.compute_loop = [this](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) {
                 ++geometry_calls_;
-                pre_pairs_.clear(); pre_out_.clear(); pre_dim_ = 0;
+                auto pairs = std::make_shared<std::vector<BFMatcherL2X::Pair>>();
+                auto outs = std::make_shared<std::vector<std::vector<DMatch>>>();
+                int pdim = 0;
                 const int nd = geo_.MAX_DIRS;
                 for (int d = da; d < da + nd; ++d) {                   // the pairing rule of compute_correspond_features (frame pair)
                     const int dn = d % nd, dold = ((db - da + nd) % nd + d) % nd;
@@ -56,18 +105,46 @@ public:
                         const int nx = (int)x.landmarks_2d.size(), ny = (int)y.landmarks_2d.size();
                         if (nx > 0 && ny > 0 && x.feature_descriptor.size() % nx == 0) {
                             const int dim = (int)(x.feature_descriptor.size() / nx);
-                            if (pre_dim_ == 0) pre_dim_ = dim;
-                            if (dim == pre_dim_ && (int)y.feature_descriptor.size() == ny * dim)
-                                pre_pairs_.push_back({x.feature_descriptor.data(), nx, y.feature_descriptor.data(), ny});
+                            if (pdim == 0) pdim = dim;
+                            if (dim == pdim && (int)y.feature_descriptor.size() == ny * dim)
+                                pairs->push_back({x.feature_descriptor.data(), nx, y.feature_descriptor.data(), ny});
                         }
                     }
                 }
-                if (pre_pairs_.size() > 1) bf_.match_multi(pre_pairs_, pre_dim_, pre_out_); else pre_pairs_.clear();
-                const bool ok = inner(a, b, da, db, im);
-                pre_pairs_.clear(); pre_out_.clear();
-                return ok;
+                if (pairs->size() > 1) bf_.match_multi(*pairs, pdim, *outs); else pairs->clear();
+                // the geometry on a copy of the parameters whose matcher answers from the pairs matched above (anything else: the single-pair call,
+                // which only this thread may make)
+                auto work = [this, g0 = geo_, pairs, outs, pdim, &a, &b, da, db, im](bool may_use_gpu) {      // g0: copied HERE, on the detector's thread
+                    LoopGeometry g = g0;
+                    g.match = [&, may_use_gpu](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) {
+                        for (size_t p = 0; p < pairs->size(); ++p)
+                            if ((*pairs)[p].query == q && (*pairs)[p].train == t && (*pairs)[p].nq == nq && (*pairs)[p].nt == nt && pdim == dim) { out = (*outs)[p]; return; }
+                        if (!may_use_gpu) throw std::logic_error("geometry task: descriptor pair was not matched ahead");
+                        bf_.match(q, nq, t, nt, dim, out);
+                    };
+                    std::pair<bool, LoopEdge> r;
+                    r.first = g.compute_loop_core(a, b, da, db, r.second, im);
+                    return r;
+                };
+                const bool single_pair = pairs->empty();               // 0 or 1 usable direction pair: match() falls through to the GPU call
+                if (pool_ && !single_pair && a.drone_id == cfg_.self_id && b.drone_id == cfg_.self_id) {
+                    pending_.push_back(pool_->submit([work] { return work(false); }));
+                    return false;                                       // verdict deferred (see above); the edge is added by collect_geometry()
+                }
+                collect_geometry();                                     // keep the order: everything submitted earlier comes first
+                auto r = work(true);
+                if (r.first) { geo_.number_edge(r.second); edges_.push_back(r.second); }
+                return r.first;
             };
         }
+    }
+    // waits for the geometry tasks submitted so far and appends their accepted edges in submission order
+    void collect_geometry() {
+        for (auto& f : pending_) {
+            auto r = f.get();
+            if (r.first) { geo_.number_edge(r.second); edges_.push_back(r.second); }
+        }
+        pending_.clear();
     }
     int geometry_calls() const { return geometry_calls_; }
     const std::vector<LoopEdge>& edges() const { return edges_; }
@@ -134,14 +211,21 @@ public:
         for (int s = 0; s < full + (rem ? 1 : 0); ++s) {
             Lane* lane = s < full ? lanes_[s % lanes_.size()].get() : tail_lane;
             const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
+            lane->t_enqueue = std::chrono::steady_clock::now();
             if (from_host) lane->cam.enqueue_host(src, cfg_.width, true);
             else lane->cam.enqueue_dev(src, cfg_.width, true);
             pending.emplace_back(lane, first_msg_id + (int64_t)s * MB);
-            if (pending.size() >= lanes_.size()) { hits += finish(*pending.front().first, pending.front().second); pending.pop_front(); }
+            if (pending.size() >= lanes_.size()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         }
-        while (!pending.empty()) { hits += finish(*pending.front().first, pending.front().second); pending.pop_front(); }
+        while (!pending.empty()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         return hits;
     }
+
+    // latency of every micro-batch processed so far: from the start of its upload to the end of its detector / geometry step (milliseconds;
+    // every key frame of a micro-batch shares it).  The reference is batch-1 and serial (tensorrt_generic.cpp:58-75): a key frame there waits for
+    // nothing but its own 12 engine calls; here it waits for its micro-batch and for the micro-batches in flight before it.
+    const std::vector<double>& latencies_ms() const { return latencies_ms_; }
+    void clear_latencies() { latencies_ms_.clear(); }
 
     void sync() { for (auto& l : lanes_) l->sync(); for (auto& t : tail_lanes_) t.second->sync(); check(omni_ctx_sync(index_ctx_.get()), "sync"); }
 
@@ -168,6 +252,7 @@ private:
             check(omni_vlad_dev_output(vlad.handle(), &rows_dev), "omni_vlad_dev_output");
         }
         void sync() { check(omni_ctx_sync(sp_ctx.get()), "sync"); check(omni_ctx_sync(vlad_ctx.get()), "sync"); }
+        std::chrono::steady_clock::time_point t_enqueue;
         int mb;
         Context sp_ctx, vlad_ctx;
         Swarm::SuperPointHIP sp;
@@ -176,6 +261,11 @@ private:
         const float* rows_dev = nullptr;
     };
 
+    int finish_timed(Lane& lane, int64_t first_id) {
+        const int hits = finish(lane, first_id);
+        latencies_ms_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lane.t_enqueue).count());
+        return hits;
+    }
     // the micro-batch's key frames reach the detector in order, as one batch; rows and queries are taken from MobileNetVLAD's output
     // buffer in HBM ([4*mb][4096], key-frame major) -- wait() has synchronised with the MobileNetVLAD stream
     int finish(Lane& lane, int64_t first_id) {
@@ -235,6 +325,7 @@ private:
             if (c.found) { ++hits; candidates_.push_back({first_id + fi, c.old_msg_id, c.direction_new, c.direction_old}); }
             ++fi;
         }
+        collect_geometry();             // the tasks reference this micro-batch's frames (those not moved into the database live in frames_)
         frames_.clear();
         return hits;
     }
@@ -244,9 +335,9 @@ private:
     LoopDetectorCore det_;
     BFMatcherL2X bf_{index_ctx_};
     LoopGeometry geo_;
-    std::vector<BFMatcherL2X::Pair> pre_pairs_;            // descriptor pairs of the candidate being verified, matched ahead in one call
-    std::vector<std::vector<DMatch>> pre_out_;
-    int pre_dim_ = 0;
+    std::vector<double> latencies_ms_;
+    std::unique_ptr<TaskPool> pool_;
+    std::vector<std::future<std::pair<bool, LoopEdge>>> pending_;
     std::vector<LoopEdge> edges_;
     std::vector<Candidate> candidates_;
     std::vector<PoseMsg> poses_;

@@ -172,8 +172,10 @@ public:
     }
 
     // :627-836.  `old` must be a frame of the self drone (it provides the 2-D side); returns true and fills ret for an accepted loop.
-    bool compute_loop(const FisheyeFrameDescriptor& nw, const FisheyeFrameDescriptor& old, int main_dir_new, int main_dir_old, LoopEdge& ret, bool init_mode,
-                      Correspondence* out_corr = nullptr) {
+    // compute_loop = compute_loop_core (everything but the running edge id: const, safe to run for several candidates at once on copies of this
+    // object that differ only in `match`) + number_edge (the id `self_id * MAX_LOOP_ID + loop_count`, :804, in the order the loops are accepted)
+    bool compute_loop_core(const FisheyeFrameDescriptor& nw, const FisheyeFrameDescriptor& old, int main_dir_new, int main_dir_old, LoopEdge& ret, bool init_mode,
+                           Correspondence* out_corr = nullptr) const {
         if (nw.landmark_num < MIN_LOOP_NUM) return false;
         Correspondence c;
         bool success = compute_correspond_features(nw, old, main_dir_new, main_dir_old, c);
@@ -193,9 +195,13 @@ public:
         ret.keyframe_id_a = old.msg_id; ret.keyframe_id_b = nw.msg_id;
         for (int i = 0; i < 3; ++i) { ret.pos_cov[i] = loop_cov_pos; ret.ang_cov[i] = loop_cov_ang; }
         ret.pnp_inlier_num = inlier_num;
-        ret.id = (int64_t)self_id * MAX_LOOP_ID + loop_count;
-        if (!check_loop_odometry_consistency(ret)) return false;
-        ++loop_count;
+        return check_loop_odometry_consistency(ret);
+    }
+    void number_edge(LoopEdge& e) { e.id = (int64_t)self_id * MAX_LOOP_ID + loop_count; ++loop_count; }
+    bool compute_loop(const FisheyeFrameDescriptor& nw, const FisheyeFrameDescriptor& old, int main_dir_new, int main_dir_old, LoopEdge& ret, bool init_mode,
+                      Correspondence* out_corr = nullptr) {
+        if (!compute_loop_core(nw, old, main_dir_new, main_dir_old, ret, init_mode, out_corr)) return false;
+        number_edge(ret);
         return true;
     }
 

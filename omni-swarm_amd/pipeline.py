@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
            "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync",
-           "omni_pipeline_set_poses", "omni_pipeline_get_candidates", "omni_pipeline_get_edges"]
+           "omni_pipeline_set_poses", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
 _lib = None
 
 
@@ -46,6 +46,7 @@ def lib():
         L.omni_pipeline_set_poses.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]
         L.omni_pipeline_get_candidates.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
         L.omni_pipeline_get_edges.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        L.omni_pipeline_get_latencies.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -127,6 +128,13 @@ class KeyframePipeline:
         n = lib().omni_pipeline_get_edges(self.h, None, 0)
         out = np.zeros((max(n, 1), 12), np.float64)
         lib().omni_pipeline_get_edges(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return out[:n]
+
+    def latencies_ms(self, reset: bool = True) -> np.ndarray:
+        """latency of every micro-batch since the last reset: upload start -> detector (+ geometry) done, milliseconds"""
+        n = lib().omni_pipeline_get_latencies(self.h, None, 0, 0)
+        out = np.zeros(max(n, 1), np.float64)
+        lib().omni_pipeline_get_latencies(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), n, int(reset))
         return out[:n]
 
     def sync(self):

@@ -129,7 +129,9 @@ def test_rendered_scene_images_to_loop_edges_equal_the_oracle_chain_and_the_grou
     revisit_of = {i: plan[i][0] for i in range(N_PLACES, n)}                  # second visit i closes on first visit plan[i][0]
     assert {(int(a), int(b)) for a, b in cand[:, :2]} >= {(i, p) for i, p in revisit_of.items()}          # every revisit finds its first visit
     assert calls == len(cand)
-    assert len(edges) == n_edges == len(ref_edges) >= N_PLACES - 1, (len(edges), len(ref_edges))
+    got_list = [(int(e[0]), int(e[1]), int(e[4])) for e in edges]
+    ref_list = [(a, b, r["inliers"]) for a, b, r in ref_edges]
+    assert len(edges) == n_edges == len(ref_edges) >= N_PLACES - 1, (got_list, ref_list, cand.tolist())
     for e, (old_id, new_id, r) in zip(edges, ref_edges):
         assert (int(e[0]), int(e[1]), int(e[2]), int(e[3])) == (old_id, new_id, 1, 1)
         assert int(e[4]) == r["inliers"] and r["inliers"] > 100
