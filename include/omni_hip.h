@@ -246,6 +246,12 @@ int         omni_shard_preload_local(omni_shard* s, const float* rows_host, int6
  * query_row of that step and sees exactly the rows up to and including step f (add before query, loop_detector.cpp:89-98).  Two
  * ncclAllGather (rows; per-shard top-k), one pass over the shard, one D2H; D_host / I_host [F][k] = this rank's merged results. */
 int         omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k, float* D_host, int64_t* I_host);
+/* the same in two halves: _enqueue puts the whole unit -- both collectives, the scan, the copy of the lists to the host -- on the shard's stream
+ * WITHOUT waiting (the caller goes on enqueuing CNN work); _rows_consumed blocks until rows_dev has been gathered and may be overwritten;
+ * _wait blocks on the unit's completion event, merges this rank's results and moves the global row count.  One unit in flight at a time. */
+int         omni_shard_step_enqueue(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k);
+int         omni_shard_rows_consumed(omni_shard* s);
+int         omni_shard_step_wait(omni_shard* s, float* D_host, int64_t* I_host);
 /* collective: the same nq <= 64 queries on every rank -> the unsharded index's top-k on every rank */
 int         omni_shard_search(omni_shard* s, int nq, const float* q_host, int k, float* D, int64_t* I);
 

@@ -35,7 +35,7 @@ SYMBOLS = [
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
     "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
-    "omni_shard_unique_id", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev",
+    "omni_shard_unique_id", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait",
     "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
 
@@ -163,6 +163,9 @@ def lib():
     sig("omni_shard_ntotal", C.c_int64, [_vp])
     sig("omni_shard_preload_local", C.c_int, [_vp, _fp, C.c_int64, C.c_int64])
     sig("omni_shard_step_batch_dev", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _fp, _i64p])
+    sig("omni_shard_step_enqueue", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int])
+    sig("omni_shard_rows_consumed", C.c_int, [_vp])
+    sig("omni_shard_step_wait", C.c_int, [_vp, _fp, _i64p])
     sig("omni_shard_search", C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp, _i64p])
     if L.omni_abi_version() != 1:
         raise OmniError("libomni_hip.so ABI version mismatch")
@@ -650,6 +653,21 @@ class Shard:
         D = np.empty((F, k), np.float32)
         I = np.empty((F, k), np.int64)
         _check(lib().omni_shard_step_batch_dev(self.h, F, m, rows_dev, query_row, k, _pf(D), I.ctypes.data_as(_i64p)))
+        return D, I
+
+    def step_enqueue(self, F: int, m: int, rows_dev: int, query_row: int, k: int):
+        """asynchronous half of step_batch_dev: the whole exchange unit is put on the shard's stream, nothing is waited for"""
+        self._pend = (F, k)
+        _check(lib().omni_shard_step_enqueue(self.h, F, m, rows_dev, query_row, k))
+
+    def rows_consumed(self):
+        _check(lib().omni_shard_rows_consumed(self.h))
+
+    def step_wait(self):
+        F, k = self._pend
+        D = np.empty((F, k), np.float32)
+        I = np.empty((F, k), np.int64)
+        _check(lib().omni_shard_step_wait(self.h, _pf(D), I.ctypes.data_as(_i64p)))
         return D, I
 
     def search(self, q: np.ndarray, k: int):

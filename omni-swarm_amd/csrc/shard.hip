@@ -105,6 +105,12 @@ struct omni_shard {
     ncclComm_t comm = nullptr;
     omni::DevBuf all_rows, owned, send, recv, qrows;
     omni::HostBuf hrecv, hq;
+    // one exchange may be in flight (omni_shard_step_enqueue -> omni_shard_step_wait): its shape, the local row count to restore on failure, and
+    // two events on the shard's stream: e_rows = the caller's row buffer has been gathered (it may be overwritten), e_done = the lists are on the host
+    hipEvent_t e_rows = nullptr, e_done = nullptr;
+    bool pending = false;
+    int pend_F = 0, pend_m = 0, pend_k = 0;
+    int64_t pend_local_before = 0;
     std::mutex mu;
 };
 
@@ -130,6 +136,9 @@ omni_shard* omni_shard_create(omni_ctx* ctx, omni_index* local, int dim, int ran
     s->local = local; s->ctx = ctx; s->rank = rank; s->world = world; s->dim = dim;
     ncclUniqueId id;
     memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+    if (hipEventCreateWithFlags(&s->e_rows, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->e_done, hipEventDisableTiming) != hipSuccess) {
+        omni::set_error("hipEventCreate failed"); delete s; return nullptr;
+    }
     ncclResult_t r = rccl().CommInitRank(&s->comm, world, id, rank);
     if (r != ncclSuccess) { omni::set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r)); delete s; return nullptr; }
     return s;
@@ -140,6 +149,8 @@ void omni_shard_destroy(omni_shard* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->comm) (void)rccl().CommDestroy(s->comm);
+    if (s->e_rows) (void)hipEventDestroy(s->e_rows);
+    if (s->e_done) (void)hipEventDestroy(s->e_done);
     s->all_rows.release(); s->owned.release(); s->send.release(); s->recv.release(); s->qrows.release(); s->hrecv.release(); s->hq.release();
     delete s;
 }
@@ -174,11 +185,16 @@ static int merge_mine(const omni_shard* s, const char* h, int per_shard, int k, 
     return OMNI_OK;
 }
 
-int omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k, float* D_host, int64_t* I_host) {
-    OMNI_REQUIRE(s && rows_dev && D_host && I_host, OMNI_ERR_INVALID, "null argument");
+// One exchange unit, asynchronous half: everything up to the copy of the gathered lists to the host is ENQUEUED on the shard's stream (the
+// context stream of the local index: the detector's own stream, not one of the CNN streams) -- no host synchronisation, so the caller can go on
+// enqueuing the next micro-batch's CNN work while the collectives, the scan and the copy run.  omni_shard_rows_consumed() / omni_shard_step_wait()
+// are the two points where the host (or, through an event, another stream) meets it again.
+int omni_shard_step_enqueue(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k) {
+    OMNI_REQUIRE(s && rows_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(F >= 1 && m >= 1 && query_row >= 0 && query_row < m && k >= 1, OMNI_ERR_INVALID, "bad F/m/query_row/k");
     OMNI_REQUIRE((int64_t)F * s->world <= 4096, OMNI_ERR_CAPACITY, "F * world = %d queries per exchange is too many", F * s->world);
     std::lock_guard<std::mutex> lk(s->mu);
+    OMNI_REQUIRE(!s->pending, OMNI_ERR_INVALID, "an exchange is already in flight: call omni_shard_step_wait first");
     OMNI_REQUIRE(s->ntotal % s->world == 0, OMNI_ERR_INVALID, "global row count %lld is not a multiple of the world size", (long long)s->ntotal);
     (void)hipSetDevice(s->ctx->device);
     hipStream_t st = s->ctx->stream;
@@ -194,6 +210,7 @@ int omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev
     if ((rc = s->hrecv.ensure(list_bytes * W))) return rc;
     // 1. every rank's new rows
     OMNI_RCCL_TRY(rccl().AllGather(rows_dev, s->all_rows.p, mine, ncclFloat32, s->comm, st));
+    OMNI_HIP_TRY(hipEventRecord(s->e_rows, st));                 // rows_dev is free again from here on (stream order)
     // 2. append the rows this rank owns, in global-id order
     hipLaunchKernelGGL(shard_pick_rows_kernel, dim3(F * m), dim3(256), 0, st, s->all_rows.as<float>(), W, F, m, dim, s->rank, s->owned.as<float>());
     OMNI_LAUNCH_CHECK();
@@ -218,23 +235,58 @@ int omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev
                                                          reinterpret_cast<int64_t*>(sb) + (size_t)q0 * k)))
                 return rc;
         }
-        // 4. the per-shard lists of every query, to everybody
+        // 4. the per-shard lists of every query, to everybody, and on to the host
         OMNI_RCCL_TRY(rccl().AllGather(s->send.p, s->recv.p, list_bytes, ncclInt8, s->comm, st));
         OMNI_HIP_TRY(hipMemcpyAsync(s->hrecv.p, s->recv.p, list_bytes * W, hipMemcpyDeviceToHost, st));
-        OMNI_HIP_TRY(hipStreamSynchronize(st));
+        OMNI_HIP_TRY(hipEventRecord(s->e_done, st));
         return OMNI_OK;
     }();
     if (rc) { (void)omni_index_truncate(s->local, local_before); return rc; }
-    s->ntotal += (int64_t)F * W * m;
+    s->pending = true; s->pend_F = F; s->pend_m = m; s->pend_k = k; s->pend_local_before = local_before;
+    return OMNI_OK;
+}
+
+// blocks until the row buffer handed to the exchange in flight has been gathered (its first collective): the caller may overwrite it
+int omni_shard_rows_consumed(omni_shard* s) {
+    OMNI_REQUIRE(s, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->pending) return OMNI_OK;
+    (void)hipSetDevice(s->ctx->device);
+    OMNI_HIP_TRY(hipEventSynchronize(s->e_rows));
+    return OMNI_OK;
+}
+
+// second half: waits for the exchange in flight (an event, not the stream: later work on the stream is not waited for), merges the lists of
+// THIS rank's F queries (D_host, I_host: [F][k]) and moves the global row count
+int omni_shard_step_wait(omni_shard* s, float* D_host, int64_t* I_host) {
+    OMNI_REQUIRE(s && D_host && I_host, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OMNI_REQUIRE(s->pending, OMNI_ERR_INVALID, "no exchange in flight");
+    (void)hipSetDevice(s->ctx->device);
+    const int F = s->pend_F, W = s->world, k = s->pend_k;
+    s->pending = false;
+    if (hipEventSynchronize(s->e_done) != hipSuccess) {
+        (void)omni_index_truncate(s->local, s->pend_local_before);
+        omni::set_error("hipEventSynchronize failed while waiting for the exchange");
+        return OMNI_ERR_HIP;
+    }
+    s->ntotal += (int64_t)F * W * s->pend_m;
     // 5. merge the lists of MY queries (query f*W + rank)
     std::vector<int> which(F);
     for (int f = 0; f < F; ++f) which[f] = f * W + s->rank;
-    return merge_mine(s, s->hrecv.as<char>(), nq, k, which.data(), F, D_host, I_host);
+    return merge_mine(s, s->hrecv.as<char>(), F * W, k, which.data(), F, D_host, I_host);
+}
+
+int omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k, float* D_host, int64_t* I_host) {
+    OMNI_REQUIRE(s && rows_dev && D_host && I_host, OMNI_ERR_INVALID, "null argument");
+    const int rc = omni_shard_step_enqueue(s, F, m, rows_dev, query_row, k);
+    return rc ? rc : omni_shard_step_wait(s, D_host, I_host);
 }
 
 int omni_shard_search(omni_shard* s, int nq, const float* q_host, int k, float* D, int64_t* I) {
     OMNI_REQUIRE(s && q_host && D && I && nq >= 1 && nq <= 64 && k >= 1, OMNI_ERR_INVALID, "bad argument (1 <= nq <= 64)");
     std::lock_guard<std::mutex> lk(s->mu);
+    OMNI_REQUIRE(!s->pending, OMNI_ERR_INVALID, "an exchange is in flight: call omni_shard_step_wait first");
     (void)hipSetDevice(s->ctx->device);
     hipStream_t st = s->ctx->stream;
     const int W = s->world;

@@ -94,57 +94,75 @@ public:
             }
             det_.compute_loop = [this](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) {
                 ++geometry_calls_;
-                auto pairs = std::make_shared<std::vector<BFMatcherL2X::Pair>>();
-                auto outs = std::make_shared<std::vector<std::vector<DMatch>>>();
-                int pdim = 0;
-                const int nd = geo_.MAX_DIRS;
-                for (int d = da; d < da + nd; ++d) {                   // the pairing rule of compute_correspond_features (frame pair)
-                    const int dn = d % nd, dold = ((db - da + nd) % nd + d) % nd;
-                    if (dn < (int)a.images.size() && dold < (int)b.images.size() && b.images[dold].landmark_num > 0 && a.images[dn].landmark_num > 0) {
-                        const ImageDescriptor &x = a.images[dn], &y = b.images[dold];
-                        const int nx = (int)x.landmarks_2d.size(), ny = (int)y.landmarks_2d.size();
-                        if (nx > 0 && ny > 0 && x.feature_descriptor.size() % nx == 0) {
-                            const int dim = (int)(x.feature_descriptor.size() / nx);
-                            if (pdim == 0) pdim = dim;
-                            if (dim == pdim && (int)y.feature_descriptor.size() == ny * dim)
-                                pairs->push_back({x.feature_descriptor.data(), nx, y.feature_descriptor.data(), ny});
-                        }
-                    }
+                if (a.drone_id == cfg_.self_id && b.drone_id == cfg_.self_id) {      // verdict not needed by the detector: deferred to collect_geometry()
+                    deferred_.push_back({&a, &b, da, db, im});
+                    return false;
                 }
-                if (pairs->size() > 1) bf_.match_multi(*pairs, pdim, *outs); else pairs->clear();
-                // the geometry on a copy of the parameters whose matcher answers from the pairs matched above (anything else: the single-pair call,
-                // which only this thread may make)
-                auto work = [this, g0 = geo_, pairs, outs, pdim, &a, &b, da, db, im](bool may_use_gpu) {      // g0: copied HERE, on the detector's thread
-                    LoopGeometry g = g0;
-                    g.match = [&, may_use_gpu](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) {
-                        for (size_t p = 0; p < pairs->size(); ++p)
-                            if ((*pairs)[p].query == q && (*pairs)[p].train == t && (*pairs)[p].nq == nq && (*pairs)[p].nt == nt && pdim == dim) { out = (*outs)[p]; return; }
-                        if (!may_use_gpu) throw std::logic_error("geometry task: descriptor pair was not matched ahead");
-                        bf_.match(q, nq, t, nt, dim, out);
-                    };
-                    std::pair<bool, LoopEdge> r;
-                    r.first = g.compute_loop_core(a, b, da, db, r.second, im);
-                    return r;
-                };
-                const bool single_pair = pairs->empty();               // 0 or 1 usable direction pair: match() falls through to the GPU call
-                if (pool_ && !single_pair && a.drone_id == cfg_.self_id && b.drone_id == cfg_.self_id) {
-                    pending_.push_back(pool_->submit([work] { return work(false); }));
-                    return false;                                       // verdict deferred (see above); the edge is added by collect_geometry()
-                }
-                collect_geometry();                                     // keep the order: everything submitted earlier comes first
-                auto r = work(true);
-                if (r.first) { geo_.number_edge(r.second); edges_.push_back(r.second); }
-                return r.first;
+                collect_geometry();                                     // keep the order: everything deferred earlier comes first
+                deferred_.push_back({&a, &b, da, db, im});
+                const size_t before = edges_.size();
+                collect_geometry();
+                return edges_.size() > before;
             };
         }
     }
-    // waits for the geometry tasks submitted so far and appends their accepted edges in submission order
+    // The geometry of every deferred candidate: (1) ONE GPU round trip matches the direction pairs of all of them (compute_correspond_features
+    // pairs up to four directions per candidate, loop_detector.cpp:431-537; the matcher is a pure function of its two descriptor sets);
+    // (2) one task per candidate on the pool: flag filter, homography-RANSAC masks, PnP-RANSAC + refit, verification (f64), its match() calls
+    // served from (1); (3) the accepted edges are numbered and appended in candidate order.
     void collect_geometry() {
-        for (auto& f : pending_) {
-            auto r = f.get();
+        if (deferred_.empty()) return;
+        struct Prepared { size_t first = 0, count = 0; };
+        std::vector<BFMatcherL2X::Pair> pairs;
+        std::vector<Prepared> prep(deferred_.size());
+        int pdim = 0;
+        const int nd = geo_.MAX_DIRS;
+        for (size_t ci = 0; ci < deferred_.size(); ++ci) {
+            const FisheyeFrameDescriptor &a = *deferred_[ci].a, &b = *deferred_[ci].b;
+            const int da = deferred_[ci].da, db = deferred_[ci].db;
+            prep[ci].first = pairs.size();
+            for (int d = da; d < da + nd; ++d) {                       // the pairing rule of compute_correspond_features (frame pair)
+                const int dn = d % nd, dold = ((db - da + nd) % nd + d) % nd;
+                if (dn < (int)a.images.size() && dold < (int)b.images.size() && b.images[dold].landmark_num > 0 && a.images[dn].landmark_num > 0) {
+                    const ImageDescriptor &x = a.images[dn], &y = b.images[dold];
+                    const int nx = (int)x.landmarks_2d.size(), ny = (int)y.landmarks_2d.size();
+                    if (nx > 0 && ny > 0 && x.feature_descriptor.size() % nx == 0) {
+                        const int dim = (int)(x.feature_descriptor.size() / nx);
+                        if (pdim == 0) pdim = dim;
+                        if (dim == pdim && (int)y.feature_descriptor.size() == ny * dim) pairs.push_back({x.feature_descriptor.data(), nx, y.feature_descriptor.data(), ny});
+                    }
+                }
+            }
+            prep[ci].count = pairs.size() - prep[ci].first;
+        }
+        std::vector<std::vector<DMatch>> outs;
+        if (!pairs.empty()) bf_.match_multi(pairs, pdim, outs);
+        using Result = std::pair<bool, LoopEdge>;
+        std::vector<std::future<Result>> futs;
+        for (size_t ci = 0; ci < deferred_.size(); ++ci) {
+            auto mine_p = std::make_shared<std::vector<BFMatcherL2X::Pair>>(pairs.begin() + prep[ci].first, pairs.begin() + prep[ci].first + prep[ci].count);
+            auto mine_o = std::make_shared<std::vector<std::vector<DMatch>>>();
+            for (size_t j = 0; j < prep[ci].count; ++j) mine_o->push_back(std::move(outs[prep[ci].first + j]));
+            const Deferred c = deferred_[ci];
+            auto work = [g0 = geo_, mine_p, mine_o, pdim, c]() -> Result {      // g0: the parameters, copied on this thread
+                LoopGeometry g = g0;
+                g.match = [&](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) {
+                    for (size_t p = 0; p < mine_p->size(); ++p)
+                        if ((*mine_p)[p].query == q && (*mine_p)[p].train == t && (*mine_p)[p].nq == nq && (*mine_p)[p].nt == nt && pdim == dim) { out = (*mine_o)[p]; return; }
+                    out.clear();                                        // a pair the rule above did not list has no usable descriptors: no matches
+                };
+                Result r;
+                r.first = g.compute_loop_core(*c.a, *c.b, c.da, c.db, r.second, c.im);
+                return r;
+            };
+            if (pool_) futs.push_back(pool_->submit(work));
+            else { std::promise<Result> pr; pr.set_value(work()); futs.push_back(pr.get_future()); }
+        }
+        deferred_.clear();
+        for (auto& f : futs) {
+            Result r = f.get();
             if (r.first) { geo_.number_edge(r.second); edges_.push_back(r.second); }
         }
-        pending_.clear();
     }
     int geometry_calls() const { return geometry_calls_; }
     const std::vector<LoopEdge>& edges() const { return edges_; }
@@ -211,6 +229,7 @@ public:
         for (int s = 0; s < full + (rem ? 1 : 0); ++s) {
             Lane* lane = s < full ? lanes_[s % lanes_.size()].get() : tail_lane;
             const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
+            if (pend_lane_ == lane) check(omni_shard_rows_consumed(shard_), "omni_shard_rows_consumed");      // its row buffer is the exchange's input
             lane->t_enqueue = std::chrono::steady_clock::now();
             if (from_host) lane->cam.enqueue_host(src, cfg_.width, true);
             else lane->cam.enqueue_dev(src, cfg_.width, true);
@@ -218,6 +237,7 @@ public:
             if (pending.size() >= lanes_.size()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         }
         while (!pending.empty()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
+        hits += collect_exchange();
         return hits;
     }
 
@@ -261,6 +281,23 @@ private:
         const float* rows_dev = nullptr;
     };
 
+    // waits for the exchange in flight (if any) and applies the reference's rule (loop_detector.cpp:232: recency + threshold) on GLOBAL row ids
+    int collect_exchange() {
+        if (!pend_lane_) return 0;
+        const int k = LoopDetectorCore::SEARCH_NEAREST_NUM + cfg_.match_index_dist, mb = pend_mb_;
+        D_.resize((size_t)mb * k); I_.resize((size_t)mb * k);
+        pend_lane_ = nullptr;
+        check(omni_shard_step_wait(shard_, D_.data(), I_.data()), "omni_shard_step_wait");
+        int hits = 0;
+        for (int m = 0; m < mb; ++m) {
+            const int64_t nt = pend_base_ + (int64_t)(m + 1) * world_ * 4;          // ntotal as of this key frame's step
+            for (int j = 0; j < k; ++j) {
+                const int64_t id = I_[(size_t)m * k + j];
+                if (id >= 0 && id <= nt - cfg_.match_index_dist && D_[(size_t)m * k + j] > cfg_.inner_product_thres) { ++hits; break; }
+            }
+        }
+        return hits;
+    }
     int finish_timed(Lane& lane, int64_t first_id) {
         const int hits = finish(lane, first_id);
         latencies_ms_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lane.t_enqueue).count());
@@ -271,18 +308,12 @@ private:
     int finish(Lane& lane, int64_t first_id) {
         const omni_cam_result r = lane.cam.wait();
         if (shard_) {
+            // the exchange of THIS micro-batch is enqueued (two collectives, the scan, the copy of the lists: no host wait) and its results are
+            // collected when the NEXT micro-batch gets here (or at the end of run()): meanwhile the host enqueues the next CNN unit
+            int hits = collect_exchange();
             const int k = LoopDetectorCore::SEARCH_NEAREST_NUM + cfg_.match_index_dist;
-            D_.resize((size_t)lane.mb * k); I_.resize((size_t)lane.mb * k);
-            const int64_t base = omni_shard_ntotal(shard_);
-            check(omni_shard_step_batch_dev(shard_, lane.mb, 4, lane.rows_dev, 1, k, D_.data(), I_.data()), "omni_shard_step_batch_dev");
-            int hits = 0;
-            for (int m = 0; m < lane.mb; ++m) {
-                const int64_t nt = base + (int64_t)(m + 1) * world_ * 4;          // ntotal as of this key frame's step
-                for (int j = 0; j < k; ++j) {
-                    const int64_t id = I_[(size_t)m * k + j];
-                    if (id >= 0 && id <= nt - cfg_.match_index_dist && D_[(size_t)m * k + j] > cfg_.inner_product_thres) { ++hits; break; }
-                }
-            }
+            check(omni_shard_step_enqueue(shard_, lane.mb, 4, lane.rows_dev, 1, k), "omni_shard_step_enqueue");
+            pend_lane_ = &lane; pend_mb_ = lane.mb; pend_base_ = omni_shard_ntotal(shard_);
             return hits;
         }
         const int n = r.n_dirs, M = r.max_num, D = r.desc_dim;
@@ -304,7 +335,10 @@ private:
                 f.landmark_num += im.landmark_num;
                 if (cfg_.geometry) {
                     // the stereo half of generate_stereo_image_descriptor (loop_cam.cpp:341-454): the down image of this direction, lifting, triangulation
-                    ImageDescriptor down;
+                    // (one task per direction on the geometry pool: ~170 SVD triangulations each; joined before the frames reach the detector)
+                    if (downs_.size() < (size_t)4 * lane.mb) downs_.resize((size_t)4 * lane.mb);
+                    ImageDescriptor& down = downs_[(size_t)i];
+                    down = ImageDescriptor{};
                     const int j = n + i, nd = r.n_kps[j];
                     down.landmarks_2d.resize(nd);
                     for (int k = 0; k < nd; ++k) down.landmarks_2d[k] = {r.kps_xy[((size_t)j * M + k) * 2], r.kps_xy[((size_t)j * M + k) * 2 + 1]};
@@ -316,10 +350,15 @@ private:
                     im.pose_drone = down.pose_drone = f.pose_drone;
                     im.camera_extrinsic = to_msg(view_extrinsic(d, true)); down.camera_extrinsic = to_msg(view_extrinsic(d, false));
                     im.direction = d;
-                    fill_stereo_landmarks(im, down, r.match_up + (size_t)i * M, r.match_down + (size_t)i * M, r.n_matches[i], cfg_.triangle_thres, cfg_.accept_min_3d_pts);
+                    auto tri = [this, &im, &down, r, i, M] {
+                        fill_stereo_landmarks(im, down, r.match_up + (size_t)i * M, r.match_down + (size_t)i * M, r.n_matches[i], cfg_.triangle_thres, cfg_.accept_min_3d_pts);
+                    };
+                    if (pool_) stereo_tasks_.push_back(pool_->submit(tri)); else tri();
                 }
             }
         }
+        for (auto& t : stereo_tasks_) t.get();
+        stereo_tasks_.clear();
         int hits = 0, fi = 0;
         for (auto& c : det_.on_images_recv_batch(std::move(frames_), lane.rows_dev)) {
             if (c.found) { ++hits; candidates_.push_back({first_id + fi, c.old_msg_id, c.direction_new, c.direction_old}); }
@@ -337,7 +376,10 @@ private:
     LoopGeometry geo_;
     std::vector<double> latencies_ms_;
     std::unique_ptr<TaskPool> pool_;
-    std::vector<std::future<std::pair<bool, LoopEdge>>> pending_;
+    std::vector<ImageDescriptor> downs_;        // the down-camera halves of the micro-batch being finished
+    std::vector<std::future<void>> stereo_tasks_;
+    struct Deferred { const FisheyeFrameDescriptor *a, *b; int da, db; bool im; };
+    std::vector<Deferred> deferred_;            // candidates waiting for collect_geometry(): references into the database / the current micro-batch
     std::vector<LoopEdge> edges_;
     std::vector<Candidate> candidates_;
     std::vector<PoseMsg> poses_;
@@ -349,6 +391,9 @@ private:
     std::unique_ptr<IndexFlatIP> shard_index_;
     omni_shard* shard_ = nullptr;
     int world_ = 1;
+    Lane* pend_lane_ = nullptr;                 // the micro-batch whose exchange is in flight
+    int pend_mb_ = 0;
+    int64_t pend_base_ = 0;
     std::vector<float> D_;
     std::vector<int64_t> I_;
 };

@@ -131,6 +131,10 @@ def test_rendered_scene_images_to_loop_edges_equal_the_oracle_chain_and_the_grou
     assert calls == len(cand)
     got_list = [(int(e[0]), int(e[1]), int(e[4])) for e in edges]
     ref_list = [(a, b, r["inliers"]) for a, b, r in ref_edges]
+    if got_list != ref_list:                                                  # leave the evidence where a GPU-box run can be read back from
+        import json, os
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump({"product": got_list, "oracle": ref_list, "candidates": cand.tolist(), "plan": [(p, rv, sg) for p, rv, sg, _ in plan]}, open("gpurun_out/e2e_debug.json", "w"))
     assert len(edges) == n_edges == len(ref_edges) >= N_PLACES - 1, (got_list, ref_list, cand.tolist())
     for e, (old_id, new_id, r) in zip(edges, ref_edges):
         assert (int(e[0]), int(e[1]), int(e[2]), int(e[3])) == (old_id, new_id, 1, 1)
