@@ -168,7 +168,10 @@ def main():
     MATCH_INDEX_DIST, QUERY_THRES, INIT_THRES = 5, 0.3, 0.2   # launch values
     K_SEARCH = 5 + MATCH_INDEX_DIST
     MB = max(1, args.microbatch)
-    cpp_host = args.host == "cpp" and (world == 1 or not one_gpu)      # N > 1: C++ loop + RCCL inside the library; gloo bring-up stays Python
+    # N > 1: C++ loop + RCCL inside the library.  The one-GPU bring-up (gloo for the torch side) stays on the Python loop unless OMNI_RCCL_LIB
+    # points the library at the single-GPU stand-in for librccl (tests/stub_rccl): then the REAL N > 1 flow of this file -- the C++ loop on
+    # omni_shard_*, the unique id broadcast, barriers, MAX over ranks -- runs with every rank on GPU 0: a rehearsal, not a scaling number
+    cpp_host = args.host == "cpp" and (world == 1 or not one_gpu or bool(os.environ.get("OMNI_RCCL_LIB")))
 
     sp_w = weights.superpoint_synth_weights(0)
     comp, mean = synth.pca()
@@ -504,7 +507,7 @@ def main():
             for s in range(0, rows_here, 32768):
                 midx.add(gen.rows(min(32768, rows_here - s)))
         mq = RowFactory(99).rows(1)
-        native_p50 = world > 1 and not one_gpu and cpp_host
+        native_p50 = world > 1 and cpp_host
         if world > 1 and not native_p50:
             big = shard.ShardedIndex(midx, rank, world, dist, coll_dev)
             for s in range(0, rows_here, 32768):

@@ -562,6 +562,7 @@ struct Fuse1aArgs {
     const uint32_t* lut_hl;       // [256] half(x) | half(x - half(x)) << 16,  x = float(double(i) * (1.0 / 255.0))
     unsigned long long* trace;    // OMNI_PP_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
     const char* zero_page;        // OMNI_ZERO_PAGE_BYTES of zeros: DMA source of the halo pixels outside the image (set by the launcher)
+    uint32_t magic_tpi, magic_tx; // ceil(2^32 / tiles_per_img), ceil(2^32 / tiles_x) (set by the launcher)
 };
 
 template <bool POOL, int ABL, bool FUSE1A>
@@ -598,10 +599,14 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         }
     const uint32_t a_base0 = lds0 + lane * 16, a_base1 = a_base0 + 18 * 2048;
 
+    // t / tiles_per_img and r / tiles_x by multiply-high with ceil(2^32 / d) (exact while t * d < 2^32: the launcher checks): the service phase
+    // calls this three times per tile, next to a partner wave that leaves it few issue slots -- two hardware-less integer divisions each were
+    // ~200 instructions per phase
     auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
-        b = t / tiles_per_img;
+        b = fz.magic_tpi ? (int)__umulhi((uint32_t)t, fz.magic_tpi) : t;             // magic 0 = divisor 1 (2^32 does not fit)
         const int r = t - b * tiles_per_img;
-        ty0 = (r / tiles_x) * CONV_TH; tx0 = (r % tiles_x) * CONV_TW;
+        const int ry = fz.magic_tx ? (int)__umulhi((uint32_t)r, fz.magic_tx) : r;
+        ty0 = ry * CONV_TH; tx0 = (r - ry * tiles_x) * CONV_TW;
     };
     // per-lane source offsets (bytes, relative to the halo origin) of this wave's 11 DMA instructions, valid for interior tiles
     uint32_t goff[11];
@@ -688,7 +693,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         pv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (b * H + yy) * fz.gstride + xo, 0, 0);
     };
     // table reads and operand packing of all three fragments first (their latencies overlap), then MFMAs + stores per fragment
-    auto build_finish = [&](int t, uint32_t pv) {
+    auto build_finish = [&](int t, uint32_t pv, unsigned long long* stamp = nullptr) {
         int b, ty0, tx0;
         tile_origin(t, b, ty0, tx0);
         const int cx0 = (tx0 - 2) & ~3, xsh = (tx0 - 2) - cx0;
@@ -735,32 +740,45 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
             B0[fi] = __builtin_bit_cast(half8_t, make_uint4(T[0], T[1], T[2], T[3]));
             B1[fi] = __builtin_bit_cast(half8_t, make_uint4(b1[0], b1[1], b1[2], b1[3]));
         }
+        if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();                  // operands of all three fragments packed (patch landed, table read)
+        // all 12 MFMAs of the wave's three fragments first -- the six of K step 0, then the six of K step 1, each depending on one issued six
+        // instructions earlier -- and only then the conversions: one fragment at a time left every ReLU / pack waiting for the matrix pipe
+        // (~250 cycles per fragment; the accumulators of the tile just written back are free registers here).
+        // The partner wave streams MFMAs back to back at priority 2: without outranking it for these twelve, each of them waits for a gap in a
+        // matrix pipe that has none
+        floatx16 a1[3][2];
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) {
+            if (fi >= nf) continue;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a1[fi][m][i] = 0.f;
+                a1[fi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][m], B0[fi], a1[fi][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) {
+            if (fi >= nf) continue;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a1[fi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][m], B1[fi], a1[fi][m], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();                  // the twelve MFMAs issued
 #pragma unroll
         for (int fi = 0; fi < 3; ++fi) {
             if (fi >= nf) continue;
             const int p = (3 * wl + fi) * 32 + n;
             const uint32_t sw = (uint32_t)((p >> 1) & 7);
             char* const prow = buf + p * 128 + 8 * hh;
-            floatx16 a1[2];
-            // the partner wave streams MFMAs back to back at priority 2: without outranking it for these four, each of them
-            // waits for a gap in a matrix pipe that has none
-            __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) a1[m][i] = 0.f;
-                a1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][m], B0[fi], a1[m], 0, 0, 0);
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m) a1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][m], B1[fi], a1[m], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
             if (p < C64_PIX) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
                         *reinterpret_cast<uint2*>(prow + (((uint32_t)(m * 4 + gq) ^ sw) << 4)) =
-                            make_uint2(pack_relu_f16(a1[m][4 * gq + 0], a1[m][4 * gq + 1], 1), pack_relu_f16(a1[m][4 * gq + 2], a1[m][4 * gq + 3], 1));
+                            make_uint2(pack_relu_f16(a1[fi][m][4 * gq + 0], a1[fi][m][4 * gq + 1], 1), pack_relu_f16(a1[fi][m][4 * gq + 2], a1[fi][m][4 * gq + 3], 1));
             }
         }
     };
@@ -868,7 +886,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
             }
             if (tr) fz.trace[p * 8 + 2] = __builtin_amdgcn_s_memtime();
             if (load && FUSE1A) {
-                if constexpr (FUSE1A) build_finish(wg + k_load * nwg, pv);
+                if constexpr (FUSE1A) build_finish(wg + k_load * nwg, pv, tr ? fz.trace + p * 8 + 6 : nullptr);
                 if (tr) fz.trace[p * 8 + 3] = __builtin_amdgcn_s_memtime();
                 k_load += 2;
             } else if (load) {
@@ -904,6 +922,9 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
     OMNI_REQUIRE(a.zero_page, OMNI_ERR_INVALID, "conv: ConvArgs.zero_page is not set");
     Fuse1aArgs fzz = fz;
     fzz.zero_page = reinterpret_cast<const char*>(a.zero_page);
+    OMNI_REQUIRE((int64_t)total * (tiles_x * tiles_y) < (1ll << 32), OMNI_ERR_INVALID, "conv: too many tiles for the multiply-high division");
+    fzz.magic_tpi = (uint32_t)(((1ull << 32) + (uint64_t)(tiles_x * tiles_y) - 1) / (uint64_t)(tiles_x * tiles_y));
+    fzz.magic_tx = (uint32_t)(((1ull << 32) + (uint64_t)tiles_x - 1) / (uint64_t)tiles_x);
     hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), smem_bytes, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
                        tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg, fzz);
@@ -1368,9 +1389,9 @@ int conv1ab_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gs
         static int printed = 0;
         if (printed++ == 20)
             for (int p = 2; p < 6; ++p)
-                fprintf(stderr, "pp trace phase %d: service start %llu issue +%llu epilogue +%llu build +%llu | mfma loop %llu cycles (start +%lld vs service start)\n", p,
-                        h[p * 8], h[p * 8 + 1] - h[p * 8], h[p * 8 + 2] - h[p * 8 + 1], h[p * 8 + 3] - h[p * 8 + 2], h[p * 8 + 5] - h[p * 8 + 4],
-                        (long long)(h[p * 8 + 4] - h[p * 8]));
+                fprintf(stderr, "pp trace phase %d: service start %llu issue +%llu epilogue +%llu build +%llu (operands ready +%llu, first fragment +%llu) | mfma loop %llu cycles (start +%lld vs service start)\n", p,
+                        h[p * 8], h[p * 8 + 1] - h[p * 8], h[p * 8 + 2] - h[p * 8 + 1], h[p * 8 + 3] - h[p * 8 + 2], h[p * 8 + 6] - h[p * 8 + 2], h[p * 8 + 7] - h[p * 8 + 6],
+                        h[p * 8 + 5] - h[p * 8 + 4], (long long)(h[p * 8 + 4] - h[p * 8]));
     }
     return rc;
 }
