@@ -1,17 +1,19 @@
 #!/bin/bash
 # Run on the MI355X box (via gpurun): kernel trace + PMC passes of the default bench workload.
-#   tools/profile_gpu.sh <tag>        -> gpurun_out/<tag>_*  (summaries are copied into profiles/ by hand afterwards)
+#   tools/profile_gpu.sh <tag> [extra bench.py arguments, e.g. --precision split]   -> gpurun_out/<tag>_*  (summaries are copied into profiles/ by hand afterwards)
 # PMC passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa traces).
 set -u
 TAG=${1:-r01x}
+shift
+EXTRA="$*"
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-db-keyframes 0"
+LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-db-keyframes 0 --parity-steps 0 --c5-rows 0 $EXTRA"
 BENCH="python bench.py --steps 40 --warmup 8 --min-time 0 $LEGS"
 BENCH_PMC="python bench.py --steps 8 --warmup 8 --min-time 0 --match-db-rows 100000 $LEGS"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ${TAG} -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.err
-python tools/rocprof_summary.py $(ls $OUT/${TAG}_trace/*_results.db $OUT/${TAG}_trace/*/*_results.db 2>/dev/null | head -1) "(${TAG}; $BENCH; f16; 1x MI355X)" > $OUT/${TAG}_kernel_stats.md 2>> $OUT/${TAG}_trace.err
+python tools/rocprof_summary.py $(ls $OUT/${TAG}_trace/*_results.db $OUT/${TAG}_trace/*/*_results.db 2>/dev/null | head -1) "(${TAG}; $BENCH; 1x MI355X)" > $OUT/${TAG}_kernel_stats.md 2>> $OUT/${TAG}_trace.err
 i=0
 for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
