@@ -71,14 +71,15 @@ def pmc_traffic(key):
     `tools/profile_gpu.sh` output: bench.py cannot collect PMC counters on itself).  None when no profile is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
-        return None
-    try:
-        t = json.load(open(files[-1]))
-        return {"bytes_per_launch": t[key]["bytes_per_launch"], "images_per_launch": t[key].get("images_per_launch"),
-                "source": os.path.relpath(files[-1], ROOT)}
-    except Exception:
-        return None
+    for f in reversed(files):                      # the newest pass that profiled this kernel (passes differ in precision / legs)
+        try:
+            t = json.load(open(f))
+            if key in t:
+                return {"bytes_per_launch": t[key]["bytes_per_launch"], "images_per_launch": t[key].get("images_per_launch"),
+                        "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
 def parse():
@@ -490,7 +491,8 @@ def main():
                                           "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 "
                                           "in one launch; FLOP counted for conv1b only", "achieved": round(achieved, 1),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                **traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", args.precision == "f16", n_img),
+                **(traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", args.precision == "f16", n_img) if args.precision != "split" else
+                   traffic_fields("conv3x3_split_kernel<cin64,POOL> (conv1b: the larger half of the launches)", True, n_img)),
                 "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
                 "conv_stack_tflops": round(sp_flop_executed(args.precision, MAXN, True) * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
                 "conv_stack_note": "FLOP executed by the stages named conv* (fp16 path: without convDa / convDb, which run only at the cells around the key points "
