@@ -11,9 +11,9 @@
 // multiply-with-carry generator, getSubset re-draw rule, RANSACUpdateNumIters, inlier test err <= thresh^2 in float) and the homography
 // kernel (Hartley-normalised DLT through the 9x9 LtL eigen-decomposition, collinearity + orientation checkSubset) are restated from the
 // published OpenCV 3.4 sources (modules/calib3d/src/ptsetreg.cpp, fundam.cpp); only the inlier MASK of findHomography is consumed by the
-// reference, so the LM refinement of H is not needed.  solvePnPRansac deviates by spec: OpenCV's minimal kernel is EPnP on 5 points, here
-// it is a 6-point DLT + orthogonal projection; the final pose is, as in OpenCV (SOLVEPNP_ITERATIVE), the Levenberg-Marquardt least-squares
-// refit on the inlier set started from a DLT -- the same objective, so the converged poses agree to solver tolerance.
+// reference, so the LM refinement of H is not needed.  solvePnPRansac (round 3): the minimal kernel is EPnP on 5 points restated from OpenCV's
+// epnp.cpp, the final pose is, as in OpenCV (SOLVEPNP_ITERATIVE), the Levenberg-Marquardt least-squares refit on the inlier set started from
+// a DLT (cvFindExtrinsicCameraParams2's own start for >= 6 non-coplanar points).
 // swarm_msgs (Swarm::Pose, DeltaPose, quat2eulers) is un-vendored too; the definitions below are the conventional ones the call sites
 // imply (pose composition p*q, DeltaPose(a,b) = a^-1 b or its yaw-only form, ZYX Euler angles).
 #pragma once
@@ -430,16 +430,216 @@ inline void pnp_refine(const std::vector<Vec3>& X, const std::vector<Vec2>& u, c
         if (!improved) return;
     }
 }
+// ---- EPnP (Lepetit, Moreno-Noguer, Fua 2009) as OpenCV 3.4 implements it (modules/calib3d/src/epnp.cpp) with K = I: the minimal solver of
+// cv::solvePnPRansac (5 points, SOLVEPNP_EPNP).  Steps and names follow epnp.cpp: choose_control_points, compute_barycentric_coordinates,
+// fill_M, the four null vectors of M^T M, compute_L_6x10 / compute_rho, find_betas_approx_1..3 + gauss_newton, compute_R_and_t (Arun's
+// alignment), best of the three by reprojection error.  Where an SVD's output is not unique the choice is fixed (eigenvector signs: largest
+// component positive; the two-dimensional null space of a 5-point M: the Gram-Schmidt of its projections of e0, e1, ...) so that this code and the
+// numpy oracle walk the same numbers.
+inline Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// M = U diag(s) V^T through the eigen-decomposition of M^T M (s descending; U, V as columns)
+inline void svd3(const Mat3& M, Mat3& U, double s[3], Mat3& V) {
+    double A[3][3], W[3], E[3][3];
+    const Mat3 MtM = M.T() * M;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = MtM.m[i][j];
+    jacobi_eigen<3>(A, W, E);
+    Vec3 v[3], u[3];
+    for (int i = 0; i < 3; ++i) { v[i] = {E[i][0], E[i][1], E[i][2]}; s[i] = std::sqrt(std::max(W[i], 0.0)); }
+    for (int i = 0; i < 2; ++i) u[i] = s[i] > 1e-300 ? (1.0 / s[i]) * (M * v[i]) : Vec3{i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, 0};
+    u[2] = cross(u[0], u[1]);
+    if (s[2] > 1e-12 * std::max(s[0], 1e-300)) { const Vec3 m2 = (1.0 / s[2]) * (M * v[2]); if (dot(u[2], m2) < 0) u[2] = -1.0 * u[2]; }
+    for (int i = 0; i < 3; ++i) { U.m[0][i] = u[i].x; U.m[1][i] = u[i].y; U.m[2][i] = u[i].z; V.m[0][i] = v[i].x; V.m[1][i] = v[i].y; V.m[2][i] = v[i].z; }
+}
+// least squares x = argmin |A x - b| for a ROWS x N system (N <= 5) through the eigen-decomposition of A^T A (pseudo-inverse: eigenvalues below
+// 1e-26 x the largest count as zero -- numpy.linalg.lstsq's cut-off on the singular values, squared)
+template <int ROWS, int N>
+inline void lstsq_small(const double (&A)[ROWS][N], const double (&b)[ROWS], double (&x)[N]) {
+    double AtA[N][N], Atb[N], W[N], V[N][N];
+    for (int i = 0; i < N; ++i) { Atb[i] = 0; for (int r = 0; r < ROWS; ++r) Atb[i] += A[r][i] * b[r]; for (int j = 0; j < N; ++j) { AtA[i][j] = 0; for (int r = 0; r < ROWS; ++r) AtA[i][j] += A[r][i] * A[r][j]; } }
+    jacobi_eigen<N>(AtA, W, V);
+    for (int i = 0; i < N; ++i) x[i] = 0;
+    for (int k = 0; k < N; ++k) {
+        if (!(W[k] > 1e-26 * std::max(W[0], 1e-300))) continue;
+        double c = 0;
+        for (int i = 0; i < N; ++i) c += V[k][i] * Atb[i];
+        c /= W[k];
+        for (int i = 0; i < N; ++i) x[i] += c * V[k][i];
+    }
+}
+inline bool epnp(const std::vector<Vec3>& X, const std::vector<Vec2>& u, const int* idx, int n, Rt& out) {
+    if (n < 4 || n > 64) return false;
+    Vec3 P[64]; Vec2 q[64];
+    for (int i = 0; i < n; ++i) { P[i] = X[idx[i]]; q[i] = u[idx[i]]; }
+    // choose_control_points: the centroid and the principal axes scaled by sqrt(eigenvalue / n)
+    Vec3 c0;
+    for (int i = 0; i < n; ++i) c0 = c0 + P[i];
+    c0 = (1.0 / n) * c0;
+    double C[3][3] = {}, dc[3], uct[3][3];
+    for (int i = 0; i < n; ++i) { const double d[3] = {P[i].x - c0.x, P[i].y - c0.y, P[i].z - c0.z}; for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a][b] += d[a] * d[b]; }
+    jacobi_eigen<3>(C, dc, uct);
+    Vec3 cws[4];
+    cws[0] = c0;
+    for (int i = 0; i < 3; ++i) {
+        int big = 0;
+        for (int k = 1; k < 3; ++k) if (std::fabs(uct[i][k]) > std::fabs(uct[i][big])) big = k;
+        const double sg = uct[i][big] < 0 ? -1.0 : 1.0, k = std::sqrt(std::max(dc[i], 0.0) / n);
+        cws[i + 1] = c0 + (sg * k) * Vec3{uct[i][0], uct[i][1], uct[i][2]};
+    }
+    // compute_barycentric_coordinates: pseudo-inverse of [c1-c0 | c2-c0 | c3-c0] (cvInvert(..., CV_SVD): coplanar points give rank 2)
+    Mat3 CC;
+    for (int j = 0; j < 3; ++j) { const Vec3 d = cws[j + 1] - cws[0]; CC.m[0][j] = d.x; CC.m[1][j] = d.y; CC.m[2][j] = d.z; }
+    Mat3 CCinv;
+    {
+        double A[3][3], W[3], V[3][3];
+        const Mat3 CtC = CC.T() * CC;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = CtC.m[i][j];
+        jacobi_eigen<3>(A, W, V);
+        Mat3 S;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            S.m[i][j] = 0;
+            for (int k = 0; k < 3; ++k) if (W[k] > 1e-20 * std::max(W[0], 1e-300)) S.m[i][j] += V[k][i] * V[k][j] / W[k];
+        }
+        CCinv = S * CC.T();
+    }
+    double al[64][4];
+    for (int i = 0; i < n; ++i) {
+        const Vec3 a = CCinv * (P[i] - cws[0]);
+        al[i][1] = a.x; al[i][2] = a.y; al[i][3] = a.z; al[i][0] = 1.0 - a.x - a.y - a.z;
+    }
+    // fill_M (fu = fv = 1, uc = vc = 0) and M^T M
+    double MtM[12][12] = {}, Wm[12], Vm[12][12];
+    for (int i = 0; i < n; ++i) {
+        double m1[12], m2[12];
+        for (int j = 0; j < 4; ++j) { m1[3 * j] = al[i][j]; m1[3 * j + 1] = 0; m1[3 * j + 2] = -al[i][j] * q[i].x; m2[3 * j] = 0; m2[3 * j + 1] = al[i][j]; m2[3 * j + 2] = -al[i][j] * q[i].y; }
+        for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) MtM[a][b] += m1[a] * m1[b] + m2[a] * m2[b];
+    }
+    jacobi_eigen<12>(MtM, Wm, Vm);
+    double v[4][12];
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 12; ++k) v[i][k] = Vm[11 - i][k];          // v[0] = the smallest eigenvalue's vector
+    if (n == 5) {                                                                         // canonical basis of the two-dimensional null space
+        double Pn[12][12];
+        for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) Pn[a][b] = v[0][a] * v[0][b] + v[1][a] * v[1][b];
+        double basis[2][12];
+        int nb = 0;
+        for (int k = 0; k < 12 && nb < 2; ++k) {
+            double c[12];
+            for (int a = 0; a < 12; ++a) c[a] = Pn[a][k];
+            for (int b = 0; b < nb; ++b) { double d = 0; for (int a = 0; a < 12; ++a) d += c[a] * basis[b][a]; for (int a = 0; a < 12; ++a) c[a] -= d * basis[b][a]; }
+            double nr = 0;
+            for (int a = 0; a < 12; ++a) nr += c[a] * c[a];
+            nr = std::sqrt(nr);
+            if (nr > 1e-3) { for (int a = 0; a < 12; ++a) basis[nb][a] = c[a] / nr; ++nb; }
+        }
+        if (nb == 2) for (int a = 0; a < 12; ++a) { v[0][a] = basis[0][a]; v[1][a] = basis[1][a]; }
+    }
+    for (int i = 0; i < 4; ++i) {
+        int big = 0;
+        for (int k = 1; k < 12; ++k) if (std::fabs(v[i][k]) > std::fabs(v[i][big])) big = k;
+        if (v[i][big] < 0) for (int k = 0; k < 12; ++k) v[i][k] = -v[i][k];
+    }
+    // compute_L_6x10, compute_rho
+    static const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    double L[6][10], rho[6];
+    for (int r = 0; r < 6; ++r) {
+        double d[4][3];
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 3; ++k) d[i][k] = v[i][3 * pa[r] + k] - v[i][3 * pb[r] + k];
+        auto dt = [&](int a, int b) { return d[a][0] * d[b][0] + d[a][1] * d[b][1] + d[a][2] * d[b][2]; };
+        const double row[10] = {dt(0, 0), 2 * dt(0, 1), dt(1, 1), 2 * dt(0, 2), 2 * dt(1, 2), dt(2, 2), 2 * dt(0, 3), 2 * dt(1, 3), 2 * dt(2, 3), dt(3, 3)};
+        for (int k = 0; k < 10; ++k) L[r][k] = row[k];
+        const Vec3 dd = cws[pa[r]] - cws[pb[r]];
+        rho[r] = dot(dd, dd);
+    }
+    auto gauss_newton = [&](double (&be)[4]) {
+        for (int it = 0; it < 5; ++it) {
+            double A[6][4], bb[6], x[4];
+            for (int r = 0; r < 6; ++r) {
+                const double* l = L[r];
+                A[r][0] = 2 * l[0] * be[0] + l[1] * be[1] + l[3] * be[2] + l[6] * be[3];
+                A[r][1] = l[1] * be[0] + 2 * l[2] * be[1] + l[4] * be[2] + l[7] * be[3];
+                A[r][2] = l[3] * be[0] + l[4] * be[1] + 2 * l[5] * be[2] + l[8] * be[3];
+                A[r][3] = l[6] * be[0] + l[7] * be[1] + l[8] * be[2] + 2 * l[9] * be[3];
+                bb[r] = rho[r] - (l[0] * be[0] * be[0] + l[1] * be[0] * be[1] + l[2] * be[1] * be[1] + l[3] * be[0] * be[2] + l[4] * be[1] * be[2] + l[5] * be[2] * be[2] +
+                                  l[6] * be[0] * be[3] + l[7] * be[1] * be[3] + l[8] * be[2] * be[3] + l[9] * be[3] * be[3]);
+            }
+            lstsq_small<6, 4>(A, bb, x);
+            for (int k = 0; k < 4; ++k) be[k] += x[k];
+        }
+    };
+    // compute_R_and_t: control points in the camera frame from the betas, sign from the first point's depth, Arun's alignment, reprojection error
+    auto r_and_t = [&](const double (&be)[4], Rt& rt) -> double {
+        Vec3 ccs[4];
+        for (int j = 0; j < 4; ++j) { double c[3] = {0, 0, 0}; for (int i = 0; i < 4; ++i) for (int k = 0; k < 3; ++k) c[k] += be[i] * v[i][3 * j + k]; ccs[j] = {c[0], c[1], c[2]}; }
+        Vec3 pcs[64];
+        for (int i = 0; i < n; ++i) { Vec3 p; for (int j = 0; j < 4; ++j) p = p + al[i][j] * ccs[j]; pcs[i] = p; }
+        if (pcs[0].z < 0) { for (int j = 0; j < 4; ++j) ccs[j] = -1.0 * ccs[j]; for (int i = 0; i < n; ++i) pcs[i] = -1.0 * pcs[i]; }
+        Vec3 pc0, pw0;
+        for (int i = 0; i < n; ++i) { pc0 = pc0 + pcs[i]; pw0 = pw0 + P[i]; }
+        pc0 = (1.0 / n) * pc0; pw0 = (1.0 / n) * pw0;
+        Mat3 ABt;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) ABt.m[a][b] = 0;
+        for (int i = 0; i < n; ++i) {
+            const Vec3 a = pcs[i] - pc0, b = P[i] - pw0;
+            const double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) ABt.m[r][c] += av[r] * bv[c];
+        }
+        Mat3 U, V;
+        double sv[3];
+        svd3(ABt, U, sv, V);
+        rt.R = U * V.T();
+        if (det(rt.R) < 0) for (int c = 0; c < 3; ++c) rt.R.m[2][c] = -rt.R.m[2][c];
+        rt.t = pc0 - rt.R * pw0;
+        double sum = 0;
+        for (int i = 0; i < n; ++i) { const Vec3 c = rt.R * P[i] + rt.t; const double dx = c.x / c.z - q[i].x, dy = c.y / c.z - q[i].y; sum += std::sqrt(dx * dx + dy * dy); }
+        return sum / n;
+    };
+    bool have = false;
+    double best_err = 0;
+    for (int ap = 1; ap <= 3; ++ap) {
+        double be[4] = {0, 0, 0, 0};
+        bool ok = true;
+        if (ap == 1) {                                         // betas10 columns (B11 B12 B13 B14)
+            double A[6][4], x[4];
+            for (int r = 0; r < 6; ++r) { A[r][0] = L[r][0]; A[r][1] = L[r][1]; A[r][2] = L[r][3]; A[r][3] = L[r][6]; }
+            lstsq_small<6, 4>(A, rho, x);
+            const double b0 = std::sqrt(std::fabs(x[0])), sg = x[0] < 0 ? -1.0 : 1.0;
+            if (!(b0 > 0)) ok = false;
+            else { be[0] = b0; be[1] = sg * x[1] / b0; be[2] = sg * x[2] / b0; be[3] = sg * x[3] / b0; }
+        } else if (ap == 2) {                                  // (B11 B12 B22)
+            double A[6][3], x[3];
+            for (int r = 0; r < 6; ++r) { A[r][0] = L[r][0]; A[r][1] = L[r][1]; A[r][2] = L[r][2]; }
+            lstsq_small<6, 3>(A, rho, x);
+            if (x[0] < 0) { be[0] = std::sqrt(-x[0]); be[1] = x[2] < 0 ? std::sqrt(-x[2]) : 0.0; }
+            else { be[0] = std::sqrt(x[0]); be[1] = x[2] > 0 ? std::sqrt(x[2]) : 0.0; }
+            if (x[1] < 0) be[0] = -be[0];
+        } else {                                               // (B11 B12 B22 B13 B23)
+            double A[6][5], x[5];
+            for (int r = 0; r < 6; ++r) for (int k = 0; k < 5; ++k) A[r][k] = L[r][k];
+            lstsq_small<6, 5>(A, rho, x);
+            if (x[0] < 0) { be[0] = std::sqrt(-x[0]); be[1] = x[2] < 0 ? std::sqrt(-x[2]) : 0.0; }
+            else { be[0] = std::sqrt(x[0]); be[1] = x[2] > 0 ? std::sqrt(x[2]) : 0.0; }
+            if (x[1] < 0) be[0] = -be[0];
+            if (be[0] == 0) ok = false; else be[2] = x[3] / be[0];
+        }
+        if (!ok || !std::isfinite(be[0]) || !std::isfinite(be[1]) || !std::isfinite(be[2]) || !std::isfinite(be[3])) continue;
+        gauss_newton(be);
+        Rt rt;
+        const double err = r_and_t(be, rt);
+        if (std::isfinite(err) && (!have || err < best_err)) { have = true; best_err = err; out = rt; }
+    }
+    return have;
+}
+
 struct PnPModel {
     const std::vector<Vec3>& X; const std::vector<Vec2>& u;
     Rt cur, best;
     bool check_subset(const int*, int) const { return true; }
-    bool run_kernel(const int* idx, int n) { if (!pnp_dlt(X, u, idx, n, cur)) return false; pnp_refine(X, u, idx, n, cur, 5); return true; }
+    bool run_kernel(const int* idx, int n) { return epnp(X, u, idx, n, cur); }
     float error(int i) const { return pnp_error(cur, X[i], u[i]); }
     void keep_best() { best = cur; }
 };
-// solvePnPRansac(objectPoints, imagePoints, K = I, no distortion, rvec, tvec, false, iterations, reprojectionError, confidence, inliers):
-// RANSAC over 6-point DLT models, then the least-squares refit (DLT + Levenberg-Marquardt) on the inliers.  inliers = indices, ascending.
+// solvePnPRansac(objectPoints, imagePoints, K = I, no distortion, rvec, tvec, false, iterations, reprojectionError, confidence, inliers), OpenCV 3.4
+// with flags = SOLVEPNP_ITERATIVE: RANSAC over EPnP models of 5 points, then solvePnP(ITERATIVE) on the inliers = a DLT start + the
+// Levenberg-Marquardt least-squares refit.  inliers = indices, ascending.
 inline bool solve_pnp_ransac(const std::vector<Vec3>& X, const std::vector<Vec2>& u, int iterations, double reproj_error, double confidence,
                              Rt& pose, std::vector<int>& inliers) {
     inliers.clear();
@@ -447,7 +647,7 @@ inline bool solve_pnp_ransac(const std::vector<Vec3>& X, const std::vector<Vec2>
     if (n < 6 || (int)u.size() != n) return false;
     PnPModel m{X, u, {}, {}};
     std::vector<uint8_t> mask;
-    if (!ransac_run(m, n, 6, reproj_error, confidence, iterations, mask)) return false;
+    if (!ransac_run(m, n, 5, reproj_error, confidence, iterations, mask)) return false;
     for (int i = 0; i < n; ++i) if (mask[i]) inliers.push_back(i);
     if ((int)inliers.size() < 6) return false;
     Rt fit;

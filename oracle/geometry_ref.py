@@ -4,8 +4,8 @@ An independent restatement (LAPACK SVD / eigh instead of the product's hand-writ
     triangulatePoint                       /root/reference/swarm_loop/src/loop_cam.cpp:73-106
     the up/down triangulation loop         loop_cam.cpp:397-444
     cv::findHomography(RANSAC, 3) mask     as used at swarm_loop/src/loop_detector.cpp:589-598 (OpenCV 3.4 ptsetreg.cpp / fundam.cpp)
-    cv::solvePnPRansac(K = I)              as used at loop_detector.cpp:390-391 -- spec of omni-swarm_amd/host/geometry.hpp: cv::RNG driven RANSAC
-                                           over 6-point DLT models + LM refit on the inliers (OpenCV's minimal kernel is EPnP on 5 points)
+    cv::solvePnPRansac(K = I)              as used at loop_detector.cpp:390-391: cv::RNG driven RANSAC over EPnP models of 5 points (OpenCV 3.4
+                                           epnp.cpp restated) + solvePnP(ITERATIVE) on the inliers (DLT start + LM refit)
     PnPRestoCamPose, RPerror, pnp_result_verify, rotate_pt_norm2d, compute_correspond_features, compute_relative_pose, compute_loop
                                            loop_utils.cpp:69-81, loop_detector.cpp:317-353,415-429,431-624,355-413,627-836
 Poses are (pos[3], quat wxyz[4]) tuples of float64 arrays.
@@ -363,17 +363,183 @@ def pnp_refine(X, u, idx, Rt, max_iters=30):
     return R, t
 
 
+# ---- EPnP (Lepetit, Moreno-Noguer, Fua 2009) as OpenCV 3.4 implements it (modules/calib3d/src/epnp.cpp), K = I: the minimal solver of
+# cv::solvePnPRansac (5 points, SOLVEPNP_EPNP) ---------------------------------------------------------------------------------------
+def _epnp_null_basis(MtM, n_points):
+    """the four eigenvectors of M^T M with the smallest eigenvalues, v[0] = smallest.  With exactly 5 points M has rank <= 10: the two smallest
+    eigenvalues are zero and ANY basis of that plane is a valid eigen-decomposition (it depends on the SVD routine); a canonical one is taken --
+    the projections of e0, e1, ... onto the plane, Gram-Schmidt -- so that two implementations walk the same numbers."""
+    w, V = np.linalg.eigh(MtM)                  # ascending
+    v = [V[:, i].copy() for i in range(4)]
+    if n_points == 5:
+        P = np.outer(v[0], v[0]) + np.outer(v[1], v[1])        # projector onto the null plane: basis independent
+        basis = []
+        for k in range(12):
+            c = P[:, k].copy()
+            for b in basis:
+                c -= (c @ b) * b
+            nrm = np.linalg.norm(c)
+            if nrm > 1e-3:
+                basis.append(c / nrm)
+            if len(basis) == 2:
+                break
+        if len(basis) == 2:
+            v[0], v[1] = basis
+    for i in range(4):                          # an eigenvector's sign is arbitrary: largest component positive
+        if v[i][np.argmax(np.abs(v[i]))] < 0:
+            v[i] = -v[i]
+    return v
+
+
+def _svd3(M):
+    """M = U diag(s) V^T for a 3x3 matrix through the eigen-decomposition of M^T M (s descending; a zero singular value's u is the cross product
+    of the other two) -- the same arithmetic path as the product's host code, so that the two agree beyond the solver's tolerance"""
+    w, V = np.linalg.eigh(M.T @ M)
+    w, V = w[::-1], V[:, ::-1]
+    s = np.sqrt(np.maximum(w, 0.0))
+    U = np.zeros((3, 3))
+    for i in range(2):
+        U[:, i] = M @ V[:, i] / s[i] if s[i] > 1e-300 else np.eye(3)[:, i]
+    u2 = np.cross(U[:, 0], U[:, 1])
+    if s[2] > 1e-12 * max(s[0], 1e-300):
+        m2 = M @ V[:, 2] / s[2]
+        u2 = u2 if u2 @ m2 >= 0 else -u2
+    U[:, 2] = u2
+    return U, s, V
+
+
+def _pinv3(A, rel=1e-10):
+    """pseudo-inverse of a 3x3 matrix through the eigen-decomposition of A^T A; singular values below rel * the largest count as zero"""
+    w, V = np.linalg.eigh(A.T @ A)
+    inv = np.where(w > (rel * rel) * max(w.max(), 1e-300), 1.0 / np.maximum(w, 1e-300), 0.0)
+    return (V * inv) @ V.T @ A.T
+
+
+def epnp(X, u):
+    """-> (R, t) or None.  X [n, 3], u [n, 2] normalised image points, n >= 4."""
+    X, u = np.asarray(X, np.float64), np.asarray(u, np.float64)
+    n = len(X)
+    if n < 4:
+        return None
+    # choose_control_points
+    c0 = X.mean(0)
+    PW0 = X - c0
+    dc, uct = np.linalg.eigh(PW0.T @ PW0)
+    dc, uct = dc[::-1], uct[:, ::-1].T                          # descending, eigenvectors as rows (cvSVD with CV_SVD_U_T)
+    for i in range(3):                                          # a fixed sign per axis (the SVD's is arbitrary): largest component positive
+        if uct[i, np.argmax(np.abs(uct[i]))] < 0:
+            uct[i] = -uct[i]
+    cws = np.stack([c0] + [c0 + math.sqrt(max(dc[i], 0.0) / n) * uct[i] for i in range(3)])
+    # compute_barycentric_coordinates
+    CC = (cws[1:] - cws[0]).T
+    a123 = (_pinv3(CC) @ (X - cws[0]).T).T                                          # cvInvert(CC, CC_inv, CV_SVD): pseudo-inverse (coplanar points: rank 2)
+    alphas = np.concatenate([1.0 - a123.sum(1, keepdims=True), a123], 1)            # [n, 4]
+    # fill_M (fu = fv = 1, uc = vc = 0)
+    M = np.zeros((2 * n, 12))
+    for j in range(4):
+        M[0::2, 3 * j] = alphas[:, j]
+        M[0::2, 3 * j + 2] = -alphas[:, j] * u[:, 0]
+        M[1::2, 3 * j + 1] = alphas[:, j]
+        M[1::2, 3 * j + 2] = -alphas[:, j] * u[:, 1]
+    v = _epnp_null_basis(M.T @ M, n)
+    # compute_L_6x10 / compute_rho
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    dv = np.array([[v[i][3 * a:3 * a + 3] - v[i][3 * b:3 * b + 3] for (a, b) in pairs] for i in range(4)])          # [4][6][3]
+    L = np.zeros((6, 10))
+    for r in range(6):
+        d = dv[:, r]
+        L[r] = [d[0] @ d[0], 2 * d[0] @ d[1], d[1] @ d[1], 2 * d[0] @ d[2], 2 * d[1] @ d[2], d[2] @ d[2], 2 * d[0] @ d[3], 2 * d[1] @ d[3], 2 * d[2] @ d[3],
+                d[3] @ d[3]]
+    rho = np.array([((cws[a] - cws[b]) ** 2).sum() for (a, b) in pairs])
+
+    def lsq(A, b):
+        """least squares through the eigen-decomposition of A^T A (pseudo-inverse, eigenvalues below 1e-26 x the largest = 0): the product's path"""
+        w, V = np.linalg.eigh(A.T @ A)
+        keep = w > 1e-26 * max(w.max(), 1e-300)
+        c = (V.T @ (A.T @ b))
+        return V[:, keep] @ (c[keep] / w[keep])
+
+    def approx_1():
+        b4 = lsq(L[:, [0, 1, 3, 6]], rho)
+        if b4[0] < 0:
+            b0 = math.sqrt(-b4[0])
+            return np.array([b0, -b4[1] / b0, -b4[2] / b0, -b4[3] / b0]) if b0 > 0 else None
+        b0 = math.sqrt(b4[0])
+        return np.array([b0, b4[1] / b0, b4[2] / b0, b4[3] / b0]) if b0 > 0 else None
+
+    def approx_2():
+        b3 = lsq(L[:, [0, 1, 2]], rho)
+        if b3[0] < 0:
+            be = [math.sqrt(-b3[0]), math.sqrt(-b3[2]) if b3[2] < 0 else 0.0]
+        else:
+            be = [math.sqrt(b3[0]), math.sqrt(b3[2]) if b3[2] > 0 else 0.0]
+        if b3[1] < 0:
+            be[0] = -be[0]
+        return np.array([be[0], be[1], 0.0, 0.0])
+
+    def approx_3():
+        b5 = lsq(L[:, [0, 1, 2, 3, 4]], rho)
+        if b5[0] < 0:
+            be = [math.sqrt(-b5[0]), math.sqrt(-b5[2]) if b5[2] < 0 else 0.0]
+        else:
+            be = [math.sqrt(b5[0]), math.sqrt(b5[2]) if b5[2] > 0 else 0.0]
+        if b5[1] < 0:
+            be[0] = -be[0]
+        if be[0] == 0:
+            return None
+        return np.array([be[0], be[1], b5[3] / be[0], 0.0])
+
+    def gauss_newton(be):
+        be = be.copy()
+        for _ in range(5):
+            A = np.stack([2 * L[:, 0] * be[0] + L[:, 1] * be[1] + L[:, 3] * be[2] + L[:, 6] * be[3],
+                          L[:, 1] * be[0] + 2 * L[:, 2] * be[1] + L[:, 4] * be[2] + L[:, 7] * be[3],
+                          L[:, 3] * be[0] + L[:, 4] * be[1] + 2 * L[:, 5] * be[2] + L[:, 8] * be[3],
+                          L[:, 6] * be[0] + L[:, 7] * be[1] + L[:, 8] * be[2] + 2 * L[:, 9] * be[3]], 1)
+            bb = rho - (L[:, 0] * be[0] ** 2 + L[:, 1] * be[0] * be[1] + L[:, 2] * be[1] ** 2 + L[:, 3] * be[0] * be[2] + L[:, 4] * be[1] * be[2] +
+                        L[:, 5] * be[2] ** 2 + L[:, 6] * be[0] * be[3] + L[:, 7] * be[1] * be[3] + L[:, 8] * be[2] * be[3] + L[:, 9] * be[3] ** 2)
+            be = be + lsq(A, bb)
+        return be
+
+    def r_and_t(be):
+        ccs = sum(be[i] * v[i].reshape(4, 3) for i in range(4))                      # control points in the camera frame
+        pcs = alphas @ ccs
+        if pcs[0, 2] < 0:                                                           # solve_for_sign
+            ccs, pcs = -ccs, -pcs
+        pc0, pw0 = pcs.mean(0), X.mean(0)
+        ABt = (pcs - pc0).T @ (X - pw0)
+        U, _, V = _svd3(ABt)
+        R = U @ V.T
+        if np.linalg.det(R) < 0:
+            R[2] = -R[2]
+        t = pc0 - R @ pw0
+        c = X @ R.T + t
+        err = np.sqrt(((c[:, :2] / c[:, 2:3] - u) ** 2).sum(1)).sum() / n
+        return R, t, err
+
+    best = None
+    for ap in (approx_1, approx_2, approx_3):
+        be = ap()
+        if be is None or not np.all(np.isfinite(be)):
+            continue
+        R, t, err = r_and_t(gauss_newton(be))
+        if np.isfinite(err) and (best is None or err < best[2]):
+            best = (R, t, err)
+    return None if best is None else (best[0], best[1])
+
+
 def solve_pnp_ransac(X, u, iterations, reproj_error, confidence):
+    """cv::solvePnPRansac (OpenCV 3.4, flags = SOLVEPNP_ITERATIVE): RANSAC over EPnP models of 5 points, then solvePnP(ITERATIVE) on the inliers
+    = a DLT start + the Levenberg-Marquardt least-squares refit."""
     X, u = np.asarray(X, np.float64).reshape(-1, 3), np.asarray(u, np.float64).reshape(-1, 2)
     n = len(X)
     if n < 6:
         return None, []
 
     def kernel(idx):
-        m = pnp_dlt(X, u, idx)
-        return None if m is None else pnp_refine(X, u, idx, m, 5)
+        return epnp(X[idx], u[idx])
 
-    best, mask = ransac_run(n, 6, reproj_error, confidence, iterations, kernel, lambda m: pnp_errors(X, u, m))
+    best, mask = ransac_run(n, 5, reproj_error, confidence, iterations, kernel, lambda m: pnp_errors(X, u, m))
     if best is None:
         return None, []
     inl = [int(i) for i in np.nonzero(mask)[0]]

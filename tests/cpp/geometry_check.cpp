@@ -87,6 +87,15 @@ int main() {
             std::printf("PNP %d %zu", ok ? 1 : 0, inl.size());
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) std::printf(" %.17g", rt.R.m[r][c]);
             std::printf(" %.17g %.17g %.17g\n", rt.t.x, rt.t.y, rt.t.z);
+        } else if (cmd == "epnp") {                      // the minimal solver alone: n points (X, u), all of them used
+            int n; std::cin >> n;
+            std::vector<Vec3> X(n); std::vector<Vec2> u(n); std::vector<int> idx(n);
+            for (int i = 0; i < n; ++i) { std::cin >> X[i].x >> X[i].y >> X[i].z >> u[i].x >> u[i].y; idx[i] = i; }
+            Rt rt;
+            const bool ok = epnp(X, u, idx.data(), n, rt);
+            std::printf("EPNP %d", ok ? 1 : 0);
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) std::printf(" %.17g", rt.R.m[r][c]);
+            std::printf(" %.17g %.17g %.17g\n", rt.t.x, rt.t.y, rt.t.z);
         } else if (cmd == "rng") {
             int n; std::cin >> n;
             CvRng r;

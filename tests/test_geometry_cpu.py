@@ -190,6 +190,52 @@ def test_pnp_ransac_pose(exe):
     assert run(exe, "pnp 5 100 3.0 0.99\n" + "\n".join(fmt(rng.uniform(0, 1, 5)) for _ in range(5)))[0][1] == "0"     # fewer than 6 points
 
 
+def test_epnp_minimal_solver(exe):
+    """EPnP on minimal sets (cv::solvePnPRansac's kernel: 5 points, OpenCV 3.4 epnp.cpp restated): exact data -> the exact pose, in the C++ host code
+    and in the numpy oracle, which agree with each other to 1e-7 -- on random point clouds and on the walls-of-a-room configuration of the
+    rendered-scene test (points on four planes, image points rotated into the main camera: |u| up to ~50).  Larger sets too (the solver is
+    general).  EPnP fixes the solution's sign by the depth of the FIRST point (epnp.cpp solve_for_sign), i.e. it assumes the points in front of the
+    camera: sets with points behind it (the reference feeds such: image points of the side / rear directions rotated into the main camera) are
+    only compared between the two implementations, as are exactly coplanar sets (outside EPnP's general case, in OpenCV too)."""
+    rng = np.random.default_rng(11)
+    text, cases = [], []
+    for trial in range(120):
+        n = 5 if trial % 3 else int(rng.integers(6, 40))
+        kind = trial % 4
+        if kind == 3:                                            # a square room seen from its centre: points on the walls x = +-2, y = +-2
+            wall = rng.integers(0, 4, n)
+            a, b = rng.uniform(-1.9, 1.9, n), rng.uniform(-1.2, 1.2, n)
+            X = np.stack([np.where(wall == 0, 2.0, np.where(wall == 1, -2.0, a)), np.where(wall == 2, 2.0, np.where(wall == 3, -2.0, a)), b], 1)
+            X = X[:, [1, 2, 0]] + np.array([0.1, 0.05, 0.0])     # camera looks along +z of this frame: some points beside / behind it
+            R, t = G.rodrigues(rng.uniform(-0.05, 0.05, 3)), rng.uniform(-0.1, 0.1, 3)
+            c = X @ R.T + t
+            if np.abs(c[:, 2]).min() < 0.05 or len(set(wall.tolist())) < 2:
+                continue
+        else:
+            X = rng.uniform(-3, 3, (n, 3)) + np.array([0.5, 0.2, 6.0])
+            R, t = G.rodrigues(rng.uniform(-0.4, 0.4, 3)), rng.uniform(-0.5, 0.5, 3)
+            c = X @ R.T + t
+        u = c[:, :2] / c[:, 2:3]
+        cases.append((X, u, R, t, bool((c[:, 2] > 0).all())))
+        text.append(f"epnp {n}\n" + "\n".join(fmt(a, b) for a, b in zip(X, u)))
+    out = run(exe, "\n".join(text))
+    worst = 0.0
+    n_front = 0
+    for (X, u, R, t, front), o in zip(cases, out):
+        got = np.array(o[2:], np.float64)
+        ref = G.epnp(X, u)
+        assert o[1] == "1" and ref is not None
+        assert np.abs(got[:9].reshape(3, 3) - ref[0]).max() < 1e-7 and np.abs(got[9:] - ref[1]).max() < 1e-7 * max(1.0, np.abs(ref[1]).max())
+        if front:
+            n_front += 1
+            worst = max(worst, np.abs(got[:9].reshape(3, 3) - R).max(), np.abs(got[9:] - t).max())
+    assert worst < 1e-6 and n_front > 80 and len(cases) - n_front > 5, (worst, n_front, len(cases))
+    # coplanar minimal set: defined output, nothing more
+    Xp = np.array([[0, 0, 5.0], [1, 0, 5], [0, 1, 5], [1, 1, 5], [0.3, 0.7, 5]])
+    o = run(exe, "epnp 5\n" + "\n".join(fmt(a, a[:2] / a[2]) for a in Xp))[0]
+    assert all(np.isfinite(float(x)) for x in o[2:])
+
+
 def test_compute_loop_end_to_end(exe, scene):
     new, old = scene["new"], scene["old"]
     for (dn, dold, init_mode, is4) in ((1, 1, 0, 1), (1, 1, 1, 0), (0, 0, 0, 1)):
