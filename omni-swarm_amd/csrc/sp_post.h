@@ -44,6 +44,12 @@ struct SpSparseDesc {
     const void* a4b = nullptr;      // [B][Hc][Wc][128] fp16; null = in_f16 is the dense cDa map
     const void* da_w = nullptr; const float* da_bias = nullptr; int da_g32_first = 0;
     void* da_compact = nullptr;
+    // fp32 variant (OMNI_PREC_F32 / OMNI_PREC_SPLIT): convDb + L2 norm in exact f32 only at the <= 4 * max_num cells the sampler reads.
+    // cda_f32: the heads layer's cDa half, NHWC fp32 with pixel stride in_cstride floats; wdb_f32: conv_pack_weights_f32 of convDb; cx / cy:
+    // scratch [ceil8(batch * max_num * 4)][256] fp32 each.  Bit-identical to the dense map + sp_sample_kernel (a 1x1 conv and the per-cell norm
+    // do not look at neighbours).
+    const float* cda_f32 = nullptr; const void* wdb_f32 = nullptr; float* cx = nullptr; float* cy = nullptr;
+    int n_cu = 0; const void* zero_page = nullptr;
 };
 
 // semi: [B][H][W] f32 probability map; desc_nhwc: [B][H/8][W/8][256] f32 (channel-normalised coarse descriptors; unused when sparse.in_f16 is set)

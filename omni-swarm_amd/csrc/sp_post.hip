@@ -315,6 +315,55 @@ sp_sample_kernel(const float* __restrict__ desc_nhwc, int W, int H, int max_num,
     }
 }
 
+// the coarse cell and weight of corner j (0: y0x0, 1: y0x1, 2: y1x0, 3: y1x1) of key point (kx, ky): sp_sample_kernel's arithmetic
+__device__ __forceinline__ void sample_corner(float kx, float ky, int W, int H, int j, int& cx, int& cy, float& wgt) {
+    const int Wc = W >> 3, Hc = H >> 3;
+    const float fW = (float)W, fH = (float)H, fWc = (float)Wc, fHc = (float)Hc;
+    const float gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, kx), fW), 1.0f);
+    const float gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, ky), fH), 1.0f);
+    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), fWc), 1.0f), 2.0f);
+    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), fHc), 1.0f), 2.0f);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
+    cx = (int)fx0 + (j & 1); cy = (int)fy0 + (j >> 1);
+    wgt = ((j & 1) ? wx1 : wx0) * ((j >> 1) ? wy1 : wy0);
+}
+// fp32 sparse descriptor head, step 1: the cDa vectors of the four coarse cells around every key point, compactly: row ((b * max_num + i) * 4 + j);
+// cells outside the map and key points beyond n_kps give zero rows (never read back).  grid = (max_num, batch), thread = channel
+__global__ void __launch_bounds__(256)
+sp_gather_cells_kernel(const float* __restrict__ cda, int cstride, int W, int H, int max_num, const float* __restrict__ kps_xy, const int* __restrict__ n_kps,
+                       float* __restrict__ out) {
+    const int b = blockIdx.y, i = blockIdx.x, c = threadIdx.x;
+    const int Wc = W >> 3, Hc = H >> 3;
+    float* o = out + ((int64_t)b * max_num + i) * 4 * 256 + c;
+    if (i >= n_kps[b]) { o[0] = o[256] = o[512] = o[768] = 0.f; return; }
+    const float kx = kps_xy[((int64_t)b * max_num + i) * 2 + 0], ky = kps_xy[((int64_t)b * max_num + i) * 2 + 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int cx, cy; float wgt;
+        sample_corner(kx, ky, W, H, j, cx, cy, wgt);
+        o[j * 256] = (cx >= 0 && cx < Wc && cy >= 0 && cy < Hc) ? cda[(((int64_t)b * Hc + cy) * Wc + cx) * cstride + c] : 0.f;
+    }
+}
+// step 3: sp_sample_kernel on the compact rows (same taps, same order, same products: the same bits as sampling the dense map)
+__global__ void __launch_bounds__(256)
+sp_sample_compact_kernel(const float* __restrict__ rows, int W, int H, int max_num, const float* __restrict__ kps_xy, const int* __restrict__ n_kps,
+                         float* __restrict__ raw_desc) {
+    const int b = blockIdx.y, i = blockIdx.x, c = threadIdx.x;
+    if (i >= n_kps[b]) return;
+    const int Wc = W >> 3, Hc = H >> 3;
+    const float kx = kps_xy[((int64_t)b * max_num + i) * 2 + 0], ky = kps_xy[((int64_t)b * max_num + i) * 2 + 1];
+    const float* r = rows + ((int64_t)b * max_num + i) * 4 * 256 + c;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int cx, cy; float wgt;
+        sample_corner(kx, ky, W, H, j, cx, cy, wgt);
+        if (cx >= 0 && cx < Wc && cy >= 0 && cy < Hc) v += r[j * 256] * wgt;
+    }
+    raw_desc[((int64_t)b * max_num + i) * 256 + c] = v;
+}
+
 // Pass 1b: every CHANNEL is divided by its L2 norm ACROSS the image's key points -- torch::norm(desc, 2, /*dim=*/1) on the
 // [256, n] tensor (:214): the reference normalises channels across key points, not descriptors across channels.
 // Sum of squares in NORM_SEGS fixed segments of key points (grid = segments x images, thread = channel); the consumers add
@@ -451,6 +500,22 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
         int rc = convdb_sparse_sample(stream, sparse.ctx, sparse.in_f16, sparse.in_cstride, sparse.wfrag, sparse.bias, p.width, p.height, p.max_num,
                                       b.kps_xy, b.n_kps, b.raw_desc, batch, false);
         if (rc) return rc;
+    } else if (sparse.cda_f32) {
+        // exact-f32 descriptor head only where the sampler reads: gather the cells -> the SAME 1x1 convolution kernel and per-cell norm the dense
+        // map uses, on [8][N / 8] pixels instead of [batch][Hc][Wc] -> sample the compact rows
+        const int64_t n_rows = (((int64_t)batch * p.max_num * 4) + 7) & ~(int64_t)7;
+        hipLaunchKernelGGL(sp_gather_cells_kernel, dim3(p.max_num, batch), dim3(256), 0, stream, sparse.cda_f32, sparse.in_cstride, p.width, p.height, p.max_num,
+                           b.kps_xy, b.n_kps, sparse.cx);
+        OMNI_LAUNCH_CHECK();
+        ConvArgs a;
+        a.in = sparse.cx; a.out = sparse.cy; a.w_packed = sparse.wdb_f32; a.bias = sparse.bias; a.batch = 1; a.H = 8; a.W = (int)(n_rows / 8); a.cin = 256;
+        a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false; a.out_f32 = true; a.in_cstride = 256; a.n_cu = sparse.n_cu; a.zero_page = sparse.zero_page;
+        int rc = conv_mfma(stream, OMNI_PREC_F32, a);
+        if (rc) return rc;
+        if ((rc = l2norm_channels(stream, sparse.cy, n_rows))) return rc;
+        hipLaunchKernelGGL(sp_sample_compact_kernel, dim3(p.max_num, batch), dim3(256), 0, stream, sparse.cy, p.width, p.height, p.max_num, b.kps_xy, b.n_kps,
+                           b.raw_desc);
+        OMNI_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(p.max_num, SAMPLE_KPB), batch), dim3(256), 0, stream, desc_nhwc, p.width, p.height,
                            p.max_num, b.kps_xy, b.n_kps, b.raw_desc);

@@ -45,6 +45,7 @@ struct omni_sp {
     bool sparse_da = true;                   // ... and convDa itself only there too (conv_c128_sparse); OMNI_SP_SPARSE_DA=0: convDa stays dense
     void* headsP = nullptr;                  // [B][Hc][Wc][256] cPa alone (sparse_da passes)
     void* da_compact = nullptr;              // [B][max_num][4][256] fp16: cDa at the corner cells of the key points
+    float *cx32 = nullptr, *cy32 = nullptr;  // fp32 paths: the gathered cDa rows / their convDb + norm, [ceil8(B * max_num * 4)][256] each
     bool dense_valid = false, dense_possible = false;   // `draw` holds / `heads` can still produce the dense map of the last forward pass
     int last_batch = 0;
     void* wDbFrag = nullptr;                    // convDb as register-resident fp16 A fragments (fused convDb + L2 norm, fp16 path)
@@ -183,6 +184,11 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         OMNI_HIP_TRY(hipMalloc(&s->headsP, B * (H / 8) * (W / 8) * 256 * e));
         OMNI_HIP_TRY(hipMalloc(&s->da_compact, B * (size_t)s->max_num * 4 * 256 * 2));
     }
+    if (s->precision != OMNI_PREC_F16) {
+        const size_t rows = ((B * (size_t)s->max_num * 4) + 7) & ~(size_t)7;
+        OMNI_HIP_TRY(hipMalloc((void**)&s->cx32, rows * 256 * 4));
+        OMNI_HIP_TRY(hipMalloc((void**)&s->cy32, rows * 256 * 4));
+    }
     OMNI_HIP_TRY(hipMalloc((void**)&s->draw, B * (H / 8) * (W / 8) * 256 * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->semi, B * H * W * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->gray_stage, B * H * W));
@@ -264,6 +270,8 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if ((rc = conv(L4B, s->a4a, s->a4b, s->bias[L4B], H / 8, W / 8, 128, 128, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
     const bool sparse = s->precision == OMNI_PREC_F16 && s->conv_variant == 0 && s->sparse_desc && run_post;
+    // fp32 / split paths: the exact-f32 convDb + norm likewise only at the cells around the key points (sp_post.hip), the dense map on demand
+    const bool sparse32 = s->precision != OMNI_PREC_F16 && s->conv_variant == 0 && s->sparse_desc && run_post && s->cx32;
     const bool sparse_da = sparse && s->sparse_da && s->headsP;
     // the detector branch needs cPa everywhere; cDa (output channels 256-511 of the fused heads layer) is only read around the key points
     const void* cpa = sparse_da ? s->headsP : s->heads;
@@ -277,8 +285,8 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     } else if ((rc = detector_head_mfma(st, PH, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
                                         s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
-    s->dense_valid = !sparse; s->dense_possible = true; s->last_batch = batch;
-    if (sparse) {
+    s->dense_valid = !sparse && !sparse32; s->dense_possible = true; s->last_batch = batch;
+    if (sparse || sparse32) {
         // nothing here: convDb runs inside the post-processing, at the key points only
     } else if (s->precision == OMNI_PREC_F16 && s->conv_variant == 0) {
         // convDb + descriptor L2 norm in one HBM pass (channels [256,512) = cDa of the fused heads buffer, pixel stride 512)
@@ -299,6 +307,10 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         SpSparseDesc sd;
         if (sparse) { sd.ctx = s->ctx; sd.in_f16 = (const char*)s->heads + (size_t)256 * s->esz; sd.in_cstride = 512; sd.wfrag = s->wDbFrag; sd.bias = s->bias[LDB]; }
         if (sparse_da) { sd.a4b = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_compact = s->da_compact; }
+        if (sparse32) {
+            sd.cda_f32 = reinterpret_cast<const float*>(s->heads) + 256; sd.in_cstride = 512; sd.wdb_f32 = s->wpk[LDB]; sd.bias = s->bias[LDB];
+            sd.cx = s->cx32; sd.cy = s->cy32; sd.n_cu = s->ctx->prop.multiProcessorCount; sd.zero_page = s->ctx->zero_page;
+        }
         if ((rc = sp_postprocess(st, post_params(s), s->pb, s->semi, s->draw, batch, sd))) return rc;
     }
     if ((rc = mark())) return rc;
@@ -310,6 +322,16 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
 static int sp_make_dense(omni_sp* s) {
     hipStream_t st = s->ctx->stream;
     int rc;
+    if (s->precision != OMNI_PREC_F16) {       // the heads layer's fp32 output is still in HBM: dense convDb + norm from it
+        ConvArgs a;
+        a.in = (const char*)s->heads + (size_t)256 * 4; a.out = s->draw; a.w_packed = s->wpk[LDB]; a.bias = s->bias[LDB];
+        a.batch = s->last_batch; a.H = s->Hc; a.W = s->Wc; a.cin = 256; a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false;
+        a.out_f32 = true; a.in_cstride = 512;
+        if ((rc = conv_mfma(st, OMNI_PREC_F32, a))) return rc;
+        if ((rc = l2norm_channels(st, s->draw, (int64_t)s->last_batch * s->Hc * s->Wc))) return rc;
+        s->dense_valid = true;
+        return OMNI_OK;
+    }
     ConvArgs a;
     a.in = s->a4b; a.out = s->heads; a.w_packed = s->wpk[LPA]; a.bias = s->bias_heads; a.batch = s->last_batch; a.H = s->Hc; a.W = s->Wc; a.cin = 128;
     a.cout = 512; a.ksize = 3; a.relu = true; a.pool = false; a.out_f32 = false;
@@ -387,7 +409,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); if (s->bias_s[l]) (void)hipFree(s->bias_s[l]); }
     void* ptrs[] = {s->wPbA16, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
-                    s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
+                    s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->cx32, s->cy32, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     s->hstage.release(); s->dense_tmp.release();

@@ -162,6 +162,34 @@ def test_f16_sparse_descriptors_are_bit_identical_to_the_dense_map_path(omni, ct
             assert np.array_equal(res[flag][2][0][1], res[flag][0][nb - 1][1])          # batch 1 == batch n, sparse paths
 
 
+@pytest.mark.parametrize("prec", ["PREC_F32", "PREC_SPLIT"])
+def test_fp32_sparse_descriptor_head_is_bit_identical_to_the_dense_map_path(omni, ctx, monkeypatch, prec):
+    """OMNI_PREC_F32 / OMNI_PREC_SPLIT: convDb + L2 norm in exact f32 only at the cells around the key points (gather -> the dense path's own 1x1
+    convolution kernel and per-cell norm on the compact rows -> sampling) against the dense map + sp_sample_kernel (OMNI_SP_SPARSE_DESC=0): same
+    descriptors BIT FOR BIT -- with and without PCA, odd sizes, few / many / no key points, an odd number of rows (the compact buffer is padded to
+    a multiple of 8), several images per launch; omni_sp_get_dense after a sparse pass == the dense pass's map."""
+    weights = S.synth_weights(0)
+    comp, mean = synth.pca()
+    for (h, w, nb, thr, maxn, pca) in ((480, 600, 2, 0.015, 200, True), (96, 128, 3, 0.015, 37, False), (104, 136, 1, 0.2, 200, True),
+                                       (64, 96, 2, 0.001, 1000, True), (64, 96, 1, 0.999, 51, True)):
+        imgs = np.stack([synth.image_u8(310 + i, h, w, n_shapes=60) for i in range(nb)])
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("OMNI_SP_SPARSE_DESC", flag)
+            sp = omni.capi.SuperPoint(ctx, weights, comp if pca else None, mean if pca else None, w, h, thr, maxn, getattr(omni.capi, prec), nb)
+            out = sp.inference(imgs, fisheye_mask=(h == 480))
+            dense = sp.get_dense(nb)
+            one = sp.inference(imgs[nb - 1], fisheye_mask=(h == 480))
+            res[flag] = (out, dense, one)
+            sp.close()
+        for b in range(nb):
+            (k1, d1, s1), (k0, d0, s0) = res["1"][0][b], res["0"][0][b]
+            assert (len(k1) > 0 or thr > 0.9) and np.array_equal(k1, k0) and np.array_equal(s1, s0)
+            assert np.array_equal(d1, d0), (h, w, b, np.abs(d1 - d0).max())
+        assert np.array_equal(res["1"][1][0], res["0"][1][0]) and np.array_equal(res["1"][1][1], res["0"][1][1])
+        assert np.array_equal(res["1"][2][0][1], res["1"][0][nb - 1][1])
+
+
 def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, monkeypatch):
     """The cin=64 kernels (v3 8-wave ping-pong, v2 persistent LDS-DMA) and the generic kernel accumulate K in the same
     order: same bits.  Odd sizes exercise border tiles, partial tiles and workgroups with a single tile.
