@@ -154,12 +154,16 @@ __device__ __forceinline__ void spl_store_pair(const float (&a)[8], const float4
     }
 }
 
-template <bool C128, bool POOL, bool OUT_F32>
+// TRN (cin = 128, no pooling): transposed tiles -- the 32-pixel fragments run along y, the two fragment rows along x (the LDS image, the k order
+// and every MFMA are those of the plain kernel; only the pixel <-> address maps and the tap the weights are loaded for differ).  A 60x75 layer
+// is 2 x 38 tiles instead of 3 x 30: 75-pixel rows fill 2.3 of 3 fragments, 60-pixel columns 1.9 of 2.
+template <bool C128, bool POOL, bool OUT_F32, bool TRN = false>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const _Float16* __restrict__ wp, const float* __restrict__ bias,
                      float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, const char* __restrict__ zero_page) {
     extern __shared__ __attribute__((aligned(256))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    static_assert(!TRN || (C128 && !POOL), "transposed tiles: cin = 128 without pooling only");
     constexpr int TH = C128 ? 2 : 4, ITH = TH + 2;
     constexpr int PIXB = C128 ? 512 : 256;                  // bytes per input pixel in HBM
     constexpr int NPIECES = C128 ? 68 : 51, PPW = C128 ? 17 : 13;
@@ -177,7 +181,11 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         const int cb = C128 ? part : 0, ncb = C128 ? 2 : 1;
         const _Float16* wbase = wp + ((int64_t)g32 * ncb + cb) * (2 * 36 * 512) + lane * 8;
 #pragma unroll
-        for (int s = 0; s < 72; ++s) wreg[s] = *reinterpret_cast<const half8_t*>(wbase + s * 512);
+        for (int s = 0; s < 72; ++s) {
+            const int hl = s / 36, tk = (s % 36) / 4, kq = s % 4;
+            const int tap = TRN ? (tk % 3) * 3 + tk / 3 : tk;          // transposed tiles: the kernel's (row, column) shifts are the image's (column, row)
+            wreg[s] = *reinterpret_cast<const half8_t*>(wbase + ((hl * 9 + tap) * 4 + kq) * 512);
+        }
     }
     float* const bias_lds = reinterpret_cast<float*>(smem_raw + 2 * SPL_BUF_BYTES + SPL_XCH_BYTES);
     if (tid < 64) bias_lds[tid] = bias[cg * 64 + tid];
@@ -185,14 +193,15 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
         b = t / tiles_per_img;
         const int r = t - b * tiles_per_img;
-        ty0 = (r / tiles_x) * TH; tx0 = (r % tiles_x) * 32;
+        ty0 = (r / tiles_x) * (TRN ? 32 : TH); tx0 = (r % tiles_x) * (TRN ? TH : 32);
     };
     // DMA piece p (1 KiB) = virtual pixels [4 p, 4 p + 4): lane -> (virtual pixel vp, 16-byte chunk slot); the chunk stored in slot s of
     // virtual pixel vp is the pixel block's chunk s ^ (vp & 15).  cin = 64: vp = halo pixel (6 x 34); cin = 128: vp = block * 136 + halo pixel
     auto src_of = [&](int vp, int slot, int& iy, int& ix) -> uint32_t {
         int blk = 0, p = vp;
         if constexpr (C128) { blk = vp >= 136 ? 1 : 0; p = vp - 136 * blk; }
-        iy = p / SPL_ITW; ix = p - iy * SPL_ITW;
+        const int iv = p / SPL_ITW, iu = p - iv * SPL_ITW;
+        iy = TRN ? iu : iv; ix = TRN ? iv : iu;
         return (uint32_t)(blk * 256 + ((slot ^ (vp & 15)) << 4));
     };
     uint32_t goff[PPW];                       // interior tiles: byte offset of this lane's chunk of piece j relative to the halo origin
@@ -211,7 +220,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         const int y0 = ty0 - 1, x0 = tx0 - 1;
         const char* img = in + (int64_t)b * H * W * PIXB;
         char* base = smem_raw + which * SPL_BUF_BYTES + wave * PPW * 1024;
-        if (y0 >= 0 && y0 + ITH <= H && x0 >= 0 && x0 + SPL_ITW <= W) {             // interior (wave-uniform)
+        if (y0 >= 0 && y0 + (TRN ? SPL_ITW : ITH) <= H && x0 >= 0 && x0 + (TRN ? ITH : SPL_ITW) <= W) {             // interior (wave-uniform)
             const char* org = img + ((int64_t)y0 * W + x0) * PIXB;
 #pragma unroll
             for (int j = 0; j < PPW; ++j)
@@ -347,8 +356,9 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
             } else {
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
-                    char* o = outc + (((int64_t)b * Ho + (ty0 + f)) * Wo + ox) * opix + ofrag;
-                    spl_store_pair<OUT_F32>(a8[f], b0, b1, inv, relu, o, part, hh, (ty0 + f < H) && (ox < W));
+                    const int oy = TRN ? ty0 + n : ty0 + f, oxx = TRN ? tx0 + f : ox;
+                    char* o = outc + (((int64_t)b * Ho + oy) * Wo + oxx) * opix + ofrag;
+                    spl_store_pair<OUT_F32>(a8[f], b0, b1, inv, relu, o, part, hh, (oy < H) && (oxx < W));
                 }
             }
         }
@@ -357,12 +367,19 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     }
 }
 
-template <bool C128, bool POOL, bool OUT_F32>
+template <bool C128, bool POOL, bool OUT_F32, bool TRN = false>
 static int launch_split(hipStream_t st, const ConvArgs& a) {
-    auto kfn = conv3x3_split_kernel<C128, POOL, OUT_F32>;
+    if constexpr (C128 && !POOL && !TRN) {
+        // the tile orientation with fewer tiles (OMNI_SPLIT_TRN=0/1 forces one: A/B hook; it fixes the order the taps are summed in)
+        static const int force = [] { const char* e = getenv("OMNI_SPLIT_TRN"); return e ? atoi(e) : -1; }();
+        const int plain = cdiv(a.W, 32) * cdiv(a.H, 2), trn = cdiv(a.H, 32) * cdiv(a.W, 2);
+        if (force == 1 || (force < 0 && trn < plain)) return launch_split<C128, POOL, OUT_F32, true>(st, a);
+    }
+    auto kfn = conv3x3_split_kernel<C128, POOL, OUT_F32, TRN>;
     static DynSmemState smem_state;
     OMNI_HIP_TRY(ensure_dyn_smem(smem_state, (const void*)kfn, SPL_SMEM));
-    const int tiles_x = cdiv(a.W, 32), tiles_y = cdiv(a.H, C128 ? 2 : 4), n_cg = a.cout / 64;
+    constexpr int TH = C128 ? 2 : 4;
+    const int tiles_x = cdiv(a.W, TRN ? TH : 32), tiles_y = cdiv(a.H, TRN ? 32 : TH), n_cg = a.cout / 64;
     const int total = a.batch * tiles_x * tiles_y;
     int per_cg = a.n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
