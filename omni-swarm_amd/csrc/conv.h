@@ -52,7 +52,13 @@ float conv_split_act_scale();
 int conv_split(hipStream_t stream, const ConvArgs& a);
 int conv1a_split(hipStream_t stream, const uint8_t* gray, int stride, int batch, int H, int W, int fisheye_mask, const float* w, const float* bias,
                  const float* u8_lut, void* out_split);
-int split_to_nchw_f32(hipStream_t stream, const void* in_split, float* out, int batch, int C, int HW);   // test hook
+int split_to_nchw_f32(hipStream_t stream, const void* in_split, float* out, int batch, int C, int H, int W);   // test hook
+// A split-64 H x W map lives in a zero frame of split_frame_h(H) rows x split_frame_w(W) pixels, pixel (y, x) at row y + 1, column x + 1:
+// one pixel of zero padding all round plus the overhang of the last 32-pixel tile in either direction.  The frame must be zeroed once
+// (the kernels only ever write the map).
+__host__ __device__ inline int split_frame_w(int W) { return ((W + 31) & ~31) + 2; }
+__host__ __device__ inline int split_frame_h(int H) { return ((H + 31) & ~31) + 2; }
+inline size_t split_frame_bytes(int H, int W, int C) { return (size_t)split_frame_h(H) * split_frame_w(W) * C * 4; }
 
 // conv1a + conv1b + ReLU + 2x2 max-pool fused (fp16 path): conv1a runs on the matrix cores inside conv1b's ping-pong kernel
 // with split fp16 operands (conv.hip); a = the conv1b layer (a.in unused).  Host-side packers for its constant inputs.

@@ -171,14 +171,22 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     }
     // activations
     const size_t B = s->max_batch, H = s->H, W = s->W, e = s->esz;
-    OMNI_HIP_TRY(hipMalloc(&s->a1a, B * H * W * 64 * e));
-    OMNI_HIP_TRY(hipMalloc(&s->a1b, B * (H / 2) * (W / 2) * 64 * e));
-    OMNI_HIP_TRY(hipMalloc(&s->a2a, B * (H / 2) * (W / 2) * 64 * e));
-    OMNI_HIP_TRY(hipMalloc(&s->a2b, B * (H / 4) * (W / 4) * 64 * e));
-    OMNI_HIP_TRY(hipMalloc(&s->a3a, B * (H / 4) * (W / 4) * 128 * e));
-    OMNI_HIP_TRY(hipMalloc(&s->a3b, B * (H / 8) * (W / 8) * 128 * e));
-    OMNI_HIP_TRY(hipMalloc(&s->a4a, B * (H / 8) * (W / 8) * 128 * e));
-    OMNI_HIP_TRY(hipMalloc(&s->a4b, B * (H / 8) * (W / 8) * 128 * e));
+    {
+        // OMNI_PREC_SPLIT: every map in its zero frame (conv.h), zeroed here once
+        struct Act { void** p; size_t h, w, c; };
+        const Act acts[] = {{&s->a1a, H, W, 64},         {&s->a1b, H / 2, W / 2, 64},  {&s->a2a, H / 2, W / 2, 64},  {&s->a2b, H / 4, W / 4, 64},
+                            {&s->a3a, H / 4, W / 4, 128}, {&s->a3b, H / 8, W / 8, 128}, {&s->a4a, H / 8, W / 8, 128}, {&s->a4b, H / 8, W / 8, 128}};
+        for (const Act& a : acts) {
+            if (s->precision == OMNI_PREC_SPLIT) {
+                const size_t bytes = B * split_frame_bytes((int)a.h, (int)a.w, (int)a.c);
+                OMNI_HIP_TRY(hipMalloc(a.p, bytes));
+                OMNI_HIP_TRY(hipMemsetAsync(*a.p, 0, bytes, st));
+            } else {
+                OMNI_HIP_TRY(hipMalloc(a.p, B * a.h * a.w * a.c * e));
+            }
+        }
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
+    }
     OMNI_HIP_TRY(hipMalloc(&s->heads, B * (H / 8) * (W / 8) * 512 * e));
     if (s->precision == OMNI_PREC_F16) {
         OMNI_HIP_TRY(hipMalloc(&s->headsP, B * (H / 8) * (W / 8) * 256 * e));
@@ -535,7 +543,7 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
         const size_t n = (size_t)batch * e.c * h * w;
         int rc;
         if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
-        if (e.prec == OMNI_PREC_SPLIT) { if ((rc = omni::split_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc; }
+        if (e.prec == OMNI_PREC_SPLIT) { if ((rc = omni::split_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h, w))) return rc; }
         else if ((rc = omni::nhwc_any_to_nchw_f32(s->ctx->stream, e.prec, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc;
         OMNI_HIP_TRY(hipMemcpyAsync(out_nchw_host, s->dense_tmp.p, n * 4, hipMemcpyDeviceToHost, s->ctx->stream));
         OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
