@@ -94,15 +94,15 @@ __device__ __forceinline__ void spl_wait(half8_t& f) { asm volatile("s_waitcnt l
 // and with one wave per SIMD nothing else hides it.
 //
 // Everything else a tile needs rides in the shadow of this stream (one wave per SIMD: whatever is not issued between two MFMAs idles the
-// matrix cores): the "dense" steps (4 MFMAs = 128 cycles) each carry one SLICE of the PREVIOUS tile's epilogue (scale + bias + ReLU +
-// hi / lo split of 4 values per lane, the cross-lane swap and, every second slice, the stores), the other steps the LDS-DMA
+// matrix cores): the "dense" steps (4 MFMAs = 128 cycles) each carry one PART of the PREVIOUS tile's epilogue (scale + bias + ReLU +
+// hi / lo split of 2 values per lane; every second part the cross-lane swap, every fourth the stores), the other steps the LDS-DMA
 // instructions of the NEXT tile one at a time (a burst of 17 behind the stores stalls the wave in the VMEM issue queue for 2 000
 // cycles; measured with the s_memtime trace below).
 #define SPL_NB 8
 constexpr bool spl_dense(int L) { return ((L / 8) % 4 == 1 || (L / 8) % 4 == 2) && L % 8 < 4; }
 constexpr int spl_dense_before(int L) { int c = 0; for (int l = 0; l < L; ++l) c += spl_dense(l) ? 1 : 0; return c; }
 
-#define SPL_MID_STEP 12                               // cin = 128 has at most 4 slices (dense steps 8-11): all behind it
+#define SPL_MID_STEP 20                               // cin = 128 has at most 8 epilogue parts (dense steps 8-11, 16-19): all behind it
 template <int L, int NSL, int NDMA, bool MID, typename Epi, typename Dma>
 __device__ __forceinline__ void spl_steps(uint32_t row_base, int n_eff, int hh, const half8_t (&wreg)[72], floatx16 (&acc)[2], half8_t (&fb)[SPL_NB],
                                           Epi&& epi, Dma&& dma) {
@@ -124,11 +124,11 @@ __device__ __forceinline__ void spl_steps(uint32_t row_base, int n_eff, int hh, 
         if constexpr (spl_dense(L)) {
             if constexpr (nd < NSL) {
                 epi(std::integral_constant<int, nd>{});
-                // one MFMA, then a quarter of the slice in its shadow
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                // one MFMA, then a quarter of the part in its shadow
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
         } else {
             if constexpr (nn < NDMA) dma(std::integral_constant<int, nn>{});
@@ -164,20 +164,26 @@ template <bool C128, bool POOL>
 struct SplEpi {
     static constexpr int NV = C128 ? 16 : 32;
     static constexpr int NPK = C128 ? (POOL ? 1 : 2) : (POOL ? 2 : 4);
-    static constexpr int NSL = 2 * NPK;
     static constexpr int NPO = POOL ? 1 : 2;
     float v[NV];
     spl_f4 p[C128 ? 4 : 1];       // cin = 128: the partner wave's partial sums of the same values (read from LDS at the top of the next tile)
     __amdgpu_buffer_rsrc_t img;   // the output image (raw buffer: a store beyond its bytes is dropped)
     uint32_t off[NPO];            // byte offset of the wave's 32-channel fragment of the lane's pixel in output row f; SPL_NO_STORE: nothing to store
-    SplPacked pk;
+    SplPacked pk;                 // the pair being built
+    uint32_t qh, ql;              // ... and the first two values of the half being built
 };
 #define SPL_NO_STORE 0x80000000u   // >= the bytes of any image (checked by the launcher), also after the in-fragment offset is added
 typedef uint32_t spl_u4 __attribute__((ext_vector_type(4)));
 
+// Part S of a tile's epilogue.  A pair is done in four parts (OUT_F32: two): part q of half h computes the hi / lo dwords of two values
+// (q = 0: values 2h, 2h+1; q = 1: values 4+2h, 5+2h); the second part of a half swaps the dwords across the half-waves, the last part of a
+// pair stores it.  ~13 VALU instructions each: one part per dense step stays inside the shadow of the step's four MFMAs (a whole half per
+// step -- 26 instructions against 128 cycles -- overran it by ~100 cycles per step; measured with the trace).
+template <bool OUT_F32> constexpr int spl_parts_per_pair() { return OUT_F32 ? 2 : 4; }
 template <int S, bool C128, bool POOL, bool OUT_F32>
-__device__ __forceinline__ void spl_epi_slice(SplEpi<C128, POOL>& e, const float4 (&bs)[C128 ? 2 : 4], float inv, int relu, int hh, int part) {
-    constexpr int i = S >> 1, h = S & 1;
+__device__ __forceinline__ void spl_epi_part(SplEpi<C128, POOL>& e, const float4 (&bs)[C128 ? 2 : 4], float inv, int relu, int hh, int part) {
+    constexpr int PP = spl_parts_per_pair<OUT_F32>();
+    constexpr int i = S / PP, h = OUT_F32 ? S % 2 : (S % 4) >> 1, q = OUT_F32 ? 0 : S & 1;
     constexpr int f = POOL ? 0 : (C128 ? i : i >> 1);
     constexpr int gpc = C128 ? 0 : (POOL ? i : i & 1);
     const int gp = C128 ? part : gpc;
@@ -209,39 +215,35 @@ __device__ __forceinline__ void spl_epi_slice(SplEpi<C128, POOL>& e, const float
         __builtin_amdgcn_raw_buffer_store_b128(d, e.img, e.off[f] + (16 * gp + 4 * hh + 8 * h) * 4, 0, 0);
     } else {
         const float lo_lim = relu ? 0.f : -65000.f;
-        float y[4];
-        y[0] = fmaf(raw(std::integral_constant<int, 2 * h>{}), inv, h ? b0.z : b0.x);
-        y[1] = fmaf(raw(std::integral_constant<int, 2 * h + 1>{}), inv, h ? b0.w : b0.y);
-        y[2] = fmaf(raw(std::integral_constant<int, 4 + 2 * h>{}), inv, h ? b1.z : b1.x);
-        y[3] = fmaf(raw(std::integral_constant<int, 5 + 2 * h>{}), inv, h ? b1.w : b1.y);
-        uint32_t dh[2], dl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float x0 = __builtin_amdgcn_fmed3f(y[2 * j], lo_lim, 65000.f), x1 = __builtin_amdgcn_fmed3f(y[2 * j + 1], lo_lim, 65000.f);
-            float2v_t fv; fv[0] = x0; fv[1] = x1;
-            const half2v_t hv = __builtin_convertvector(fv, half2v_t);
-            float2v_t rv; rv[0] = x0 - (float)hv[0]; rv[1] = x1 - (float)hv[1];
-            const half2v_t lv = __builtin_convertvector(rv, half2v_t);
-            dh[j] = __builtin_bit_cast(uint32_t, hv);
-            dl[j] = __builtin_bit_cast(uint32_t, lv);
-        }
-        const auto rh = __builtin_amdgcn_permlane32_swap(dh[0], dh[1], false, false);
-        const auto rl = __builtin_amdgcn_permlane32_swap(dl[0], dl[1], false, false);
-        if constexpr (h == 0) { e.pk.a.x = rh[0]; e.pk.a.z = rh[1]; e.pk.b.x = rl[0]; e.pk.b.z = rl[1]; }
+        const float4 bb = q ? b1 : b0;
+        const float y0 = fmaf(raw(std::integral_constant<int, 4 * q + 2 * h>{}), inv, h ? bb.z : bb.x);
+        const float y1 = fmaf(raw(std::integral_constant<int, 4 * q + 2 * h + 1>{}), inv, h ? bb.w : bb.y);
+        const float x0 = __builtin_amdgcn_fmed3f(y0, lo_lim, 65000.f), x1 = __builtin_amdgcn_fmed3f(y1, lo_lim, 65000.f);
+        float2v_t fv; fv[0] = x0; fv[1] = x1;
+        const half2v_t hv = __builtin_convertvector(fv, half2v_t);
+        float2v_t rv; rv[0] = x0 - (float)hv[0]; rv[1] = x1 - (float)hv[1];
+        const half2v_t lv = __builtin_convertvector(rv, half2v_t);
+        const uint32_t dh = __builtin_bit_cast(uint32_t, hv), dl = __builtin_bit_cast(uint32_t, lv);
+        if constexpr (q == 0) { e.qh = dh; e.ql = dl; }
         else {
-            e.pk.a.y = rh[0]; e.pk.a.w = rh[1]; e.pk.b.y = rl[0]; e.pk.b.w = rl[1];
-            // no branch in the stream: lanes with nothing to store carry an offset outside the buffer
-            const uint32_t vo = e.off[f] + (16 * gp + 8 * hh) * 2;
-            const spl_u4 da = {e.pk.a.x, e.pk.a.y, e.pk.a.z, e.pk.a.w}, db = {e.pk.b.x, e.pk.b.y, e.pk.b.z, e.pk.b.w};
-            __builtin_amdgcn_raw_buffer_store_b128(da, e.img, vo, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(db, e.img, vo + 128, 0, 0);
+            const auto rh = __builtin_amdgcn_permlane32_swap(e.qh, dh, false, false);
+            const auto rl = __builtin_amdgcn_permlane32_swap(e.ql, dl, false, false);
+            if constexpr (h == 0) { e.pk.a.x = rh[0]; e.pk.a.z = rh[1]; e.pk.b.x = rl[0]; e.pk.b.z = rl[1]; }
+            else {
+                e.pk.a.y = rh[0]; e.pk.a.w = rh[1]; e.pk.b.y = rl[0]; e.pk.b.w = rl[1];
+                // no branch in the stream: lanes with nothing to store carry an offset outside the buffer
+                const uint32_t vo = e.off[f] + (16 * gp + 8 * hh) * 2;
+                const spl_u4 da = {e.pk.a.x, e.pk.a.y, e.pk.a.z, e.pk.a.w}, db = {e.pk.b.x, e.pk.b.y, e.pk.b.z, e.pk.b.w};
+                __builtin_amdgcn_raw_buffer_store_b128(da, e.img, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(db, e.img, vo + 128, 0, 0);
+            }
         }
     }
 }
 template <int S, bool C128, bool POOL, bool OUT_F32>
 __device__ __forceinline__ void spl_epi_all(SplEpi<C128, POOL>& e, const float4 (&bs)[C128 ? 2 : 4], float inv, int relu, int hh, int part) {
-    if constexpr (S < SplEpi<C128, POOL>::NSL) {
-        spl_epi_slice<S, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part);
+    if constexpr (S < SplEpi<C128, POOL>::NPK * spl_parts_per_pair<OUT_F32>()) {
+        spl_epi_part<S, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part);
         spl_epi_all<S + 1, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part);
     }
 }
@@ -378,7 +380,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     for (int i = 0; i < Epi::NPO; ++i) e.off[i] = SPL_NO_STORE;                    // nothing pending before the first tile
     const uint32_t out_img_bytes = (uint32_t)((int64_t)Hof * Wof * opix);
     e.img = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_img_bytes, 0x00020000);
-    e.pk.a = make_uint4(0, 0, 0, 0); e.pk.b = e.pk.a;
+    e.pk.a = make_uint4(0, 0, 0, 0); e.pk.b = e.pk.a; e.qh = e.ql = 0;
 
     // cin = 128, K split over the wave pair (co, 0) / (co, 1): wave `part` finishes register groups 2 part, 2 part + 1 (channels [16 part, +16) of
     // the fragment, both rows) and hands the partner the other two.  The hand-over rides on the barrier that ends the tile: partial sums ->
@@ -412,8 +414,8 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         spl_prime(row_base, n_eff, hh, fb);
         stamp(1);
         __builtin_amdgcn_sched_barrier(0);
-        spl_steps<0, Epi::NSL, PPW, C128>(row_base, n_eff, hh, wreg, acc, fb,
-            [&](auto SC) { spl_epi_slice<decltype(SC)::value, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part); },
+        spl_steps<0, Epi::NPK * spl_parts_per_pair<OUT_F32>(), PPW, C128>(row_base, n_eff, hh, wreg, acc, fb,
+            [&](auto SC) { spl_epi_part<decltype(SC)::value, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part); },
             [&](auto JC) { dma_piece(org_n, cur ^ 1, decltype(JC)::value); });
         stamp(2);
 
@@ -517,7 +519,7 @@ static int launch_split(hipStream_t st, const ConvArgs& a) {
         OMNI_HIP_TRY(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, st));
         OMNI_HIP_TRY(hipStreamSynchronize(st));
         static int launches = 0;
-        if (launches++ < 3)                        // per instantiation: the first launches of a layer shape
+        if (total >= 8 * per_cg && launches++ < 2)  // per instantiation: the first launches with at least eight tiles per workgroup
             for (int w = 0; w < 2; ++w)
                 for (int k = 0; k < 4; ++k) {
                     const unsigned long long* q = h + w * 32 + k * 8;
