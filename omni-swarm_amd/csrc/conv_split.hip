@@ -138,6 +138,10 @@ __device__ __forceinline__ void spl_steps(uint32_t row_base, int n_eff, int hh, 
         spl_steps<L + 1, NSL, NDMA, MID>(row_base, n_eff, hh, wreg, acc, fb, epi, dma);
     }
 }
+template <int J, int N, typename F>
+__device__ __forceinline__ void spl_for_each(F&& f) {
+    if constexpr (J < N) { f(std::integral_constant<int, J>{}); spl_for_each<J + 1, N>(f); }
+}
 // the first SPL_NB - 1 fragments of a tile
 template <int L = 0>
 __device__ __forceinline__ void spl_prime(uint32_t row_base, int n_eff, int hh, half8_t (&fb)[SPL_NB]) {
@@ -317,23 +321,29 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         goff[j] = (uint32_t)(iy * Wf + ix) * PIXB + inner;
     }
     // piece j of this wave (the last wave of a cin = 64 workgroup has 12: its 13th is the 12th again).  Buffer addressing: descriptor = the
-    // image's frame, scalar offset = the halo origin, per-lane offset = goff[j]: no vector arithmetic per instruction
+    // image's frame, scalar offset = the halo origin, per-lane offset = goff[j]: no vector arithmetic per instruction.  Four consecutive
+    // pieces share one M0 (the LDS base) and differ in the instruction's immediate offset, which moves the LDS address AND the memory
+    // address by k KiB: the scalar offset takes the k KiB back (the descriptor starts 4 KiB in front of the frame so that it stays positive).
+    // A write to M0 waits for the LDS-DMA instructions in flight to have consumed the old value -- 17 writes per tile cost the stream
+    // ~600 cycles.
     const uint32_t in_img_bytes = (uint32_t)Hf * Wf * PIXB;
     auto origin = [&](const SplTileIx& q) -> SplOrg {
         SplOrg o;
-        o.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in) + (int64_t)q.b * in_img_bytes, 0, in_img_bytes, 0x00020000);
+        o.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in) + (int64_t)q.b * in_img_bytes - 4096, 0, in_img_bytes + 8192, 0x00020000);
         // halo origin (ty0 - 1, tx0 - 1) = frame pixel (ty0, tx0)
-        o.soff = (uint32_t)(q.ty * (TRN ? 32 : TH) * Wf + q.tx * (TRN ? TH : 32)) * PIXB;
+        o.soff = (uint32_t)(q.ty * (TRN ? 32 : TH) * Wf + q.tx * (TRN ? TH : 32)) * PIXB + 4096;
         return o;
     };
-    auto dma_piece = [&](const SplOrg& o, int which, int j) {
-        int piece = wave * PPW + j;
-        piece = piece < NPIECES ? piece : NPIECES - 1;
+    auto dma_piece = [&](const SplOrg& o, int which, auto JC) {
+        constexpr int j = decltype(JC)::value, g = j / 4;
+        [[maybe_unused]] constexpr int k = j % 4;
+        int first = wave * PPW + 4 * g;                                  // the group's first piece
+        first = first < NPIECES ? first : NPIECES - 1;
 #if __HIP_DEVICE_COMPILE__          // hipcc's host pass has no target for this builtin and silently drops the kernel's launch stub when it meets it
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(o.r, (__attribute__((address_space(3))) void*)(smem_raw + which * SPL_BUF_BYTES + piece * 1024), 16,
-                                                 goff[j], o.soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(o.r, (__attribute__((address_space(3))) void*)(smem_raw + which * SPL_BUF_BYTES + first * 1024), 16,
+                                                 goff[j], o.soff - k * 1024, k * 1024, 0);
 #else
-        (void)o; (void)which; (void)piece;
+        (void)o; (void)which; (void)first;
 #endif
     };
 
@@ -359,8 +369,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     }
     if (t < total) {
         const SplOrg o = origin(cur_ix);
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) dma_piece(o, 0, j);
+        spl_for_each<0, PPW>([&](auto JC) { dma_piece(o, 0, JC); });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -416,7 +425,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         __builtin_amdgcn_sched_barrier(0);
         spl_steps<0, Epi::NPK * spl_parts_per_pair<OUT_F32>(), PPW, C128>(row_base, n_eff, hh, wreg, acc, fb,
             [&](auto SC) { spl_epi_part<decltype(SC)::value, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part); },
-            [&](auto JC) { dma_piece(org_n, cur ^ 1, decltype(JC)::value); });
+            [&](auto JC) { dma_piece(org_n, cur ^ 1, JC); });
         stamp(2);
 
         // this tile's raw values and addresses become the pending epilogue
