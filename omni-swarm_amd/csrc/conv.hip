@@ -821,7 +821,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 pp_load_step<1>(a_base0, a_base1, bb, fa0[1], fa1[1], fb0[1], fb1[1]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(dbg & 16)) __builtin_amdgcn_s_setprio(2);       // the matrix-pipe wave outranks its SIMD partner's service work
-                const bool trc = FUSE1A && fz.trace && blockIdx.x == 0 && wl == 0 && lane == 0 && p >= 2 && p < 6;
+                const bool trc = fz.trace && blockIdx.x == 0 && wl == 0 && lane == 0 && p >= 2 && p < 6;
                 if (trc) fz.trace[p * 8 + 4] = __builtin_amdgcn_s_memtime();
                 pp_mfma_steps<0, ABL>(a_base0, a_base1, bb, acc, fa0, fa1, fb0, fb1);
                 if (trc) fz.trace[p * 8 + 5] = __builtin_amdgcn_s_memtime();
@@ -838,7 +838,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
             const bool load = k_load < n_mine && !(dbg & 1);
             if (dbg & 32) __builtin_amdgcn_s_setprio(3);
             uint32_t pv = 0;
-            const bool tr = FUSE1A && fz.trace && blockIdx.x == 0 && wl == 0 && lane == 0 && p >= 2 && p < 6;
+            const bool tr = fz.trace && blockIdx.x == 0 && wl == 0 && lane == 0 && p >= 2 && p < 6;
             if (tr) fz.trace[p * 8 + 0] = __builtin_amdgcn_s_memtime();
             if (load) {
                 if constexpr (FUSE1A) build_issue(wg + k_load * nwg, pv);   // the patch load flies under the epilogue
@@ -899,6 +899,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                if (tr) fz.trace[p * 8 + 3] = __builtin_amdgcn_s_memtime();
                 k_load += 2;
             }
         }
@@ -925,10 +926,29 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
     OMNI_REQUIRE((int64_t)total * (tiles_x * tiles_y) < (1ll << 32), OMNI_ERR_INVALID, "conv: too many tiles for the multiply-high division");
     fzz.magic_tpi = (uint32_t)(((1ull << 32) + (uint64_t)(tiles_x * tiles_y) - 1) / (uint64_t)(tiles_x * tiles_y));
     fzz.magic_tx = (uint32_t)(((1ull << 32) + (uint64_t)tiles_x - 1) / (uint64_t)tiles_x);
+    // OMNI_PP_TRACE=1 (debug): s_memtime stamps of workgroup 0's phases 2-5 for the layers without the conv1a fusion (conv1ab_fused prints its own)
+    static const bool want_trace = [] { const char* e = getenv("OMNI_PP_TRACE"); return e && e[0] == '1'; }();
+    static unsigned long long* trace_dev = nullptr;
+    if (want_trace && !FUSE1A) {
+        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
+        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * 8, st));
+        fzz.trace = trace_dev;
+    }
     hipLaunchKernelGGL(kfn, dim3(per_ct * n_ct), dim3(PP_THREADS), smem_bytes, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_ct,
                        tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, dbg, fzz);
     OMNI_LAUNCH_CHECK();
+    if (want_trace && !FUSE1A) {
+        unsigned long long h[64];
+        OMNI_HIP_TRY(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, st));
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
+        static int launches = 0;
+        if (total >= 16 * per_ct && launches++ < 2)
+            for (int p = 2; p < 6; ++p)
+                if (h[p * 8])
+                    fprintf(stderr, "pp trace pool=%d H=%d W=%d cout=%d phase %d: service: issue %llu epilogue %llu dma wait %llu | partner mfma loop %llu\n", (int)POOL, a.H, a.W,
+                            a.cout, p, h[p * 8 + 1] - h[p * 8], h[p * 8 + 2] - h[p * 8 + 1], h[p * 8 + 3] - h[p * 8 + 2], h[(p ^ 1) * 8 + 5] - h[(p ^ 1) * 8 + 4]);
+    }
     return OMNI_OK;
 }
 template <bool POOL>
