@@ -13,7 +13,11 @@
 // type fingerprints cannot be reproduced here.  The encoding below follows LCM's rules (fingerprint first, big-endian scalars, every
 // variable-length array preceded by its own length member) over the fields loop_net.cpp reads and writes, with fingerprints of our own:
 // two builds of THIS library interoperate; byte-level interop with a reference drone needs the .lcm definitions.
-// Deviation: message ids come from a per-object counter mixed with the drone id instead of rand() + nsec (loop_net.cpp:28,81): deterministic.
+// Pinned: tests/cpp/wire_pin.cpp compiles the reference's own LoopNet (class + loop_net.cpp, extracted at build time) against stand-in ROS /
+// LCM / swarm_msgs types and runs it next to this class: same messages out of broadcast_fisheye_desc, same frames out of frame_desc_callback
+// under complete, lossy and shuffled delivery.
+// Deviations (both asserted by that test): message ids come from a per-object counter mixed with the drone id instead of rand() + nsec
+// (loop_net.cpp:28,81): deterministic; a header always activates its image, also when a landmark packet overtook it (see on_header).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -136,7 +140,9 @@ public:
         wire::ImageDescriptorHeader h;
         h.timestamp = img.timestamp; h.drone_id = img.drone_id; h.image_desc = img.image_desc; h.pose_drone = img.pose_drone;
         h.camera_extrinsic = img.camera_extrinsic; h.prevent_adding_db = img.prevent_adding_db; h.msg_id = img.msg_id; h.frame_id = img.frame_id;
-        h.feature_num = SEND_ALL_FEATURES ? img.landmark_num : feature_num; h.direction = img.direction;
+        // the landmarks WITH a 3-D point, also under SEND_ALL_FEATURES (loop_net.cpp:62): the receiver then closes the image after that many
+        // packets and drops the rest -- the reference's behaviour, kept so that its drones and ours read each other's headers the same way
+        h.feature_num = feature_num; h.direction = img.direction;
         size_t bytes = 0;
         { auto b = wire::encode(h); bytes += b.size(); publish(wire::CH_HEADER, b); }
         for (int i = 0; i < img.landmark_num; ++i) {

@@ -1,6 +1,10 @@
 """LoopNet's wire side (omni-swarm_amd/host/loop_net_wire.hpp; swarm_loop/src/loop_net.cpp:19-120,143-324): header + per-landmark packets,
 LCM-style big-endian encoding, reassembly under shuffling and loss with the reference's time-outs, self-sent filter, corrupt packets rejected.
-CPU only: g++ builds tests/cpp/wire_check.cpp."""
+CPU only: g++ builds tests/cpp/wire_check.cpp.
+
+test_wire_is_pinned_to_the_reference_text: the reference's OWN LoopNet (loop_net.h's class + loop_net.cpp, extracted at build time into
+oracle/_ref/, never committed) compiled verbatim against stand-in ROS / LCM / swarm_msgs types runs next to LoopNetWire
+(tests/cpp/wire_pin.cpp, built by oracle/Makefile)."""
 import os
 import subprocess
 
@@ -52,3 +56,26 @@ def test_split_and_reassemble(exe, seed):
                     assert prevent == (1 if d == 1 else 0)
             assert fr[-2] == "1.500" and fr[-1] == "0.600"
         assert total == flagged - lost
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_wire_is_pinned_to_the_reference_text(seed):
+    """Same key frames through LoopNet::broadcast_fisheye_desc and LoopNetWire::broadcast_fisheye_desc -> the same header / landmark messages
+    field for field (also with SEND_ALL_FEATURES, where the header keeps announcing only the landmarks with a 3-D point, loop_net.cpp:62);
+    the same packets into both receivers -- in order, with lost landmarks, with lost headers, shuffled -- under the reference's time-outs ->
+    the same FisheyeFrameDescriptor sequence and the same receive rates; a landmark overtaking its header: the reference never delivers that
+    image, LoopNetWire does (the one deliberate difference)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "wire_pin")
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/wire_pin"])
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/wire_pin is built from /root/reference, which is absent here")
+    r = subprocess.run([exe, str(seed)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[-1] == "OK 0"
+    tags = [ln.split()[0] for ln in lines]
+    assert tags.count("SEND") == 2 and tags.count("RECV") == 4 and tags.count("OVERTAKE") == 1
+    for ln in lines:
+        if ln.startswith("RECV"):
+            assert int(ln.split()[3]) >= 3                                     # frames were actually delivered in every schedule
