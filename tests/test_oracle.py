@@ -363,6 +363,106 @@ def test_nms2_restatement_is_pinned_to_the_reference_text():
     assert diff > 0            # the quirk is real (and only reachable at the frame's left / right edge)
 
 
+def _ref_sp_post():
+    """oracle/_ref/libref_sp_post.so (+ _nopca): the REFERENCE'S OWN SuperPointTensorRT::getKeyPoints and ::computeDescriptors text
+    (superpoint_tensorrt.cpp:164-230, with pt_conf_comp / NMS2 behind them) compiled verbatim against the real libtorch C++ API of this image,
+    the cv:: stand-in and a three-expression Eigen stand-in (oracle/ref_build/sp_post_wrap.cpp)."""
+    import ctypes
+    import subprocess
+    import torch                                                    # libtorch must be in the process before the .so is opened
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "ref"])
+    libs = []
+    for name in ("libref_sp_post.so", "libref_sp_post_nopca.so"):
+        path = os.path.join(root, "oracle", "_ref", name)
+        if not os.path.exists(path):
+            pytest.skip("oracle/_ref/%s not built (needs /root/reference once)" % name)
+        libs.append(ctypes.CDLL(path))
+    fp = ctypes.POINTER(ctypes.c_float)
+    ci = ctypes.c_int
+
+    def fn(L, name, argtypes):
+        f = getattr(L, name)
+        f.restype = ci
+        f.argtypes = argtypes
+        return f
+    gk = fn(libs[0], "ref_sp_get_keypoints", [fp, ci, ci, ctypes.c_float, ci, fp])
+    cd = fn(libs[0], "ref_sp_compute_descriptors", [fp, ci, ci, fp, ci, ci, ci, fp, fp, ci, fp])
+    cd_raw = fn(libs[1], "ref_sp_compute_descriptors_nopca", [fp, ci, ci, fp, ci, ci, ci, fp, fp, ci, fp])
+
+    def keypoints(prob, thres, max_num):
+        prob = np.ascontiguousarray(prob, np.float32)
+        out = np.zeros((prob.size, 2), np.float32)
+        n = gk(prob.ctypes.data_as(fp), prob.shape[1], prob.shape[0], thres, max_num, out.ctypes.data_as(fp))
+        return out[:n].copy()
+
+    def descriptors(desc, xy, W, H, comp=None, mean=None):
+        desc = np.ascontiguousarray(desc, np.float32)
+        xy = np.ascontiguousarray(xy, np.float32)
+        d_out = 256 if comp is None else comp.shape[0]
+        out = np.zeros((max(len(xy), 1), d_out), np.float32)
+        if comp is None:
+            n = cd_raw(desc.ctypes.data_as(fp), desc.shape[1], desc.shape[2], xy.ctypes.data_as(fp), len(xy), W, H, None, None, 256, out.ctypes.data_as(fp))
+        else:
+            comp = np.ascontiguousarray(comp, np.float32)
+            mean = np.ascontiguousarray(mean, np.float32)
+            n = cd(desc.ctypes.data_as(fp), desc.shape[1], desc.shape[2], xy.ctypes.data_as(fp), len(xy), W, H, comp.ctypes.data_as(fp), mean.ctypes.data_as(fp),
+                   d_out, out.ctypes.data_as(fp))
+        assert n == len(xy) * d_out
+        return out[:len(xy)]
+    return keypoints, descriptors
+
+
+def test_postprocessing_restatement_is_pinned_to_the_reference_text():
+    """oracle.postproc_ref.get_keypoints / compute_descriptors -- the checkers of every key-point and descriptor parity test -- against the
+    reference's own getKeyPoints and computeDescriptors compiled from their own text with the real libtorch:
+      * key points: `prob > thres`, findNonZero order, the confidence column, NMS2(border 0, dist 4, width, height, max_num): identical sets in
+        identical order, on heat maps of the network itself (seeded weights, synthetic frames) and on random maps, interior candidates
+        (the left / right edge wrap-around of NMS2 is covered by test_nms2_restatement_is_pinned_to_the_reference_text);
+      * descriptors in front of the PCA (grid = 2 x / width - 1, grid_sampler(…, 0, 0, 0), the norm over dim 1 = ACROSS the key points, div,
+        transpose): bit-identical to the restatement;
+      * with the PCA: (desc - mean) * comp^T to 2e-6 (the Eigen product is a stand-in: summation order unpinned)."""
+    import torch
+    from oracle import superpoint_ref as S
+    from omni_swarm_amd import synth
+    ref_kp, ref_desc = _ref_sp_post()
+    comp, mean = synth.pca()
+    w = S.synth_weights(0)
+    checked = 0
+    for (H, W, seed) in ((96, 128, 3), (120, 160, 5), (64, 96, 8)):
+        img = synth.image_u8(900 + seed, H, W, n_shapes=40)[None]
+        semi, desc = S.forward(w, S.preprocess_u8(img, False))
+        prob = semi[0].copy()
+        prob[:4] = 0; prob[-4:] = 0; prob[:, :4] = 0; prob[:, -4:] = 0                 # interior candidates only (NMS2's edge quirk is pinned elsewhere)
+        for thr, maxn in ((0.015, 200), (0.05, 30), (0.3, 200)):
+            xy, _, _, _ = P.get_keypoints(prob, thr, maxn)
+            got = ref_kp(prob, thr, maxn)
+            assert np.array_equal(got, xy.astype(np.float32)), (H, W, thr, maxn)
+            if len(xy) == 0:
+                continue
+            d64, d256 = P.compute_descriptors(desc[0], xy, W, H, comp, mean)
+            r256 = ref_desc(desc[0], xy, W, H)
+            assert np.array_equal(r256, d256), np.abs(r256 - d256).max()               # the torch part: same library, same calls, same bits
+            r64 = ref_desc(desc[0], xy, W, H, comp, mean)
+            assert np.abs(r64 - d64).max() < 2e-6 * max(1.0, np.abs(d64).max())
+            checked += len(xy)
+    rng = np.random.default_rng(7)
+    for trial in range(10):                                                             # random maps and descriptor planes, odd sizes
+        H, W = 8 * int(rng.integers(4, 10)), 8 * int(rng.integers(4, 12))
+        prob = np.zeros((H, W), np.float32)
+        n = int(rng.integers(10, 200))
+        ys, xs = rng.integers(4, H - 4, n), rng.integers(4, W - 4, n)
+        prob[ys, xs] = rng.permutation(n).astype(np.float32) / n * 0.9 + 0.05
+        desc = rng.standard_normal((256, H // 8, W // 8)).astype(np.float32)
+        xy, _, _, _ = P.get_keypoints(prob, 0.1, 50)
+        assert np.array_equal(ref_kp(prob, 0.1, 50), xy.astype(np.float32))
+        d64, d256 = P.compute_descriptors(desc, xy, W, H, comp, mean)
+        assert np.array_equal(ref_desc(desc, xy, W, H), d256)
+        assert np.abs(ref_desc(desc, xy, W, H, comp, mean) - d64).max() < 2e-6 * max(1.0, np.abs(d64).max())
+        checked += len(xy)
+    assert checked > 500
+
+
 def test_mobilenetvlad_backbone_matches_an_independent_mobilenetv2():
     """The reference ships no MobileNetVLAD graph (parity unpinned, assumed architecture).  What CAN be checked offline: the assumed backbone --
     MobileNetV2 at width 0.35 up to the 112-channel block -- against an INDEPENDENT implementation of that architecture (Hugging Face
