@@ -559,7 +559,7 @@ struct Fuse1aArgs {
     const uint8_t* gray; int gstride; int mask_r0, mask_r1;
     const _Float16* w1a_frag;     // [2 k-halves][2 m][64 lanes][8 halfs] A fragments of the split conv1a weights
     const float* bias1a;          // [64]
-    const uint32_t* lut_hl;       // [256] half(x) | half(x - half(x)) << 16,  x = float(double(i) * (1.0 / 255.0))
+    const uint32_t* lut_hl;       // [256] half(x) | half(x - half(x)) << 16,  x = float(i) * float(1 / 255.0)
     unsigned long long* trace;    // OMNI_PP_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
     const char* zero_page;        // OMNI_ZERO_PAGE_BYTES of zeros: DMA source of the halo pixels outside the image (set by the launcher)
     uint32_t magic_tpi, magic_tx; // ceil(2^32 / tiles_per_img), ceil(2^32 / tiles_x) (set by the launcher)
@@ -1431,7 +1431,8 @@ void conv1a_pack_split_weights(const float* w, const float* bias, uint16_t* frag
 }
 void conv1a_make_split_lut(uint32_t* lut /*256*/) {
     for (int i = 0; i < 256; ++i) {
-        const float x = (float)((double)i * (1.0 / 255.0));                  // cv::Mat::convertTo(CV_32F, 1/255.0)
+        const volatile float alpha = (float)(1.0 / 255.0);
+        const float x = (float)i * alpha;                                       // cv::Mat::convertTo(CV_32F, 1/255.0): OpenCV 3.4 scales 8-bit sources in float
         const uint16_t hi = f2h_bits(x);
         lut[i] = (uint32_t)hi | ((uint32_t)f2h_bits(x - h2f(hi)) << 16);
     }

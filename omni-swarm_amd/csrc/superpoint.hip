@@ -110,9 +110,10 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         memcpy(bh.data() + 256, w->bias[LDA], 256 * 4);
         if ((rc = dev_upload((void**)&s->bias_heads, bh.data(), 512 * 4, st))) return rc;
     }
-    {   // cv::Mat::convertTo(CV_32F, 1/255.0): float(double(u8) * (1.0/255.0))  (superpoint_tensorrt.cpp:127)
+    {   // cv::Mat::convertTo(CV_32F, 1/255.0) (superpoint_tensorrt.cpp:127): OpenCV 3.4 scales 8-bit sources in float (cvt_32f): float(u8) * float(1/255.0)
         float lut[256];
-        for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i * (1.0 / 255.0));
+        const volatile float alpha = (float)(1.0 / 255.0);                    // (volatile: one fp32 multiply, no contraction / folding in double)
+        for (int i = 0; i < 256; ++i) lut[i] = (float)i * alpha;
         if ((rc = dev_upload((void**)&s->lut, lut, sizeof(lut), st))) return rc;
     }
     if (s->precision == OMNI_PREC_F16) {

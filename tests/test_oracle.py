@@ -85,7 +85,7 @@ def test_preprocess_is_opencv_convert_to():
     u = np.arange(256, dtype=np.uint8)[None]
     x = S.preprocess_u8(u)
     assert x.dtype == np.float32 and x[0, 255] == np.float32(1.0) and x[0, 0] == 0
-    assert np.array_equal(x[0], (u[0].astype(np.float64) * (1.0 / 255.0)).astype(np.float32))
+    assert np.array_equal(x[0], u[0].astype(np.float32) * np.float32(1.0 / 255.0))          # OpenCV 3.4 cvt_32f: float scale
     img = np.full((8, 4), 9, np.uint8)
     assert (S.preprocess_u8(img, fisheye_mask=True)[6:] == 0).all() and (S.preprocess_u8(img, True)[:6] > 0).all()
 
