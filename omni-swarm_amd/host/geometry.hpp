@@ -681,7 +681,9 @@ inline double rp_error(const Pose& p_drone_old_in_new, const Pose& drone_pose_ol
 
 struct VerifyParams {              // loop_defines.h:16-26,62 and the launch parameters of swarm_loop.cpp:221-226
     int min_loop_num = 15, init_mode_min_loop_num = 10;
-    double accept_loop_yaw_rad = 30 * M_PI / 180, max_loop_dis = 5.0, rperr_thres = 10 * M_PI / 180;
+    // loop_defines.h:24 spells the degree as DEG2RAD = 0.01745277777777778 (pi / 180 is 0.0174532925...): the gates sit 3e-5 below 30 and 10 degrees
+    static constexpr double DEG2RAD = 0.01745277777777778;
+    double accept_loop_yaw_rad = 30 * DEG2RAD, max_loop_dis = 5.0, rperr_thres = 10 * DEG2RAD;
 };
 // pnp_result_verify (loop_detector.cpp:317-334)
 inline bool pnp_result_verify(bool pnp_success, bool init_mode, int inliers, double rperr, const Pose& dp_old_to_new, const VerifyParams& vp) {

@@ -572,7 +572,10 @@ def rp_error(p_drone_old_in_new, drone_pose_old, drone_pose_now):
     return float(np.linalg.norm(quat2eulers(a_old) - quat2eulers(a_new)))
 
 
-def pnp_result_verify(ok, init_mode, inliers, rperr, dp, min_loop_num=15, init_min=10, yaw_rad=math.radians(30), max_dis=5.0, rperr_thres=math.radians(10)):
+DEG2RAD = 0.01745277777777778          # loop_defines.h:24 (not pi / 180: the reference's own literal)
+
+
+def pnp_result_verify(ok, init_mode, inliers, rperr, dp, min_loop_num=15, init_min=10, yaw_rad=30 * DEG2RAD, max_dis=5.0, rperr_thres=10 * DEG2RAD):
     if not ok or rperr > rperr_thres:
         return False
     need = init_min if init_mode else min_loop_num

@@ -261,3 +261,92 @@ def test_compute_loop_end_to_end(exe, scene):
     # too few landmarks in the new frame (:633)
     few = dict(new, landmark_num=10)
     assert run(exe, f"loop 1 1 0 1\n{frame_text(few)}\n{frame_text(old)}")[0][1] == "0"
+
+
+# ---- the control flow of LoopGeometry against the reference's own text ----------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def pin_exe():
+    """tests/cpp/loopgeo_pin.cpp: loop_detector.cpp:317-836 (+ PnPRestoCamPose, reduceVector, loop_params.cpp), extracted at build time and compiled
+    verbatim next to LoopGeometry (oracle/Makefile, _ref/loopgeo_pin)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "loopgeo_pin")
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/loopgeo_pin"])
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/loopgeo_pin is built from /root/reference, which is absent here")
+    return exe
+
+
+def _thin(frame, keep_dirs=None, every=1, drone_id=None, msg_id=None):
+    """a copy of a frame with some directions emptied / every n-th landmark kept / another sender"""
+    f = dict(frame)
+    imgs = []
+    for d, im in enumerate(frame["images"]):
+        im = dict(im)
+        if keep_dirs is not None and d not in keep_dirs:
+            sel = np.zeros(0, np.int64)
+        else:
+            sel = np.arange(0, im["landmark_num"], every)
+        for k in ("landmarks_2d", "landmarks_2d_norm", "landmarks_3d", "landmarks_flag", "feature_descriptor"):
+            im[k] = im[k][sel]
+        im["landmark_num"] = len(sel)
+        imgs.append(im)
+    f["images"] = imgs
+    f["landmark_num"] = int(sum(i["landmark_num"] for i in imgs))
+    if drone_id is not None:
+        f["drone_id"] = drone_id
+    if msg_id is not None:
+        f["msg_id"] = msg_id
+    return f
+
+
+def test_loop_geometry_control_flow_is_pinned_to_the_reference_text(pin_exe, scene):
+    """One session of key-frame pairs through LoopGeometry::compute_loop and through the reference's own LoopDetector::compute_loop (same numerical
+    kernels behind both): the same verdicts, inlier counts, LoopEdge fields, edge ids (self_id * MAX_LOOP_ID + loop_count, numbered only when the
+    odometry gate lets the edge through) and relative poses; the frame-pair correspondence function alone returns the same points, 3-D
+    landmarks, per-direction index lists and direction pairs (and its index maps agree with them); the inter-drone counters grow by two per
+    accepted loop.  Cases: main directions equal and rotated, init mode, 6-dof, a direction without landmarks, thinned frames (direction and
+    feature-count gates), another place, an intra-drone edge refused by the odometry gate, an inter-drone edge that the gate does not touch."""
+    new, old = scene["new"], scene["old"]
+    rng = np.random.default_rng(5)
+    pts2 = rng.standard_normal((800, 3)) * 3 + np.array([0, 0, 1.0])
+    d2 = rng.standard_normal((800, 64))
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    other = make_frame(pts2, d2, scene["pose_new"], 11, 1, rng)
+    cases = [
+        (1, 1, 0, 1, 0, new, old), (1, 1, 1, 0, 0, new, old), (0, 0, 0, 1, 0, new, old), (2, 2, 0, 1, 0, new, old), (3, 3, 1, 1, 0, new, old),
+        (2, 1, 0, 1, 0, new, old),                                         # main directions that do not face each other: pairs (2,1) (3,2) (0,3) (1,0)
+        (1, 1, 0, 1, 0, _thin(new, keep_dirs=(0, 1, 2)), old),             # a direction without landmarks on one side
+        (1, 1, 0, 1, 0, new, _thin(old, keep_dirs=(1, 2))),                # only two common directions: MIN_DIRECTION_LOOP fails
+        (1, 1, 0, 1, 0, _thin(new, every=6), old),                         # thin frames: per-direction and total feature gates
+        (1, 1, 1, 1, 0, _thin(new, every=6), _thin(old, every=2)),
+        (1, 1, 0, 1, 0, _thin(new, every=25), old),                        # fewer than 4 flagged matches per image pair: the ignored return value
+        (1, 1, 0, 1, 0, other, old),                                       # another place
+        (1, 1, 0, 1, 0, dict(new, landmark_num=10), old),                  # :633
+        (1, 1, 0, 1, 1, new, old),                                         # the odometry gate refuses an intra-drone edge: no id consumed
+        (1, 1, 0, 1, 1, _thin(new, drone_id=2, msg_id=21), old),           # ... and does not look at an inter-drone one
+        (1, 1, 0, 1, 0, _thin(new, drone_id=3, msg_id=31), old),
+        (0, 0, 1, 1, 0, new, old),
+    ]
+    ver = run(pin_exe, "verify\n")[-1]                                     # the gates' constants and comparison operators on a straddling grid
+    assert ver[0] == "VERIFY" and int(ver[1]) > 5000 and ver[2] == "0", ver
+    text = "\n".join(f"loop {dn} {dold} {im} {is4} {rej}\n{frame_text(a)}\n{frame_text(b)}" for dn, dold, im, is4, rej, a, b in cases)
+    out = [ln for ln in run(pin_exe, text) if ln and ln[0] in ("PROD", "REF", "CORR", "COUNTS")]     # (the reference text prints its own progress lines)
+    assert len(out) == 4 * len(cases)
+    accepted = 0
+    for i, case in enumerate(cases):
+        prod, ref, corr, counts = out[4 * i: 4 * i + 4]
+        assert prod[0] == "PROD" and ref[0] == "REF" and corr[0] == "CORR" and counts[0] == "COUNTS"
+        assert prod[1:8] == ref[1:8], (i, prod[:11], ref[:11])             # verdict, inliers, id, key-frame ids, drone ids
+        assert prod[10] == ref[10]                                           # loops numbered so far
+        if prod[1] == "1":
+            accepted += 1
+            assert abs(float(prod[8]) - float(ref[8])) < 1e-6 and abs(float(prod[9]) - float(ref[9])) < 1e-6          # time stamps (sec + nsec)
+            a, b = np.array(prod[11:18], np.float64), np.array(ref[11:18], np.float64)
+            assert np.abs(a - b).max() < 1e-9, (i, a, b)
+            assert prod[18:] == ref[18:]                                     # covariances
+        assert corr[1] == "1" and corr[2] == corr[3], (i, corr)              # the correspondence sets, element by element
+        assert int(counts[1]) == 2 * accepted
+    verdicts = [out[4 * i][1] for i in range(len(cases))]
+    assert verdicts.count("1") >= 8 and verdicts.count("0") >= 5, verdicts  # both outcomes are exercised
+    assert verdicts[13] == "0" and verdicts[14] == "1"                      # the gate: intra-drone refused, inter-drone untouched
+    assert out[4 * 14][3] == str(1 * 100000000 + sum(v == "1" for v in verdicts[:14]))     # the refused edge consumed no id
