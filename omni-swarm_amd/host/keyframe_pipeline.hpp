@@ -351,7 +351,12 @@ private:
                     im.camera_extrinsic = to_msg(view_extrinsic(d, true)); down.camera_extrinsic = to_msg(view_extrinsic(d, false));
                     im.direction = d;
                     auto tri = [this, &im, &down, r, i, M] {
-                        fill_stereo_landmarks(im, down, r.match_up + (size_t)i * M, r.match_down + (size_t)i * M, r.n_matches[i], cfg_.triangle_thres, cfg_.accept_min_3d_pts);
+                        // the triangulation lifts the pixels again, in double (loop_cam.cpp:403-407); the message keeps the float points
+                        const std::function<geom::Vec2(const Point2f&)> lift64 = [this](const Point2f& p) {
+                            return geom::Vec2{((double)p.x - cfg_.cx) / cfg_.fx, ((double)p.y - cfg_.cy) / cfg_.fy};
+                        };
+                        fill_stereo_landmarks(im, down, r.match_up + (size_t)i * M, r.match_down + (size_t)i * M, r.n_matches[i], cfg_.triangle_thres, cfg_.accept_min_3d_pts,
+                                              &lift64);
                     };
                     if (pool_) stereo_tasks_.push_back(pool_->submit(tri)); else tri();
                 }

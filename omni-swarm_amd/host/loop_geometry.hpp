@@ -37,17 +37,19 @@ struct LoopEdge {                                // swarm_msgs::LoopEdge as comp
 };
 
 // generate_stereo_image_descriptor's triangulation (loop_cam.cpp:397-444) on one direction's up / down messages: fills landmarks_3d and
-// landmarks_flag of both from the up<->down match list (ids_up / ids_down as omni_cam returns them).  Needs landmarks_2d_norm (camera
-// lifting stays with the caller: camodocal is un-vendored), pose_drone and camera_extrinsic.  Skipped, as in the reference (:385), unless
-// the up image has more than accept_min_3d_pts key points.
+// landmarks_flag of both from the up<->down match list (ids_up / ids_down as omni_cam returns them).  Needs pose_drone and camera_extrinsic.
+// The reference lifts the matched PIXELS again, in double, for the triangulation (cam->liftProjective, :403-407) -- the float
+// landmarks_2d_norm of the message (extractor_img_desc_deepnet :558-566) are not what it triangulates from: pass the camera's lifting as
+// `lift` (camodocal is un-vendored: it stays with the caller); without it the message's float points are used.  Skipped, as in the
+// reference (:385), unless the up image has more than accept_min_3d_pts key points.
 inline int fill_stereo_landmarks(ImageDescriptor& up, ImageDescriptor& down, const int* ids_up, const int* ids_down, int n_matches, double triangle_thres,
-                                 int accept_min_3d_pts) {
+                                 int accept_min_3d_pts, const std::function<geom::Vec2(const Point2f&)>* lift = nullptr) {
     auto init = [](ImageDescriptor& im) { im.landmarks_3d.assign(im.landmarks_2d.size(), Point3f{}); im.landmarks_flag.assign(im.landmarks_2d.size(), 0); };
     init(up); init(down);
     if ((int)up.landmarks_2d.size() <= accept_min_3d_pts) return 0;
-    std::vector<geom::Vec2> nu(up.landmarks_2d_norm.size()), nd(down.landmarks_2d_norm.size());
-    for (size_t i = 0; i < nu.size(); ++i) nu[i] = {up.landmarks_2d_norm[i].x, up.landmarks_2d_norm[i].y};
-    for (size_t i = 0; i < nd.size(); ++i) nd[i] = {down.landmarks_2d_norm[i].x, down.landmarks_2d_norm[i].y};
+    std::vector<geom::Vec2> nu(up.landmarks_2d.size()), nd(down.landmarks_2d.size());
+    for (size_t i = 0; i < nu.size(); ++i) nu[i] = lift ? (*lift)(up.landmarks_2d[i]) : geom::Vec2{up.landmarks_2d_norm[i].x, up.landmarks_2d_norm[i].y};
+    for (size_t i = 0; i < nd.size(); ++i) nd[i] = lift ? (*lift)(down.landmarks_2d[i]) : geom::Vec2{down.landmarks_2d_norm[i].x, down.landmarks_2d_norm[i].y};
     std::vector<geom::Vec3> l3u, l3d;
     std::vector<uint8_t> fu, fd;
     const int count = geom::stereo_landmarks(to_pose(up.pose_drone), to_pose(up.camera_extrinsic), to_pose(down.camera_extrinsic), nu, nd, ids_up, ids_down,

@@ -64,6 +64,8 @@ struct ImageDescriptor_t {
     std::vector<int8_t> landmarks_flag;
     std::vector<float> feature_descriptor;
     int32_t direction = 0;
+    int32_t image_desc_size = 0, feature_descriptor_size = 0, image_size = 0;
+    std::vector<float> image_desc;
 };
 struct FisheyeFrameDescriptor_t {
     int32_t image_num = 0;
@@ -110,6 +112,7 @@ public:
     unsigned char* data = nullptr;
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(int r, int c, int type, void* user) { create(r, c, type); if (r > 0 && c > 0) std::memcpy(data, user, (size_t)r * c * esz); }     // (a copy: the views are read-only here)
     Mat(const Mat& o) : rows(o.rows), cols(o.cols), esz(o.esz), buf(o.buf) { data = buf.empty() ? nullptr : buf.data(); }
     Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; esz = o.esz; buf = o.buf; data = buf.empty() ? nullptr : buf.data(); return *this; }
     void create(int r, int c, int type) {
@@ -121,6 +124,7 @@ public:
     template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + ((size_t)r * cols + c) * esz); }
     bool empty() const { return rows == 0 || cols == 0; }
     int channels() const { return 1; }
+    void copyTo(Mat& o) const { o = *this; }
 };
 template <typename T>
 class Mat_ : public Mat {

@@ -350,3 +350,47 @@ def test_loop_geometry_control_flow_is_pinned_to_the_reference_text(pin_exe, sce
     assert verdicts.count("1") >= 8 and verdicts.count("0") >= 5, verdicts  # both outcomes are exercised
     assert verdicts[13] == "0" and verdicts[14] == "1"                      # the gate: intra-drone refused, inter-drone untouched
     assert out[4 * 14][3] == str(1 * 100000000 + sum(v == "1" for v in verdicts[:14]))     # the refused edge consumed no id
+
+
+# ---- the stereo half (triangulation, acceptance, flags) against the reference's own text -------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cam_pin_exe():
+    """tests/cpp/loopcam_pin.cpp: triangulatePoint, match_HFNet_local_features and generate_stereo_image_descriptor (loop_cam.cpp:73-106, 141-175,
+    341-523), extracted at build time and compiled verbatim next to fill_stereo_landmarks (oracle/Makefile, _ref/loopcam_pin)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "loopcam_pin")
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/loopcam_pin"])
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/loopcam_pin is built from /root/reference, which is absent here")
+    return exe
+
+
+def test_stereo_landmarks_are_pinned_to_the_reference_text(cam_pin_exe, scene):
+    """The up / down key points and descriptors of every direction of two key frames through fill_stereo_landmarks (the matcher's list, the
+    pipeline's double lifting) and through the reference's own generate_stereo_image_descriptor (its own matching call, lifting, triangulatePoint,
+    acceptance test, flag and landmark bookkeeping): the same number of landmarks, the same flags on BOTH images, the same 3-D points (float
+    message fields: equal to 1e-6 relative); nothing is triangulated unless the up image has more than ACCEPT_MIN_3D_PTS key points (:385)."""
+    total = 0
+    for f in (scene["new"], scene["old"]):
+        for d in range(4):
+            up = f["images"][d]
+            down = up["stereo"][0]
+            for accept_min in (50, 10 ** 6):
+                text = (f"stereo {fpose(f['pose_drone'])} {fpose(up['camera_extrinsic'])} {fpose(down['camera_extrinsic'])} {up['landmark_num']} {down['landmark_num']} "
+                        f"0.006 {accept_min} {F} {F} {CX} {CY}\n{fmt(up['landmarks_2d'])}\n{fmt(up['feature_descriptor'])}\n{fmt(down['landmarks_2d'])}\n{fmt(down['feature_descriptor'])}")
+                out = [ln for ln in run(cam_pin_exe, text) if ln and ln[0] in ("PROD", "REF", "META")]
+                prod, ref, meta = out
+                assert prod[1] == ref[1], (d, accept_min, prod[1], ref[1])
+                sep_p, sep_r = prod.index("|"), ref.index("|")
+                assert sep_p == sep_r
+                for a, b in ((prod[2:sep_p], ref[2:sep_r]), (prod[sep_p + 1:], ref[sep_r + 1:])):
+                    a, b = np.array(a, np.float64).reshape(-1, 4), np.array(b, np.float64).reshape(-1, 4)
+                    assert np.array_equal(a[:, 0], b[:, 0])                                   # flags, up and down
+                    assert np.abs(a[:, 1:] - b[:, 1:]).max(initial=0) <= 1e-6 * max(1.0, np.abs(b[:, 1:]).max(initial=0))
+                if accept_min > up["landmark_num"]:
+                    assert prod[1] == "0"
+                else:
+                    total += int(prod[1])
+                    assert int(prod[1]) == up["stereo"][3]                                     # and the numpy oracle's count
+                assert meta[1:4] == ["1", "77", "1"]                                           # drone id, frame id, the up camera's extrinsic
+    assert total > 300

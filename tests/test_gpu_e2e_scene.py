@@ -71,10 +71,11 @@ def oracle_frame(sp_w, vw, comp, mean, imgs, msg_id, pose):
         (xu, du), (xd, dd) = per[d], per[4 + d]
         lift = lambda x: np.stack([((x[:, 0] - CX) / FX), ((x[:, 1] - CY) / FY)], 1).astype(np.float32).astype(np.float64)     # float in the message
         nu, nd = lift(xu), lift(xd)
+        lift64 = lambda x: np.stack([((x[:, 0] - CX) / FX), ((x[:, 1] - CY) / FY)], 1)             # the triangulation lifts the pixels again, in double (loop_cam.cpp:403-407)
         qi, ti, _ = M.bf_match(du, dd, 0)
         l3u, fu = np.zeros((len(xu), 3)), np.zeros(len(xu), np.uint8)
         if len(xu) > 50:                                                       # ACCEPT_MIN_3D_PTS (loop_cam.cpp:385)
-            _, l3u, fu, _, _ = G.stereo_landmarks(pose, extrinsic(d, True), extrinsic(d, False), nu, nd, qi, ti, 0.006)
+            _, l3u, fu, _, _ = G.stereo_landmarks(pose, extrinsic(d, True), extrinsic(d, False), lift64(xu), lift64(xd), qi, ti, 0.006)
         images.append({"landmark_num": len(xu), "landmarks_2d": xu, "landmarks_2d_norm": nu, "feature_descriptor": du, "camera_extrinsic": extrinsic(d, True),
                        "landmarks_3d": l3u.astype(np.float32).astype(np.float64), "landmarks_flag": fu})
     return {"msg_id": msg_id, "drone_id": 1, "timestamp": float(msg_id), "pose_drone": pose, "images": images,
