@@ -24,6 +24,40 @@ def test_undist_maps_cpp_equal_oracle(omni):
     assert side.shape == (312, 600, 2)                                         # sideImgHeight = 2 * 300 * tan(27.5 deg)
 
 
+def test_undist_maps_are_pinned_to_the_reference_text():
+    """oracle.flatten_ref.generate_all_undist_maps against the reference's own FisheyeUndist::generateAllUndistMap / genOneUndistMap compiled from
+    their own text (oracle/_ref/libref_flatten.so; camodocal's MEI projection, Eigen's quaternion algebra and cv::Mat as stand-ins): the same
+    number of views, the same side-image height (integer truncation of 2 f tan(fov_side / 2)), the same maps -- the rotation sequence (incl. the
+    cam_id == 1 flip), the two focal lengths and the pixel -> ray map -- to float32 rounding (the oracle composes rotation matrices, the
+    reference quaternions)."""
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "ref"])
+    path = os.path.join(root, "oracle", "_ref", "libref_flatten.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_flatten.so not built (needs /root/reference once)")
+    L = ctypes.CDLL(path)
+    L.ref_flatten_maps.restype = ctypes.c_int
+    L.ref_flatten_maps.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+    mei = (ctypes.c_double * 9)(*MEI)
+    for fov, cam_id, width in ((235.0, 0, 600), (235.0, 1, 600), (190.0, 0, 400), (170.0, 0, 320), (200.0, 1, 256)):
+        out = np.zeros(5 * width * width * 2, np.float32)
+        heights = (ctypes.c_int * 5)()
+        n = L.ref_flatten_maps(mei, width, fov, cam_id, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), heights)
+        ref = F.generate_all_undist_maps(MEI, width, fov, cam_id)
+        assert n == len(ref)
+        o = 0
+        for m in range(n):
+            h = heights[m]
+            assert (h, width, 2) == ref[m].shape
+            got = out[o:o + h * width * 2].reshape(h, width, 2)
+            o += h * width * 2
+            assert np.abs(got - ref[m]).max() <= 2e-4 * max(1.0, np.abs(ref[m]).max() / 1000), (fov, cam_id, m, np.abs(got - ref[m]).max())
+            assert (got != ref[m]).mean() < 0.05                                     # float32 rounding of 1e-13 differences: a few last-place flips at most
+
+
 @pytest.mark.gpu
 def test_remap_bit_exact_and_feeds_superpoint(omni, ctx):
     from omni_swarm_amd import flatten
