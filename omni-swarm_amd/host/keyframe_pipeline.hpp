@@ -110,8 +110,25 @@ public:
     // pairs up to four directions per candidate, loop_detector.cpp:431-537; the matcher is a pure function of its two descriptor sets);
     // (2) one task per candidate on the pool: flag filter, homography-RANSAC masks, PnP-RANSAC + refit, verification (f64), its match() calls
     // served from (1); (3) the accepted edges are numbered and appended in candidate order.
-    void collect_geometry() {
-        if (deferred_.empty()) return;
+    // start_geometry() does (1) and submits (2); drain_geometry() does (3).  finish() leaves a micro-batch's tasks running while the host
+    // waits for the NEXT micro-batch's CNN unit and drains them before it starts that one's geometry: batches are drained in the order they
+    // were started and candidates in the order the detector returned them, so edges, ids and latencies are those of the serial flow.
+    void collect_geometry() { drain_geometry(); start_geometry(nullptr); drain_geometry(); }
+    void drain_geometry() {
+        while (!geo_inflight_.empty()) {
+            GeoBatch& gb = geo_inflight_.front();
+            for (auto& f : gb.futs) {
+                std::pair<bool, LoopEdge> r = f.get();
+                if (r.first) { geo_.number_edge(r.second); edges_.push_back(r.second); }
+            }
+            if (gb.timed) latencies_ms_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - gb.t_enqueue).count());
+            geo_inflight_.pop_front();
+        }
+    }
+    // held: frames of the micro-batch that were not moved into the database (the tasks point into them); t_enqueue: its latency is recorded
+    // when its last task has been collected.  Returns true when tasks were left in flight.
+    bool start_geometry(std::vector<FisheyeFrameDescriptor>* held, const std::chrono::steady_clock::time_point* t_enqueue = nullptr) {
+        if (deferred_.empty()) return false;
         struct Prepared { size_t first = 0, count = 0; };
         std::vector<BFMatcherL2X::Pair> pairs;
         std::vector<Prepared> prep(deferred_.size());
@@ -138,7 +155,11 @@ public:
         std::vector<std::vector<DMatch>> outs;
         if (!pairs.empty()) bf_.match_multi(pairs, pdim, outs);
         using Result = std::pair<bool, LoopEdge>;
-        std::vector<std::future<Result>> futs;
+        geo_inflight_.emplace_back();
+        GeoBatch& gb = geo_inflight_.back();
+        if (held) gb.held = std::move(*held);                      // (a moved vector keeps its elements where they are)
+        if (t_enqueue) { gb.timed = true; gb.t_enqueue = *t_enqueue; }
+        std::vector<std::future<Result>>& futs = gb.futs;
         for (size_t ci = 0; ci < deferred_.size(); ++ci) {
             auto mine_p = std::make_shared<std::vector<BFMatcherL2X::Pair>>(pairs.begin() + prep[ci].first, pairs.begin() + prep[ci].first + prep[ci].count);
             auto mine_o = std::make_shared<std::vector<std::vector<DMatch>>>();
@@ -159,10 +180,7 @@ public:
             else { std::promise<Result> pr; pr.set_value(work()); futs.push_back(pr.get_future()); }
         }
         deferred_.clear();
-        for (auto& f : futs) {
-            Result r = f.get();
-            if (r.first) { geo_.number_edge(r.second); edges_.push_back(r.second); }
-        }
+        return true;
     }
     int geometry_calls() const { return geometry_calls_; }
     const std::vector<LoopEdge>& edges() const { return edges_; }
@@ -238,6 +256,7 @@ public:
         }
         while (!pending.empty()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         hits += collect_exchange();
+        drain_geometry();
         return hits;
     }
 
@@ -299,8 +318,10 @@ private:
         return hits;
     }
     int finish_timed(Lane& lane, int64_t first_id) {
+        geo_left_in_flight_ = false;
         const int hits = finish(lane, first_id);
-        latencies_ms_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lane.t_enqueue).count());
+        if (!geo_left_in_flight_)                                   // (otherwise drain_geometry() records it, when the micro-batch's last edge is in)
+            latencies_ms_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lane.t_enqueue).count());
         return hits;
     }
     // the micro-batch's key frames reach the detector in order, as one batch; rows and queries are taken from MobileNetVLAD's output
@@ -369,7 +390,11 @@ private:
             if (c.found) { ++hits; candidates_.push_back({first_id + fi, c.old_msg_id, c.direction_new, c.direction_old}); }
             ++fi;
         }
-        collect_geometry();             // the tasks reference this micro-batch's frames (those not moved into the database live in frames_)
+        // the previous micro-batch's tasks ran while this one's CNN unit was waited for; this one's run until the next gets here.  The tasks
+        // reference this micro-batch's frames: those moved into the database live there (std::map: stable), the others are handed over
+        drain_geometry();
+        geo_left_in_flight_ = start_geometry(&frames_, &lane.t_enqueue);
+        if (!async_geometry_) { drain_geometry(); }
         frames_.clear();
         return hits;
     }
@@ -380,6 +405,15 @@ private:
     BFMatcherL2X bf_{index_ctx_};
     LoopGeometry geo_;
     std::vector<double> latencies_ms_;
+    struct GeoBatch {                           // the geometry tasks of one micro-batch, in candidate order
+        std::vector<std::future<std::pair<bool, LoopEdge>>> futs;
+        std::vector<FisheyeFrameDescriptor> held;
+        std::chrono::steady_clock::time_point t_enqueue;
+        bool timed = false;
+    };
+    std::deque<GeoBatch> geo_inflight_;         // (declared before the pool: outlives its threads)
+    bool geo_left_in_flight_ = false;
+    bool async_geometry_ = !(getenv("OMNI_GEOMETRY_ASYNC") && atoi(getenv("OMNI_GEOMETRY_ASYNC")) == 0);
     std::unique_ptr<TaskPool> pool_;
     std::vector<ImageDescriptor> downs_;        // the down-camera halves of the micro-batch being finished
     std::vector<std::future<void>> stereo_tasks_;
