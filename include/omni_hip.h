@@ -108,10 +108,18 @@ void     omni_sp_destroy(omni_sp* sp);
 int      omni_sp_desc_dim(const omni_sp* sp);              /* pca_dim, or 256 without PCA */
 int      omni_sp_image_size(const omni_sp* sp, int* width, int* height);   /* the size the handle was created for (:122 asserts it per call) */
 
+/* The rows the fisheye mask blanks in an image of `height` rows: [*row0, *row1) = cv::Rect(0, rows*3/4, cols, rows/4) of
+ * LoopCam::extractor_img_desc_deepnet (loop_cam.cpp:536-539; integer divisions: a height that is not a multiple of 4 keeps its last rows).
+ * fisheye_mask == 0: an empty range at the end of the image.  Every kernel that reads the gray image takes its mask rows from here. */
+static inline void omni_fisheye_mask_rows(int height, int fisheye_mask, int* row0, int* row1) {
+    *row0 = fisheye_mask ? height * 3 / 4 : height;
+    *row1 = fisheye_mask ? height * 3 / 4 + height / 4 : height;
+}
+
 /* SuperPointTensorRT::inference(const cv::Mat&, std::vector<cv::Point2f>&, std::vector<float>&)
  * (superpoint_tensorrt.cpp:117-162) for `batch` images.
  *   gray      : batch images, u8, row stride `stride` bytes, image i at gray + i*stride*height
- *   fisheye_mask != 0 zeroes rows [3H/4, H) first (LoopCam::extractor_img_desc_deepnet, loop_cam.cpp:536-539)
+ *   fisheye_mask != 0 zeroes the rows omni_fisheye_mask_rows() names first (LoopCam::extractor_img_desc_deepnet, loop_cam.cpp:536-539)
  *   kps_xy    : [batch][max_num][2] float (x, y) integer-valued; order = (confidence desc, row-major index asc)
  *   n_kps     : [batch]
  *   desc      : [batch][max_num][desc_dim] float

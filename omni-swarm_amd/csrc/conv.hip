@@ -1383,7 +1383,7 @@ int conv1ab_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gs
                  "conv1ab_fused: image rows must be 4-byte aligned (stride %d)", gstride);
     Fuse1aArgs fz;
     fz.gray = gray; fz.gstride = gstride;
-    fz.mask_r0 = fisheye_mask ? a.H * 3 / 4 : a.H; fz.mask_r1 = fisheye_mask ? a.H * 3 / 4 + a.H / 4 : a.H;   // cv::Rect(0, rows*3/4, cols, rows/4)
+    omni_fisheye_mask_rows(a.H, fisheye_mask, &fz.mask_r0, &fz.mask_r1);   // cv::Rect(0, rows*3/4, cols, rows/4)
     fz.w1a_frag = w1a_frag; fz.bias1a = bias1a; fz.lut_hl = lut_hl; fz.trace = nullptr;
     static const bool want_trace = [] { const char* e = getenv("OMNI_PP_TRACE"); return e && e[0] == '1'; }();
     static unsigned long long* trace_dev = nullptr;
@@ -1522,7 +1522,8 @@ conv1a_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, int ma
 
 int conv1a_direct(hipStream_t st, int precision, const uint8_t* gray, int stride, int batch, int H, int W, int fisheye_mask,
                   const float* w, const float* bias, const float* lut, void* out) {
-    const int r0 = fisheye_mask ? H * 3 / 4 : H, r1 = fisheye_mask ? H * 3 / 4 + H / 4 : H;   // cv::Rect(0, rows*3/4, cols, rows/4)
+    int r0, r1;
+    omni_fisheye_mask_rows(H, fisheye_mask, &r0, &r1);   // cv::Rect(0, rows*3/4, cols, rows/4)
     dim3 grid(cdiv(W, 32) * cdiv(H, 8), batch);
     if (precision == OMNI_PREC_F16)
         hipLaunchKernelGGL(conv1a_kernel<_Float16>, grid, dim3(256), 0, st, gray, stride, H, W, r0, r1, w, bias, lut, (_Float16*)out);

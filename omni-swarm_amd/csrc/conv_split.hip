@@ -620,7 +620,8 @@ conv1a_split_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, 
 
 int conv1a_split(hipStream_t st, const uint8_t* gray, int stride, int batch, int H, int W, int fisheye_mask, const float* w, const float* bias,
                  const float* lut, void* out) {
-    const int r0 = fisheye_mask ? H * 3 / 4 : H, r1 = fisheye_mask ? H * 3 / 4 + H / 4 : H;   // cv::Rect(0, rows*3/4, cols, rows/4)
+    int r0, r1;
+    omni_fisheye_mask_rows(H, fisheye_mask, &r0, &r1);   // cv::Rect(0, rows*3/4, cols, rows/4)
     dim3 grid(cdiv(W, 32) * cdiv(H, 8), batch);
     hipLaunchKernelGGL(conv1a_split_kernel, grid, dim3(256), 0, st, gray, stride, H, W, r0, r1, w, bias, lut, (_Float16*)out);
     OMNI_LAUNCH_CHECK();

@@ -1007,7 +1007,8 @@ static int upload(float** dst, const float* src, size_t n, hipStream_t st) {
 static int vlad_backbone_unfused(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, int* cur_out) {
     hipStream_t st = v->ctx->stream;
     const int H = v->H, W = v->W;
-    const int m0 = fisheye_mask ? H * 3 / 4 : H, m1 = fisheye_mask ? H * 3 / 4 + H / 4 : H;
+    int m0, m1;
+    omni_fisheye_mask_rows(H, fisheye_mask, &m0, &m1);
     int cur = -1;             // index of the buffer holding the current activation
     int block_in = -1;        // buffer holding the inverted-residual block input (for pw_linear_res)
     auto pick = [&](int a, int b2) { for (int i = 0; i < 3; ++i) if (i != a && i != b2) return i; return 0; };
@@ -1143,7 +1144,8 @@ vlad_stem_b0_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, 
 static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, int* cur_out) {
     hipStream_t st = v->ctx->stream;
     const int H = v->H, W = v->W;
-    const int m0 = fisheye_mask ? H * 3 / 4 : H, m1 = fisheye_mask ? H * 3 / 4 + H / 4 : H;
+    int m0, m1;
+    omni_fisheye_mask_rows(H, fisheye_mask, &m0, &m1);
     const VladLayerDev& S = v->layers[0];
     int cur = 0, rc;
     size_t first = 0;

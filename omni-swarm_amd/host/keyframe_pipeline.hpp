@@ -339,49 +339,38 @@ private:
         }
         const int n = r.n_dirs, M = r.max_num, D = r.desc_dim;
         frames_.resize(lane.mb);
+        const int G = r.global_dim;
         for (int m = 0; m < lane.mb; ++m) {
             FisheyeFrameDescriptor& f = frames_[m];
-            f.msg_id = first_id + m; f.drone_id = cfg_.self_id; f.prevent_adding_db = false; f.landmark_num = 0;
-            f.timestamp = (double)f.msg_id;
-            f.pose_drone = (f.msg_id >= pose_base_ && f.msg_id < pose_base_ + (int64_t)poses_.size()) ? poses_[(size_t)(f.msg_id - pose_base_)] : PoseMsg{};
+            const int64_t kf_id = first_id + m;
+            const double stamp = (double)kf_id;
+            const PoseMsg pose = (kf_id >= pose_base_ && kf_id < pose_base_ + (int64_t)poses_.size()) ? poses_[(size_t)(kf_id - pose_base_)] : PoseMsg{};
+            f.prevent_adding_db = false;
             f.images.resize(4);
             for (int d = 0; d < 4; ++d) {
                 const int i = 4 * m + d;                                            // image i of the up cameras
                 ImageDescriptor& im = f.images[d];
-                im.drone_id = cfg_.self_id; im.landmark_num = r.n_kps[i];
-                im.image_desc.assign(r.global_desc + (size_t)i * r.global_dim, r.global_desc + (size_t)(i + 1) * r.global_dim);
-                im.feature_descriptor.assign(r.desc + (size_t)i * M * D, r.desc + ((size_t)i * M + im.landmark_num) * D);
-                im.landmarks_2d.resize(im.landmark_num);
-                for (int k = 0; k < im.landmark_num; ++k) im.landmarks_2d[k] = {r.kps_xy[((size_t)i * M + k) * 2], r.kps_xy[((size_t)i * M + k) * 2 + 1]};
-                f.landmark_num += im.landmark_num;
+                // extractor_img_desc_deepnet (loop_cam.cpp:525-585) + the stamps of generate_stereo_image_descriptor (:362-374)
+                fill_image_descriptor(im, r.kps_xy + (size_t)i * M * 2, r.n_kps[i], r.desc + (size_t)i * M * D, D, r.global_desc + (size_t)i * G, G, lift64_);
+                stamp_image_descriptor(im, stamp, cfg_.self_id, to_msg(view_extrinsic(d, true)), pose, kf_id);
                 if (cfg_.geometry) {
-                    // the stereo half of generate_stereo_image_descriptor (loop_cam.cpp:341-454): the down image of this direction, lifting, triangulation
+                    // the stereo half of generate_stereo_image_descriptor (loop_cam.cpp:341-454): the down image of this direction, triangulation
                     // (one task per direction on the geometry pool: ~170 SVD triangulations each; joined before the frames reach the detector)
                     if (downs_.size() < (size_t)4 * lane.mb) downs_.resize((size_t)4 * lane.mb);
                     ImageDescriptor& down = downs_[(size_t)i];
                     down = ImageDescriptor{};
-                    const int j = n + i, nd = r.n_kps[j];
-                    down.landmarks_2d.resize(nd);
-                    for (int k = 0; k < nd; ++k) down.landmarks_2d[k] = {r.kps_xy[((size_t)j * M + k) * 2], r.kps_xy[((size_t)j * M + k) * 2 + 1]};
-                    auto lift = [&](ImageDescriptor& x) {
-                        x.landmarks_2d_norm.resize(x.landmarks_2d.size());
-                        for (size_t k = 0; k < x.landmarks_2d.size(); ++k) x.landmarks_2d_norm[k] = {(float)((x.landmarks_2d[k].x - cfg_.cx) / cfg_.fx), (float)((x.landmarks_2d[k].y - cfg_.cy) / cfg_.fy)};
-                    };
-                    lift(im); lift(down);
-                    im.pose_drone = down.pose_drone = f.pose_drone;
-                    im.camera_extrinsic = to_msg(view_extrinsic(d, true)); down.camera_extrinsic = to_msg(view_extrinsic(d, false));
-                    im.direction = d;
+                    const int j = n + i;
+                    fill_image_descriptor(down, r.kps_xy + (size_t)j * M * 2, r.n_kps[j], nullptr, D, nullptr, 0, lift64_);     // (its descriptors were matched on the device)
+                    stamp_image_descriptor(down, stamp, cfg_.self_id, to_msg(view_extrinsic(d, false)), pose, kf_id);
                     auto tri = [this, &im, &down, r, i, M] {
                         // the triangulation lifts the pixels again, in double (loop_cam.cpp:403-407); the message keeps the float points
-                        const std::function<geom::Vec2(const Point2f&)> lift64 = [this](const Point2f& p) {
-                            return geom::Vec2{((double)p.x - cfg_.cx) / cfg_.fx, ((double)p.y - cfg_.cy) / cfg_.fy};
-                        };
                         fill_stereo_landmarks(im, down, r.match_up + (size_t)i * M, r.match_down + (size_t)i * M, r.n_matches[i], cfg_.triangle_thres, cfg_.accept_min_3d_pts,
-                                              &lift64);
+                                              &lift64_);
                     };
                     if (pool_) stereo_tasks_.push_back(pool_->submit(tri)); else tri();
                 }
             }
+            finish_frame_descriptor(f, stamp, kf_id, pose, cfg_.self_id);             // on_flattened_images (loop_cam.cpp:178-217)
         }
         for (auto& t : stereo_tasks_) t.get();
         stereo_tasks_.clear();
@@ -400,6 +389,8 @@ private:
     }
 
     Config cfg_;
+    // cam->liftProjective of the flattened (pinhole) views, then the division by z: in double, as the reference's camera model
+    const std::function<geom::Vec2(const Point2f&)> lift64_ = [this](const Point2f& p) { return geom::Vec2{((double)p.x - cfg_.cx) / cfg_.fx, ((double)p.y - cfg_.cy) / cfg_.fy}; };
     Context index_ctx_;
     LoopDetectorCore det_;
     BFMatcherL2X bf_{index_ctx_};

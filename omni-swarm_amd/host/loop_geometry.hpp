@@ -6,6 +6,7 @@
 //   LoopGeometry::compute_loop                               :627-836  the LoopEdge the back end consumes (visualisation left out)
 //   LoopGeometry::check_loop_odometry_consistency            :295-315  Mahalanobis gate against the ego-motion trajectory (pluggable source)
 //   fill_stereo_landmarks                                    loop_cam.cpp:397-444 on the messages of one direction
+//   fill_image_descriptor / stamp_image_descriptor / finish_frame_descriptor   loop_cam.cpp:525-585, 362-374, 178-217: the messages themselves
 //
 // The descriptor matcher is a callback: omni::BFMatcherL2X (the HIP matcher, bit-identical to cv::BFMatcher's cross-check semantics) in the
 // product, a CPU matcher in the host-only tests.  Numerical core: geometry.hpp (see its header for what is restated from OpenCV 3.4 and where
@@ -35,6 +36,39 @@ struct LoopEdge {                                // swarm_msgs::LoopEdge as comp
     geom::Pose relative_pose, self_pose_a, self_pose_b;
     double pos_cov[3] = {0, 0, 0}, ang_cov[3] = {0, 0, 0};
 };
+
+// What LoopCam::extractor_img_desc_deepnet returns for one image (loop_cam.cpp:525-585, the TensorRT branch), from the networks' outputs: the
+// key points (pixels), their descriptors, the global descriptor when the image is the main camera's (!superpoint_mode; `global_desc` null
+// otherwise), the key points lifted by the camera model and stored as FLOATS (:558-566), a zero landmark and a zero flag per key point.
+// `lift` = cam->liftProjective followed by the division by z (camodocal is un-vendored: the camera model stays with the caller).
+// `desc` may be null (a message whose descriptors were already consumed on the device, e.g. the down camera's).
+inline void fill_image_descriptor(ImageDescriptor& im, const float* kps_xy, int n, const float* desc, int desc_dim, const float* global_desc, int global_dim,
+                                  const std::function<geom::Vec2(const Point2f&)>& lift) {
+    im.landmark_num = n;
+    im.landmarks_2d.resize((size_t)n);
+    for (int k = 0; k < n; ++k) im.landmarks_2d[(size_t)k] = {kps_xy[2 * k], kps_xy[2 * k + 1]};
+    if (desc) im.feature_descriptor.assign(desc, desc + (size_t)n * desc_dim); else im.feature_descriptor.clear();
+    if (global_desc) im.image_desc.assign(global_desc, global_desc + global_dim); else im.image_desc.clear();
+    im.landmarks_2d_norm.resize((size_t)n);
+    for (int k = 0; k < n; ++k) { const geom::Vec2 q = lift(im.landmarks_2d[(size_t)k]); im.landmarks_2d_norm[(size_t)k] = {(float)q.x, (float)q.y}; }
+    im.landmarks_3d.assign((size_t)n, Point3f{});
+    im.landmarks_flag.assign((size_t)n, 0);
+}
+// The per-image fields generate_stereo_image_descriptor stamps on both messages of a direction (loop_cam.cpp:362-374)
+inline void stamp_image_descriptor(ImageDescriptor& im, double stamp, int self_id, const PoseMsg& camera_extrinsic, const PoseMsg& pose_drone, int64_t keyframe_id) {
+    im.timestamp = stamp; im.drone_id = self_id; im.camera_extrinsic = camera_extrinsic; im.pose_drone = pose_drone; im.frame_id = keyframe_id;
+}
+// The frame-level fields of LoopCam::on_flattened_images (loop_cam.cpp:178-217) once f.images holds the per-direction messages
+inline void finish_frame_descriptor(FisheyeFrameDescriptor& f, double stamp, int64_t keyframe_id, const PoseMsg& pose_drone, int self_id) {
+    f.timestamp = stamp;
+    for (size_t i = 0; i < f.images.size(); ++i) f.images[i].direction = (int)i;
+    f.image_num = (int)f.images.size();
+    f.msg_id = keyframe_id;
+    f.pose_drone = pose_drone;
+    f.landmark_num = 0;
+    for (const ImageDescriptor& im : f.images) f.landmark_num += im.landmark_num;
+    f.drone_id = self_id;
+}
 
 // generate_stereo_image_descriptor's triangulation (loop_cam.cpp:397-444) on one direction's up / down messages: fills landmarks_3d and
 // landmarks_flag of both from the up<->down match list (ids_up / ids_down as omni_cam returns them).  Needs pose_drone and camera_extrinsic.

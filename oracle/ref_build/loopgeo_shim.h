@@ -23,6 +23,7 @@
 #include <functional>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -92,6 +93,7 @@ inline geometry_msgs::Pose toROSPose(const Pose_t& p) {
 }
 }  // namespace swarm_msgs
 
+#define CV_8U 0
 #define CV_32F 5
 #define CV_64F 6
 #define CV_32S 4
@@ -104,27 +106,47 @@ struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float a, float b)
 inline Point2f operator+(const Point2f& a, const Point2f& b) { return Point2f(a.x + b.x, a.y + b.y); }
 struct Point3f { float x, y, z; Point3f() : x(0), y(0), z(0) {} Point3f(float a, float b, float c) : x(a), y(b), z(c) {} };
 struct DMatch { int queryIdx, trainIdx; float distance; DMatch() : queryIdx(-1), trainIdx(-1), distance(0) {} DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), distance(d) {} };
-struct Scalar { Scalar(double = 0, double = 0, double = 0, double = 0) {} };
-class Mat {
+struct Scalar { double v0; Scalar(double a = 0, double = 0, double = 0, double = 0) : v0(a) {} };
+struct Rect { int x, y, width, height; Rect(int a, int b, int c, int d) : x(a), y(b), width(c), height(d) {} };
+class Mat {                                      // cv::Mat's sharing semantics: copies and ROIs are views of one buffer, copyTo / clone are deep
 public:
     int rows = 0, cols = 0, esz = 0;
-    std::vector<unsigned char> buf;
+    size_t step = 0;                             // bytes between rows
+    std::shared_ptr<std::vector<unsigned char>> buf;
     unsigned char* data = nullptr;
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
     Mat(int r, int c, int type, void* user) { create(r, c, type); if (r > 0 && c > 0) std::memcpy(data, user, (size_t)r * c * esz); }     // (a copy: the views are read-only here)
-    Mat(const Mat& o) : rows(o.rows), cols(o.cols), esz(o.esz), buf(o.buf) { data = buf.empty() ? nullptr : buf.data(); }
-    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; esz = o.esz; buf = o.buf; data = buf.empty() ? nullptr : buf.data(); return *this; }
     void create(int r, int c, int type) {
-        rows = r; cols = c; esz = type == CV_64F ? 8 : 4;
-        buf.assign((size_t)r * c * esz + 8, 0);
-        data = buf.data();
+        rows = r; cols = c; esz = type == CV_64F ? 8 : (type == CV_8U ? 1 : 4);
+        step = (size_t)c * esz;
+        buf = std::make_shared<std::vector<unsigned char>>((size_t)r * c * esz + 8, 0);
+        data = buf->data();
     }
-    template <typename T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + ((size_t)r * cols + c) * esz); }
-    template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + ((size_t)r * cols + c) * esz); }
+    Mat operator()(const Rect& r) const {
+        assert(r.x >= 0 && r.y >= 0 && r.x + r.width <= cols && r.y + r.height <= rows);
+        Mat o = *this;
+        o.rows = r.height; o.cols = r.width; o.data = data + (size_t)r.y * step + (size_t)r.x * esz;
+        return o;
+    }
+    Mat& setTo(const Scalar& s) {
+        assert(esz == 1);
+        for (int r = 0; r < rows; ++r) std::memset(data + (size_t)r * step, (int)s.v0, (size_t)cols);
+        return *this;
+    }
+    template <typename T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + (size_t)r * step + (size_t)c * esz); }
+    template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + (size_t)r * step + (size_t)c * esz); }
     bool empty() const { return rows == 0 || cols == 0; }
     int channels() const { return 1; }
-    void copyTo(Mat& o) const { o = *this; }
+    Mat clone() const {
+        Mat o;
+        o.rows = rows; o.cols = cols; o.esz = esz; o.step = (size_t)cols * esz;
+        o.buf = std::make_shared<std::vector<unsigned char>>((size_t)rows * cols * esz + 8, 0);
+        o.data = o.buf->data();
+        for (int r = 0; r < rows; ++r) std::memcpy(o.data + (size_t)r * o.step, data + (size_t)r * step, (size_t)cols * esz);
+        return o;
+    }
+    void copyTo(Mat& o) const { o = clone(); }
 };
 template <typename T>
 class Mat_ : public Mat {

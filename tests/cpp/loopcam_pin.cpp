@@ -14,159 +14,7 @@
 // ACCEPT_MIN_3D_PTS early return, the match bookkeeping (ids_up / ids_down), that the pixel is lifted AGAIN in double for the triangulation.
 //
 // stdin: "stereo" commands (see tests/test_geometry_cpu.py);  stdout: PROD / REF lines
-#include <chrono>
-#include <cstdio>
-#include <iostream>
-
-#include "../../omni-swarm_amd/host/loop_geometry.hpp"
-
-extern "C" int oracle_bf_match(const float* q, int nq, const float* t, int nt, int dim, int mode, int* q_idx, int* t_idx, float* dist_out);
-
-#include "../../oracle/ref_build/loopgeo_shim.h"
-#include "swarm_loop/loop_defines.h"
-
-using namespace swarm_msgs;
-using namespace std::chrono;
-
-// ---------------------------------------------------------------------------------------------------------------- a small Eigen
-namespace Eigen {
-enum { ComputeFullV = 1 };
-template <int R, int C> struct Mat;
-template <int C> struct RowExpr { double v[C]; };
-template <int C> RowExpr<C> operator*(double s, const RowExpr<C>& a) { RowExpr<C> o; for (int j = 0; j < C; ++j) o.v[j] = s * a.v[j]; return o; }
-template <int C> RowExpr<C> operator-(const RowExpr<C>& a, const RowExpr<C>& b) { RowExpr<C> o; for (int j = 0; j < C; ++j) o.v[j] = a.v[j] - b.v[j]; return o; }
-template <int R, int C>
-struct RowRef {
-    Mat<R, C>& m; int i;
-    operator RowExpr<C>() const { RowExpr<C> o; for (int j = 0; j < C; ++j) o.v[j] = m.d[i][j]; return o; }
-    RowRef& operator=(const RowExpr<C>& e) { for (int j = 0; j < C; ++j) m.d[i][j] = e.v[j]; return *this; }
-};
-template <int R, int C> RowExpr<C> operator*(double s, const RowRef<R, C>& a) { return s * (RowExpr<C>)a; }
-template <int R, int C> RowExpr<C> operator-(const RowExpr<C>& a, const RowRef<R, C>& b) { return a - (RowExpr<C>)b; }
-template <int R, int C, int N>
-struct ColsRef {
-    Mat<R, C>& m; int j0;
-    ColsRef& operator=(const Mat<R, N>& s) { for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) m.d[i][j0 + j] = s.d[i][j]; return *this; }
-    operator Mat<R, N>() const { Mat<R, N> o; for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) o.d[i][j] = m.d[i][j0 + j]; return o; }
-};
-template <int R, int C>
-struct Mat {
-    double d[R][C];
-    Mat() { for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) d[i][j] = 0; }
-    Mat(double a, double b) { static_assert(R * C == 2, ""); d[0][0] = a; (C == 1 ? d[1 % R][0] : d[0][1 % C]) = b; }
-    Mat(double a, double b, double c) { static_assert(R == 3 && C == 1, ""); d[0][0] = a; d[1][0] = b; d[2][0] = c; }
-    static Mat Zero() { return Mat(); }
-    double& operator()(int i, int j) { return d[i][j]; }
-    double operator()(int i, int j) const { return d[i][j]; }
-    double& operator()(int i) { static_assert(C == 1, ""); return d[i][0]; }
-    double operator()(int i) const { static_assert(C == 1, ""); return d[i][0]; }
-    double& operator[](int i) { static_assert(C == 1, ""); return d[i][0]; }
-    double operator[](int i) const { static_assert(C == 1, ""); return d[i][0]; }
-    double& x() { return d[0][0]; } double& y() { return d[1][0]; } double& z() { return d[2][0]; }
-    double x() const { return d[0][0]; } double y() const { return d[1][0]; } double z() const { return d[2][0]; }
-    Mat<C, R> transpose() const { Mat<C, R> o; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) o.d[j][i] = d[i][j]; return o; }
-    Mat operator-() const { Mat o; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) o.d[i][j] = -d[i][j]; return o; }
-    Mat operator-(const Mat& b) const { Mat o; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) o.d[i][j] = d[i][j] - b.d[i][j]; return o; }
-    RowRef<R, C> row(int i) { return RowRef<R, C>{*this, i}; }
-    template <int N> ColsRef<R, C, N> leftCols() { return ColsRef<R, C, N>{*this, 0}; }
-    template <int N> ColsRef<R, C, N> rightCols() { return ColsRef<R, C, N>{*this, C - N}; }
-    double norm() const { double s = 0; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) s += d[i][j] * d[i][j]; return std::sqrt(s); }
-    int rows() const { return R; }
-    // JacobiSVD(ComputeFullV).matrixV(): right singular vectors as columns, singular values descending
-    struct Svd {
-        Mat<C, C> V;
-        Mat<C, C> matrixV() const { return V; }
-    };
-    Svd jacobiSvd(int) const {
-        static_assert(R == 4 && C == 4, "");
-        double A[4][4], W[4], E[4][4];
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { A[i][j] = 0; for (int k = 0; k < 4; ++k) A[i][j] += d[k][i] * d[k][j]; }
-        omni::geom::jacobi_eigen<4>(A, W, E);                        // eigenvalues descending, eigenvectors as ROWS
-        Svd s;
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s.V.d[j][i] = E[i][j];
-        return s;
-    }
-};
-template <int R, int C, int K> Mat<R, K> operator*(const Mat<R, C>& a, const Mat<C, K>& b) {
-    Mat<R, K> o;
-    for (int i = 0; i < R; ++i) for (int j = 0; j < K; ++j) { double s = 0; for (int k = 0; k < C; ++k) s += a.d[i][k] * b.d[k][j]; o.d[i][j] = s; }
-    return o;
-}
-typedef Mat<2, 1> Vector2d;
-typedef Mat<3, 1> Vector3d;
-typedef Mat<4, 1> Vector4d;
-typedef Mat<3, 3> Matrix3d;
-typedef Mat<4, 4> Matrix4d;
-template <typename T, int R, int C> using Matrix = Mat<R, C>;
-// Eigen::MatrixXd, as triangulatePoint uses it: a 4 x 1 column filled with the comma initialiser, the product design * pts, norm(), rows()
-struct MatrixXd {
-    int r = 0, c = 0; std::vector<double> v;
-    MatrixXd() {}
-    MatrixXd(int rr, int cc) : r(rr), c(cc), v((size_t)rr * cc, 0.0) {}
-    MatrixXd(const Mat<4, 1>& m) : r(4), c(1), v{m.d[0][0], m.d[1][0], m.d[2][0], m.d[3][0]} {}
-    struct Init { MatrixXd& m; int i; Init& operator,(double x) { m.v[i++] = x; return *this; } };
-    Init operator<<(double x) { Init it{*this, 0}; it, x; return it; }
-    double norm() const { double s = 0; for (double x : v) s += x * x; return std::sqrt(s); }
-    int rows() const { return r; }
-};
-inline MatrixXd operator*(const Matrix4d& a, const MatrixXd& b) {
-    MatrixXd o(4, 1);
-    for (int i = 0; i < 4; ++i) { double s = 0; for (int k = 0; k < 4; ++k) s += a.d[i][k] * b.v[k]; o.v[i] = s; }
-    return o;
-}
-struct Quaterniond {
-    omni::geom::Quat q;
-    Quaterniond() {}
-    explicit Quaterniond(omni::geom::Quat a) : q(a) {}
-    Matrix3d toRotationMatrix() const { const omni::geom::Mat3 r = q.R(); Matrix3d o; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.d[i][j] = r.m[i][j]; return o; }
-    Quaterniond inverse() const { return Quaterniond(q.inverse()); }
-    Vector3d operator*(const Vector3d& p) const { const omni::geom::Vec3 o = q * omni::geom::Vec3{p.x(), p.y(), p.z()}; return Vector3d(o.x, o.y, o.z); }
-};
-}  // namespace Eigen
-
-namespace Swarm {
-class Pose {
-public:
-    omni::geom::Pose p;
-    Pose() {}
-    explicit Pose(const omni::geom::Pose& q) : p(q) {}
-    Pose(const geometry_msgs::Pose& m) {
-        omni::PoseMsg pm;
-        pm.position[0] = m.position.x; pm.position[1] = m.position.y; pm.position[2] = m.position.z;
-        pm.quat_wxyz[0] = m.orientation.w; pm.quat_wxyz[1] = m.orientation.x; pm.quat_wxyz[2] = m.orientation.y; pm.quat_wxyz[3] = m.orientation.z;
-        p = omni::to_pose(pm);
-    }
-    Eigen::Quaterniond att() const { return Eigen::Quaterniond(p.att); }
-    Eigen::Vector3d pos() const { return Eigen::Vector3d(p.pos.x, p.pos.y, p.pos.z); }
-    friend Pose operator*(Pose a, Pose b) { return Pose(a.p * b.p); }
-};
-}  // namespace Swarm
-
-// ---------------------------------------------------------------------------------------------------------------- what LoopCam needs
-struct StereoFrame {                             // swarm_msgs / VINS FlattenImages as generate_stereo_image_descriptor reads it
-    ros::Time stamp;
-    int64_t keyframe_id = 0;
-    std::vector<cv::Mat> left_images, right_images;
-    std::vector<geometry_msgs::Pose> left_extrisincs, right_extrisincs;
-    geometry_msgs::Pose pose_drone;
-};
-namespace swarm_msgs {
-inline Time_t toLCMTime(const ros::Time& t) { Time_t o; o.sec = (int32_t)std::floor(t.toSec()); o.nsec = (int32_t)std::llround((t.toSec() - std::floor(t.toSec())) * 1e9); return o; }
-inline Pose_t fromROSPose(const geometry_msgs::Pose& m) {
-    Pose_t p;
-    p.position[0] = m.position.x; p.position[1] = m.position.y; p.position[2] = m.position.z;
-    p.orientation[0] = m.orientation.w; p.orientation[1] = m.orientation.x; p.orientation[2] = m.orientation.y; p.orientation[3] = m.orientation.z;
-    return p;
-}
-}  // namespace swarm_msgs
-namespace cv {
-inline void arrowedLine(Mat&, Point2f, Point2f, Scalar, int = 1) {}
-}
-struct PinholeCam {                              // camodocal::Camera::liftProjective for a pinhole (the flattened views)
-    double fx = 1, fy = 1, cx = 0, cy = 0;
-    void liftProjective(const Eigen::Vector2d& p, Eigen::Vector3d& P) const { P = Eigen::Vector3d((p.x() - cx) / fx, (p.y() - cy) / fy, 1.0); }
-};
-typedef PinholeCam* CameraPtr;
+#include "loopcam_common.h"
 
 class LoopCam {
 public:

@@ -394,3 +394,70 @@ def test_stereo_landmarks_are_pinned_to_the_reference_text(cam_pin_exe, scene):
                     assert int(prod[1]) == up["stereo"][3]                                     # and the numpy oracle's count
                 assert meta[1:4] == ["1", "77", "1"]                                           # drone id, frame id, the up camera's extrinsic
     assert total > 300
+
+
+# ---- the messages themselves (on_flattened_images -> generate_stereo_image_descriptor -> extractor_img_desc_deepnet) against the reference's own text ------
+@pytest.fixture(scope="module")
+def front_pin_exe():
+    """tests/cpp/loopfront_pin.cpp: the whole message-building chain of LoopCam (loop_cam.cpp:178-229, 341-523, 525-634; the two networks are hooks),
+    extracted at build time and compiled verbatim next to fill_image_descriptor / stamp_image_descriptor / finish_frame_descriptor and
+    omni_fisheye_mask_rows (oracle/Makefile, _ref/loopfront_pin)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "loopfront_pin")
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/loopfront_pin"])
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/loopfront_pin is built from /root/reference, which is absent here")
+    return exe
+
+
+def test_keyframe_messages_and_mask_rows_are_pinned_to_the_reference_text(front_pin_exe, scene):
+    """One key frame's network outputs (key points, descriptors, global descriptors of 4 x (up, down) images) through the functions
+    KeyframePipeline::finish() builds its frames with, and through the reference's own on_flattened_images -> generate_stereo_image_descriptor ->
+    extractor_img_desc_deepnet: the same frame stamps, the same per-image stamps, the same key points, float-lifted points, flags and landmarks,
+    a global descriptor on the main camera's images only; the rows the reference blanks in every image (cv::Rect(0, rows*3/4, cols, rows/4) on
+    a cv::Mat that shares its pixels with the caller's) are the rows omni_fisheye_mask_rows names -- also for heights that are not multiples
+    of 4 -- and BOTH networks see the blanked image."""
+    rng = np.random.default_rng(77)
+    cases = 0
+    for f, (H, W), accept_min, gdim in ((scene["new"], (48, 60), 50, 8), (scene["old"], (47, 33), 50, 5), (scene["new"], (45, 16), 10 ** 6, 3),
+                                        (scene["old"], (42, 21), 50, 4), (scene["new"], (7, 9), 50, 2)):
+        kf_id, stamp, self_id = 1000 + cases, 17.25 + cases, 3
+        seed = int(rng.integers(1, 2 ** 31))
+        lines = [f"frame {H} {W} 4 {gdim} {accept_min} 0.006 {self_id} {kf_id} {stamp!r} {F} {F} {CX} {CY} {seed} {fpose(f['pose_drone'])}"]
+        gdescs = rng.standard_normal((4, gdim)).astype(np.float32)
+        for d in range(4):
+            up = f["images"][d]
+            down = up["stereo"][0]
+            lines.append(f"{fpose(up['camera_extrinsic'])} {fpose(down['camera_extrinsic'])}")
+            for im in (up, down):
+                lines.append(f"{im['landmark_num']} {fmt(im['landmarks_2d'])} {fmt(im['feature_descriptor'])}")
+            lines.append(fmt(gdescs[d]))
+        out = [ln for ln in run(front_pin_exe, "\n".join(lines)) if ln and ln[0] in ("PROD", "REF")]
+        prod = [ln[1:] for ln in out if ln[0] == "PROD"]
+        ref = [ln[1:] for ln in out if ln[0] == "REF"]
+        assert not any(ln[0] == "SIZES-DIFFER" for ln in ref)                                  # the *_size fields equal the vectors' sizes, image_size 0
+        # frame stamps: exact
+        assert prod[0] == ref[0] and prod[0][0] == "FRAME", (prod[0], ref[0])
+        assert prod[0][prod[0].index("image_num") + 1] == "4" and prod[0][prod[0].index("msg_id") + 1] == str(kf_id)
+        assert int(prod[0][prod[0].index("landmark_num") + 1]) == sum(im["landmark_num"] for im in f["images"])
+        # images: header fields exact (direction, drone, frame id, time, extrinsic, pose, counts, sizes, descriptor sums), arrays to float precision
+        for d in range(4):
+            p, r = prod[1 + d], ref[1 + d]
+            cp, cr = p.index(":"), r.index(":")
+            assert p[:cp] == r[:cr], (p[:cp], r[:cr])
+            assert p[p.index("dir") + 1] == str(d) and p[p.index("gd") + 1] == str(gdim)
+            a, b = np.array(p[cp + 1:], np.float64).reshape(-1, 8), np.array(r[cr + 1:], np.float64).reshape(-1, 8)
+            assert np.array_equal(a[:, :5], b[:, :5])                                          # pixels, float-lifted points, flags
+            assert np.abs(a[:, 5:] - b[:, 5:]).max(initial=0) <= 1e-6 * max(1.0, np.abs(b[:, 5:]).max(initial=0))
+            n_flag = int(a[:, 4].sum())
+            assert n_flag == (0 if accept_min > f["images"][d]["landmark_num"] else f["images"][d]["stereo"][3])
+        # the mask: the caller's images after the reference ran == the rows the kernels blank; both networks saw exactly that
+        pix_p, pix_r = prod[5], ref[5]
+        assert pix_p[0] == pix_r[0] == "PIX" and pix_p == pix_r, (H, W)
+        seen_sp, seen_vlad, kfc = ref[6], ref[7], ref[8]
+        assert seen_sp[0] == "SEEN-SP" and seen_sp[1:] == pix_r[1:]                            # SuperPoint: all 8 images, blanked
+        assert seen_vlad[0] == "SEEN-VLAD"
+        assert seen_vlad[1::2] == pix_r[1::2] and all(v == "0" for v in seen_vlad[2::2])       # MobileNetVLAD: the up images only, blanked
+        assert kfc == ["KF-COUNT", "1"]
+        cases += 1
+    assert cases == 5
