@@ -39,9 +39,15 @@ struct ConvArgs {
     const void* zero_page = nullptr;   // omni_ctx::zero_page (the persistent LDS-DMA kernels need it; null = generic kernels only)
     float split_inv = 0.f; // OMNI_PREC_SPLIT: 2^-k of conv_pack_weights_split (the epilogue's factor)
     int variant = 0;       // test hook (OMNI_CONV_V1): 0 = best kernel per layer, 1 = generic kernel everywhere, 2 = v2 persistent kernel,
-                           // 3 = v3 ping-pong kernel without the conv1a fusion
+                           // 3 = v3 ping-pong kernel without the conv1a fusion    // Tile rectangle [skip_ty0, skip_ty1) x [skip_tx0, skip_tx1) of the CONV_TH x CONV_TW output-tile grid of every image whose results ALREADY
+    // stand in `out` (the caller filled them: see superpoint.hip, "constant region of the fisheye mask"): the persistent cin = 64 fp16 kernel
+    // leaves those tiles out of its tile walk; every other kernel ignores the hint and recomputes them (same values).  Empty = nothing to skip.
+    int skip_ty0 = 0, skip_ty1 = 0, skip_tx0 = 0, skip_tx1 = 0;
 };
 int conv_mfma(hipStream_t stream, int precision, const ConvArgs& a);
+// fp16 NHWC maps: `vec` (C halfs) <- pixel (y, x) of image 0;  every pixel of rows [y0, y1) x cols [x0, x1) of `batch` images <- `vec`
+int conv_read_pixel_f16(hipStream_t stream, const void* map, int Ho, int Wo, int C, int y, int x, void* vec);
+int conv_fill_rect_f16(hipStream_t stream, void* map, int batch, int Ho, int Wo, int C, int y0, int y1, int x0, int x1, const void* vec);
 
 // OMNI_PREC_SPLIT (conv_split.hip): 3x3 conv, cin 64 / 128, on the fp16 matrix cores with every operand split into hi + lo halfs (fp32-class).
 // Activations are "split-64" NHWC: per pixel and block of 64 channels [hi x 64 | lo x 64] halfs, values x conv_split_act_scale().

@@ -562,7 +562,11 @@ struct Fuse1aArgs {
     const uint32_t* lut_hl;       // [256] half(x) | half(x - half(x)) << 16,  x = float(i) * float(1 / 255.0)
     unsigned long long* trace;    // OMNI_PP_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
     const char* zero_page;        // OMNI_ZERO_PAGE_BYTES of zeros: DMA source of the halo pixels outside the image (set by the launcher)
-    uint32_t magic_tpi, magic_tx; // ceil(2^32 / tiles_per_img), ceil(2^32 / tiles_x) (set by the launcher)
+    uint32_t magic_tpi, magic_tx; // ceil(2^32 / act_per_img), ceil(2^32 / tiles_x) (set by the launcher)
+    // ConvArgs::skip_*: the tile walk of an image = the tile rows above the rectangle (n_above tiles), the tiles left and right of it in its
+    // rows (skip_bw per row, up to n_upto), the tile rows below it; no rectangle: n_above = n_upto = act_per_img = tiles_per_img
+    int act_per_img, n_above, n_upto, skip_y0, skip_y1, skip_x0, skip_w, skip_bw;
+    uint32_t magic_bw;            // ceil(2^32 / skip_bw)
 };
 
 template <bool POOL, int ABL, bool FUSE1A>
@@ -577,8 +581,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
     const int grp = wave >> 2, wl = wave & 3;
     const int n = lane & 31, hh = lane >> 5;
     const int ct = blockIdx.x % n_ct, wg = blockIdx.x / n_ct, nwg = gridDim.x / n_ct;
-    const int tiles_per_img = tiles_x * tiles_y;
-    const int total = batch * tiles_per_img;
+    const int total = batch * fz.act_per_img;
     const int n_mine = wg < total ? (total - wg + nwg - 1) / nwg : 0;      // tiles of this workgroup: t_k = wg + k * nwg
 
     {   // weights for this cout tile: 9 taps x 8 KB, fragment order (see pack_weights)
@@ -604,9 +607,19 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
     // ~200 instructions per phase
     auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
         b = fz.magic_tpi ? (int)__umulhi((uint32_t)t, fz.magic_tpi) : t;             // magic 0 = divisor 1 (2^32 does not fit)
-        const int r = t - b * tiles_per_img;
-        const int ry = fz.magic_tx ? (int)__umulhi((uint32_t)r, fz.magic_tx) : r;
-        ty0 = ry * CONV_TH; tx0 = (r - ry * tiles_x) * CONV_TW;
+        int r = t - b * fz.act_per_img, ry, rx;
+        if (r < fz.n_above || r >= fz.n_upto) {                                      // full tile rows above / below the skipped rectangle
+            int base = 0;
+            if (r >= fz.n_upto) { r -= fz.n_upto; base = fz.skip_y1; }
+            ry = fz.magic_tx ? (int)__umulhi((uint32_t)r, fz.magic_tx) : r;
+            rx = r - ry * tiles_x; ry += base;
+        } else {                                                                     // its rows: the tiles left and right of it
+            r -= fz.n_above;
+            const int q = fz.magic_bw ? (int)__umulhi((uint32_t)r, fz.magic_bw) : r;
+            const int c = r - q * fz.skip_bw;
+            ry = fz.skip_y0 + q; rx = c < fz.skip_x0 ? c : c + fz.skip_w;
+        }
+        ty0 = ry * CONV_TH; tx0 = rx * CONV_TW;
     };
     // per-lane source offsets (bytes, relative to the halo origin) of this wave's 11 DMA instructions, valid for interior tiles
     uint32_t goff[11];
@@ -916,16 +929,27 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
     static_assert(smem_bytes <= 160 * 1024, "LDS budget");
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes));
     const int tiles_x = cdiv(a.W, CONV_TW), tiles_y = cdiv(a.H, CONV_TH), n_ct = a.cout / 64;
-    const int total = a.batch * tiles_x * tiles_y;
+    Fuse1aArgs fzz = fz;
+    // the tile walk of one image, without the rectangle the caller already holds (ConvArgs::skip_*)
+    const bool skip = a.skip_ty1 > a.skip_ty0 && a.skip_tx1 > a.skip_tx0;
+    OMNI_REQUIRE(!skip || (a.skip_ty0 >= 0 && a.skip_ty1 <= tiles_y && a.skip_tx0 >= 0 && a.skip_tx1 <= tiles_x), OMNI_ERR_INVALID, "conv: skip rectangle outside the tile grid");
+    fzz.skip_y0 = skip ? a.skip_ty0 : 0; fzz.skip_y1 = skip ? a.skip_ty1 : 0; fzz.skip_x0 = skip ? a.skip_tx0 : 0; fzz.skip_w = skip ? a.skip_tx1 - a.skip_tx0 : 0;
+    fzz.skip_bw = tiles_x - fzz.skip_w;
+    fzz.act_per_img = tiles_x * tiles_y - (fzz.skip_y1 - fzz.skip_y0) * fzz.skip_w;
+    fzz.n_above = skip ? fzz.skip_y0 * tiles_x : fzz.act_per_img;
+    fzz.n_upto = fzz.n_above + (fzz.skip_y1 - fzz.skip_y0) * fzz.skip_bw;
+    OMNI_REQUIRE(fzz.act_per_img > 0, OMNI_ERR_INVALID, "conv: the skip rectangle covers the whole image");
+    const int total = a.batch * fzz.act_per_img;
     int per_ct = n_cu / n_ct;
     if (per_ct < 1) per_ct = 1;
     if (per_ct > cdiv(total, 2)) per_ct = cdiv(total, 2);      // at least two tiles per workgroup: one per wave group
     OMNI_REQUIRE(a.zero_page, OMNI_ERR_INVALID, "conv: ConvArgs.zero_page is not set");
-    Fuse1aArgs fzz = fz;
     fzz.zero_page = reinterpret_cast<const char*>(a.zero_page);
     OMNI_REQUIRE((int64_t)total * (tiles_x * tiles_y) < (1ll << 32), OMNI_ERR_INVALID, "conv: too many tiles for the multiply-high division");
-    fzz.magic_tpi = (uint32_t)(((1ull << 32) + (uint64_t)(tiles_x * tiles_y) - 1) / (uint64_t)(tiles_x * tiles_y));
-    fzz.magic_tx = (uint32_t)(((1ull << 32) + (uint64_t)tiles_x - 1) / (uint64_t)tiles_x);
+    auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };      // 0 = divisor 1 (2^32 does not fit)
+    fzz.magic_tpi = magic(fzz.act_per_img);
+    fzz.magic_tx = magic(tiles_x);
+    fzz.magic_bw = magic(fzz.skip_bw);
     // OMNI_PP_TRACE=1 (debug): s_memtime stamps of workgroup 0's phases 2-5 for the layers without the conv1a fusion (conv1ab_fused prints its own)
     static const bool want_trace = [] { const char* e = getenv("OMNI_PP_TRACE"); return e && e[0] == '1'; }();
     static unsigned long long* trace_dev = nullptr;
@@ -2160,6 +2184,40 @@ int nhwc_any_to_nchw_f32(hipStream_t st, int precision_of_in, const void* in, fl
         hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<_Float16>, dim3(grid), dim3(256), 0, st, (const _Float16*)in, out, C, HW, total);
     else
         hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)in, out, C, HW, total);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+// ---- the constant region of the fisheye mask (superpoint.hip): one pixel of a map read out, a rectangle of every image filled with it ----------
+__global__ void read_pixel_f16_kernel(const uint4* __restrict__ map, int64_t chunk0, int chunks, uint4* __restrict__ vec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < chunks) vec[i] = map[chunk0 + i];
+}
+int conv_read_pixel_f16(hipStream_t st, const void* map, int Ho, int Wo, int C, int y, int x, void* vec) {
+    OMNI_REQUIRE(C % 8 == 0 && y >= 0 && y < Ho && x >= 0 && x < Wo, OMNI_ERR_INVALID, "conv_read_pixel_f16: bad pixel");
+    const int chunks = C / 8;
+    hipLaunchKernelGGL(read_pixel_f16_kernel, dim3(cdiv(chunks, 64)), dim3(64), 0, st, (const uint4*)map, ((int64_t)y * Wo + x) * chunks, chunks, (uint4*)vec);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+// one thread per 16-byte chunk of the rectangle (a pixel's chunks are consecutive: coalesced row segments)
+__global__ void fill_rect_f16_kernel(uint4* __restrict__ map, int Ho, int Wo, int chunks, int y0, int x0, int rh, int rw, const uint4* __restrict__ vec, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // ((b * rh + y) * rw + x) * chunks + c
+    if (i >= total) return;
+    const int c = (int)(i % chunks);
+    const int64_t px = i / chunks;
+    const int x = (int)(px % rw);
+    const int64_t by = px / rw;
+    const int y = (int)(by % rh);
+    const int64_t b = by / rh;
+    map[((b * Ho + y0 + y) * Wo + x0 + x) * chunks + c] = vec[c];
+}
+int conv_fill_rect_f16(hipStream_t st, void* map, int batch, int Ho, int Wo, int C, int y0, int y1, int x0, int x1, const void* vec) {
+    OMNI_REQUIRE(C % 8 == 0 && y0 >= 0 && y1 <= Ho && x0 >= 0 && x1 <= Wo, OMNI_ERR_INVALID, "conv_fill_rect_f16: rectangle outside the map");
+    if (y1 <= y0 || x1 <= x0 || batch <= 0) return OMNI_OK;
+    const int chunks = C / 8;
+    const int64_t total = (int64_t)batch * (y1 - y0) * (x1 - x0) * chunks;
+    hipLaunchKernelGGL(fill_rect_f16_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (uint4*)map, Ho, Wo, chunks, y0, x0, y1 - y0, x1 - x0, (const uint4*)vec, total);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }

@@ -66,6 +66,24 @@ struct omni_sp {
     omni::DevBuf dense_tmp;
     hipEvent_t ev[OMNI_SP_NUM_STAGES + 1] = {};
     int conv_variant = 0;                    // OMNI_CONV_V1=1: generic conv kernel everywhere, 2: v2 persistent kernel (A/B and debugging)
+    // The constant region of the fisheye mask (fp16 path; OMNI_SP_MASK_SKIP=0 switches it off).  LoopCam blanks rows [3H/4, 3H/4 + H/4) of every image before the
+    // network sees it (loop_cam.cpp:536-539): a few pixels inside that band -- one per 3x3 convolution, doubling with every pool -- every
+    // activation is ONE vector per layer, whatever the image (its whole receptive field is zeros; the arithmetic of a pixel does not depend on
+    // where it is).  The vectors are read once from a pass over an all-zero image (sp_calibrate_mask_skip) and written once into the rectangle
+    // of CONV_TH x CONV_TW tiles that lies inside the region, in every image slot of the activation buffers; the persistent cin = 64 kernel then
+    // leaves those tiles out of its walk (ConvArgs::skip_*).  Results are bit-identical to the dense pass (tests/test_gpu_mask_skip.py).  A pass
+    // without the mask (or on another path) overwrites the rectangles: the next masked pass calibrates again.
+    struct MaskSkip {
+        int ty0 = 0, ty1 = 0, tx0 = 0, tx1 = 0;      // tile rectangle in the layer's conv-output tile grid (before the pool)
+        int oy0 = 0, oy1 = 0, ox0 = 0, ox1 = 0;      // the same rectangle in the layer's output map (after the pool)
+        int oh = 0, ow = 0, oc = 0;                  // output map: rows, cols, channels
+        void* vec = nullptr;                         // [oc] halfs: the constant
+        void** map = nullptr;                        // the activation buffer
+    };
+    MaskSkip mskip[4];                       // conv1b (+pool), conv2a, conv2b (+pool), conv3a
+    bool mask_skip = false, mask_skip_ready = false, mask_skip_calibrating = false;
+    uint8_t* zero_gray = nullptr;
+    size_t zero_gray_bytes = 0;
     std::mutex mu;
 };
 
@@ -75,6 +93,39 @@ static int dev_upload(void** dst, const void* src, size_t bytes, hipStream_t st)
     OMNI_HIP_TRY(hipMalloc(dst, bytes));
     OMNI_HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
     OMNI_HIP_TRY(hipStreamSynchronize(st));
+    return OMNI_OK;
+}
+
+// Where every layer's output is constant under the fisheye mask, and the tile rectangle inside it (see omni_sp::MaskSkip)
+static int sp_plan_mask_skip(omni_sp* s) {
+    const char* e = getenv("OMNI_SP_MASK_SKIP");
+    s->mask_skip = false;
+    if ((e && e[0] == '0') || s->precision != OMNI_PREC_F16 || s->conv_variant != 0) return OMNI_OK;     // OMNI_SP_MASK_SKIP=0: the dense pass (A/B, tests)
+    int m0, m1;
+    omni_fisheye_mask_rows(s->H, 1, &m0, &m1);
+    int h = s->H, w = s->W;
+    // conv1a's output is relu(bias) on the rows whose three input rows are blanked (the zero padding below the image counts as blanked), in
+    // every column (the padding left and right of the image is zeros too)
+    int a = m0 + 1, b = (m1 == h) ? h - 1 : m1 - 2, c = 0, d = w - 1;
+    void** maps[4] = {&s->a1b, &s->a2a, &s->a2b, &s->a3a};
+    const bool pool[4] = {true, false, true, false};
+    const int chans[4] = {64, 64, 64, 128};
+    for (int i = 0; i < 4; ++i) {
+        a += 1; b -= 1; c += 1; d -= 1;                    // a 3x3 convolution (zero padding is NOT the constant): one pixel in from every side
+        omni_sp::MaskSkip& k = s->mskip[i];
+        k = omni_sp::MaskSkip{};
+        if (b < a || d < c) break;                         // nothing constant from here on
+        k.ty0 = (a + CONV_TH - 1) / CONV_TH; k.ty1 = (b + 1) / CONV_TH; k.tx0 = (c + CONV_TW - 1) / CONV_TW; k.tx1 = (d + 1) / CONV_TW;
+        if (k.ty1 <= k.ty0 || k.tx1 <= k.tx0) k.ty0 = k.ty1 = k.tx0 = k.tx1 = 0;
+        const int f = pool[i] ? 2 : 1;
+        k.oy0 = k.ty0 * CONV_TH / f; k.oy1 = k.ty1 * CONV_TH / f; k.ox0 = k.tx0 * CONV_TW / f; k.ox1 = k.tx1 * CONV_TW / f;
+        if (pool[i]) { a = (a + 1) / 2; b = (b - 1) >> 1; c = (c + 1) / 2; d = (d - 1) >> 1; h /= 2; w /= 2; }      // pooled pixel r = conv pixels 2r, 2r + 1
+        k.oh = h; k.ow = w; k.oc = chans[i]; k.map = maps[i];
+        if (k.ty1 > k.ty0) {
+            OMNI_HIP_TRY(hipMalloc(&k.vec, (size_t)k.oc * 2));
+            s->mask_skip = true;
+        }
+    }
     return OMNI_OK;
 }
 
@@ -222,6 +273,32 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     s->pb.pca_mean = s->pca_mean;
     for (int i = 0; i <= OMNI_SP_NUM_STAGES; ++i) OMNI_HIP_TRY(hipEventCreate(&s->ev[i]));
     OMNI_HIP_TRY(hipStreamSynchronize(st));
+    return sp_plan_mask_skip(s);
+}
+
+static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, bool with_events, bool run_post);
+// One dense pass over an all-zero image with the mask on; every planned layer's constant is read from the middle of its rectangle and written
+// into that rectangle of every image slot of the layer's activation buffer.
+static int sp_calibrate_mask_skip(omni_sp* s, int stride) {
+    hipStream_t st = s->ctx->stream;
+    const size_t need = (size_t)stride * s->H;
+    if (s->zero_gray_bytes < need) {
+        if (s->zero_gray) (void)hipFree(s->zero_gray);
+        s->zero_gray = nullptr; s->zero_gray_bytes = 0;
+        OMNI_HIP_TRY(hipMalloc((void**)&s->zero_gray, need));
+        s->zero_gray_bytes = need;
+        OMNI_HIP_TRY(hipMemsetAsync(s->zero_gray, 0, need, st));
+    }
+    s->mask_skip_calibrating = true;
+    int rc = sp_forward(s, s->zero_gray, stride, 1, 1, false, false);
+    s->mask_skip_calibrating = false;
+    if (rc) return rc;
+    for (const omni_sp::MaskSkip& k : s->mskip) {
+        if (k.ty1 <= k.ty0) continue;
+        if ((rc = conv_read_pixel_f16(st, *k.map, k.oh, k.ow, k.oc, (k.oy0 + k.oy1) / 2, (k.ox0 + k.ox1) / 2, k.vec))) return rc;
+        if ((rc = conv_fill_rect_f16(st, *k.map, s->max_batch, k.oh, k.ow, k.oc, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
+    }
+    s->mask_skip_ready = true;
     return OMNI_OK;
 }
 
@@ -239,13 +316,23 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const int H = s->H, W = s->W, P = s->precision;
     int rc, stage = 0;
     if ((rc = s->ctx->ensure_zero_page())) return rc;
+    const bool fuse1a = (P == OMNI_PREC_F16 && s->conv_variant == 0 && stride % 4 == 0 && ((uintptr_t)gray_dev & 3) == 0);   // else: separate conv1a
+    // the constant region of the fisheye mask (omni_sp::MaskSkip): only on the production path (conv1a fused into conv1b)
+    const bool use_skip = s->mask_skip && fisheye_mask && fuse1a && !s->mask_skip_calibrating;
+    if (!use_skip && !s->mask_skip_calibrating) s->mask_skip_ready = false;          // this pass overwrites the filled rectangles
+    if (use_skip && !s->mask_skip_ready && (rc = sp_calibrate_mask_skip(s, stride))) return rc;
     auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
+    auto skip_of = [&](int l, ConvArgs& a) {
+        const int i = l == L1B ? 0 : l == L2A ? 1 : l == L2B ? 2 : l == L3A ? 3 : -1;
+        if (use_skip && i >= 0) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
+    };
     auto conv = [&](int l, const void* in, void* out, const float* bias, int h, int w, int cin, int cout, int ks, bool relu,
                     bool pool, bool out_f32) -> int {
         ConvArgs a;
         a.in = in; a.out = out; a.w_packed = s->wpk[l]; a.bias = bias; a.batch = batch; a.H = h; a.W = w; a.cin = cin;
         a.cout = cout; a.ksize = ks; a.relu = relu; a.pool = pool; a.out_f32 = out_f32;
         a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page; a.variant = s->conv_variant;
+        skip_of(l, a);
         if (P == OMNI_PREC_SPLIT) {     // split-64 activations in and (unless out_f32) out; the scaled bias goes with scaled outputs
             a.split_inv = s->winv[l];
             if (!out_f32) a.bias = s->bias_s[l];
@@ -255,7 +342,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     };
     const int PH = P == OMNI_PREC_SPLIT ? OMNI_PREC_F32 : P;      // the heads' tails: OMNI_PREC_SPLIT hands them fp32 activations
     if ((rc = mark())) return rc;
-    s->fuse1a = (P == OMNI_PREC_F16 && s->conv_variant == 0 && stride % 4 == 0 && ((uintptr_t)gray_dev & 3) == 0);   // else: separate conv1a
+    s->fuse1a = fuse1a;
     if (P == OMNI_PREC_SPLIT) { if ((rc = conv1a_split(st, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
     else if (!s->fuse1a) { if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
     if ((rc = mark())) return rc;
@@ -263,6 +350,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         ConvArgs a;
         a.in = nullptr; a.out = s->a1b; a.w_packed = s->wpk[L1B]; a.bias = s->bias[L1B]; a.batch = batch; a.H = H; a.W = W; a.cin = 64;
         a.cout = 64; a.ksize = 3; a.relu = true; a.pool = true; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page;
+        skip_of(L1B, a);
         if ((rc = conv1ab_fused(st, a, gray_dev, stride, fisheye_mask, reinterpret_cast<const _Float16*>(s->w1a_frag), s->bias[L1A], s->lut_hl))) return rc;
     } else if ((rc = conv(L1B, s->a1a, s->a1b, s->bias[L1B], H, W, 64, 64, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;
@@ -421,6 +509,8 @@ void omni_sp_destroy(omni_sp* s) {
                     s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->cx32, s->cy32, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (s->zero_gray) (void)hipFree(s->zero_gray);
+    for (auto& k : s->mskip) if (k.vec) (void)hipFree(k.vec);
     s->hstage.release(); s->dense_tmp.release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
@@ -575,13 +665,14 @@ double omni_sp_stage_flops(const omni_sp* s, int stage) {
 }
 
 int omni_sp_profile(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms) {
+    static const int prof_mask = [] { const char* e = getenv("OMNI_SP_PROFILE_MASK"); return (e && e[0] == '1') ? 1 : 0; }();   // stage times with the fisheye mask on (as the key-frame pipeline runs)
     OMNI_REQUIRE(s && gray_dev && stage_ms && reps >= 1, OMNI_ERR_INVALID, "bad argument");
     OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
     std::lock_guard<std::mutex> lk(s->mu);
     (void)hipSetDevice(s->ctx->device);
     for (int i = 0; i < OMNI_SP_NUM_STAGES; ++i) stage_ms[i] = 0.f;
     for (int r = 0; r < reps; ++r) {
-        int rc = omni::sp_forward(s, gray_dev, stride, batch, 0, true, true);
+        int rc = omni::sp_forward(s, gray_dev, stride, batch, prof_mask, true, true);
         if (rc) return rc;
         OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
         for (int i = 0; i < ST_COUNT; ++i) {
