@@ -32,6 +32,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("OMNI_SP_PROFILE_MASK", "1")      # omni_sp_profile: stage times with the fisheye mask on, as the key-frame pipeline runs the network
 
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
 PEAK_F32_TFLOPS = 157.3       # f32-input MFMA = vector peak
@@ -43,13 +44,38 @@ KF_IMAGES = 8                 # reference-faithful key frame: 8 SuperPoint + 4 M
 SP_DA_FLOP_PER_CELL, SP_DB_FLOP_PER_CELL, SP_CELLS = 2.0 * 9 * 128 * 256, 2.0 * 256 * 256, 4500
 
 
-def sp_flop_executed(precision, max_num, conv_stages_only=False):
+def mask_skip_plan(H, W, TH=8, TW=32):
+    """The tile rectangles the fp16 path leaves out of conv1b / conv2a / conv2b / conv3a under the fisheye mask (csrc/superpoint.hip, sp_plan_mask_skip:
+    the rows LoopCam blanks, loop_cam.cpp:536-539, make every activation a few pixels inside them one constant vector per layer, written once):
+    {layer: (fraction of the layer's tiles, dense FLOP of the layer per image)}."""
+    out = {}
+    if os.environ.get("OMNI_SP_MASK_SKIP", "1") == "0":
+        return out
+    m0 = H * 3 // 4
+    m1 = m0 + H // 4
+    h, w = H, W
+    a, b, c, d = m0 + 1, (h - 1 if m1 == h else m1 - 2), 0, w - 1
+    for name, pool, cin, cout in (("conv1b", True, 64, 64), ("conv2a", False, 64, 64), ("conv2b", True, 64, 64), ("conv3a", False, 64, 128)):
+        a, b, c, d = a + 1, b - 1, c + 1, d - 1
+        if b < a or d < c:
+            break
+        ty0, ty1, tx0, tx1 = -(-a // TH), (b + 1) // TH, -(-c // TW), (d + 1) // TW
+        tiles = -(-h // TH) * -(-w // TW)
+        out[name] = (max(0, ty1 - ty0) * max(0, tx1 - tx0) / tiles, 2.0 * h * w * cin * cout * 9)
+        if pool:
+            a, b, c, d, h, w = (a + 1) // 2, (b - 1) >> 1, (c + 1) // 2, (d - 1) >> 1, h // 2, w // 2
+    return out
+
+
+def sp_flop_executed(precision, max_num, conv_stages_only=False, masked=True):
     """FLOP per image actually executed (conv_stages_only: by the stages named conv*, i.e. without the sparse descriptor kernels, which run inside the
-    post-processing stage)."""
+    post-processing stage; masked: with the fisheye mask on, as the key-frame pipeline runs the network)."""
     sparse_db = precision == "f16" and os.environ.get("OMNI_SP_SPARSE_DESC", "1") != "0"
     sparse_da = sparse_db and os.environ.get("OMNI_SP_SPARSE_DA", "1") != "0"
     cells = 0 if conv_stages_only else min(4 * max_num, SP_CELLS)
     f = SP_FLOP_PER_IMAGE
+    if precision == "f16" and masked:
+        f -= sum(frac * flop for frac, flop in mask_skip_plan(480, 600).values())
     if sparse_db:
         f -= SP_DB_FLOP_PER_CELL * (SP_CELLS - cells)
     if sparse_da:
@@ -487,6 +513,8 @@ def main():
     peak = PEAK_F32_TFLOPS if args.precision == "f32" else PEAK_F16_TFLOPS
     mfma_terms = 3 if args.precision == "split" else 1          # OMNI_PREC_SPLIT executes three fp16 MFMA terms per algorithmic product
     achieved = mfma_terms * c1b_flop / (c1b["ms"] * 1e-3) / 1e12
+    skip = mask_skip_plan(H, W) if args.precision == "f16" else {}
+    c1b_skip = skip.get("conv1b", (0.0, 0.0))[0]
     roofline = {"bound": "mfma", "kernel": "conv3x3_split_kernel<cin 64, POOL> = conv1b 3x3 64->64 + ReLU + maxpool2 with split (hi, lo) fp16 operands: MFMA FLOP = 3 x algorithmic" if args.precision == "split" else
                                           "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 "
                                           "in one launch; FLOP counted for conv1b only", "achieved": round(achieved, 1),
@@ -494,6 +522,12 @@ def main():
                 **(traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", args.precision == "f16", n_img) if args.precision != "split" else
                    traffic_fields("conv3x3_split_kernel<cin64,POOL> (conv1b: the larger half of the launches)", True, n_img)),
                 "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
+                "flop_executed_per_launch": c1b_flop * (1.0 - c1b_skip), "frac_executed": round(achieved * (1.0 - c1b_skip) / peak, 4),
+                "mask_skip": {"note": "stage times with the fisheye mask on, as the key-frame pipeline runs the network (loop_cam.cpp:536-539): the tiles whose whole "
+                                      "receptive field lies in the blanked rows hold one constant vector per layer, written once, and are left out of the tile walk "
+                                      "(bit-identical: tests/test_gpu_mask_skip.py; OMNI_SP_MASK_SKIP=0 = the dense pass). `achieved` / `frac` count the ALGORITHMIC "
+                                      "FLOP of the layer (the contract's definition), `frac_executed` only the FLOP of the tiles that ran",
+                              "tiles_left_out": {k: round(v[0], 4) for k, v in skip.items()}},
                 "conv_stack_tflops": round(sp_flop_executed(args.precision, MAXN, True) * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
                 "conv_stack_note": "FLOP executed by the stages named conv* (fp16 path: without convDa / convDb, which run only at the cells around the key points "
                                    "inside the post-processing stage) / their time",
