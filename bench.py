@@ -523,6 +523,8 @@ def main():
                    traffic_fields("conv3x3_split_kernel<cin64,POOL> (conv1b: the larger half of the launches)", True, n_img)),
                 "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
                 "flop_executed_per_launch": c1b_flop * (1.0 - c1b_skip), "frac_executed": round(achieved * (1.0 - c1b_skip) / peak, 4),
+                **({"traffic_note": "collected on the dense pass (before the mask's constant region was left out): the stores of the tiles left out (their share of "
+                                    "589.8 MB per 64 images) are no longer issued"} if c1b_skip > 0 else {}),
                 "mask_skip": {"note": "stage times with the fisheye mask on, as the key-frame pipeline runs the network (loop_cam.cpp:536-539): the tiles whose whole "
                                       "receptive field lies in the blanked rows hold one constant vector per layer, written once, and are left out of the tile walk "
                                       "(bit-identical: tests/test_gpu_mask_skip.py; OMNI_SP_MASK_SKIP=0 = the dense pass). `achieved` / `frac` count the ALGORITHMIC "
