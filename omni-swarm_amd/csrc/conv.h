@@ -48,6 +48,11 @@ int conv_mfma(hipStream_t stream, int precision, const ConvArgs& a);
 // fp16 NHWC maps: `vec` (C halfs) <- pixel (y, x) of image 0;  every pixel of rows [y0, y1) x cols [x0, x1) of `batch` images <- `vec`
 int conv_read_pixel_f16(hipStream_t stream, const void* map, int Ho, int Wo, int C, int y, int x, void* vec);
 int conv_fill_rect_f16(hipStream_t stream, void* map, int batch, int Ho, int Wo, int C, int y0, int y1, int x0, int x1, const void* vec);
+// the same for any map of `pix_bytes`-byte pixels (a multiple of 16) laid out as image stride / row stride / origin of pixel (0, 0), all in bytes
+// (framed split-64 maps: origin = one row + one pixel into the frame)
+int conv_read_pixel_bytes(hipStream_t stream, const void* map, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y, int x, void* vec);
+int conv_fill_rect_bytes(hipStream_t stream, void* map, int batch, int64_t img_bytes, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y0, int y1, int x0, int x1,
+                         const void* vec);
 
 // OMNI_PREC_SPLIT (conv_split.hip): 3x3 conv, cin 64 / 128, on the fp16 matrix cores with every operand split into hi + lo halfs (fp32-class).
 // Activations are "split-64" NHWC: per pixel and block of 64 channels [hi x 64 | lo x 64] halfs, values x conv_split_act_scale().
@@ -56,8 +61,9 @@ int conv_fill_rect_f16(hipStream_t stream, void* map, int batch, int Ho, int Wo,
 float conv_pack_weights_split(const float* w_oihw, int cin, int cout, uint16_t* out);
 float conv_split_act_scale();
 int conv_split(hipStream_t stream, const ConvArgs& a);
+// skip_tr0 / skip_tr1: the 8-row tile rows [skip_tr0, skip_tr1) already stand in out_split (the mask's constant band) and are not computed
 int conv1a_split(hipStream_t stream, const uint8_t* gray, int stride, int batch, int H, int W, int fisheye_mask, const float* w, const float* bias,
-                 const float* u8_lut, void* out_split);
+                 const float* u8_lut, void* out_split, int skip_tr0 = 0, int skip_tr1 = 0);
 int split_to_nchw_f32(hipStream_t stream, const void* in_split, float* out, int batch, int C, int H, int W);   // test hook
 // A split-64 H x W map lives in a zero frame of split_frame_h(H) rows x split_frame_w(W) pixels, pixel (y, x) at row y + 1, column x + 1:
 // one pixel of zero padding all round plus the overhang of the last 32-pixel tile in either direction.  The frame must be zeroed once

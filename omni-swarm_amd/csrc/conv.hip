@@ -2222,4 +2222,35 @@ int conv_fill_rect_f16(hipStream_t st, void* map, int batch, int Ho, int Wo, int
     return OMNI_OK;
 }
 
+__global__ void fill_rect_bytes_kernel(char* __restrict__ map, int64_t img_bytes, int64_t row_bytes, int64_t org_bytes, int chunks, int y0, int x0, int rh, int rw,
+                                       const uint4* __restrict__ vec, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // ((b * rh + y) * rw + x) * chunks + c
+    if (i >= total) return;
+    const int c = (int)(i % chunks);
+    const int64_t px = i / chunks;
+    const int x = (int)(px % rw);
+    const int64_t by = px / rw;
+    const int y = (int)(by % rh);
+    const int64_t b = by / rh;
+    *reinterpret_cast<uint4*>(map + b * img_bytes + org_bytes + (y0 + y) * row_bytes + ((int64_t)(x0 + x) * chunks + c) * 16) = vec[c];
+}
+int conv_read_pixel_bytes(hipStream_t st, const void* map, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y, int x, void* vec) {
+    OMNI_REQUIRE(pix_bytes % 16 == 0 && y >= 0 && x >= 0 && (org_bytes + y * row_bytes + (int64_t)x * pix_bytes) % 16 == 0, OMNI_ERR_INVALID, "conv_read_pixel_bytes: bad pixel");
+    const int chunks = pix_bytes / 16;
+    hipLaunchKernelGGL(read_pixel_f16_kernel, dim3(cdiv(chunks, 64)), dim3(64), 0, st, (const uint4*)map, (org_bytes + y * row_bytes + (int64_t)x * pix_bytes) / 16, chunks, (uint4*)vec);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+int conv_fill_rect_bytes(hipStream_t st, void* map, int batch, int64_t img_bytes, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y0, int y1, int x0, int x1,
+                         const void* vec) {
+    OMNI_REQUIRE(pix_bytes % 16 == 0 && img_bytes % 16 == 0 && row_bytes % 16 == 0 && org_bytes % 16 == 0 && y0 >= 0 && x0 >= 0, OMNI_ERR_INVALID, "conv_fill_rect_bytes: bad layout");
+    if (y1 <= y0 || x1 <= x0 || batch <= 0) return OMNI_OK;
+    const int chunks = pix_bytes / 16;
+    const int64_t total = (int64_t)batch * (y1 - y0) * (x1 - x0) * chunks;
+    hipLaunchKernelGGL(fill_rect_bytes_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (char*)map, img_bytes, row_bytes, org_bytes, chunks, y0, x0, y1 - y0,
+                       x1 - x0, (const uint4*)vec, total);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 }  // namespace omni

@@ -161,7 +161,10 @@ __device__ __forceinline__ void spl_prime(uint32_t row_base, int n_eff, int hh, 
 // A SLICE is half a pair (slice h of a pair: values 2h, 2h+1, 4+2h, 5+2h -> dword h of the four 8-byte halves; OUT_F32: values 4h .. 4h+3);
 // the pair's stores go with its second slice.  Every lane runs every slice (the swap is a cross-lane operation); pred guards the stores.
 struct SplPacked { uint4 a, b; };
-struct SplTileIx { int b, ty, tx; };                                  // image, tile row, tile column
+struct SplTileIx { int b, r, ty, tx; };                               // image, index among the image's tiles that run, tile row, tile column
+// ConvArgs::skip_* for this kernel's tile grid: the tiles of an image that run = the tile rows above the rectangle (n_above tiles), the tiles
+// left and right of it in its own rows (bw per row, up to n_upto), the tile rows below; no rectangle: n_above = n_upto = act = tiles_x * tiles_y
+struct SplSkip { int act, n_above, n_upto, y0, y1, x0, w, bw; uint32_t magic_tx, magic_bw; };
 struct SplOrg { __amdgpu_buffer_rsrc_t r; uint32_t soff; };           // a halo tile's DMA source: the image's frame + the scalar offset of the halo origin
 typedef float spl_f4 __attribute__((ext_vector_type(4)));
 template <bool C128, bool POOL>
@@ -258,7 +261,7 @@ __device__ __forceinline__ void spl_epi_all(SplEpi<C128, POOL>& e, const float4 
 template <bool C128, bool POOL, bool OUT_F32, bool TRN = false>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const _Float16* __restrict__ wp, const float* __restrict__ bias,
-                     float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu,
+                     float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, SplSkip sk,
                      int dbg /* OMNI_SPLIT_DBG (timing experiments, WRONG results): 1 = no stores, 2 = every DMA reads tile 0 */,
                      unsigned long long* trace /* OMNI_SPLIT_TRACE=1: s_memtime stamps of workgroup 0, waves 0 and 3 (debug only), else nullptr */) {
     extern __shared__ __attribute__((aligned(256))) char smem_raw[];
@@ -272,7 +275,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     const int co = wave & 1, part = wave >> 1;
     const int n = lane & 31, hh = lane >> 5;
     const int cg = blockIdx.x % n_cg, wg = blockIdx.x / n_cg, nwg = gridDim.x / n_cg;
-    const int tiles_per_img = tiles_x * tiles_y;
+    const int tiles_per_img = sk.act;                       // (the tiles that run)
     const int total = batch * tiles_per_img;
     const int g32 = cg * 2 + co;
 
@@ -290,15 +293,41 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     float* const bias_lds = reinterpret_cast<float*>(smem_raw + 2 * SPL_BUF_BYTES + SPL_XCH_BYTES);
     if (tid < 64) bias_lds[tid] = bias[cg * 64 + tid];
 
-    // tile t = (image b, tile row ty, tile column tx); a workgroup walks t = wg, wg + nwg, ...: the indices advance by carries, no division per tile
+    // tile t = (image b, tile r of the image's tiles that run); a workgroup walks t = wg, wg + nwg, ...: (b, r) advance by a carry, (tile row,
+    // tile column) come from r by multiply-high divisions (scalar: a dozen SALU instructions per tile)
+    // (cin = 128 has no rectangle to leave out -- the launcher refuses one: its walk stays on carries alone, r unused)
     const int step_b = nwg / tiles_per_img, step_r = nwg - step_b * tiles_per_img;
     const int step_y = step_r / tiles_x, step_x = step_r - step_y * tiles_x;
+    auto decode = [&](SplTileIx& q) {
+        int r = q.r, ty, tx;                                            // (locals, assigned to q once: stores in both branches send the struct to scratch)
+        if constexpr (C128) {
+            ty = r / tiles_x; tx = r - ty * tiles_x;
+        } else if (r < sk.n_above || r >= sk.n_upto) {                  // full tile rows above / below the rectangle
+            int base = 0;
+            if (r >= sk.n_upto) { r -= sk.n_upto; base = sk.y1; }
+            const int ry = sk.magic_tx ? (int)__umulhi((uint32_t)r, sk.magic_tx) : r;      // magic 0 = divisor 1
+            tx = r - ry * tiles_x; ty = ry + base;
+        } else {                                                        // its rows: the tiles left and right of it
+            r -= sk.n_above;
+            const int qy = sk.magic_bw ? (int)__umulhi((uint32_t)r, sk.magic_bw) : r;
+            const int c = r - qy * sk.bw;
+            ty = sk.y0 + qy; tx = c < sk.x0 ? c : c + sk.w;
+        }
+        q.ty = ty; q.tx = tx;
+    };
     auto advance = [&](SplTileIx& q) {
-        q.tx += step_x;
-        if (q.tx >= tiles_x) { q.tx -= tiles_x; ++q.ty; }
-        q.ty += step_y;
-        if (q.ty >= tiles_y) { q.ty -= tiles_y; ++q.b; }
-        q.b += step_b;
+        if constexpr (C128) {
+            q.tx += step_x;
+            if (q.tx >= tiles_x) { q.tx -= tiles_x; ++q.ty; }
+            q.ty += step_y;
+            if (q.ty >= tiles_y) { q.ty -= tiles_y; ++q.b; }
+            q.b += step_b;
+        } else {
+            q.r += step_r;
+            if (q.r >= tiles_per_img) { q.r -= tiles_per_img; ++q.b; }
+            q.b += step_b;
+            decode(q);
+        }
     };
     // DMA piece p (1 KiB) = virtual pixels [4 p, 4 p + 4): lane -> (virtual pixel vp, 16-byte chunk slot); the chunk stored in slot s of
     // virtual pixel vp is the pixel block's chunk s ^ (vp & 15).  cin = 64: vp = halo pixel (6 x 34); cin = 128: vp = block * 136 + halo pixel
@@ -327,11 +356,11 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     // A write to M0 waits for the LDS-DMA instructions in flight to have consumed the old value -- 17 writes per tile cost the stream
     // ~600 cycles.
     const uint32_t in_img_bytes = (uint32_t)Hf * Wf * PIXB;
-    auto origin = [&](const SplTileIx& q) -> SplOrg {
+    auto origin = [&](int qb, int qty, int qtx) -> SplOrg {
         SplOrg o;
-        o.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in) + (int64_t)q.b * in_img_bytes - 4096, 0, in_img_bytes + 8192, 0x00020000);
+        o.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in) + (int64_t)qb * in_img_bytes - 4096, 0, in_img_bytes + 8192, 0x00020000);
         // halo origin (ty0 - 1, tx0 - 1) = frame pixel (ty0, tx0)
-        o.soff = (uint32_t)(q.ty * (TRN ? 32 : TH) * Wf + q.tx * (TRN ? TH : 32)) * PIXB + 4096;
+        o.soff = (uint32_t)(qty * (TRN ? 32 : TH) * Wf + qtx * (TRN ? TH : 32)) * PIXB + 4096;
         return o;
     };
     auto dma_piece = [&](const SplOrg& o, int which, auto JC) {
@@ -362,13 +391,13 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     SplTileIx cur_ix, nxt_ix;
     {
         cur_ix.b = t / tiles_per_img;
-        const int r = t - cur_ix.b * tiles_per_img;
-        cur_ix.ty = r / tiles_x; cur_ix.tx = r - cur_ix.ty * tiles_x;
+        cur_ix.r = t - cur_ix.b * tiles_per_img;
+        decode(cur_ix);
         nxt_ix = cur_ix;
         advance(nxt_ix);
     }
     if (t < total) {
-        const SplOrg o = origin(cur_ix);
+        const SplOrg o = origin(cur_ix.b, cur_ix.ty, cur_ix.tx);
         spl_for_each<0, PPW>([&](auto JC) { dma_piece(o, 0, JC); });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -412,7 +441,8 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     for (; t < total; t += nwg, cur ^= 1) {
         stamp(0);
         // the next tile's DMA (the last tile of this workgroup loads its own tile again: no branch in the stream; nobody reads that buffer)
-        const SplOrg org_n = origin((dbg & 2) ? SplTileIx{0, 0, 0} : (t + nwg < total ? nxt_ix : cur_ix));
+        const bool has_next = t + nwg < total;                          // (field by field: a select between the two structs sends them to scratch)
+        const SplOrg org_n = (dbg & 2) ? origin(0, 0, 0) : origin(has_next ? nxt_ix.b : cur_ix.b, has_next ? nxt_ix.ty : cur_ix.ty, has_next ? nxt_ix.tx : cur_ix.tx);
         const uint32_t row_base = lds0 + cur * SPL_BUF_BYTES + n_eff * 256;
         floatx16 acc[2];
 #pragma unroll
@@ -507,7 +537,19 @@ static int launch_split(hipStream_t st, const ConvArgs& a) {
     OMNI_HIP_TRY(ensure_dyn_smem(smem_state, (const void*)kfn, SPL_SMEM));
     constexpr int TH = C128 ? 2 : 4;
     const int tiles_x = cdiv(a.W, TRN ? TH : 32), tiles_y = cdiv(a.H, TRN ? 32 : TH), n_cg = a.cout / 64;
-    const int total = a.batch * tiles_x * tiles_y;
+    // the tiles of an image that run: all of them, or all but the rectangle the caller already holds (ConvArgs::skip_*, in THIS kernel's tile grid)
+    const bool skip = !C128 && a.skip_ty1 > a.skip_ty0 && a.skip_tx1 > a.skip_tx0;      // (the cin = 128 kernel recomputes a rectangle it is offered: same values)
+    OMNI_REQUIRE(!skip || (a.skip_ty0 >= 0 && a.skip_ty1 <= tiles_y && a.skip_tx0 >= 0 && a.skip_tx1 <= tiles_x), OMNI_ERR_INVALID, "conv_split: skip rectangle outside the tile grid");
+    SplSkip sk;
+    sk.y0 = skip ? a.skip_ty0 : 0; sk.y1 = skip ? a.skip_ty1 : 0; sk.x0 = skip ? a.skip_tx0 : 0; sk.w = skip ? a.skip_tx1 - a.skip_tx0 : 0;
+    sk.bw = tiles_x - sk.w;
+    sk.act = tiles_x * tiles_y - (sk.y1 - sk.y0) * sk.w;
+    sk.n_above = skip ? sk.y0 * tiles_x : sk.act;
+    sk.n_upto = sk.n_above + (sk.y1 - sk.y0) * sk.bw;
+    OMNI_REQUIRE(sk.act > 0, OMNI_ERR_INVALID, "conv_split: the skip rectangle covers the whole image");
+    auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };      // exact for n * d < 2^32; 0 = divisor 1
+    sk.magic_tx = magic(tiles_x); sk.magic_bw = magic(sk.bw);
+    const int total = a.batch * sk.act;
     int per_cg = a.n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
     if (per_cg > total) per_cg = total;
@@ -521,7 +563,7 @@ static int launch_split(hipStream_t st, const ConvArgs& a) {
     }
     hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), SPL_SMEM, st, reinterpret_cast<const char*>(a.in), a.out,
                        reinterpret_cast<const _Float16*>(a.w_packed), a.bias, inv, a.H, a.W, a.cout, n_cg, tiles_x, tiles_y, a.batch, a.relu ? 1 : 0,
-                       dbg, want_trace ? trace_dev : nullptr);
+                       sk, dbg, want_trace ? trace_dev : nullptr);
     OMNI_LAUNCH_CHECK();
     if (want_trace) {
         unsigned long long h[64];
@@ -566,14 +608,16 @@ float conv_split_act_scale() { return SPL_ACT_SCALE; }
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 conv1a_split_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, int mask_row0, int mask_row1, const float* __restrict__ w,
-                    const float* __restrict__ bias, const float* __restrict__ lut, _Float16* __restrict__ out) {
+                    const float* __restrict__ bias, const float* __restrict__ lut, _Float16* __restrict__ out, int skip_tr0, int skip_ntr) {
     __shared__ float tile[10][36];
     __shared__ float wsm[9][64];
     __shared__ float bsm[64];
     __shared__ float lsm[256];
     const int tid = threadIdx.x;
     const int tiles_x = (W + 31) / 32;
-    const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 32;
+    int tr = blockIdx.x / tiles_x;
+    if (tr >= skip_tr0) tr += skip_ntr;                    // the tile rows [skip_tr0, skip_tr0 + skip_ntr) already stand in `out` (the mask's constant band)
+    const int ty0 = tr * 8, tx0 = (blockIdx.x % tiles_x) * 32;
     const int b = blockIdx.y;
     const uint8_t* g = gray + (int64_t)b * stride * H;
     lsm[tid] = lut[tid];
@@ -619,11 +663,13 @@ conv1a_split_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, 
 }
 
 int conv1a_split(hipStream_t st, const uint8_t* gray, int stride, int batch, int H, int W, int fisheye_mask, const float* w, const float* bias,
-                 const float* lut, void* out) {
+                 const float* lut, void* out, int skip_tr0, int skip_tr1) {
     int r0, r1;
     omni_fisheye_mask_rows(H, fisheye_mask, &r0, &r1);   // cv::Rect(0, rows*3/4, cols, rows/4)
-    dim3 grid(cdiv(W, 32) * cdiv(H, 8), batch);
-    hipLaunchKernelGGL(conv1a_split_kernel, grid, dim3(256), 0, st, gray, stride, H, W, r0, r1, w, bias, lut, (_Float16*)out);
+    const int tiles_y = cdiv(H, 8), skip_n = skip_tr1 > skip_tr0 ? skip_tr1 - skip_tr0 : 0;
+    OMNI_REQUIRE(skip_n == 0 || (skip_tr0 >= 0 && skip_tr1 <= tiles_y && skip_n < tiles_y), OMNI_ERR_INVALID, "conv1a_split: skipped tile rows outside the image");
+    dim3 grid(cdiv(W, 32) * (tiles_y - skip_n), batch);
+    hipLaunchKernelGGL(conv1a_split_kernel, grid, dim3(256), 0, st, gray, stride, H, W, r0, r1, w, bias, lut, (_Float16*)out, skip_n ? skip_tr0 : tiles_y, skip_n);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }

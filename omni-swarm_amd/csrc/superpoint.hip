@@ -77,10 +77,12 @@ struct omni_sp {
         int ty0 = 0, ty1 = 0, tx0 = 0, tx1 = 0;      // tile rectangle in the layer's conv-output tile grid (before the pool)
         int oy0 = 0, oy1 = 0, ox0 = 0, ox1 = 0;      // the same rectangle in the layer's output map (after the pool)
         int oh = 0, ow = 0, oc = 0;                  // output map: rows, cols, channels
-        void* vec = nullptr;                         // [oc] halfs: the constant
+        int pix_bytes = 0;                           // its layout: bytes per pixel, per row, per image, offset of pixel (0, 0) (fp16: NHWC; split: framed split-64)
+        int64_t row_bytes = 0, img_bytes = 0, org_bytes = 0;
+        void* vec = nullptr;                         // [pix_bytes]: the constant
         void** map = nullptr;                        // the activation buffer
     };
-    MaskSkip mskip[4];                       // conv1b (+pool), conv2a, conv2b (+pool), conv3a
+    MaskSkip mskip[5];                       // conv1a (OMNI_PREC_SPLIT only: fused away on the fp16 path), conv1b (+pool), conv2a, conv2b (+pool), conv3a
     bool mask_skip = false, mask_skip_ready = false, mask_skip_calibrating = false;
     uint8_t* zero_gray = nullptr;
     size_t zero_gray_bytes = 0;
@@ -98,33 +100,58 @@ static int dev_upload(void** dst, const void* src, size_t bytes, hipStream_t st)
 
 // Where every layer's output is constant under the fisheye mask, and the tile rectangle inside it (see omni_sp::MaskSkip)
 static int sp_plan_mask_skip(omni_sp* s) {
-    const char* e = getenv("OMNI_SP_MASK_SKIP");
     s->mask_skip = false;
-    if ((e && e[0] == '0') || s->precision != OMNI_PREC_F16 || s->conv_variant != 0) return OMNI_OK;     // OMNI_SP_MASK_SKIP=0: the dense pass (A/B, tests)
+    const bool split = s->precision == OMNI_PREC_SPLIT;
+    if (s->conv_variant != 0 || s->precision == OMNI_PREC_F32) return OMNI_OK;
+    if (split) { const char* e = getenv("OMNI_SP_MASK_SKIP_SPLIT"); if (!(e && e[0] == '1')) return OMNI_OK; }      // (not yet validated on hardware: off unless asked for)
+    else { const char* e = getenv("OMNI_SP_MASK_SKIP"); if (e && e[0] == '0') return OMNI_OK; }                     // OMNI_SP_MASK_SKIP=0: the dense pass (A/B, tests)
     int m0, m1;
     omni_fisheye_mask_rows(s->H, 1, &m0, &m1);
     int h = s->H, w = s->W;
     // conv1a's output is relu(bias) on the rows whose three input rows are blanked (the zero padding below the image counts as blanked), in
     // every column (the padding left and right of the image is zeros too)
     int a = m0 + 1, b = (m1 == h) ? h - 1 : m1 - 2, c = 0, d = w - 1;
+    auto layout = [&](omni_sp::MaskSkip& k) -> int {
+        if (split) {
+            k.pix_bytes = k.oc * 4;
+            k.row_bytes = (int64_t)split_frame_w(k.ow) * k.pix_bytes;
+            k.img_bytes = (int64_t)split_frame_bytes(k.oh, k.ow, k.oc);
+            k.org_bytes = k.row_bytes + k.pix_bytes;
+        } else {
+            k.pix_bytes = k.oc * 2; k.row_bytes = (int64_t)k.ow * k.pix_bytes; k.img_bytes = k.row_bytes * k.oh; k.org_bytes = 0;
+        }
+        if (k.ty1 > k.ty0) {
+            OMNI_HIP_TRY(hipMalloc(&k.vec, (size_t)k.pix_bytes));
+            s->mask_skip = true;
+        }
+        return OMNI_OK;
+    };
+    int rc;
+    for (auto& k : s->mskip) k = omni_sp::MaskSkip{};
+    if (split && b >= a) {                                 // conv1a_split: 8-row tile rows, the whole width
+        omni_sp::MaskSkip& k = s->mskip[0];
+        k.ty0 = (a + 7) / 8; k.ty1 = (b + 1) / 8; k.tx0 = 0; k.tx1 = (w + 31) / 32;
+        if (k.ty1 <= k.ty0) k.ty0 = k.ty1 = k.tx0 = k.tx1 = 0;
+        k.oy0 = k.ty0 * 8; k.oy1 = k.ty1 * 8 < h ? k.ty1 * 8 : h; k.ox0 = 0; k.ox1 = k.ty1 > k.ty0 ? w : 0;
+        k.oh = h; k.ow = w; k.oc = 64; k.map = &s->a1a;
+        if ((rc = layout(k))) return rc;
+    }
     void** maps[4] = {&s->a1b, &s->a2a, &s->a2b, &s->a3a};
     const bool pool[4] = {true, false, true, false};
     const int chans[4] = {64, 64, 64, 128};
+    const int TH = split ? 4 : CONV_TH, TW = 32;           // the cin = 64 kernels' output tiles (conv_split.hip: 4 x 32, conv.hip: CONV_TH x CONV_TW)
+    static_assert(CONV_TW == 32, "tile width");
     for (int i = 0; i < 4; ++i) {
         a += 1; b -= 1; c += 1; d -= 1;                    // a 3x3 convolution (zero padding is NOT the constant): one pixel in from every side
-        omni_sp::MaskSkip& k = s->mskip[i];
-        k = omni_sp::MaskSkip{};
+        omni_sp::MaskSkip& k = s->mskip[1 + i];
         if (b < a || d < c) break;                         // nothing constant from here on
-        k.ty0 = (a + CONV_TH - 1) / CONV_TH; k.ty1 = (b + 1) / CONV_TH; k.tx0 = (c + CONV_TW - 1) / CONV_TW; k.tx1 = (d + 1) / CONV_TW;
+        k.ty0 = (a + TH - 1) / TH; k.ty1 = (b + 1) / TH; k.tx0 = (c + TW - 1) / TW; k.tx1 = (d + 1) / TW;
         if (k.ty1 <= k.ty0 || k.tx1 <= k.tx0) k.ty0 = k.ty1 = k.tx0 = k.tx1 = 0;
         const int f = pool[i] ? 2 : 1;
-        k.oy0 = k.ty0 * CONV_TH / f; k.oy1 = k.ty1 * CONV_TH / f; k.ox0 = k.tx0 * CONV_TW / f; k.ox1 = k.tx1 * CONV_TW / f;
+        k.oy0 = k.ty0 * TH / f; k.oy1 = k.ty1 * TH / f; k.ox0 = k.tx0 * TW / f; k.ox1 = k.tx1 * TW / f;
         if (pool[i]) { a = (a + 1) / 2; b = (b - 1) >> 1; c = (c + 1) / 2; d = (d - 1) >> 1; h /= 2; w /= 2; }      // pooled pixel r = conv pixels 2r, 2r + 1
         k.oh = h; k.ow = w; k.oc = chans[i]; k.map = maps[i];
-        if (k.ty1 > k.ty0) {
-            OMNI_HIP_TRY(hipMalloc(&k.vec, (size_t)k.oc * 2));
-            s->mask_skip = true;
-        }
+        if ((rc = layout(k))) return rc;
     }
     return OMNI_OK;
 }
@@ -295,8 +322,8 @@ static int sp_calibrate_mask_skip(omni_sp* s, int stride) {
     if (rc) return rc;
     for (const omni_sp::MaskSkip& k : s->mskip) {
         if (k.ty1 <= k.ty0) continue;
-        if ((rc = conv_read_pixel_f16(st, *k.map, k.oh, k.ow, k.oc, (k.oy0 + k.oy1) / 2, (k.ox0 + k.ox1) / 2, k.vec))) return rc;
-        if ((rc = conv_fill_rect_f16(st, *k.map, s->max_batch, k.oh, k.ow, k.oc, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
+        if ((rc = conv_read_pixel_bytes(st, *k.map, k.row_bytes, k.org_bytes, k.pix_bytes, (k.oy0 + k.oy1) / 2, (k.ox0 + k.ox1) / 2, k.vec))) return rc;
+        if ((rc = conv_fill_rect_bytes(st, *k.map, s->max_batch, k.img_bytes, k.row_bytes, k.org_bytes, k.pix_bytes, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
     }
     s->mask_skip_ready = true;
     return OMNI_OK;
@@ -318,12 +345,12 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if ((rc = s->ctx->ensure_zero_page())) return rc;
     const bool fuse1a = (P == OMNI_PREC_F16 && s->conv_variant == 0 && stride % 4 == 0 && ((uintptr_t)gray_dev & 3) == 0);   // else: separate conv1a
     // the constant region of the fisheye mask (omni_sp::MaskSkip): only on the production path (conv1a fused into conv1b)
-    const bool use_skip = s->mask_skip && fisheye_mask && fuse1a && !s->mask_skip_calibrating;
+    const bool use_skip = s->mask_skip && fisheye_mask && (fuse1a || P == OMNI_PREC_SPLIT) && !s->mask_skip_calibrating;
     if (!use_skip && !s->mask_skip_calibrating) s->mask_skip_ready = false;          // this pass overwrites the filled rectangles
     if (use_skip && !s->mask_skip_ready && (rc = sp_calibrate_mask_skip(s, stride))) return rc;
     auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
     auto skip_of = [&](int l, ConvArgs& a) {
-        const int i = l == L1B ? 0 : l == L2A ? 1 : l == L2B ? 2 : l == L3A ? 3 : -1;
+        const int i = l == L1B ? 1 : l == L2A ? 2 : l == L2B ? 3 : l == L3A ? 4 : -1;
         if (use_skip && i >= 0) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
     };
     auto conv = [&](int l, const void* in, void* out, const float* bias, int h, int w, int cin, int cout, int ks, bool relu,
@@ -343,7 +370,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const int PH = P == OMNI_PREC_SPLIT ? OMNI_PREC_F32 : P;      // the heads' tails: OMNI_PREC_SPLIT hands them fp32 activations
     if ((rc = mark())) return rc;
     s->fuse1a = fuse1a;
-    if (P == OMNI_PREC_SPLIT) { if ((rc = conv1a_split(st, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
+    if (P == OMNI_PREC_SPLIT) { if ((rc = conv1a_split(st, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a, use_skip ? s->mskip[0].ty0 : 0, use_skip ? s->mskip[0].ty1 : 0))) return rc; }
     else if (!s->fuse1a) { if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
     if ((rc = mark())) return rc;
     if (s->fuse1a) {   // conv1a is computed inside conv1b's kernel: the conv1a activation tensor is never materialised

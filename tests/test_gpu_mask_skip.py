@@ -20,21 +20,25 @@ def _same(a, b):
         assert np.array_equal(k0, k1) and np.array_equal(s0, s1) and np.array_equal(d0, d1)
 
 
+@pytest.mark.parametrize("prec", ["PREC_F16", "PREC_SPLIT"])
 @pytest.mark.parametrize("shape,batch", [((480, 600), 3), ((480, 640), 2), ((240, 320), 2), ((64, 96), 2)])
-def test_mask_skip_is_bit_identical_to_the_dense_pass(omni, ctx, shape, batch, monkeypatch):
+def test_mask_skip_is_bit_identical_to_the_dense_pass(omni, ctx, shape, batch, prec, monkeypatch):
+    """(OMNI_PREC_SPLIT: the same region for conv1a -- a tensor of its own there -- and the four cin = 64 layers of the split kernel, 4 x 32 tiles;
+    OMNI_SP_MASK_SKIP_SPLIT=1 switches it on)"""
     h, w = shape
+    env = "OMNI_SP_MASK_SKIP" if prec == "PREC_F16" else "OMNI_SP_MASK_SKIP_SPLIT"
     weights = S.synth_weights(0)
     comp, mean = synth.pca()
     imgs = np.stack([synth.image_u8(900 + i, h, w, n_shapes=60 if h < 100 else 200) for i in range(batch)])
     imgs2 = np.stack([synth.image_u8(950 + i, h, w, n_shapes=60 if h < 100 else 200) for i in range(batch + 1)])
     sps = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("OMNI_SP_MASK_SKIP", flag)
-        sps.append(omni.capi.SuperPoint(ctx, weights, comp, mean, w, h, 0.015, 200, omni.capi.PREC_F16, batch + 1))
+        monkeypatch.setenv(env, flag)
+        sps.append(omni.capi.SuperPoint(ctx, weights, comp, mean, w, h, 0.015, 200, getattr(omni.capi, prec), batch + 1))
     dense, skip = sps
     # 1. masked pass: every output and every layer
     _same(dense.inference(imgs, True), skip.inference(imgs, True))
-    for n in LAYERS:
+    for n in LAYERS + (["conv1a"] if prec == "PREC_SPLIT" else []):
         a, b = dense.debug_layer(n, batch), skip.debug_layer(n, batch)
         assert np.array_equal(a, b), (n, int((a != b).sum()), np.argwhere(a != b)[:4].tolist())
     (s0, d0), (s1, d1) = dense.get_dense(batch), skip.get_dense(batch)
@@ -45,7 +49,7 @@ def test_mask_skip_is_bit_identical_to_the_dense_pass(omni, ctx, shape, batch, m
     for n in ("conv1b", "conv3a", "conv4b"):
         assert np.array_equal(dense.debug_layer(n, batch + 1), skip.debug_layer(n, batch + 1)), n
     # 3. and the masked band really is constant where the plan says so (480 x 600: conv1b's pooled rows 184-235, columns 16-287)
-    if (h, w) == (480, 600):
+    if (h, w) == (480, 600) and prec == "PREC_F16":
         a = skip.debug_layer("conv1b", batch)
         band = a[:, :, 184:236, 16:288]
         assert np.array_equal(band, np.broadcast_to(band[:1, :, :1, :1], band.shape))
