@@ -44,43 +44,39 @@ KF_IMAGES = 8                 # reference-faithful key frame: 8 SuperPoint + 4 M
 SP_DA_FLOP_PER_CELL, SP_DB_FLOP_PER_CELL, SP_CELLS = 2.0 * 9 * 128 * 256, 2.0 * 256 * 256, 4500
 
 
-def mask_skip_plan(H, W, TH=8, TW=32):
-    """The tile rectangles the fp16 path leaves out of conv1b / conv2a / conv2b / conv3a under the fisheye mask (csrc/superpoint.hip, sp_plan_mask_skip:
-    the rows LoopCam blanks, loop_cam.cpp:536-539, make every activation a few pixels inside them one constant vector per layer, written once):
-    {layer: (fraction of the layer's tiles, dense FLOP of the layer per image)}."""
-    out = {}
-    if os.environ.get("OMNI_SP_MASK_SKIP", "1") == "0":
-        return out
-    m0 = H * 3 // 4
-    m1 = m0 + H // 4
-    h, w = H, W
-    a, b, c, d = m0 + 1, (h - 1 if m1 == h else m1 - 2), 0, w - 1
-    for name, pool, cin, cout in (("conv1b", True, 64, 64), ("conv2a", False, 64, 64), ("conv2b", True, 64, 64), ("conv3a", False, 64, 128)):
-        a, b, c, d = a + 1, b - 1, c + 1, d - 1
-        if b < a or d < c:
-            break
-        ty0, ty1, tx0, tx1 = -(-a // TH), (b + 1) // TH, -(-c // TW), (d + 1) // TW
-        tiles = -(-h // TH) * -(-w // TW)
-        out[name] = (max(0, ty1 - ty0) * max(0, tx1 - tx0) / tiles, 2.0 * h * w * cin * cout * 9)
-        if pool:
-            a, b, c, d, h, w = (a + 1) // 2, (b - 1) >> 1, (c + 1) // 2, (d - 1) >> 1, h // 2, w // 2
-    return out
-
-
-def sp_flop_executed(precision, max_num, conv_stages_only=False, masked=True):
+def sp_flop_executed(precision, max_num, conv_stages_only=False, left_out_flop=0.0):
     """FLOP per image actually executed (conv_stages_only: by the stages named conv*, i.e. without the sparse descriptor kernels, which run inside the
-    post-processing stage; masked: with the fisheye mask on, as the key-frame pipeline runs the network)."""
+    post-processing stage; left_out_flop: the FLOP of the tiles a fisheye-masked pass leaves out of the tile walk -- the constant region of the mask,
+    csrc/superpoint.hip sp_plan_mask_skip -- summed from the library's own per-stage figures, omni_sp_stage_flops x omni_sp_stage_tiles_left_out)."""
     sparse_db = precision == "f16" and os.environ.get("OMNI_SP_SPARSE_DESC", "1") != "0"
     sparse_da = sparse_db and os.environ.get("OMNI_SP_SPARSE_DA", "1") != "0"
     cells = 0 if conv_stages_only else min(4 * max_num, SP_CELLS)
-    f = SP_FLOP_PER_IMAGE
-    if precision == "f16" and masked:
-        f -= sum(frac * flop for frac, flop in mask_skip_plan(480, 600).values())
+    f = SP_FLOP_PER_IMAGE - left_out_flop
     if sparse_db:
         f -= SP_DB_FLOP_PER_CELL * (SP_CELLS - cells)
     if sparse_da:
         f -= SP_DA_FLOP_PER_CELL * (SP_CELLS - cells)
     return f
+
+
+def rocprof_trace(pattern):
+    """Launch duration of a kernel from the newest committed rocprofv3 kernel trace (profiles/*_kernel_times.json, written by tools/rocprof_summary.py
+    from the same bench command under `rocprofv3 --kernel-trace --stats`): the number the HIP-event time of this run must agree with."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_times.json")))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        for name, v in t.get("kernels", {}).items():
+            if pattern in name:
+                return {"kernel": name[:100], "median_us": v["median_us"], "avg_us": v["avg_us"], "calls": v["calls"], "source": os.path.relpath(f, ROOT),
+                        "command": t.get("label", "")}
+    return None
+
+
+def mfma_terms_of(precision):
+    return 3 if precision == "split" else 1
 
 
 def traffic_fields(key, enabled=True, images_per_launch=None):
@@ -132,7 +128,7 @@ def parse():
     ap.add_argument("--geometry-steps", type=int, default=64, help="key frames of the leg with the geometric verification stage on (with_geometry); 0 = skip")
     ap.add_argument("--python-steps", type=int, default=64, help="key frames of the Python-host leg (python_host); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-keyframes", type=int, default=4, help="key frames timed on the host cores for cpu_baseline")
+    ap.add_argument("--cpu-keyframes", type=int, default=10, help="key frames timed on the host cores for cpu_baseline (after 2 warm-ups; the median is reported)")
     return ap.parse_args()
 
 
@@ -505,35 +501,57 @@ def main():
     else:
         prof_sp = capi.SuperPoint(ictx, sp_w, comp, mean, W, H, THRES, MAXN, prec, n_img)
     pool_dev = ictx.to_device(pool[0])
-    prof = prof_sp.profile(pool_dev, W, n_img, reps=10)
+    prof = prof_sp.profile(pool_dev, W, n_img, reps=21)
     conv_ms = sum(p["ms"] for p in prof if p["stage"].startswith("conv")) / MB
     sp_ms = sum(p["ms"] for p in prof) / MB
-    c1b = next(p for p in prof if p["stage"].startswith("conv1b"))
-    c1b_flop = c1b["flops_per_image"] * n_img
     peak = PEAK_F32_TFLOPS if args.precision == "f32" else PEAK_F16_TFLOPS
-    mfma_terms = 3 if args.precision == "split" else 1          # OMNI_PREC_SPLIT executes three fp16 MFMA terms per algorithmic product
-    achieved = mfma_terms * c1b_flop / (c1b["ms"] * 1e-3) / 1e12
-    skip = mask_skip_plan(H, W) if args.precision == "f16" else {}
-    c1b_skip = skip.get("conv1b", (0.0, 0.0))[0]
-    roofline = {"bound": "mfma", "kernel": "conv3x3_split_kernel<cin 64, POOL> = conv1b 3x3 64->64 + ReLU + maxpool2 with split (hi, lo) fp16 operands: MFMA FLOP = 3 x algorithmic" if args.precision == "split" else
-                                          "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 "
-                                          "in one launch; FLOP counted for conv1b only", "achieved": round(achieved, 1),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                **(traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", args.precision == "f16", n_img) if args.precision != "split" else
-                   traffic_fields("conv3x3_split_kernel<cin64,POOL> (conv1b: the larger half of the launches)", True, n_img)),
-                "flop_per_launch": c1b_flop, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img,
-                "flop_executed_per_launch": c1b_flop * (1.0 - c1b_skip), "frac_executed": round(achieved * (1.0 - c1b_skip) / peak, 4),
-                **({"traffic_note": "collected on the dense pass (before the mask's constant region was left out): the stores of the tiles left out (their share of "
-                                    "589.8 MB per 64 images) are no longer issued"} if c1b_skip > 0 else {}),
-                "mask_skip": {"note": "stage times with the fisheye mask on, as the key-frame pipeline runs the network (loop_cam.cpp:536-539): the tiles whose whole "
-                                      "receptive field lies in the blanked rows hold one constant vector per layer, written once, and are left out of the tile walk "
-                                      "(bit-identical: tests/test_gpu_mask_skip.py; OMNI_SP_MASK_SKIP=0 = the dense pass). `achieved` / `frac` count the ALGORITHMIC "
-                                      "FLOP of the layer (the contract's definition), `frac_executed` only the FLOP of the tiles that ran",
-                              "tiles_left_out": {k: round(v[0], 4) for k, v in skip.items()}},
-                "conv_stack_tflops": round(sp_flop_executed(args.precision, MAXN, True) * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
-                "conv_stack_note": "FLOP executed by the stages named conv* (fp16 path: without convDa / convDb, which run only at the cells around the key points "
-                                   "inside the post-processing stage) / their time",
-                "stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof}, "superpoint_ms_per_keyframe": round(sp_ms, 3)}
+    left_out_flop = sum(p["flops_per_image"] * p["tiles_left_out"] for p in prof)       # per image, by the library's own plan
+
+    def conv1b_roofline(stages, precision):
+        """`frac` = FLOP the launch EXECUTED / its HIP-event time / peak: the tiles that ran (a fisheye-masked pass leaves the constant region of the mask
+        out of the tile walk) x 3 MFMA terms per product in OMNI_PREC_SPLIT; the layer's algorithmic FLOP / time is kept as frac_algorithmic."""
+        c1b = next(p for p in stages if p["stage"].startswith("conv1b"))
+        alg = c1b["flops_per_image"] * n_img
+        terms = 3 if precision == "split" else 1          # OMNI_PREC_SPLIT executes three fp16 MFMA terms per algorithmic product
+        executed = terms * alg * (1.0 - c1b["tiles_left_out"])
+        t = c1b["ms"] * 1e-3
+        pk = PEAK_F32_TFLOPS if precision == "f32" else PEAK_F16_TFLOPS
+        split = precision == "split"
+        trace = rocprof_trace("conv3x3_split_kernelILb0ELb1ELb0" if split else "conv3x3_c64_pp_kernelILb1ELi0ELb1")
+        return {"bound": "mfma",
+                "kernel": ("conv3x3_split_kernel<cin 64, POOL> = conv1b 3x3 64->64 + ReLU + maxpool2 with split (hi, lo) fp16 operands: three MFMA terms per product" if split else
+                           "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 in one launch; "
+                           "FLOP counted for conv1b only"),
+                "achieved": round(executed / t / 1e12, 1), "peak": pk, "unit": "TFLOP/s", "frac": round(executed / t / 1e12 / pk, 4),
+                "definition": "achieved = MFMA FLOP of the tiles the launch ran / HIP-event time between the stage markers on the kernel's own stream",
+                "flop_executed_per_launch": executed, "launch_ms": round(c1b["ms"], 4), "images_per_launch": n_img, "tiles_left_out": round(c1b["tiles_left_out"], 4),
+                "flop_algorithmic_per_launch": alg, "achieved_algorithmic": round(alg / t / 1e12, 1), "frac_algorithmic": round(alg / t / 1e12 / pk, 4),
+                "rocprof_trace": trace,
+                "rocprof_trace_note": "median launch duration of the same kernel under rocprofv3 --kernel-trace (committed summary); frac recomputed from it = "
+                                      + (str(round(executed / (trace["median_us"] * 1e-6) / 1e12 / pk, 4)) if trace else "n/a: no trace committed yet"),
+                **(traffic_fields("conv3x3_split_kernel<cin64,POOL> (conv1b: the larger half of the launches)", True, n_img) if split else
+                   traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", precision == "f16", n_img))}
+
+    roofline = conv1b_roofline(prof, args.precision)
+    roofline.update({
+        "mask_skip": {"note": "stage times with the fisheye mask on, as the key-frame pipeline runs the network (loop_cam.cpp:536-539): the tiles whose whole "
+                              "receptive field lies in the blanked rows hold one constant vector per layer, written once, and are left out of the tile walk "
+                              "(bit-identical: tests/test_gpu_mask_skip.py; OMNI_SP_MASK_SKIP=0 / OMNI_SP_MASK_SKIP_SPLIT=0 = the dense pass)",
+                      "tiles_left_out": {p["stage"]: round(p["tiles_left_out"], 4) for p in prof if p["tiles_left_out"] > 0}},
+        "conv_stack_tflops": round(mfma_terms_of(args.precision) * sp_flop_executed(args.precision, MAXN, True, left_out_flop) * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
+        "conv_stack_note": "MFMA FLOP executed by the stages named conv* (fp16 path: without convDa / convDb, which run only at the cells around the key points "
+                           "inside the post-processing stage; split: x 3 terms) / their time",
+        "stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof}, "superpoint_ms_per_keyframe": round(sp_ms, 3)})
+    # the same kernel figure for the precision that meets north_star's tolerance (value_parity's conv1b), in the default run
+    roofline_parity = None
+    if args.precision == "f16" and args.parity_steps > 0 and world == 1:
+        sp_split = capi.SuperPoint(ictx, sp_w, comp, mean, W, H, THRES, MAXN, capi.PREC_SPLIT, n_img)
+        prof_s = sp_split.profile(pool_dev, W, n_img, reps=11)
+        sp_split.close()
+        roofline_parity = conv1b_roofline(prof_s, "split")
+        roofline_parity.update({"stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof_s},
+                                "superpoint_ms_per_keyframe": round(sum(p["ms"] for p in prof_s) / MB, 3),
+                                "tiles_left_out_by_stage": {p["stage"]: round(p["tiles_left_out"], 4) for p in prof_s if p["tiles_left_out"] > 0}})
     ictx.free(pool_dev)
 
     # ---- p50 loop-match latency on big DBs (node total rows, sharded when N > 1): 100k rows and 100k key frames = 400k rows ----------
@@ -615,6 +633,12 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu, parity, parity_split = cpu_baseline(args.cpu_keyframes, W, H, THRES, MAXN, comp, mean, sp_w, vl_w, vl_specs, vl_shape, capi, ictx, prec)
 
+    librccl = None
+    if world > 1 and cpp_host:
+        try:
+            librccl = capi.shard_library_path()
+        except Exception as e:                                    # noqa: BLE001
+            librccl = f"unavailable: {e}"
     if rank == 0:
         line = {
             "metric": "keyframes/sec (4x fisheye 600x480) + p50 loop-match ms @ 100k-frame DB",
@@ -633,10 +657,11 @@ def main():
                        "parallelism": f"dp{world} keyframes + {world}-way row-sharded index" if world > 1 else "single GPU",
                        "device": info["name"], "n_cu": info["n_cu"]},
             "loop_candidates_found": hits,
-            "gflop_per_keyframe_superpoint": round(sp_flop_executed(args.precision, MAXN) * KF_IMAGES / 1e9, 1),
+            "gflop_per_keyframe_superpoint": round(sp_flop_executed(args.precision, MAXN, False, left_out_flop) * KF_IMAGES / 1e9, 1),
             "gflop_per_keyframe_superpoint_dense": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
-            "achieved_tflops_end_to_end": round(kfps * sp_flop_executed(args.precision, MAXN) * KF_IMAGES / 1e12 / world, 1),
-            "roofline": roofline, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
+            "achieved_tflops_end_to_end": round(kfps * sp_flop_executed(args.precision, MAXN, False, left_out_flop) * KF_IMAGES / 1e12 / world, 1),
+            "rccl_ranks": world if (world > 1 and cpp_host) else (1 if world == 1 else 0), "librccl": librccl,
+            "roofline": roofline, "roofline_parity": roofline_parity, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
             "db100k": db100k, "with_geometry": with_geometry, "value_f32": value_f32, "value_parity": value_parity, "c5_shard": c5_shard,
             "python_host": python_host, "parity": parity, "parity_split": parity_split, "cpu_baseline": cpu,
         }
@@ -677,15 +702,18 @@ def cpu_baseline(n_kf, W, H, thres, max_num, comp, mean, sp_w, vl_w, vl_specs, v
         match_ref.ip_search_numpy(db, g[1], 10)
         last.update(kps=kps, feats=feats, g=g)
 
-    keyframe()                                  # warm-up
-    t = time.perf_counter()
+    keyframe()                                  # warm-ups
+    keyframe()
+    dts = []
     for _ in range(n_kf):
+        t = time.perf_counter()
         keyframe()
-    dt = (time.perf_counter() - t) / n_kf
+        dts.append(time.perf_counter() - t)
+    dt = float(np.median(dts))
     cpu = {"value": round(1.0 / dt, 4), "unit": "keyframes/s", "cores": cores, "kind": "port",
-           "sample": f"{n_kf} key frames (8 SuperPoint + 4 MobileNetVLAD 600x480, post-processing, 4 BF matches, 1 search over 4000 rows) "
-                     f"after 1 warm-up (bounded sample, not the median-of-20 of SURVEY 8d); torch {torch.__version__} fp32, {cores} threads of {avail} host CPUs",
-           "ms_per_keyframe": round(dt * 1e3, 1)}
+           "sample": f"median of {n_kf} key frames (8 SuperPoint + 4 MobileNetVLAD 600x480, post-processing, 4 BF matches, 1 search over 4000 rows) "
+                     f"after 2 warm-ups (a bounded sample: SURVEY 8d's median of >= 20 would take a minute); torch {torch.__version__} fp32, {cores} threads of {avail} host CPUs",
+           "ms_per_keyframe": round(dt * 1e3, 1), "ms_per_keyframe_minmax": [round(min(dts) * 1e3, 1), round(max(dts) * 1e3, 1)]}
     # GPU path on the same key frame vs the oracle's outputs
     vl = capi.MobileNetVLAD(ictx, vl_w, vl_specs, *vl_shape, W, H, 4)
     g = vl.inference(imgs[:4], fisheye_mask=True)

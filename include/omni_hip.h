@@ -145,11 +145,18 @@ int omni_sp_postprocess_dense(omni_sp* sp, const float* semi_host, const float* 
  * "conv4b","heads","desc"}; post-ReLU, post-pool where the layer pools).  out may be NULL to query the shape only. */
 int omni_sp_debug_layer(omni_sp* sp, const char* name, int batch, float* out_nchw_host, int* C, int* H, int* W);
 /* per-stage device time: runs the network `reps` times on HBM-resident input with HIP events between stages.
- * stage_ms [OMNI_SP_NUM_STAGES] average ms per call; names via omni_sp_stage_name(). */
+ * stage_ms [OMNI_SP_NUM_STAGES] MEDIAN ms per call over the repetitions; names via omni_sp_stage_name(). */
 #define OMNI_SP_NUM_STAGES 16
 int         omni_sp_profile(omni_sp* sp, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms);
 const char* omni_sp_stage_name(int stage);
 double      omni_sp_stage_flops(const omni_sp* sp, int stage);   /* algorithmic FLOP per image for that stage */
+/* share of the stage's output tiles a fisheye-masked pass leaves out of the kernel's tile walk (the constant region of the mask, loop_cam.cpp:536-539:
+ * written once per handle, bit-identical results); 0 when the stage computes every tile */
+double      omni_sp_stage_tiles_left_out(const omni_sp* sp, int stage);
+/* the plan itself (pure arithmetic on the image size and the kernels' tile shapes; no device needed): layer 0 = conv1a (OMNI_PREC_SPLIT only), 1..4 =
+ * conv1b, conv2a, conv2b, conv3a; rect = {tile row 0, tile row 1, tile column 0, tile column 1} of the layer's conv-output tile grid (empty = nothing
+ * left out), frac = its share of the layer's tiles */
+int         omni_sp_mask_skip_plan(int width, int height, int precision, int layer, int* rect, double* frac);
 
 /* ---- MobileNetVLAD (ASSUMED architecture -- the reference ships only the I/O contract) --------- */
 enum { OMNI_VLAD_CONV3X3_RELU6 = 0, OMNI_VLAD_PW_RELU6 = 1, OMNI_VLAD_DW3X3_RELU6 = 2,
@@ -243,6 +250,8 @@ int         omni_index_last_scan_ms(omni_index* idx, float* ms);
  * faiss::IndexFlatIP::search result of the UNSHARDED index (global ids, score desc, ties -> lower id).  RCCL is resolved at run time
  * (dlopen librccl.so.1); the launcher only has to carry the 128-byte unique id from rank 0 to the other ranks (any channel). */
 #define OMNI_SHARD_ID_BYTES 128
+/* the file the collective entry points (ncclAllGather ...) were resolved from: librccl of the process's ROCm stack, or what OMNI_RCCL_LIB names */
+int         omni_shard_library_path(char* out, int cap);
 int         omni_shard_unique_id(char* id_out /* [OMNI_SHARD_ID_BYTES], ncclGetUniqueId */);
 /* collective: every rank calls it with the same id; `local` must be an empty index on ctx; its rows/ids are managed by the shard from here on */
 omni_shard* omni_shard_create(omni_ctx* ctx, omni_index* local, int dim, int rank, int world, const char* unique_id);

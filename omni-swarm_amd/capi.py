@@ -29,13 +29,13 @@ SYMBOLS = [
     "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_image_size", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
-    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block",
+    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_sp_stage_tiles_left_out", "omni_sp_mask_skip_plan", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block",
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
     "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
-    "omni_shard_unique_id", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait",
+    "omni_shard_unique_id", "omni_shard_library_path", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait",
     "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
 
@@ -117,6 +117,8 @@ def lib():
     sig("omni_sp_profile", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _fp])
     sig("omni_sp_stage_name", C.c_char_p, [C.c_int])
     sig("omni_sp_stage_flops", C.c_double, [_vp, C.c_int])
+    sig("omni_sp_stage_tiles_left_out", C.c_double, [_vp, C.c_int])
+    sig("omni_sp_mask_skip_plan", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)])
     sig("omni_vlad_create", _vp, [_vp, C.POINTER(_VladWeights), C.c_int, C.c_int, C.c_int])
     sig("omni_vlad_destroy", None, [_vp])
     sig("omni_vlad_set_precision", C.c_int, [_vp, C.c_int])
@@ -158,6 +160,7 @@ def lib():
     sig("omni_flatten_out_bytes", C.c_int64, [_vp])
     sig("omni_flatten_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp])
     sig("omni_shard_unique_id", C.c_int, [C.c_char_p])
+    sig("omni_shard_library_path", C.c_int, [C.c_char_p, C.c_int])
     sig("omni_shard_create", _vp, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p])
     sig("omni_shard_destroy", None, [_vp])
     sig("omni_shard_ntotal", C.c_int64, [_vp])
@@ -371,7 +374,8 @@ class SuperPoint:
         for i in range(SP_NUM_STAGES):
             name = lib().omni_sp_stage_name(i).decode()
             if name:
-                out.append({"stage": name, "ms": float(ms[i]), "flops_per_image": lib().omni_sp_stage_flops(self.h, i)})
+                out.append({"stage": name, "ms": float(ms[i]), "flops_per_image": lib().omni_sp_stage_flops(self.h, i),
+                            "tiles_left_out": lib().omni_sp_stage_tiles_left_out(self.h, i)})
         return out
 
 
@@ -617,6 +621,22 @@ def shard_unique_id() -> bytes:
     buf = C.create_string_buffer(SHARD_ID_BYTES)
     _check(lib().omni_shard_unique_id(buf))
     return buf.raw
+
+
+def sp_mask_skip_plan(width: int, height: int, precision: int, layer: int):
+    """((tile row 0, tile row 1, tile column 0, tile column 1), share of the layer's tiles) a fisheye-masked pass leaves out of layer `layer`
+    (0 = conv1a [split only], 1..4 = conv1b, conv2a, conv2b, conv3a): csrc/superpoint.hip, pure arithmetic (no device)."""
+    rect = (C.c_int * 4)()
+    frac = C.c_double()
+    _check(lib().omni_sp_mask_skip_plan(width, height, precision, layer, rect, C.byref(frac)))
+    return tuple(rect), frac.value
+
+
+def shard_library_path() -> str:
+    """The file ncclAllGather & co. were resolved from (the process's librccl, or what OMNI_RCCL_LIB names)."""
+    buf = C.create_string_buffer(1024)
+    _check(lib().omni_shard_library_path(buf, 1024))
+    return buf.value.decode()
 
 
 class Shard:

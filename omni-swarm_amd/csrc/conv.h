@@ -65,6 +65,10 @@ int conv_split(hipStream_t stream, const ConvArgs& a);
 int conv1a_split(hipStream_t stream, const uint8_t* gray, int stride, int batch, int H, int W, int fisheye_mask, const float* w, const float* bias,
                  const float* u8_lut, void* out_split, int skip_tr0 = 0, int skip_tr1 = 0);
 int split_to_nchw_f32(hipStream_t stream, const void* in_split, float* out, int batch, int C, int H, int W);   // test hook
+// conv1a + conv1b + ReLU + 2x2 max-pool in one launch (OMNI_PREC_SPLIT): conv1b's halo tiles are built from the u8 image inside the kernel (conv1a on the
+// matrix cores with split operands); a = the conv1b layer (a.in unused); w1a_frag from conv1a_split_pack_fused, lut_hl from conv1a_make_split_lut
+void conv1a_split_pack_fused(const float* w /*[64][9]*/, const float* bias /*[64]*/, uint16_t* frag /*[2048]*/);
+int conv1ab_split_fused(hipStream_t stream, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const void* w1a_frag, const uint32_t* lut_hl);
 // A split-64 H x W map lives in a zero frame of split_frame_h(H) rows x split_frame_w(W) pixels, pixel (y, x) at row y + 1, column x + 1:
 // one pixel of zero padding all round plus the overhang of the last 32-pixel tile in either direction.  The frame must be zeroed once
 // (the kernels only ever write the map).

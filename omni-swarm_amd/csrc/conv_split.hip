@@ -85,27 +85,37 @@ __device__ __forceinline__ void spl_read(uint32_t row_base /* lds + n_eff * 256 
     const uint32_t addr = (row_base + pc * 256 + ((((pc + n_eff) & 15) ^ hh) << 4)) ^ (kg << 5);
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
+// (measured in round 4 and not kept: the pixel block as the instruction's immediate offset and a wait without the fragment as an operand (no s_nop
+// in front of the MFMA) remove ~120 instructions per tile, but hipcc then keeps two dozen more addresses in registers and splits more weight
+// fragments' live ranges (v_accvgpr_mov x 4 in front of their MFMAs): same time)
 template <int N>
 __device__ __forceinline__ void spl_wait(half8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(N)); }
 
 // halo row r feeds output row 0 through tap row ky = r and output row 1 through ky = r - 1.  The fragments go through a ring of SPL_NB
 // registers quads, SPL_NB - 1 reads ahead of the matrix cores: a step holds 1 to 4 MFMAs (32 to 128 cycles: rows 0 and 3 feed one output
 // row only, a lo fragment meets the hi weights only), so a short look-ahead would fall under the LDS latency in the sparse stretches --
-// and with one wave per SIMD nothing else hides it.
+// and with one wave per SIMD nothing else hides it.  Both output rows sum their 9 x 64 (x 2) products in the SAME order (tap row 0, 1, 2 per tap
+// column): a pixel's value does not depend on which row of a tile it is -- what the constant region of the fisheye mask relies on.
+// (Round 4, measured and not kept: rows 0 and 3 interleaved and issued together, so that no two consecutive MFMAs accumulate into the same
+// registers -- same time, and the two rows' sums then differ in the last bit.)
 //
-// Everything else a tile needs rides in the shadow of this stream (one wave per SIMD: whatever is not issued between two MFMAs idles the
-// matrix cores): the "dense" steps (4 MFMAs = 128 cycles) each carry one PART of the PREVIOUS tile's epilogue (scale + bias + ReLU +
+// Everything else a tile needs rides in this stream (one wave per SIMD: whatever is not issued between two MFMAs idles the matrix cores):
+// the "dense" steps (4 MFMAs = 128 cycles) each carry one PART of the PREVIOUS tile's epilogue (scale + bias + ReLU +
 // hi / lo split of 2 values per lane; every second part the cross-lane swap, every fourth the stores), the other steps the LDS-DMA
 // instructions of the NEXT tile one at a time (a burst of 17 behind the stores stalls the wave in the VMEM issue queue for 2 000
-// cycles; measured with the s_memtime trace below).
+// cycles; measured with the s_memtime trace below).  The in-stream trace of round 4 (tools/fz_ablate.sh trace) prices it: the steps without
+// a part run within 3-8 % of their MFMAs' time, a part costs ~100 cycles beyond its step's four MFMAs (135 before its 27 instructions became 13).
 #define SPL_NB 8
 constexpr bool spl_dense(int L) { return ((L / 8) % 4 == 1 || (L / 8) % 4 == 2) && L % 8 < 4; }
 constexpr int spl_dense_before(int L) { int c = 0; for (int l = 0; l < L; ++l) c += spl_dense(l) ? 1 : 0; return c; }
 
 #define SPL_MID_STEP 20                               // cin = 128 has at most 8 epilogue parts (dense steps 8-11, 16-19): all behind it
-template <int L, int NSL, int NDMA, bool MID, typename Epi, typename Dma>
+// SCH: the wait in front of step L's MFMAs -- how many LDS operations may still be in flight when fragment L must have landed (LDS returns in
+// order): the ring's own look-ahead, plus (FUSE1A) the LDS operations of the tile build issued since that fragment's read
+struct SplPlainSched { static constexpr int ring_wait(int L) { return (L + SPL_NB - 1 < 96) ? SPL_NB - 1 : 95 - L; } };
+template <int L, int NSL, int NDMA, bool MID, typename SCH = SplPlainSched, typename Epi, typename Dma, typename Fz>
 __device__ __forceinline__ void spl_steps(uint32_t row_base, int n_eff, int hh, const half8_t (&wreg)[72], floatx16 (&acc)[2], half8_t (&fb)[SPL_NB],
-                                          Epi&& epi, Dma&& dma) {
+                                          Epi&& epi, Dma&& dma, Fz&& fz) {
     if constexpr (L < 96) {
         constexpr int kx = L / 32, r = (L / 8) % 4, kg = L % 8, kq = kg & 3;
         constexpr bool row0 = r <= 2, row1 = r >= 1;
@@ -113,7 +123,7 @@ __device__ __forceinline__ void spl_steps(uint32_t row_base, int n_eff, int hh, 
         constexpr int D = SPL_NB - 1;
         constexpr int nd = spl_dense_before(L), nn = L - nd;
         if constexpr (L + D < 96) spl_read<L + D>(row_base, n_eff, hh, fb[(L + D) % SPL_NB]);
-        spl_wait<(L + D < 96) ? D : 95 - L>(fb[L % SPL_NB]);
+        spl_wait<SCH::ring_wait(L)>(fb[L % SPL_NB]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (row0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[t0], fb[L % SPL_NB], acc[0], 0, 0, 0);
         if constexpr (row1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[t1], fb[L % SPL_NB], acc[1], 0, 0, 0);
@@ -133,9 +143,10 @@ __device__ __forceinline__ void spl_steps(uint32_t row_base, int n_eff, int hh, 
         } else {
             if constexpr (nn < NDMA) dma(std::integral_constant<int, nn>{});
         }
+        fz(std::integral_constant<int, L>{});                                       // FUSE1A: this step's share of the next tile's build
         if constexpr (MID && L == SPL_MID_STEP) __builtin_amdgcn_s_barrier();       // cin = 128: see the K-split exchange in the kernel
         __builtin_amdgcn_sched_barrier(0);
-        spl_steps<L + 1, NSL, NDMA, MID>(row_base, n_eff, hh, wreg, acc, fb, epi, dma);
+        spl_steps<L + 1, NSL, NDMA, MID, SCH>(row_base, n_eff, hh, wreg, acc, fb, epi, dma, fz);
     }
 }
 template <int J, int N, typename F>
@@ -223,14 +234,33 @@ __device__ __forceinline__ void spl_epi_part(SplEpi<C128, POOL>& e, const float4
     } else {
         const float lo_lim = relu ? 0.f : -65000.f;
         const float4 bb = q ? b1 : b0;
-        const float y0 = fmaf(raw(std::integral_constant<int, 4 * q + 2 * h>{}), inv, h ? bb.z : bb.x);
-        const float y1 = fmaf(raw(std::integral_constant<int, 4 * q + 2 * h + 1>{}), inv, h ? bb.w : bb.y);
+        float r0, r1;
+        if constexpr (POOL) {
+            // the 2 x 2 maximum of two values in five instructions, one statement: the vertical maxima, then the neighbour lane's through a DPP operand
+            // (written as fmed3(a, b, inf) hipcc makes it a maxnum whose operands it canonicalises first -- three instructions per maximum -- and the
+            // lane exchange a v_mov 0 + s_nop + v_mov_dpp: 27 instructions per part in the round-3 kernel, next to four MFMAs that hide about sixteen).
+            // The s_nop is the second of the two wait states a DPP read needs behind the VALU write of its source (the other maximum is the first).
+            constexpr int base = C128 ? 0 : 8 * gpc, up = C128 ? 8 : 16, j0 = 4 * q + 2 * h;
+            const float a0 = val(std::integral_constant<int, base + j0>{}), c0 = val(std::integral_constant<int, up + base + j0>{});
+            const float a1 = val(std::integral_constant<int, base + j0 + 1>{}), c1 = val(std::integral_constant<int, up + base + j0 + 1>{});
+            asm("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %4, %5\n\ts_nop 0\n\t"
+                "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(c0), "v"(a1), "v"(c1));
+        } else {
+            r0 = raw(std::integral_constant<int, 4 * q + 2 * h>{}); r1 = raw(std::integral_constant<int, 4 * q + 2 * h + 1>{});
+        }
+        const float y0 = fmaf(r0, inv, h ? bb.z : bb.x);
+        const float y1 = fmaf(r1, inv, h ? bb.w : bb.y);
         const float x0 = __builtin_amdgcn_fmed3f(y0, lo_lim, 65000.f), x1 = __builtin_amdgcn_fmed3f(y1, lo_lim, 65000.f);
         float2v_t fv; fv[0] = x0; fv[1] = x1;
         const half2v_t hv = __builtin_convertvector(fv, half2v_t);
-        float2v_t rv; rv[0] = x0 - (float)hv[0]; rv[1] = x1 - (float)hv[1];
-        const half2v_t lv = __builtin_convertvector(rv, half2v_t);
-        const uint32_t dh = __builtin_bit_cast(uint32_t, hv), dl = __builtin_bit_cast(uint32_t, lv);
+        const uint32_t dh = __builtin_bit_cast(uint32_t, hv);
+        // lo = half(x - float(hi)): one v_fma_mix{lo,hi}_f16 per value (half(fma(f16 source, -1.0, f32 source)) into the low / high half of the destination;
+        // x - float(hi) is exact in f32, so the single rounding equals convert, subtract, convert -- five instructions for the pair as hipcc writes it)
+        uint32_t dl;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dl) : "v"(dh), "v"(x0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(dl) : "v"(dh), "v"(x1));
         if constexpr (q == 0) { e.qh = dh; e.ql = dl; }
         else {
             const auto rh = __builtin_amdgcn_permlane32_swap(e.qh, dh, false, false);
@@ -255,18 +285,157 @@ __device__ __forceinline__ void spl_epi_all(SplEpi<C128, POOL>& e, const float4 
     }
 }
 
+
+// ==================================================================================================================================================
+// FUSE1A (conv1b): the NEXT tile's 6 x 34-pixel x 64-channel halo is built from the u8 image inside the stream -- conv1a (swarm_loop/superpoint.ipynb:143,
+// 1 -> 64 channels, 3x3, + ReLU) on the matrix cores with split operands, the fp16 path's scheme (conv.hip, FUSE1A there) -- instead of being DMA'd from
+// a conv1a tensor in HBM (conv1a_split_kernel wrote 4.7 GB per 64 images and conv1b read it 1.6 times over through the halos).
+//   x = float(u8) * float(1/255) = xh + xl (a 256-entry table of half pairs: OpenCV's convertTo value exactly), 32 w = wh + wl, 32 bias = bh + bl:
+//   out = xh.wh + xl.wh + xh.wl + bias (the dropped xl.wl is 2^-22 relative), K = 32 = two v_mfma_f32_32x32x16_f16 per 32 pixels x 32 channels.
+// A wave builds virtual pixels [64 w, 64 w + 64) of the halo (two 32-pixel fragments; pixels >= 204 land in the unused tail of the buffer), i.e. at
+// most 3 halo rows = a 5-row x 40-byte patch of the image: one buffer_load_dword per lane at the top of the tile, parked (rows / columns outside the
+// image and the fisheye mask's rows zeroed) in a wave-private LDS slot, from which a lane reads the bytes of ITS taps (the half-waves own disjoint
+// taps: lanes 0-31 taps 0-4, lanes 32-63 taps 5-8 and the bias slots) and then their table entries, which ARE the MFMA's operand dwords.  Results:
+// ReLU, hi = half(v), lo = half(v - hi), two 8-byte LDS stores per 4 channels straight into the swizzled halo image the stream reads next tile.
+// All of it is cut into MICRO-OPS placed in the stream's steps by a compile-time schedule (FzSched) that also counts the LDS operations in flight:
+// the ring's waits grow by the build's own operations, a micro-op that consumes LDS reads waits for exactly the operations issued since.
+struct SplFuse {
+    const uint8_t* gray = nullptr; int gstride = 0, gbytes = 0, mask_r0 = 0, mask_r1 = 0;
+    const _Float16* w1a_frag = nullptr;   // conv1a_split_pack_fused: [2 k-halves][2 m][64 lanes][8 halfs]
+    const uint32_t* lut_hl = nullptr;     // [256] half(x) | half(x - half(x)) << 16 (conv1a_make_split_lut)
+};
+#define FZ_LUT_OFF (2 * SPL_BUF_BYTES)               // inside the K-split exchange region (cin = 64 does not use it): the table, 1 KiB
+#define FZ_PATCH_OFF (FZ_LUT_OFF + 1024)             // 4 waves x 256 B
+#define FZ_W1A_OFF (FZ_LUT_OFF + 2048)               // 4 A fragments x 1 KiB
+#define FZ_ZERO_OFF (FZ_LUT_OFF + 6144)              // 128 zero bytes: where the taps of a halo pixel outside the image read from
+static_assert(FZ_ZERO_OFF + 128 <= 2 * SPL_BUF_BYTES + SPL_XCH_BYTES, "FUSE1A: LDS carve");
+
+// micro-ops (f = fragment 0 / 1, k = tap slot 0-4, i = MFMA 2 j + m: k-half j, channel fragment m, u = 8 f + 4 m + g: register group g)
+constexpr int FZ_PARK = 0;      // patch dword -> LDS (masked)
+constexpr int FZ_V = 1;         // + f: is the lane's halo pixel inside the image? -> tap base address, bias slots
+constexpr int FZ_U = 3;         // + 5 f + k: ds_read_u8 of tap slot k
+constexpr int FZ_T = 13;        // + 5 f + k: table entry of that byte
+constexpr int FZ_W = 23;        // + 4 f + i: A fragment i
+constexpr int FZ_K = 31;        // + f: pack the B operands
+constexpr int FZ_M = 33;        // + 4 f + i: the MFMA
+constexpr int FZ_EA = 41;       // + u: first half of register group (2 values: ReLU, hi, lo)
+constexpr int FZ_EB = 57;       // + u: second half + the group's two LDS stores
+constexpr int FZ_NOPS = 73;
+constexpr int FZ_PER_STEP = 3;
+constexpr int fz_nlds(int id) { return id == FZ_PARK ? 1 : (id >= FZ_U && id < FZ_K) ? 1 : (id >= FZ_EB ? 2 : 0); }
+constexpr int fz_producer(int id) {      // the micro-op whose LDS-read results `id` consumes (-1: none)
+    if (id >= FZ_T && id < FZ_W) return FZ_U + (id - FZ_T);
+    if (id >= FZ_K && id < FZ_M) return FZ_T + 5 * (id - FZ_K) + 4;      // the last table read of the fragment covers the other four (LDS returns in order)
+    if (id >= FZ_M && id < FZ_EA) return FZ_W + (id - FZ_M);
+    return -1;
+}
+struct FzSched {
+    int op[96][FZ_PER_STEP];    // micro-ops of stream step L in issue order (-1: none)
+    int step[FZ_NOPS];
+    int wait[FZ_NOPS];          // lgkmcnt in front of a consuming micro-op (-1: it consumes no LDS read)
+    int ring[96];               // lgkmcnt in front of step L's MFMAs
+    bool ok;
+};
+constexpr FzSched fz_make_sched() {
+    FzSched s{};
+    s.ok = true;
+    for (int L = 0; L < 96; ++L) for (int k = 0; k < FZ_PER_STEP; ++k) s.op[L][k] = -1;
+    for (int i = 0; i < FZ_NOPS; ++i) { s.step[i] = -1; s.wait[i] = -1; }
+    auto put = [&s](int id, int L) {
+        for (int k = 0; k < FZ_PER_STEP; ++k) if (s.op[L][k] < 0) { s.op[L][k] = id; s.step[id] = L; return; }
+        s.ok = false;
+    };
+    // The previous tile's epilogue owns the dense steps 8-11 / 16-19 (its stores are the only VMEM operations behind the patch load: the park at
+    // step 20 finds them all issued).  Splitting the results into hi / lo halves -- 18 instructions per register group -- sits in the sixteen dense
+    // steps the epilogue leaves free (40-43, 48-51 for fragment 0, 72-75, 80-83 for fragment 1), one whole group per step (two independent dependency
+    // chains); the reads, table look-ups and the eight MFMAs of the build ride in the sparse steps in front of them.
+    put(FZ_PARK, 20); put(FZ_V + 0, 21);
+    { const int st[5] = {22, 22, 23, 23, 24}; for (int k = 0; k < 5; ++k) put(FZ_U + k, st[k]); }
+    { const int st[5] = {27, 28, 29, 30, 31}; for (int k = 0; k < 5; ++k) put(FZ_T + k, st[k]); }
+    for (int i = 0; i < 4; ++i) put(FZ_W + i, 32 + i);
+    put(FZ_K + 0, 36);
+    for (int i = 0; i < 4; ++i) put(FZ_M + i, 36 + i);
+    for (int u = 0; u < 8; ++u) { const int L = (u < 4 ? 40 : 44) + u; put(FZ_EA + u, L); put(FZ_EB + u, L); }
+    put(FZ_V + 1, 44);
+    { const int st[5] = {45, 45, 46, 46, 47}; for (int k = 0; k < 5; ++k) put(FZ_U + 5 + k, st[k]); }
+    { const int st[5] = {52, 53, 54, 55, 56}; for (int k = 0; k < 5; ++k) put(FZ_T + 5 + k, st[k]); }
+    for (int i = 0; i < 4; ++i) put(FZ_W + 4 + i, 57 + i);
+    put(FZ_K + 1, 64);
+    for (int i = 0; i < 4; ++i) put(FZ_M + 4 + i, 64 + i);
+    for (int u = 0; u < 8; ++u) { const int L = (u < 4 ? 72 : 76) + u; put(FZ_EA + 8 + u, L); put(FZ_EB + 8 + u, L); }
+    // LDS operations in program order: the ring's reads 0 .. SPL_NB - 2 (spl_prime), then per step the ring's read L + SPL_NB - 1, the wait for
+    // fragment L, the step's micro-ops
+    int pos = 0, ring_pos[96] = {}, start[FZ_NOPS] = {}, end[FZ_NOPS] = {};
+    for (int r = 0; r < SPL_NB - 1; ++r) ring_pos[r] = ++pos;
+    for (int L = 0; L < 96; ++L) {
+        if (L + SPL_NB - 1 < 96) ring_pos[L + SPL_NB - 1] = ++pos;
+        const int younger = pos - ring_pos[L];
+        s.ring[L] = younger < 15 ? younger : 15;
+        for (int k = 0; k < FZ_PER_STEP; ++k) {
+            const int id = s.op[L][k];
+            if (id < 0) continue;
+            start[id] = pos; pos += fz_nlds(id); end[id] = pos;
+        }
+    }
+    for (int id = 0; id < FZ_NOPS; ++id) {
+        if (s.step[id] < 0) s.ok = false;
+        const int p = fz_producer(id);
+        if (p < 0) continue;
+        if (s.step[p] < 0 || start[id] < end[p]) { s.ok = false; continue; }      // the producer must be issued first
+        const int younger = start[id] - end[p];
+        s.wait[id] = younger < 15 ? younger : 15;
+    }
+    // program order inside the chains that are NOT tied by an LDS read: V -> U, K -> M (same or later step, later slot), M -> E
+    for (int f = 0; f < 2; ++f) {
+        for (int k = 0; k < 5; ++k) if (start[FZ_U + 5 * f + k] < 0 || s.step[FZ_V + f] > s.step[FZ_U + 5 * f + k]) s.ok = false;
+        if (s.step[FZ_PARK] > s.step[FZ_U + 5 * f]) s.ok = false;
+        for (int i = 0; i < 4; ++i) if (s.step[FZ_K + f] > s.step[FZ_M + 4 * f + i]) s.ok = false;
+        for (int u = 0; u < 8; ++u) if (s.step[FZ_M + 4 * f + 3] >= s.step[FZ_EA + 8 * f + u] || s.step[FZ_EA + 8 * f + u] > s.step[FZ_EB + 8 * f + u]) s.ok = false;
+        if (s.step[FZ_M + 4 * f] > s.step[FZ_M + 4 * f + 2] || s.step[FZ_M + 4 * f + 1] > s.step[FZ_M + 4 * f + 3]) s.ok = false;
+    }
+    if (s.step[FZ_EB + 7] >= s.step[FZ_M + 4]) s.ok = false;                     // fragment 1 takes over fragment 0's accumulators
+    return s;
+}
+inline constexpr FzSched kFzSched = fz_make_sched();
+static_assert(kFzSched.ok, "FUSE1A: the build's schedule is inconsistent");
+struct SplFuseSched { static constexpr int ring_wait(int L) { return kFzSched.ring[L]; } };
+
+// conv1a's weights and bias (x SPL_ACT_SCALE: conv1b reads scaled activations) as split A fragments [j = k-half][m][lane = 32 hh + i][8 halfs] of channel
+// 32 m + i; the K slot (j, hh, e) pairs with the B dwords FZ_K packs (T0..T4 = the table entries (xh | xl << 16) of the half-wave's own taps):
+//   hh = 0 (taps 0-4):         j = 0: [T0][T1][T2][T3] x (wh, wh) per tap      j = 1: [T4] x (wh4, wh4), [xh0 xh1] x (wl0, wl1), [xh2 xh3] x (wl2, wl3), [T4] x (wl4, 0)
+//   hh = 1 (taps 5-8, T4 idle): j = 0: [T0][T1][T2][T3] x (wh, wh) of taps 5-8   j = 1: [T4] x (0, 0),     [xh5 xh6] x (wl5, wl6), [xh7 xh8] x (wl7, wl8), [1 1] x (bias_hi, bias_lo)
+void conv1a_split_pack_fused(const float* w /*[64][9]*/, const float* bias /*[64]*/, uint16_t* frag /*[2][2][64][8]*/) {
+    for (int j = 0; j < 2; ++j)
+        for (int m = 0; m < 2; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = m * 32 + (l & 31), hh = l >> 5;
+                    auto val = [&](int t) { return SPL_ACT_SCALE * w[co * 9 + t]; };
+                    auto hi = [&](float v) { return f2h_bits(v); };
+                    auto lo = [&](float v) { return f2h_bits(v - h2f(f2h_bits(v))); };
+                    const float b = SPL_ACT_SCALE * bias[co];
+                    uint16_t v = 0;
+                    if (j == 0) v = hi(val((hh ? 5 : 0) + e / 2));
+                    else if (hh == 0) v = e < 2 ? hi(val(4)) : (e < 6 ? lo(val(e - 2)) : (e == 6 ? lo(val(4)) : 0));
+                    else v = e < 2 ? 0 : (e < 6 ? lo(val(5 + e - 2)) : (e == 6 ? hi(b) : lo(b)));
+                    frag[((j * 2 + m) * 64 + l) * 8 + e] = v;
+                }
+}
+
 // TRN (cin = 128, no pooling): transposed tiles -- the 32-pixel fragments run along y, the two fragment rows along x (the LDS image, the k order
 // and every MFMA are those of the plain kernel; only the pixel <-> address maps and the tap the weights are loaded for differ).  A 60x75 layer
 // is 2 x 38 tiles instead of 3 x 30: 75-pixel rows fill 2.3 of 3 fragments, 60-pixel columns 1.9 of 2.
-template <bool C128, bool POOL, bool OUT_F32, bool TRN = false>
+template <bool C128, bool POOL, bool OUT_F32, bool TRN = false, bool FUSE1A = false, bool FZMIX = false>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const _Float16* __restrict__ wp, const float* __restrict__ bias,
                      float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, SplSkip sk,
                      int dbg /* OMNI_SPLIT_DBG (timing experiments, WRONG results): 1 = no stores, 2 = every DMA reads tile 0 */,
-                     unsigned long long* trace /* OMNI_SPLIT_TRACE=1: s_memtime stamps of workgroup 0, waves 0 and 3 (debug only), else nullptr */) {
+                     unsigned long long* trace /* OMNI_SPLIT_TRACE=1: s_memtime stamps of workgroup 0, waves 0 and 3 (debug only), else nullptr */,
+                     SplFuse fz /* FUSE1A: the u8 image the halo tiles are built from (`in` is unused) */) {
     extern __shared__ __attribute__((aligned(256))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     static_assert(!TRN || (C128 && !POOL), "transposed tiles: cin = 128 without pooling only");
+    static_assert(!FUSE1A || (!C128 && POOL && !OUT_F32), "FUSE1A: conv1b (cin = 64, pooled, split output) only");
     constexpr int TH = C128 ? 2 : 4;
     constexpr int PIXB = C128 ? 512 : 256;                  // bytes per input pixel in HBM
     constexpr int NPIECES = C128 ? 68 : 51, PPW = C128 ? 17 : 13;
@@ -292,6 +461,12 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     }
     float* const bias_lds = reinterpret_cast<float*>(smem_raw + 2 * SPL_BUF_BYTES + SPL_XCH_BYTES);
     if (tid < 64) bias_lds[tid] = bias[cg * 64 + tid];
+    if constexpr (FUSE1A) {
+        reinterpret_cast<uint32_t*>(smem_raw + FZ_LUT_OFF)[tid] = fz.lut_hl[tid];
+        reinterpret_cast<uint4*>(smem_raw + FZ_W1A_OFF)[tid] = reinterpret_cast<const uint4*>(fz.w1a_frag)[tid];
+        if (tid < 32) reinterpret_cast<uint32_t*>(smem_raw + FZ_ZERO_OFF)[tid] = 0u;
+        reinterpret_cast<uint32_t*>(smem_raw + FZ_PATCH_OFF)[tid] = 0u;
+    }
 
     // tile t = (image b, tile r of the image's tiles that run); a workgroup walks t = wg, wg + nwg, ...: (b, r) advance by a carry, (tile row,
     // tile column) come from r by multiply-high divisions (scalar: a dozen SALU instructions per tile)
@@ -387,6 +562,161 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     const int64_t ofrag = OUT_F32 ? (int64_t)g32 * 32 * 4 : (int64_t)(g32 >> 1) * 256 + (g32 & 1) * 64;
     const uint32_t oorg = (uint32_t)((OUT_F32 ? 0 : ((int64_t)Wof + 1) * opix) + ofrag);                 // the frame's origin + the wave's fragment
 
+    // ---- FUSE1A: the tile build (see FzSched) ------------------------------------------------------------------------------------------------
+    struct FzSt { uint32_t pv, u[5], pbv, xc, wb, hq, lq; half8_t wa[4], B0, B1; floatx16 a[2]; } z;
+    int fz_b = 0, fz_ty0 = 0, fz_tx0 = 0, fz_which = 0;          // the tile being built: image, origin of its outputs, halo buffer
+    [[maybe_unused]] const int fz_r0 = (64 * wave) / SPL_ITW;                         // first halo row the wave's 64 virtual pixels touch
+    // the lane's dword of the wave's 5-row x 40-byte patch: row lane / 10, bytes [4 (lane % 10), + 4) = image row ty0 + fz_pj, columns tx0 + fz_pd ..
+    [[maybe_unused]] const int fz_pj = lane / 10 + fz_r0 - 2, fz_pd = 4 * (lane % 10) - 4;
+    [[maybe_unused]] const uint32_t fz_patch = lds0 + FZ_PATCH_OFF + wave * 256;
+    [[maybe_unused]] int fz_iy[2], fz_ix[2];
+    [[maybe_unused]] uint32_t fz_pb[2];                                              // LDS address of the byte under tap (0, 0) of the lane's pixel of fragment f
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int p = 64 * wave + 32 * f + n;
+        fz_iy[f] = p / SPL_ITW; fz_ix[f] = p - fz_iy[f] * SPL_ITW;
+        int dy = fz_iy[f] - fz_r0;
+        dy = dy > 2 ? 2 : dy;                                                       // (virtual pixels >= 204 are not part of the halo: anything inside the patch)
+        fz_pb[f] = fz_patch + dy * 40 + fz_ix[f] + 2;                               // patch column 0 = image column tx0 - 4, halo column ix = tx0 - 1 + ix
+    }
+    [[maybe_unused]] const uint32_t fz_wl = lds0 + FZ_W1A_OFF + lane * 16;
+    // where the wave's results go: pixel vp = 64 wave + 32 f + n, logical 16-byte chunk c (hi halves: c = channel / 8, lo halves: 8 + channel / 8) in
+    // slot c ^ (vp & 15); a lane holds channels 4 hh + {0..3} of a group of 8: A0 ^ (c << 4) (+ 8 KiB for fragment 1)
+    [[maybe_unused]] const uint32_t fz_a0 = (uint32_t)((64 * wave + n) * 256 + ((n & 15) << 4) + 8 * hh);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(fz.gray), 0, fz.gbytes, 0x00020000);
+    // the patch load of the tile (fz_b, fz_ty0, fz_tx0): rows / columns outside the image are clamped to valid addresses here and zeroed when parked
+    auto fz_issue = [&]() {
+        int yy = fz_ty0 + fz_pj, xx = fz_tx0 + fz_pd;
+        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+        xx = xx < 0 ? 0 : (xx > fz.gstride - 4 ? fz.gstride - 4 : xx);
+        z.pv = __builtin_amdgcn_raw_buffer_load_b32(fz_rsrc, (fz_b * H + yy) * fz.gstride + xx, 0, 0);
+        z.wb = lds0 + fz_which * SPL_BUF_BYTES + fz_a0;
+    };
+    // micro-op ID; PRO: outside the stream (the workgroup's first tile): every wait is lgkmcnt(0)
+#ifndef FZ_ABL
+#define FZ_ABL 0      // timing ablations of the build (WRONG results; separate builds of the library, tools/fz_ablate.sh): 1 = results kept alive but not split /
+#endif                // stored, 2 = split but not stored, 4 = nothing of the build inside the stream, 8 = no MFMAs of the build, 16 = no reads / table look-ups
+    auto fz_op = [&](auto IDC, auto PROC) {
+        constexpr int ID = decltype(IDC)::value;
+        constexpr bool PRO = decltype(PROC)::value;
+        if constexpr (!PRO && (FZ_ABL & 4)) return;
+        if constexpr (!PRO && (FZ_ABL & 1) && ID >= FZ_EA) {
+            constexpr int uu = ID >= FZ_EB ? ID - FZ_EB : ID - FZ_EA;
+            if constexpr (ID >= FZ_EB) asm volatile("" :: "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 2]), "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 3]));
+            else asm volatile("" :: "v"(z.a[(uu % 8) / 4][4 * (uu % 4)]), "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 1]));
+            return;
+        }
+        if constexpr (!PRO && (FZ_ABL & 8) && ID >= FZ_M && ID < FZ_EA) {
+            constexpr int mi = (ID - FZ_M) % 4;
+            if constexpr (mi / 2 == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) z.a[mi % 2][q] = __builtin_bit_cast(float, z.u[q % 5]) + (float)z.wa[mi][q % 8];
+            }
+            return;
+        }
+        if constexpr (!PRO && (FZ_ABL & 16) && ID >= FZ_U && ID < FZ_K) return;
+        [[maybe_unused]] constexpr int WAITN = PRO ? 0 : (kFzSched.wait[ID] < 0 ? 0 : kFzSched.wait[ID]);
+        if constexpr (ID == FZ_PARK) {
+            const int y = fz_ty0 + fz_pj, x = fz_tx0 + fz_pd;
+            // (no short-circuit evaluation: a branch here would split the step's scheduling region)
+            const bool ok = ((unsigned)y < (unsigned)H) & ((unsigned)(y - fz.mask_r0) >= (unsigned)(fz.mask_r1 - fz.mask_r0)) & ((unsigned)x < (unsigned)W);
+            const uint32_t v = ok ? z.pv : 0u;
+            asm volatile("ds_write_b32 %0, %1" :: "v"(fz_patch + lane * 4), "v"(v) : "memory");
+        } else if constexpr (ID < FZ_U) {                                   // V(f)
+            constexpr int f = ID - FZ_V;
+            const int gy = fz_ty0 - 1 + fz_iy[f], gx = fz_tx0 - 1 + fz_ix[f];
+            const bool valid = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            z.pbv = valid ? fz_pb[f] : lds0 + FZ_ZERO_OFF;                  // a pixel outside the image is conv1b's zero padding: taps read zeros, no bias
+            z.xc = (valid & (hh != 0)) ? 0x3C003C00u : 0u;                 // the two bias slots (lanes 32-63): (1.0, 1.0)
+        } else if constexpr (ID < FZ_T) {                                   // U(f, k): the byte under the half-wave's k-th tap
+            constexpr int k = (ID - FZ_U) % 5;
+            constexpr int c0 = (k / 3) * 40 + k % 3, tp1 = k < 4 ? 5 + k : 8, c1 = (tp1 / 3) * 40 + tp1 % 3;
+            const uint32_t addr = z.pbv + (uint32_t)hh * (uint32_t)(c1 - c0);
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(z.u[k]) : "v"(addr), "i"(c0) : "memory");
+        } else if constexpr (ID < FZ_W) {                                   // T(f, k): its table entry (xh | xl << 16)
+            constexpr int k = (ID - FZ_T) % 5;
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(z.u[k]) : "i"(WAITN));
+            const uint32_t addr = lds0 + FZ_LUT_OFF + (z.u[k] << 2);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(z.u[k]) : "v"(addr) : "memory");
+        } else if constexpr (ID < FZ_K) {                                   // W(f, i)
+            constexpr int i = (ID - FZ_W) % 4;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(z.wa[i]) : "v"(fz_wl), "i"(i * 1024) : "memory");
+        } else if constexpr (ID < FZ_M) {                                   // K(f)
+            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(z.u[0]), "+v"(z.u[1]), "+v"(z.u[2]), "+v"(z.u[3]), "+v"(z.u[4]) : "i"(WAITN));
+            const uint32_t h01 = __builtin_amdgcn_perm(z.u[1], z.u[0], 0x05040100u), h23 = __builtin_amdgcn_perm(z.u[3], z.u[2], 0x05040100u);
+            const uint32_t x = hh ? z.xc : z.u[4];
+            z.B0 = __builtin_bit_cast(half8_t, make_uint4(z.u[0], z.u[1], z.u[2], z.u[3]));
+            z.B1 = __builtin_bit_cast(half8_t, make_uint4(z.u[4], h01, h23, x));
+        } else if constexpr (ID < FZ_EA) {                                  // M(f, i)
+            constexpr int i = (ID - FZ_M) % 4, j = i / 2, m = i % 2;
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(z.wa[i]) : "i"(WAITN));
+            if constexpr (j == 0) {
+                floatx16 zero;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) zero[q] = 0.f;
+                z.a[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(z.wa[i], z.B0, zero, 0, 0, 0);
+            } else {
+                z.a[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(z.wa[i], z.B1, z.a[m], 0, 0, 0);
+            }
+        } else {                                                            // EA(u) / EB(u): two values of register group g of channel fragment m
+            constexpr bool second = ID >= FZ_EB;
+            constexpr int u = second ? ID - FZ_EB : ID - FZ_EA, f = u / 8, m = (u % 8) / 4, g = u % 4;
+            const float x0 = __builtin_amdgcn_fmed3f(z.a[m][4 * g + (second ? 2 : 0)], 0.f, 65000.f);
+            const float x1 = __builtin_amdgcn_fmed3f(z.a[m][4 * g + (second ? 3 : 1)], 0.f, 65000.f);
+            float2v_t fv; fv[0] = x0; fv[1] = x1;
+            const half2v_t hv = __builtin_convertvector(fv, half2v_t);
+            const uint32_t dh = __builtin_bit_cast(uint32_t, hv);
+            uint32_t dl;
+            if constexpr (FZMIX) {
+                // lo = half(x - float(hi)) in one instruction per value: v_fma_mix{lo,hi}_f16 = half(fma(f16 source, -1.0, f32 source)) into the low / high
+                // half of the destination (x - float(hi) is exact in f32, so the single rounding is the same as convert, subtract, convert)
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dl) : "v"(dh), "v"(x0));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(dl) : "v"(dh), "v"(x1));
+            } else {
+                float2v_t rv; rv[0] = x0 - (float)hv[0]; rv[1] = x1 - (float)hv[1];
+                dl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rv, half2v_t));
+            }
+            if constexpr (!second) { z.hq = dh; z.lq = dl; }
+            else {
+                const uint32_t ah = z.wb ^ (uint32_t)((m * 4 + g) << 4), al = z.wb ^ (uint32_t)((8 + m * 4 + g) << 4);
+                const uint2 vh = make_uint2(z.hq, dh), vl = make_uint2(z.lq, dl);
+                if constexpr (!PRO && (FZ_ABL & 2)) { asm volatile("" :: "v"(ah), "v"(vh), "v"(al), "v"(vl)); }
+                else {
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(ah), "v"(vh), "i"(f * 8192) : "memory");
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(al), "v"(vl), "i"(f * 8192) : "memory");
+                }
+            }
+        }
+    };
+    // the micro-ops of stream step L
+#ifdef SPL_STEP_TRACE      // separate build (tools/fz_ablate.sh trace): s_memtime at the end of positions 7, 15, 19, 23, 31, 63 (the values are read after the stream)
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    auto fz_step = [&](auto LC) {
+#ifdef SPL_STEP_TRACE
+        {
+            constexpr int P = decltype(LC)::value;
+            constexpr int k = P == 7 ? 0 : P == 15 ? 1 : P == 19 ? 2 : P == 23 ? 3 : P == 31 ? 4 : P == 63 ? 5 : -1;
+            if constexpr (k >= 0) asm volatile("s_memtime %0" : "=s"(ts[k]));
+        }
+#endif
+        if constexpr (FUSE1A) {
+            constexpr int L = decltype(LC)::value;
+            spl_for_each<0, FZ_PER_STEP>([&](auto KC) {
+                constexpr int id = kFzSched.op[L][decltype(KC)::value];
+                if constexpr (id >= 0) fz_op(std::integral_constant<int, id>{}, std::false_type{});
+            });
+            if constexpr (kFzSched.op[L][0] >= FZ_EA && spl_dense(L)) {
+                // a register group in a dense step: one MFMA, then four of its instructions in that MFMA's shadow (4 v_accvgpr_read, 4 v_med3, 2 v_cvt_pk +
+                // 2 v_xor; the v_fma_mix pairs and the two stores are inline asm, which the scheduler leaves behind their operands: the fourth shadow)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        }
+    };
+
     int t = wg;
     SplTileIx cur_ix, nxt_ix;
     {
@@ -396,17 +726,46 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         nxt_ix = cur_ix;
         advance(nxt_ix);
     }
-    if (t < total) {
-        const SplOrg o = origin(cur_ix.b, cur_ix.ty, cur_ix.tx);
-        spl_for_each<0, PPW>([&](auto JC) { dma_piece(o, 0, JC); });
+    if constexpr (FUSE1A) {
+        __syncthreads();                                   // the table, conv1a's fragments, the zeros
+        if (t < total) {                                   // the workgroup's first tile, outside any stream: every micro-op in order, every wait lgkmcnt(0)
+            fz_b = cur_ix.b; fz_ty0 = cur_ix.ty * TH; fz_tx0 = cur_ix.tx * 32; fz_which = 0;
+            fz_issue();
+            spl_for_each<0, FZ_NOPS>([&](auto IC) {
+                constexpr int pos = decltype(IC)::value;
+                // program order of the chains: per fragment PARK, V, U x 5, T x 5, W x 4, K, M x 4, (EA, EB) x 8
+                constexpr int f = pos < 37 ? 0 : 1, q = pos < 37 ? pos : pos - 36;      // fragment 0: positions 0-36 (with PARK), fragment 1: 37-72
+                constexpr int id = pos == 0 ? FZ_PARK :
+                                   q == 1 ? FZ_V + f :
+                                   q < 7 ? FZ_U + 5 * f + (q - 2) :
+                                   q < 12 ? FZ_T + 5 * f + (q - 7) :
+                                   q < 16 ? FZ_W + 4 * f + (q - 12) :
+                                   q == 16 ? FZ_K + f :
+                                   q < 21 ? FZ_M + 4 * f + (q - 17) :
+                                   ((q - 21) % 2 == 0 ? FZ_EA + 8 * f + (q - 21) / 2 : FZ_EB + 8 * f + (q - 21) / 2);
+                fz_op(std::integral_constant<int, id>{}, std::true_type{});
+                if constexpr (id < FZ_EA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+        if (t < total) {
+            const SplOrg o = origin(cur_ix.b, cur_ix.ty, cur_ix.tx);
+            spl_for_each<0, PPW>([&](auto JC) { dma_piece(o, 0, JC); });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // the wave's biases: cin = 64: the four register groups of its 32 channels; cin = 128: the two groups it finishes
     float4 bs[C128 ? 2 : 4];
 #pragma unroll
     for (int g = 0; g < (C128 ? 2 : 4); ++g) bs[g] = *reinterpret_cast<const float4*>(bias_lds + co * 32 + (C128 ? 16 * part : 0) + 8 * g + 4 * hh);
+    // the biases have landed before the first stream starts -- and hipcc must know it: behind the loop's back edge it otherwise puts an s_waitcnt lgkmcnt(2..3)
+    // for these reads in front of the first two epilogue parts of EVERY tile, which drains the fragment ring there (seven reads in flight -> three)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < (C128 ? 2 : 4); ++g) asm volatile("" : "+v"(bs[g].x), "+v"(bs[g].y), "+v"(bs[g].z), "+v"(bs[g].w));
 
     using Epi = SplEpi<C128, POOL>;
     Epi e;
@@ -443,6 +802,11 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         // the next tile's DMA (the last tile of this workgroup loads its own tile again: no branch in the stream; nobody reads that buffer)
         const bool has_next = t + nwg < total;                          // (field by field: a select between the two structs sends them to scratch)
         const SplOrg org_n = (dbg & 2) ? origin(0, 0, 0) : origin(has_next ? nxt_ix.b : cur_ix.b, has_next ? nxt_ix.ty : cur_ix.ty, has_next ? nxt_ix.tx : cur_ix.tx);
+        if constexpr (FUSE1A) {                                          // the next tile's patch load flies under the first fifth of the stream
+            fz_b = has_next ? nxt_ix.b : cur_ix.b; fz_ty0 = (has_next ? nxt_ix.ty : cur_ix.ty) * TH; fz_tx0 = (has_next ? nxt_ix.tx : cur_ix.tx) * 32;
+            fz_which = cur ^ 1;
+            fz_issue();
+        }
         const uint32_t row_base = lds0 + cur * SPL_BUF_BYTES + n_eff * 256;
         floatx16 acc[2];
 #pragma unroll
@@ -453,10 +817,18 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         spl_prime(row_base, n_eff, hh, fb);
         stamp(1);
         __builtin_amdgcn_sched_barrier(0);
-        spl_steps<0, Epi::NPK * spl_parts_per_pair<OUT_F32>(), PPW, C128>(row_base, n_eff, hh, wreg, acc, fb,
+        spl_steps<0, Epi::NPK * spl_parts_per_pair<OUT_F32>(), FUSE1A ? 0 : PPW, C128, std::conditional_t<FUSE1A, SplFuseSched, SplPlainSched>>(
+            row_base, n_eff, hh, wreg, acc, fb,
             [&](auto SC) { spl_epi_part<decltype(SC)::value, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part); },
-            [&](auto JC) { dma_piece(org_n, cur ^ 1, JC); });
+            [&](auto JC) { dma_piece(org_n, cur ^ 1, JC); }, fz_step);
         stamp(2);
+#ifdef SPL_STEP_TRACE
+        if (tr && tk >= 0 && tk < 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 6; ++k) trace[64 + (tid ? 32 : 0) + tk * 8 + k] = ts[k];
+        }
+#endif
 
         // this tile's raw values and addresses become the pending epilogue
         const int b = cur_ix.b, ty0 = cur_ix.ty * (TRN ? 32 : TH), tx0 = cur_ix.tx * (TRN ? TH : 32);
@@ -524,15 +896,15 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     spl_epi_all<0, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part);       // the last tile's
 }
 
-template <bool C128, bool POOL, bool OUT_F32, bool TRN = false>
-static int launch_split(hipStream_t st, const ConvArgs& a) {
+template <bool C128, bool POOL, bool OUT_F32, bool TRN = false, bool FUSE1A = false, bool FZMIX = false>
+static int launch_split(hipStream_t st, const ConvArgs& a, const SplFuse& fz = SplFuse{}) {
     if constexpr (C128 && !POOL && !TRN) {
         // the tile orientation with fewer tiles (OMNI_SPLIT_TRN=0/1 forces one: A/B hook; it fixes the order the taps are summed in)
         static const int force = [] { const char* e = getenv("OMNI_SPLIT_TRN"); return e ? atoi(e) : -1; }();
         const int plain = cdiv(a.W, 32) * cdiv(a.H, 2), trn = cdiv(a.H, 32) * cdiv(a.W, 2);
         if (force == 1 || (force < 0 && trn < plain)) return launch_split<C128, POOL, OUT_F32, true>(st, a);
     }
-    auto kfn = conv3x3_split_kernel<C128, POOL, OUT_F32, TRN>;
+    auto kfn = conv3x3_split_kernel<C128, POOL, OUT_F32, TRN, FUSE1A, FZMIX>;
     static DynSmemState smem_state;
     OMNI_HIP_TRY(ensure_dyn_smem(smem_state, (const void*)kfn, SPL_SMEM));
     constexpr int TH = C128 ? 2 : 4;
@@ -558,15 +930,15 @@ static int launch_split(hipStream_t st, const ConvArgs& a) {
     static const int dbg = [] { const char* e = getenv("OMNI_SPLIT_DBG"); return e ? atoi(e) : 0; }();
     static unsigned long long* trace_dev = nullptr;
     if (want_trace) {
-        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
-        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * 8, st));
+        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 128 * 8));
+        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 128 * 8, st));
     }
     hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), SPL_SMEM, st, reinterpret_cast<const char*>(a.in), a.out,
                        reinterpret_cast<const _Float16*>(a.w_packed), a.bias, inv, a.H, a.W, a.cout, n_cg, tiles_x, tiles_y, a.batch, a.relu ? 1 : 0,
-                       sk, dbg, want_trace ? trace_dev : nullptr);
+                       sk, dbg, want_trace ? trace_dev : nullptr, fz);
     OMNI_LAUNCH_CHECK();
     if (want_trace) {
-        unsigned long long h[64];
+        unsigned long long h[128];
         OMNI_HIP_TRY(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, st));
         OMNI_HIP_TRY(hipStreamSynchronize(st));
         static int launches = 0;
@@ -574,8 +946,15 @@ static int launch_split(hipStream_t st, const ConvArgs& a) {
             for (int w = 0; w < 2; ++w)
                 for (int k = 0; k < 4; ++k) {
                     const unsigned long long* q = h + w * 32 + k * 8;
-                    fprintf(stderr, "split trace c128=%d pool=%d f32=%d trn=%d H=%d W=%d cout=%d wave %d tile %d: origin+prime %llu stream %llu hand-over %llu vmcnt %llu barrier %llu | total %llu\n",
-                            (int)C128, (int)POOL, (int)OUT_F32, (int)TRN, a.H, a.W, a.cout, w * 3, k + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3],
+#ifdef SPL_STEP_TRACE
+                    {
+                        const unsigned long long* u = h + 64 + w * 32 + k * 8;
+                        fprintf(stderr, "split step trace c128=%d pool=%d f32=%d fuse1a=%d wave %d tile %d: positions 0-7 %llu | 8-15 %llu | 16-19 %llu | 20-23 %llu | 24-31 %llu | 32-63 %llu | 64-95 %llu\n",
+                                (int)C128, (int)POOL, (int)OUT_F32, (int)FUSE1A, w * 3, k + 2, u[0] - q[1], u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3], u[5] - u[4], q[2] - u[5]);
+                    }
+#endif
+                    fprintf(stderr, "split trace c128=%d pool=%d f32=%d trn=%d fuse1a=%d H=%d W=%d cout=%d wave %d tile %d: origin+prime %llu stream %llu hand-over %llu vmcnt %llu barrier %llu | total %llu\n",
+                            (int)C128, (int)POOL, (int)OUT_F32, (int)TRN, (int)FUSE1A, a.H, a.W, a.cout, w * 3, k + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3],
                             q[5] - q[4], q[5] - q[0]);
                 }
     }
@@ -601,6 +980,22 @@ int conv_split(hipStream_t st, const ConvArgs& a) {
 }
 
 float conv_split_act_scale() { return SPL_ACT_SCALE; }
+
+// conv1a (from the u8 image, built tile by tile inside the kernel) + conv1b + ReLU + 2x2 max-pool in one launch; a = the conv1b layer (a.in unused)
+int conv1ab_split_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const void* w1a_frag, const uint32_t* lut_hl) {
+    OMNI_REQUIRE(a.ksize == 3 && a.cin == 64 && a.cout % 64 == 0 && a.pool && !a.out_f32 && a.H % 2 == 0 && a.W % 8 == 0, OMNI_ERR_INVALID, "conv1ab_split_fused: bad layer shape");
+    OMNI_REQUIRE(a.n_cu > 0 && a.split_inv > 0.f, OMNI_ERR_INVALID, "conv1ab_split_fused: n_cu / split_inv not set");
+    OMNI_REQUIRE(gstride % 4 == 0 && gstride >= a.W && ((uintptr_t)gray & 3) == 0 && (int64_t)a.batch * a.H * gstride < (1ll << 31), OMNI_ERR_INVALID,
+                 "conv1ab_split_fused: image rows must be 4-byte aligned (stride %d)", gstride);
+    OMNI_REQUIRE((int64_t)split_frame_h(a.H / 2) * split_frame_w(a.W / 2) * a.cout * 4 < (1ll << 31), OMNI_ERR_INVALID, "conv1ab_split_fused: image too large for 32-bit pixel offsets");
+    SplFuse fz;
+    fz.gray = gray; fz.gstride = gstride; fz.gbytes = a.batch * a.H * gstride;
+    omni_fisheye_mask_rows(a.H, fisheye_mask, &fz.mask_r0, &fz.mask_r1);   // cv::Rect(0, rows*3/4, cols, rows/4)
+    fz.w1a_frag = reinterpret_cast<const _Float16*>(w1a_frag); fz.lut_hl = lut_hl;
+    // OMNI_SPLIT_FZ_MIX=0: the build's hi / lo split without v_fma_mix (convert back, subtract, convert): same values, A/B hook
+    static const bool mix = [] { const char* e = getenv("OMNI_SPLIT_FZ_MIX"); return !(e && e[0] == '0'); }();
+    return mix ? launch_split<false, true, false, false, true, true>(st, a, fz) : launch_split<false, true, false, false, true, false>(st, a, fz);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv1a (1 -> 64 channels, 3x3, ReLU) from the u8 image, exact fp32 FMAs, written as split-64 activations x SPL_ACT_SCALE

@@ -116,6 +116,15 @@ struct omni_shard {
 
 extern "C" {
 
+int omni_shard_library_path(char* out, int cap) {
+    OMNI_REQUIRE(out && cap > 1, OMNI_ERR_INVALID, "bad argument");
+    OMNI_REQUIRE(rccl().ok, OMNI_ERR_HIP, "RCCL (librccl.so.1) could not be loaded: %s", rccl().err.c_str());
+    Dl_info info;
+    const char* name = (dladdr(reinterpret_cast<const void*>(rccl().AllGather), &info) && info.dli_fname) ? info.dli_fname : "?";
+    snprintf(out, (size_t)cap, "%s", name);
+    return OMNI_OK;
+}
+
 int omni_shard_unique_id(char* id_out) {
     OMNI_REQUIRE(id_out, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(rccl().ok, OMNI_ERR_HIP, "RCCL (librccl.so.1) could not be loaded: %s", rccl().err.c_str());

@@ -6,6 +6,9 @@
 //   a1a [B][H][W][64]   a1b [B][H/2][W/2][64]   a2a  a2b [B][H/4][W/4][64]   a3a [..][128]  a3b [B][H/8][W/8][128]
 //   a4a a4b [..][128]   heads [B][Hc][Wc][512] (cPa | cDa, one fused N=512 conv)   draw [B][Hc][Wc][256] fp32
 //   semi [B][H][W] fp32
+#include <algorithm>
+#include <vector>
+
 #include "conv.h"
 #include "sp_post.h"
 
@@ -54,6 +57,8 @@ struct omni_sp {
     uint16_t* w1a_frag = nullptr;            // conv1a split-fp16 A fragments (fused conv1a+conv1b, fp16 path)
     uint32_t* lut_hl = nullptr;              // u8 -> (half hi, half lo) table
     bool fuse1a = false;
+    bool split_fuse1a = false;               // OMNI_PREC_SPLIT: conv1a is built inside conv1b's kernel (OMNI_SPLIT_FUSE1A=0: the separate conv1a_split pass)
+    bool mask_skip_cal_fused = false;        // ... and which of the two the mask's constant region was calibrated with
     float* pca_compT = nullptr;
     float* pca_mean = nullptr;
     // activations
@@ -81,6 +86,7 @@ struct omni_sp {
         int64_t row_bytes = 0, img_bytes = 0, org_bytes = 0;
         void* vec = nullptr;                         // [pix_bytes]: the constant
         void** map = nullptr;                        // the activation buffer
+        double frac = 0.0;                           // the rectangle's share of the layer's tiles (omni_sp_stage_tiles_left_out)
     };
     MaskSkip mskip[5];                       // conv1a (OMNI_PREC_SPLIT only: fused away on the fp16 path), conv1b (+pool), conv2a, conv2b (+pool), conv3a
     bool mask_skip = false, mask_skip_ready = false, mask_skip_calibrating = false;
@@ -98,20 +104,53 @@ static int dev_upload(void** dst, const void* src, size_t bytes, hipStream_t st)
     return OMNI_OK;
 }
 
-// Where every layer's output is constant under the fisheye mask, and the tile rectangle inside it (see omni_sp::MaskSkip)
+// Where every layer's output is constant under the fisheye mask, and the tile rectangle inside it (see omni_sp::MaskSkip): pure integer arithmetic
+// on (H, W) and the kernels' tile shapes; k[0] = conv1a (OMNI_PREC_SPLIT only), k[1..4] = conv1b, conv2a, conv2b, conv3a
+static void sp_mask_skip_rects(int H, int W, bool split, omni_sp::MaskSkip (&ks)[5]) {
+    int m0, m1;
+    omni_fisheye_mask_rows(H, 1, &m0, &m1);
+    int h = H, w = W;
+    for (auto& k : ks) k = omni_sp::MaskSkip{};
+    // conv1a's output is relu(bias) on the rows whose three input rows are blanked (the zero padding below the image counts as blanked), in
+    // every column (the padding left and right of the image is zeros too)
+    int a = m0 + 1, b = (m1 == h) ? h - 1 : m1 - 2, c = 0, d = w - 1;
+    if (split && b >= a) {                                 // conv1a_split: 8-row tile rows, the whole width
+        omni_sp::MaskSkip& k = ks[0];
+        k.ty0 = (a + 7) / 8; k.ty1 = (b + 1) / 8; k.tx0 = 0; k.tx1 = (w + 31) / 32;
+        if (k.ty1 <= k.ty0) k.ty0 = k.ty1 = k.tx0 = k.tx1 = 0;
+        k.oy0 = k.ty0 * 8; k.oy1 = k.ty1 * 8 < h ? k.ty1 * 8 : h; k.ox0 = 0; k.ox1 = k.ty1 > k.ty0 ? w : 0;
+        k.oh = h; k.ow = w; k.oc = 64;
+        k.frac = (double)(k.ty1 - k.ty0) / ((h + 7) / 8);
+    }
+    const bool pool[4] = {true, false, true, false};
+    const int chans[4] = {64, 64, 64, 128};
+    const int TH = split ? 4 : CONV_TH, TW = 32;           // the cin = 64 kernels' output tiles (conv_split.hip: 4 x 32, conv.hip: CONV_TH x CONV_TW)
+    static_assert(CONV_TW == 32, "tile width");
+    for (int i = 0; i < 4; ++i) {
+        a += 1; b -= 1; c += 1; d -= 1;                    // a 3x3 convolution (zero padding is NOT the constant): one pixel in from every side
+        omni_sp::MaskSkip& k = ks[1 + i];
+        if (b < a || d < c) break;                         // nothing constant from here on
+        k.ty0 = (a + TH - 1) / TH; k.ty1 = (b + 1) / TH; k.tx0 = (c + TW - 1) / TW; k.tx1 = (d + 1) / TW;
+        if (k.ty1 <= k.ty0 || k.tx1 <= k.tx0) k.ty0 = k.ty1 = k.tx0 = k.tx1 = 0;
+        k.frac = (double)(k.ty1 - k.ty0) * (k.tx1 - k.tx0) / ((double)((h + TH - 1) / TH) * ((w + TW - 1) / TW));
+        const int f = pool[i] ? 2 : 1;
+        k.oy0 = k.ty0 * TH / f; k.oy1 = k.ty1 * TH / f; k.ox0 = k.tx0 * TW / f; k.ox1 = k.tx1 * TW / f;
+        if (pool[i]) { a = (a + 1) / 2; b = (b - 1) >> 1; c = (c + 1) / 2; d = (d - 1) >> 1; h /= 2; w /= 2; }      // pooled pixel r = conv pixels 2r, 2r + 1
+        k.oh = h; k.ow = w; k.oc = chans[i];
+    }
+}
+
 static int sp_plan_mask_skip(omni_sp* s) {
     s->mask_skip = false;
     const bool split = s->precision == OMNI_PREC_SPLIT;
     if (s->conv_variant != 0 || s->precision == OMNI_PREC_F32) return OMNI_OK;
-    if (split) { const char* e = getenv("OMNI_SP_MASK_SKIP_SPLIT"); if (!(e && e[0] == '1')) return OMNI_OK; }      // (not yet validated on hardware: off unless asked for)
-    else { const char* e = getenv("OMNI_SP_MASK_SKIP"); if (e && e[0] == '0') return OMNI_OK; }                     // OMNI_SP_MASK_SKIP=0: the dense pass (A/B, tests)
-    int m0, m1;
-    omni_fisheye_mask_rows(s->H, 1, &m0, &m1);
-    int h = s->H, w = s->W;
-    // conv1a's output is relu(bias) on the rows whose three input rows are blanked (the zero padding below the image counts as blanked), in
-    // every column (the padding left and right of the image is zeros too)
-    int a = m0 + 1, b = (m1 == h) ? h - 1 : m1 - 2, c = 0, d = w - 1;
-    auto layout = [&](omni_sp::MaskSkip& k) -> int {
+    { const char* e = getenv(split ? "OMNI_SP_MASK_SKIP_SPLIT" : "OMNI_SP_MASK_SKIP"); if (e && e[0] == '0') return OMNI_OK; }      // = 0: the dense pass (A/B, tests)
+    sp_mask_skip_rects(s->H, s->W, split, s->mskip);
+    void** maps[5] = {&s->a1a, &s->a1b, &s->a2a, &s->a2b, &s->a3a};
+    for (int i = 0; i < 5; ++i) {
+        omni_sp::MaskSkip& k = s->mskip[i];
+        k.map = maps[i];
+        if (k.oc == 0) continue;
         if (split) {
             k.pix_bytes = k.oc * 4;
             k.row_bytes = (int64_t)split_frame_w(k.ow) * k.pix_bytes;
@@ -124,34 +163,6 @@ static int sp_plan_mask_skip(omni_sp* s) {
             OMNI_HIP_TRY(hipMalloc(&k.vec, (size_t)k.pix_bytes));
             s->mask_skip = true;
         }
-        return OMNI_OK;
-    };
-    int rc;
-    for (auto& k : s->mskip) k = omni_sp::MaskSkip{};
-    if (split && b >= a) {                                 // conv1a_split: 8-row tile rows, the whole width
-        omni_sp::MaskSkip& k = s->mskip[0];
-        k.ty0 = (a + 7) / 8; k.ty1 = (b + 1) / 8; k.tx0 = 0; k.tx1 = (w + 31) / 32;
-        if (k.ty1 <= k.ty0) k.ty0 = k.ty1 = k.tx0 = k.tx1 = 0;
-        k.oy0 = k.ty0 * 8; k.oy1 = k.ty1 * 8 < h ? k.ty1 * 8 : h; k.ox0 = 0; k.ox1 = k.ty1 > k.ty0 ? w : 0;
-        k.oh = h; k.ow = w; k.oc = 64; k.map = &s->a1a;
-        if ((rc = layout(k))) return rc;
-    }
-    void** maps[4] = {&s->a1b, &s->a2a, &s->a2b, &s->a3a};
-    const bool pool[4] = {true, false, true, false};
-    const int chans[4] = {64, 64, 64, 128};
-    const int TH = split ? 4 : CONV_TH, TW = 32;           // the cin = 64 kernels' output tiles (conv_split.hip: 4 x 32, conv.hip: CONV_TH x CONV_TW)
-    static_assert(CONV_TW == 32, "tile width");
-    for (int i = 0; i < 4; ++i) {
-        a += 1; b -= 1; c += 1; d -= 1;                    // a 3x3 convolution (zero padding is NOT the constant): one pixel in from every side
-        omni_sp::MaskSkip& k = s->mskip[1 + i];
-        if (b < a || d < c) break;                         // nothing constant from here on
-        k.ty0 = (a + TH - 1) / TH; k.ty1 = (b + 1) / TH; k.tx0 = (c + TW - 1) / TW; k.tx1 = (d + 1) / TW;
-        if (k.ty1 <= k.ty0 || k.tx1 <= k.tx0) k.ty0 = k.ty1 = k.tx0 = k.tx1 = 0;
-        const int f = pool[i] ? 2 : 1;
-        k.oy0 = k.ty0 * TH / f; k.oy1 = k.ty1 * TH / f; k.ox0 = k.tx0 * TW / f; k.ox1 = k.tx1 * TW / f;
-        if (pool[i]) { a = (a + 1) / 2; b = (b - 1) >> 1; c = (c + 1) / 2; d = (d - 1) >> 1; h /= 2; w /= 2; }      // pooled pixel r = conv pixels 2r, 2r + 1
-        k.oh = h; k.ow = w; k.oc = chans[i]; k.map = maps[i];
-        if ((rc = layout(k))) return rc;
     }
     return OMNI_OK;
 }
@@ -198,6 +209,16 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         std::vector<uint16_t> db(65536);
         convdb_pack_weights(w->weight[LDB], db.data());
         if ((rc = dev_upload(&s->wDbFrag, db.data(), db.size() * 2, st))) return rc;
+    }
+    if (s->precision == OMNI_PREC_SPLIT) {     // conv1a inside conv1b's kernel (conv1ab_split_fused): its weights x the activation scale, the u8 table
+        std::vector<uint16_t> fr(2048);
+        conv1a_split_pack_fused(w->weight[L1A], w->bias[L1A], fr.data());
+        if ((rc = dev_upload((void**)&s->w1a_frag, fr.data(), fr.size() * 2, st))) return rc;
+        uint32_t lh[256];
+        conv1a_make_split_lut(lh);
+        if ((rc = dev_upload((void**)&s->lut_hl, lh, sizeof(lh), st))) return rc;
+        const char* e = getenv("OMNI_SPLIT_FUSE1A");
+        s->split_fuse1a = !(e && e[0] == '0');
     }
     if (s->precision == OMNI_PREC_F16) {
         std::vector<uint16_t> fr(2048);
@@ -320,8 +341,9 @@ static int sp_calibrate_mask_skip(omni_sp* s, int stride) {
     int rc = sp_forward(s, s->zero_gray, stride, 1, 1, false, false);
     s->mask_skip_calibrating = false;
     if (rc) return rc;
+    s->mask_skip_cal_fused = s->fuse1a;
     for (const omni_sp::MaskSkip& k : s->mskip) {
-        if (k.ty1 <= k.ty0) continue;
+        if (k.ty1 <= k.ty0 || (k.map == &s->a1a && s->fuse1a)) continue;
         if ((rc = conv_read_pixel_bytes(st, *k.map, k.row_bytes, k.org_bytes, k.pix_bytes, (k.oy0 + k.oy1) / 2, (k.ox0 + k.ox1) / 2, k.vec))) return rc;
         if ((rc = conv_fill_rect_bytes(st, *k.map, s->max_batch, k.img_bytes, k.row_bytes, k.org_bytes, k.pix_bytes, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
     }
@@ -343,10 +365,12 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const int H = s->H, W = s->W, P = s->precision;
     int rc, stage = 0;
     if ((rc = s->ctx->ensure_zero_page())) return rc;
-    const bool fuse1a = (P == OMNI_PREC_F16 && s->conv_variant == 0 && stride % 4 == 0 && ((uintptr_t)gray_dev & 3) == 0);   // else: separate conv1a
+    const bool aligned4 = stride % 4 == 0 && ((uintptr_t)gray_dev & 3) == 0;
+    const bool fuse1a = ((P == OMNI_PREC_F16 && s->conv_variant == 0) || (P == OMNI_PREC_SPLIT && s->split_fuse1a)) && aligned4;   // else: separate conv1a
     // the constant region of the fisheye mask (omni_sp::MaskSkip): only on the production path (conv1a fused into conv1b)
     const bool use_skip = s->mask_skip && fisheye_mask && (fuse1a || P == OMNI_PREC_SPLIT) && !s->mask_skip_calibrating;
     if (!use_skip && !s->mask_skip_calibrating) s->mask_skip_ready = false;          // this pass overwrites the filled rectangles
+    if (use_skip && s->mask_skip_ready && s->mask_skip_cal_fused != fuse1a) s->mask_skip_ready = false;      // (conv1a's own rectangle is only filled by an unfused calibration)
     if (use_skip && !s->mask_skip_ready && (rc = sp_calibrate_mask_skip(s, stride))) return rc;
     auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
     auto skip_of = [&](int l, ConvArgs& a) {
@@ -370,7 +394,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const int PH = P == OMNI_PREC_SPLIT ? OMNI_PREC_F32 : P;      // the heads' tails: OMNI_PREC_SPLIT hands them fp32 activations
     if ((rc = mark())) return rc;
     s->fuse1a = fuse1a;
-    if (P == OMNI_PREC_SPLIT) { if ((rc = conv1a_split(st, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a, use_skip ? s->mskip[0].ty0 : 0, use_skip ? s->mskip[0].ty1 : 0))) return rc; }
+    if (P == OMNI_PREC_SPLIT && !fuse1a) { if ((rc = conv1a_split(st, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a, use_skip ? s->mskip[0].ty0 : 0, use_skip ? s->mskip[0].ty1 : 0))) return rc; }
     else if (!s->fuse1a) { if ((rc = conv1a_direct(st, P, gray_dev, stride, batch, H, W, fisheye_mask, s->w1a, s->bias[L1A], s->lut, s->a1a))) return rc; }
     if ((rc = mark())) return rc;
     if (s->fuse1a) {   // conv1a is computed inside conv1b's kernel: the conv1a activation tensor is never materialised
@@ -378,7 +402,10 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         a.in = nullptr; a.out = s->a1b; a.w_packed = s->wpk[L1B]; a.bias = s->bias[L1B]; a.batch = batch; a.H = H; a.W = W; a.cin = 64;
         a.cout = 64; a.ksize = 3; a.relu = true; a.pool = true; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page;
         skip_of(L1B, a);
-        if ((rc = conv1ab_fused(st, a, gray_dev, stride, fisheye_mask, reinterpret_cast<const _Float16*>(s->w1a_frag), s->bias[L1A], s->lut_hl))) return rc;
+        if (P == OMNI_PREC_SPLIT) {
+            a.split_inv = s->winv[L1B]; a.bias = s->bias_s[L1B];
+            if ((rc = conv1ab_split_fused(st, a, gray_dev, stride, fisheye_mask, s->w1a_frag, s->lut_hl))) return rc;
+        } else if ((rc = conv1ab_fused(st, a, gray_dev, stride, fisheye_mask, reinterpret_cast<const _Float16*>(s->w1a_frag), s->bias[L1A], s->lut_hl))) return rc;
     } else if ((rc = conv(L1B, s->a1a, s->a1b, s->bias[L1B], H, W, 64, 64, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;
     if ((rc = conv(L2A, s->a1b, s->a2a, s->bias[L2A], H / 2, W / 2, 64, 64, 3, true, false, false))) return rc;
@@ -691,6 +718,21 @@ double omni_sp_stage_flops(const omni_sp* s, int stage) {
     }
 }
 
+int omni_sp_mask_skip_plan(int width, int height, int precision, int layer, int* rect, double* frac) {
+    OMNI_REQUIRE(width > 0 && height > 0 && layer >= 0 && layer < 5, OMNI_ERR_INVALID, "bad argument");
+    omni_sp::MaskSkip ks[5];
+    if (precision != OMNI_PREC_F32) omni::sp_mask_skip_rects(height, width, precision == OMNI_PREC_SPLIT, ks);
+    if (rect) { rect[0] = ks[layer].ty0; rect[1] = ks[layer].ty1; rect[2] = ks[layer].tx0; rect[3] = ks[layer].tx1; }
+    if (frac) *frac = ks[layer].ty1 > ks[layer].ty0 ? ks[layer].frac : 0.0;
+    return OMNI_OK;
+}
+
+double omni_sp_stage_tiles_left_out(const omni_sp* s, int stage) {
+    if (!s || !s->mask_skip) return 0.0;
+    const int i = stage == ST_CONV1A ? 0 : stage == ST_CONV1B ? 1 : stage == ST_CONV2A ? 2 : stage == ST_CONV2B ? 3 : stage == ST_CONV3A ? 4 : -1;
+    return i < 0 ? 0.0 : s->mskip[i].frac;
+}
+
 int omni_sp_profile(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms) {
     static const int prof_mask = [] { const char* e = getenv("OMNI_SP_PROFILE_MASK"); return (e && e[0] == '1') ? 1 : 0; }();   // stage times with the fisheye mask on (as the key-frame pipeline runs)
     OMNI_REQUIRE(s && gray_dev && stage_ms && reps >= 1, OMNI_ERR_INVALID, "bad argument");
@@ -698,6 +740,9 @@ int omni_sp_profile(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, 
     std::lock_guard<std::mutex> lk(s->mu);
     (void)hipSetDevice(s->ctx->device);
     for (int i = 0; i < OMNI_SP_NUM_STAGES; ++i) stage_ms[i] = 0.f;
+    // the MEDIAN over the repetitions: the first passes after an idle stretch run at a lower clock (their launches are 10-20 % longer in a kernel
+    // trace of the same run); the median is the launch duration a kernel trace of the timed loop shows
+    std::vector<float> all((size_t)reps * ST_COUNT);
     for (int r = 0; r < reps; ++r) {
         int rc = omni::sp_forward(s, gray_dev, stride, batch, prof_mask, true, true);
         if (rc) return rc;
@@ -705,8 +750,13 @@ int omni_sp_profile(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, 
         for (int i = 0; i < ST_COUNT; ++i) {
             float ms = 0.f;
             OMNI_HIP_TRY(hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]));
-            stage_ms[i] += ms / reps;
+            all[(size_t)i * reps + r] = ms;
         }
+    }
+    for (int i = 0; i < ST_COUNT; ++i) {
+        float* v = all.data() + (size_t)i * reps;
+        std::sort(v, v + reps);
+        stage_ms[i] = (reps & 1) ? v[reps / 2] : 0.5f * (v[reps / 2 - 1] + v[reps / 2]);
     }
     return OMNI_OK;
 }

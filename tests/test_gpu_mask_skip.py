@@ -20,13 +20,16 @@ def _same(a, b):
         assert np.array_equal(k0, k1) and np.array_equal(s0, s1) and np.array_equal(d0, d1)
 
 
-@pytest.mark.parametrize("prec", ["PREC_F16", "PREC_SPLIT"])
+@pytest.mark.parametrize("prec", ["PREC_F16", "PREC_SPLIT", "PREC_SPLIT_UNFUSED"])
 @pytest.mark.parametrize("shape,batch", [((480, 600), 3), ((480, 640), 2), ((240, 320), 2), ((64, 96), 2)])
 def test_mask_skip_is_bit_identical_to_the_dense_pass(omni, ctx, shape, batch, prec, monkeypatch):
-    """(OMNI_PREC_SPLIT: the same region for conv1a -- a tensor of its own there -- and the four cin = 64 layers of the split kernel, 4 x 32 tiles;
-    OMNI_SP_MASK_SKIP_SPLIT=1 switches it on)"""
+    """(OMNI_PREC_SPLIT: the four cin = 64 layers of the split kernel, 4 x 32 tiles; with OMNI_SPLIT_FUSE1A=0 conv1a is a tensor of its own and has its
+    own constant band; OMNI_SP_MASK_SKIP_SPLIT=0 = the dense pass)"""
     h, w = shape
     env = "OMNI_SP_MASK_SKIP" if prec == "PREC_F16" else "OMNI_SP_MASK_SKIP_SPLIT"
+    monkeypatch.setenv("OMNI_SPLIT_FUSE1A", "0" if prec == "PREC_SPLIT_UNFUSED" else "1")
+    unfused = prec == "PREC_SPLIT_UNFUSED"
+    prec = prec.replace("_UNFUSED", "")
     weights = S.synth_weights(0)
     comp, mean = synth.pca()
     imgs = np.stack([synth.image_u8(900 + i, h, w, n_shapes=60 if h < 100 else 200) for i in range(batch)])
@@ -38,7 +41,7 @@ def test_mask_skip_is_bit_identical_to_the_dense_pass(omni, ctx, shape, batch, p
     dense, skip = sps
     # 1. masked pass: every output and every layer
     _same(dense.inference(imgs, True), skip.inference(imgs, True))
-    for n in LAYERS + (["conv1a"] if prec == "PREC_SPLIT" else []):
+    for n in LAYERS + (["conv1a"] if unfused else []):
         a, b = dense.debug_layer(n, batch), skip.debug_layer(n, batch)
         assert np.array_equal(a, b), (n, int((a != b).sum()), np.argwhere(a != b)[:4].tolist())
     (s0, d0), (s1, d1) = dense.get_dense(batch), skip.get_dense(batch)

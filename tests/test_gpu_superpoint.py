@@ -51,17 +51,20 @@ def _oracle_layers(w, x):
     return semi, desc, out
 
 
-@pytest.mark.parametrize("prec", ["PREC_F32", "PREC_SPLIT"])
+@pytest.mark.parametrize("prec", ["PREC_F32", "PREC_SPLIT", "PREC_SPLIT_UNFUSED"])
 @pytest.mark.parametrize("shape", [(64, 96), (72, 104), (480, 600), (480, 640)])    # last: BASELINE config 1 (pinhole 640x480)
-def test_f32_layers_and_dense_outputs(omni, ctx, shape, prec):
+def test_f32_layers_and_dense_outputs(omni, ctx, shape, prec, monkeypatch):
+    """PREC_SPLIT builds conv1b's input tiles from the u8 image inside conv1b's kernel (conv1a on the matrix cores, csrc/conv_split.hip FUSE1A): conv1a is
+    not a tensor there; PREC_SPLIT_UNFUSED (OMNI_SPLIT_FUSE1A=0) keeps the separate exact-f32 conv1a pass"""
     h, w = shape
     weights = S.synth_weights(0)
     comp, mean = synth.pca()
     imgs = np.stack([synth.image_u8(400 + i, h, w, n_shapes=60 if h < 100 else 200) for i in range(2)])
-    sp = omni.capi.SuperPoint(ctx, weights, comp, mean, w, h, 0.015, 200, getattr(omni.capi, prec), 2)
+    monkeypatch.setenv("OMNI_SPLIT_FUSE1A", "0" if prec == "PREC_SPLIT_UNFUSED" else "1")
+    sp = omni.capi.SuperPoint(ctx, weights, comp, mean, w, h, 0.015, 200, getattr(omni.capi, prec.replace("_UNFUSED", "")), 2)
     sp.inference(imgs)
     semi_r, desc_r, layers_r = _oracle_layers(weights, S.preprocess_u8(imgs))
-    for n in LAYERS + ["heads"]:
+    for n in (LAYERS[1:] if prec == "PREC_SPLIT" else LAYERS) + ["heads"]:
         got = sp.debug_layer(n, 2)
         ref = layers_r[n]
         assert got.shape == ref.shape, (n, got.shape, ref.shape)

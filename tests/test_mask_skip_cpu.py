@@ -55,17 +55,23 @@ def test_tile_walk_enumerates_the_tiles_outside_the_rectangle_once():
             assert sorted(seen) == want and len(set(seen)) == len(seen), (tx, ty, sy0, sy1, sx0, sx1)
 
 
-def test_plan_for_600x480_is_the_one_worked_out_by_hand(monkeypatch):
-    monkeypatch.delenv("OMNI_SP_MASK_SKIP", raising=False)
-    spec = importlib.util.spec_from_file_location("bench_for_plan", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    plan = bench.mask_skip_plan(480, 600)
+def test_plan_for_600x480_is_the_one_worked_out_by_hand():
+    """omni_sp_mask_skip_plan (the library's own plan, pure arithmetic: callable without a device) -- bench.py takes its executed-FLOP accounting from the
+    same function through omni_sp_stage_tiles_left_out"""
+    import omni_loader
+    capi = omni_loader.load().capi
+    plan = lambda h, w, prec, layer: capi.sp_mask_skip_plan(w, h, prec, layer)
+    F16, SPLIT, F32 = capi.PREC_F16, capi.PREC_SPLIT, capi.PREC_F32
     # rows 360-479 are blanked; conv1a is constant on rows 361-479; conv1b on 362-478 x 1-598 -> tile rows 46-58 (13 of 60), tile columns 1-17 (of 19)
-    assert abs(plan["conv1b"][0] - 13 * 17 / (60 * 19)) < 1e-12 and plan["conv1b"][1] == 2.0 * 480 * 600 * 64 * 64 * 9
-    assert abs(plan["conv2a"][0] - 6 * 8 / (30 * 10)) < 1e-12            # 240 x 300: rows 182-237 x columns 2-297 -> tile rows 23-28, columns 1-8
-    assert abs(plan["conv2b"][0] - 6 * 8 / (30 * 10)) < 1e-12
-    assert abs(plan["conv3a"][0] - 2 * 3 / (15 * 5)) < 1e-12             # 120 x 150: rows 93-116 x columns 3-146 -> tile rows 12-13, columns 1-3
-    assert bench.mask_skip_plan(64, 96) == {} or all(v[0] == 0 for v in bench.mask_skip_plan(64, 96).values())      # the band is thinner than a tile row
-    monkeypatch.setenv("OMNI_SP_MASK_SKIP", "0")
-    assert bench.mask_skip_plan(480, 600) == {}
+    assert plan(480, 600, F16, 1) == ((46, 59, 1, 18), 13 * 17 / (60 * 19))
+    assert plan(480, 600, F16, 2) == ((23, 29, 1, 9), 6 * 8 / (30 * 10))            # 240 x 300: rows 182-237 x columns 2-297 -> tile rows 23-28, columns 1-8
+    assert plan(480, 600, F16, 3) == ((23, 29, 1, 9), 6 * 8 / (30 * 10))
+    assert plan(480, 600, F16, 4) == ((12, 14, 1, 4), 2 * 3 / (15 * 5))             # 120 x 150: rows 93-116 x columns 3-146 -> tile rows 12-13, columns 1-3
+    assert plan(480, 600, F16, 0)[1] == 0.0                                          # conv1a is fused into conv1b on the fp16 path
+    # OMNI_PREC_SPLIT: conv1a in 8-row tile rows over the whole width (rows 361-479 -> tile rows 46-59), the cin = 64 layers in 4 x 32 tiles
+    assert plan(480, 600, SPLIT, 0) == ((46, 60, 0, 19), 14 / 60)
+    assert plan(480, 600, SPLIT, 1) == ((91, 119, 1, 18), 28 * 17 / (120 * 19))      # rows 362-478 -> 4-row tile rows 91-118
+    assert plan(480, 600, SPLIT, 2) == ((46, 59, 1, 9), 13 * 8 / (60 * 10))          # rows 182-237
+    for layer in range(5):
+        assert plan(64, 96, F16, layer)[1] == 0.0                                    # the band is thinner than a tile row
+        assert plan(480, 600, F32, layer)[1] == 0.0

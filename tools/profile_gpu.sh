@@ -13,7 +13,7 @@ LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-
 BENCH="python bench.py --steps 40 --warmup 8 --min-time 0 $LEGS"
 BENCH_PMC="python bench.py --steps 8 --warmup 8 --min-time 0 --match-db-rows 100000 $LEGS"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ${TAG} -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.err
-python tools/rocprof_summary.py $(ls $OUT/${TAG}_trace/*_results.db $OUT/${TAG}_trace/*/*_results.db 2>/dev/null | head -1) "(${TAG}; $BENCH; 1x MI355X)" > $OUT/${TAG}_kernel_stats.md 2>> $OUT/${TAG}_trace.err
+python tools/rocprof_summary.py $(ls $OUT/${TAG}_trace/*_results.db $OUT/${TAG}_trace/*/*_results.db 2>/dev/null | head -1) --json $OUT/${TAG}_kernel_times.json "(${TAG}; $BENCH; 1x MI355X)" > $OUT/${TAG}_kernel_stats.md 2>> $OUT/${TAG}_trace.err
 i=0
 for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
@@ -21,6 +21,7 @@ for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_I
   echo "pmc pass $i ($PMC) rc=$?" >> $OUT/${TAG}_trace.err
 done
 python tools/pmc_summary.py $OUT/${TAG}_pmc* > $OUT/${TAG}_pmc_summary.md 2>> $OUT/${TAG}_trace.err
+python tools/make_traffic.py ${TAG} 64 > $OUT/${TAG}_traffic.json 2>> $OUT/${TAG}_trace.err
 # keep the merge under the 64 MiB cap: drop the raw trace DBs, keep CSV counter files only if small
 find $OUT/${TAG}_trace -name '*.db' -size +20M -delete
 find $OUT -name '*kernel_trace.csv' -size +8M -delete
