@@ -153,8 +153,8 @@ double      omni_sp_stage_flops(const omni_sp* sp, int stage);   /* algorithmic 
 /* share of the stage's output tiles a fisheye-masked pass leaves out of the kernel's tile walk (the constant region of the mask, loop_cam.cpp:536-539:
  * written once per handle, bit-identical results); 0 when the stage computes every tile */
 double      omni_sp_stage_tiles_left_out(const omni_sp* sp, int stage);
-/* the plan itself (pure arithmetic on the image size and the kernels' tile shapes; no device needed): layer 0 = conv1a (OMNI_PREC_SPLIT only), 1..4 =
- * conv1b, conv2a, conv2b, conv3a; rect = {tile row 0, tile row 1, tile column 0, tile column 1} of the layer's conv-output tile grid (empty = nothing
+/* the plan itself (pure arithmetic on the image size and the kernels' tile shapes; no device needed): layer 0 = conv1a (OMNI_PREC_SPLIT only), 1..5 =
+ * conv1b, conv2a, conv2b, conv3a, conv3b (OMNI_PREC_SPLIT only); rect = {tile row 0, tile row 1, tile column 0, tile column 1} of the layer's conv-output tile grid (empty = nothing
  * left out), frac = its share of the layer's tiles */
 int         omni_sp_mask_skip_plan(int width, int height, int precision, int layer, int* rect, double* frac);
 

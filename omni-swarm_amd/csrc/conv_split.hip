@@ -318,15 +318,16 @@ constexpr int FZ_T = 13;        // + 5 f + k: table entry of that byte
 constexpr int FZ_W = 23;        // + 4 f + i: A fragment i
 constexpr int FZ_K = 31;        // + f: pack the B operands
 constexpr int FZ_M = 33;        // + 4 f + i: the MFMA
-constexpr int FZ_EA = 41;       // + u: first half of register group (2 values: ReLU, hi, lo)
-constexpr int FZ_EB = 57;       // + u: second half + the group's two LDS stores
-constexpr int FZ_NOPS = 73;
-constexpr int FZ_PER_STEP = 3;
-constexpr int fz_nlds(int id) { return id == FZ_PARK ? 1 : (id >= FZ_U && id < FZ_K) ? 1 : (id >= FZ_EB ? 2 : 0); }
+constexpr int FZ_E = 41;        // + 4 u + s: register group u = 8 f + 4 m + g (values 4 g .. 4 g + 3 of channel fragment m) in four sub-units of <= 5 instructions:
+                                //   0: values 0, 1 -> ReLU -> hi pair      1: their lo pair; values 2, 3 read out of the accumulators
+                                //   2: ReLU, hi pair, lo pair of 2, 3       3: the two LDS stores
+constexpr int FZ_NOPS = FZ_E + 64;
+constexpr int FZ_PER_STEP = 4;
+constexpr int fz_nlds(int id) { return id == FZ_PARK ? 1 : (id >= FZ_U && id < FZ_K) ? 1 : (id >= FZ_E && (id - FZ_E) % 4 == 3 ? 2 : 0); }
 constexpr int fz_producer(int id) {      // the micro-op whose LDS-read results `id` consumes (-1: none)
     if (id >= FZ_T && id < FZ_W) return FZ_U + (id - FZ_T);
     if (id >= FZ_K && id < FZ_M) return FZ_T + 5 * (id - FZ_K) + 4;      // the last table read of the fragment covers the other four (LDS returns in order)
-    if (id >= FZ_M && id < FZ_EA) return FZ_W + (id - FZ_M);
+    if (id >= FZ_M && id < FZ_E) return FZ_W + (id - FZ_M);
     return -1;
 }
 struct FzSched {
@@ -346,23 +347,37 @@ constexpr FzSched fz_make_sched() {
         s.ok = false;
     };
     // The previous tile's epilogue owns the dense steps 8-11 / 16-19 (its stores are the only VMEM operations behind the patch load: the park at
-    // step 20 finds them all issued).  Splitting the results into hi / lo halves -- 18 instructions per register group -- sits in the sixteen dense
-    // steps the epilogue leaves free (40-43, 48-51 for fragment 0, 72-75, 80-83 for fragment 1), one whole group per step (two independent dependency
-    // chains); the reads, table look-ups and the eight MFMAs of the build ride in the sparse steps in front of them.
-    put(FZ_PARK, 20); put(FZ_V + 0, 21);
-    { const int st[5] = {22, 22, 23, 23, 24}; for (int k = 0; k < 5; ++k) put(FZ_U + k, st[k]); }
-    { const int st[5] = {27, 28, 29, 30, 31}; for (int k = 0; k < 5; ++k) put(FZ_T + k, st[k]); }
-    for (int i = 0; i < 4; ++i) put(FZ_W + i, 32 + i);
+    // step 20 finds them all issued).  The in-stream trace prices the rest: an MFMA hides about five other instructions issued behind it and NOT more --
+    // the slots of one gap cannot be borrowed by another (in-order issue: the next MFMA waits behind whatever stands in front of it), and every
+    // instruction beyond costs ~5 cycles.  The ring's own address + read + wait (+ s_nop) fill the gap behind a step's LAST MFMA, so a step has
+    // 5 x (its MFMAs - 1) free slots: 15 in a dense step, 5 in a two-MFMA step, none in a one-MFMA step.  Splitting the 64 results into hi / lo halves is
+    // 20 instructions per register group of four: cut into sub-units of <= 5 and packed, in order, into the free slots behind the fragment's MFMAs.
+    // (First versions: a whole group in each of the sixteen free dense steps, or half a group in each of 32 steps: 70 cycles per group either way.)
+    // Both fragments' bytes and table entries are read early (steps 20-35), so that the sub-units of fragment 0 have steps 40-63 to themselves
+    // (eight dense steps x 3 + twelve two-MFMA steps x 1 = 36 places for 32 sub-units), those of fragment 1 steps 72-91 behind its MFMAs at 64-67.
+    put(FZ_PARK, 20); put(FZ_V + 0, 21); put(FZ_V + 1, 22);
+    { const int st[10] = {23, 23, 24, 24, 25, 25, 26, 26, 27, 27}; for (int k = 0; k < 10; ++k) put(FZ_U + k, st[k]); }
+    { const int st[10] = {28, 29, 30, 31, 32, 32, 33, 33, 34, 34}; for (int k = 0; k < 10; ++k) put(FZ_T + k, st[k]); }
+    { const int st[4] = {34, 35, 35, 35}; for (int i = 0; i < 4; ++i) put(FZ_W + i, st[i]); }
     put(FZ_K + 0, 36);
     for (int i = 0; i < 4; ++i) put(FZ_M + i, 36 + i);
-    for (int u = 0; u < 8; ++u) { const int L = (u < 4 ? 40 : 44) + u; put(FZ_EA + u, L); put(FZ_EB + u, L); }
-    put(FZ_V + 1, 44);
-    { const int st[5] = {45, 45, 46, 46, 47}; for (int k = 0; k < 5; ++k) put(FZ_U + 5 + k, st[k]); }
-    { const int st[5] = {52, 53, 54, 55, 56}; for (int k = 0; k < 5; ++k) put(FZ_T + 5 + k, st[k]); }
-    for (int i = 0; i < 4; ++i) put(FZ_W + 4 + i, 57 + i);
+    for (int i = 0; i < 4; ++i) put(FZ_W + 4 + i, 60 + i);
     put(FZ_K + 1, 64);
     for (int i = 0; i < 4; ++i) put(FZ_M + 4 + i, 64 + i);
-    for (int u = 0; u < 8; ++u) { const int L = (u < 4 ? 72 : 76) + u; put(FZ_EA + 8 + u, L); put(FZ_EB + 8 + u, L); }
+    for (int f = 0; f < 2; ++f) {
+        int L = f ? 68 : 40, n = 0;
+        for (int i = 0; i < 32; ++i) {
+            for (;; ++L, n = 0) {
+                if (L >= 96) break;
+                const int r = (L / 8) % 4, kg = L % 8;
+                const int nm = ((r == 1 || r == 2) ? 2 : 1) * (kg < 4 ? 2 : 1);
+                const int places = nm == 4 ? (spl_dense_before(L) < 8 ? 0 : 3) : (nm == 2 ? 1 : 0);
+                if (n < places && s.op[L][FZ_PER_STEP - 1] < 0 && (places > 1 || s.op[L][0] < 0)) break;     // (a two-MFMA step that already holds something: full)
+            }
+            if (L >= 96) { s.ok = false; break; }
+            put(FZ_E + 32 * f + i, L); ++n;
+        }
+    }
     // LDS operations in program order: the ring's reads 0 .. SPL_NB - 2 (spl_prime), then per step the ring's read L + SPL_NB - 1, the wait for
     // fragment L, the step's micro-ops
     int pos = 0, ring_pos[96] = {}, start[FZ_NOPS] = {}, end[FZ_NOPS] = {};
@@ -390,10 +405,10 @@ constexpr FzSched fz_make_sched() {
         for (int k = 0; k < 5; ++k) if (start[FZ_U + 5 * f + k] < 0 || s.step[FZ_V + f] > s.step[FZ_U + 5 * f + k]) s.ok = false;
         if (s.step[FZ_PARK] > s.step[FZ_U + 5 * f]) s.ok = false;
         for (int i = 0; i < 4; ++i) if (s.step[FZ_K + f] > s.step[FZ_M + 4 * f + i]) s.ok = false;
-        for (int u = 0; u < 8; ++u) if (s.step[FZ_M + 4 * f + 3] >= s.step[FZ_EA + 8 * f + u] || s.step[FZ_EA + 8 * f + u] > s.step[FZ_EB + 8 * f + u]) s.ok = false;
+        for (int i = 0; i < 32; ++i) if (s.step[FZ_M + 4 * f + 3] >= s.step[FZ_E + 32 * f + i]) s.ok = false;      // behind the fragment's MFMAs
         if (s.step[FZ_M + 4 * f] > s.step[FZ_M + 4 * f + 2] || s.step[FZ_M + 4 * f + 1] > s.step[FZ_M + 4 * f + 3]) s.ok = false;
     }
-    if (s.step[FZ_EB + 7] >= s.step[FZ_M + 4]) s.ok = false;                     // fragment 1 takes over fragment 0's accumulators
+    if (s.step[FZ_E + 31] >= s.step[FZ_M + 4]) s.ok = false;                     // fragment 1 takes over fragment 0's accumulators
     return s;
 }
 inline constexpr FzSched kFzSched = fz_make_sched();
@@ -425,7 +440,7 @@ void conv1a_split_pack_fused(const float* w /*[64][9]*/, const float* bias /*[64
 // TRN (cin = 128, no pooling): transposed tiles -- the 32-pixel fragments run along y, the two fragment rows along x (the LDS image, the k order
 // and every MFMA are those of the plain kernel; only the pixel <-> address maps and the tap the weights are loaded for differ).  A 60x75 layer
 // is 2 x 38 tiles instead of 3 x 30: 75-pixel rows fill 2.3 of 3 fragments, 60-pixel columns 1.9 of 2.
-template <bool C128, bool POOL, bool OUT_F32, bool TRN = false, bool FUSE1A = false, bool FZMIX = false>
+template <bool C128, bool POOL, bool OUT_F32, bool TRN = false, bool FUSE1A = false, bool FZMIX = true>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const _Float16* __restrict__ wp, const float* __restrict__ bias,
                      float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, SplSkip sk,
@@ -470,12 +485,12 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
 
     // tile t = (image b, tile r of the image's tiles that run); a workgroup walks t = wg, wg + nwg, ...: (b, r) advance by a carry, (tile row,
     // tile column) come from r by multiply-high divisions (scalar: a dozen SALU instructions per tile)
-    // (cin = 128 has no rectangle to leave out -- the launcher refuses one: its walk stays on carries alone, r unused)
+    // (the transposed cin = 128 tiles -- 32 rows tall -- never fit a rectangle: their walk stays on carries alone, r unused)
     const int step_b = nwg / tiles_per_img, step_r = nwg - step_b * tiles_per_img;
     const int step_y = step_r / tiles_x, step_x = step_r - step_y * tiles_x;
     auto decode = [&](SplTileIx& q) {
         int r = q.r, ty, tx;                                            // (locals, assigned to q once: stores in both branches send the struct to scratch)
-        if constexpr (C128) {
+        if constexpr (TRN) {
             ty = r / tiles_x; tx = r - ty * tiles_x;
         } else if (r < sk.n_above || r >= sk.n_upto) {                  // full tile rows above / below the rectangle
             int base = 0;
@@ -491,7 +506,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         q.ty = ty; q.tx = tx;
     };
     auto advance = [&](SplTileIx& q) {
-        if constexpr (C128) {
+        if constexpr (TRN) {
             q.tx += step_x;
             if (q.tx >= tiles_x) { q.tx -= tiles_x; ++q.ty; }
             q.ty += step_y;
@@ -563,7 +578,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     const uint32_t oorg = (uint32_t)((OUT_F32 ? 0 : ((int64_t)Wof + 1) * opix) + ofrag);                 // the frame's origin + the wave's fragment
 
     // ---- FUSE1A: the tile build (see FzSched) ------------------------------------------------------------------------------------------------
-    struct FzSt { uint32_t pv, u[5], pbv, xc, wb, hq, lq; half8_t wa[4], B0, B1; floatx16 a[2]; } z;
+    struct FzSt { uint32_t pv, u[2][5], pbv[2], xc[2], wb, hq, lq, dh, dl1; float x0, x1; half8_t wa[4], B0, B1; floatx16 a[2]; } z;
     int fz_b = 0, fz_ty0 = 0, fz_tx0 = 0, fz_which = 0;          // the tile being built: image, origin of its outputs, halo buffer
     [[maybe_unused]] const int fz_r0 = (64 * wave) / SPL_ITW;                         // first halo row the wave's 64 virtual pixels touch
     // the lane's dword of the wave's 5-row x 40-byte patch: row lane / 10, bytes [4 (lane % 10), + 4) = image row ty0 + fz_pj, columns tx0 + fz_pd ..
@@ -600,17 +615,16 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         constexpr int ID = decltype(IDC)::value;
         constexpr bool PRO = decltype(PROC)::value;
         if constexpr (!PRO && (FZ_ABL & 4)) return;
-        if constexpr (!PRO && (FZ_ABL & 1) && ID >= FZ_EA) {
-            constexpr int uu = ID >= FZ_EB ? ID - FZ_EB : ID - FZ_EA;
-            if constexpr (ID >= FZ_EB) asm volatile("" :: "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 2]), "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 3]));
-            else asm volatile("" :: "v"(z.a[(uu % 8) / 4][4 * (uu % 4)]), "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 1]));
+        if constexpr (!PRO && (FZ_ABL & 1) && ID >= FZ_E) {
+            constexpr int uu = (ID - FZ_E) / 4, ss = (ID - FZ_E) % 4;
+            if constexpr (ss < 2) asm volatile("" :: "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 2 * ss]), "v"(z.a[(uu % 8) / 4][4 * (uu % 4) + 2 * ss + 1]));
             return;
         }
-        if constexpr (!PRO && (FZ_ABL & 8) && ID >= FZ_M && ID < FZ_EA) {
+        if constexpr (!PRO && (FZ_ABL & 8) && ID >= FZ_M && ID < FZ_E) {
             constexpr int mi = (ID - FZ_M) % 4;
             if constexpr (mi / 2 == 0) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) z.a[mi % 2][q] = __builtin_bit_cast(float, z.u[q % 5]) + (float)z.wa[mi][q % 8];
+                for (int q = 0; q < 16; ++q) z.a[mi % 2][q] = __builtin_bit_cast(float, z.u[(ID - FZ_M) / 4][q % 5]) + (float)z.wa[mi][q % 8];
             }
             return;
         }
@@ -626,28 +640,29 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
             constexpr int f = ID - FZ_V;
             const int gy = fz_ty0 - 1 + fz_iy[f], gx = fz_tx0 - 1 + fz_ix[f];
             const bool valid = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-            z.pbv = valid ? fz_pb[f] : lds0 + FZ_ZERO_OFF;                  // a pixel outside the image is conv1b's zero padding: taps read zeros, no bias
-            z.xc = (valid & (hh != 0)) ? 0x3C003C00u : 0u;                 // the two bias slots (lanes 32-63): (1.0, 1.0)
+            z.pbv[f] = valid ? fz_pb[f] : lds0 + FZ_ZERO_OFF;               // a pixel outside the image is conv1b's zero padding: taps read zeros, no bias
+            z.xc[f] = (valid & (hh != 0)) ? 0x3C003C00u : 0u;              // the two bias slots (lanes 32-63): (1.0, 1.0)
         } else if constexpr (ID < FZ_T) {                                   // U(f, k): the byte under the half-wave's k-th tap
-            constexpr int k = (ID - FZ_U) % 5;
+            constexpr int f = (ID - FZ_U) / 5, k = (ID - FZ_U) % 5;
             constexpr int c0 = (k / 3) * 40 + k % 3, tp1 = k < 4 ? 5 + k : 8, c1 = (tp1 / 3) * 40 + tp1 % 3;
-            const uint32_t addr = z.pbv + (uint32_t)hh * (uint32_t)(c1 - c0);
-            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(z.u[k]) : "v"(addr), "i"(c0) : "memory");
+            const uint32_t addr = z.pbv[f] + (uint32_t)hh * (uint32_t)(c1 - c0);
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(z.u[f][k]) : "v"(addr), "i"(c0) : "memory");
         } else if constexpr (ID < FZ_W) {                                   // T(f, k): its table entry (xh | xl << 16)
-            constexpr int k = (ID - FZ_T) % 5;
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(z.u[k]) : "i"(WAITN));
-            const uint32_t addr = lds0 + FZ_LUT_OFF + (z.u[k] << 2);
-            asm volatile("ds_read_b32 %0, %1" : "=v"(z.u[k]) : "v"(addr) : "memory");
+            constexpr int f = (ID - FZ_T) / 5, k = (ID - FZ_T) % 5;
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(z.u[f][k]) : "i"(WAITN));
+            const uint32_t addr = lds0 + FZ_LUT_OFF + (z.u[f][k] << 2);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(z.u[f][k]) : "v"(addr) : "memory");
         } else if constexpr (ID < FZ_K) {                                   // W(f, i)
             constexpr int i = (ID - FZ_W) % 4;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(z.wa[i]) : "v"(fz_wl), "i"(i * 1024) : "memory");
         } else if constexpr (ID < FZ_M) {                                   // K(f)
-            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(z.u[0]), "+v"(z.u[1]), "+v"(z.u[2]), "+v"(z.u[3]), "+v"(z.u[4]) : "i"(WAITN));
-            const uint32_t h01 = __builtin_amdgcn_perm(z.u[1], z.u[0], 0x05040100u), h23 = __builtin_amdgcn_perm(z.u[3], z.u[2], 0x05040100u);
-            const uint32_t x = hh ? z.xc : z.u[4];
-            z.B0 = __builtin_bit_cast(half8_t, make_uint4(z.u[0], z.u[1], z.u[2], z.u[3]));
-            z.B1 = __builtin_bit_cast(half8_t, make_uint4(z.u[4], h01, h23, x));
-        } else if constexpr (ID < FZ_EA) {                                  // M(f, i)
+            constexpr int f = ID - FZ_K;
+            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(z.u[f][0]), "+v"(z.u[f][1]), "+v"(z.u[f][2]), "+v"(z.u[f][3]), "+v"(z.u[f][4]) : "i"(WAITN));
+            const uint32_t h01 = __builtin_amdgcn_perm(z.u[f][1], z.u[f][0], 0x05040100u), h23 = __builtin_amdgcn_perm(z.u[f][3], z.u[f][2], 0x05040100u);
+            const uint32_t x = hh ? z.xc[f] : z.u[f][4];
+            z.B0 = __builtin_bit_cast(half8_t, make_uint4(z.u[f][0], z.u[f][1], z.u[f][2], z.u[f][3]));
+            z.B1 = __builtin_bit_cast(half8_t, make_uint4(z.u[f][4], h01, h23, x));
+        } else if constexpr (ID < FZ_E) {                                   // M(f, i)
             constexpr int i = (ID - FZ_M) % 4, j = i / 2, m = i % 2;
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(z.wa[i]) : "i"(WAITN));
             if constexpr (j == 0) {
@@ -658,28 +673,42 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
             } else {
                 z.a[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(z.wa[i], z.B1, z.a[m], 0, 0, 0);
             }
-        } else {                                                            // EA(u) / EB(u): two values of register group g of channel fragment m
-            constexpr bool second = ID >= FZ_EB;
-            constexpr int u = second ? ID - FZ_EB : ID - FZ_EA, f = u / 8, m = (u % 8) / 4, g = u % 4;
-            const float x0 = __builtin_amdgcn_fmed3f(z.a[m][4 * g + (second ? 2 : 0)], 0.f, 65000.f);
-            const float x1 = __builtin_amdgcn_fmed3f(z.a[m][4 * g + (second ? 3 : 1)], 0.f, 65000.f);
-            float2v_t fv; fv[0] = x0; fv[1] = x1;
-            const half2v_t hv = __builtin_convertvector(fv, half2v_t);
-            const uint32_t dh = __builtin_bit_cast(uint32_t, hv);
-            uint32_t dl;
-            if constexpr (FZMIX) {
-                // lo = half(x - float(hi)) in one instruction per value: v_fma_mix{lo,hi}_f16 = half(fma(f16 source, -1.0, f32 source)) into the low / high
-                // half of the destination (x - float(hi) is exact in f32, so the single rounding is the same as convert, subtract, convert)
-                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dl) : "v"(dh), "v"(x0));
-                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(dl) : "v"(dh), "v"(x1));
-            } else {
-                float2v_t rv; rv[0] = x0 - (float)hv[0]; rv[1] = x1 - (float)hv[1];
-                dl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rv, half2v_t));
-            }
-            if constexpr (!second) { z.hq = dh; z.lq = dl; }
-            else {
+            // (measured and not kept: inline-asm MFMAs writing architectural registers, so that the 64 results need no v_accvgpr_read: hipcc then parks as
+            // many other values in the accumulator half and reads those back -- the same instruction count, the same time)
+        } else {                                                            // E(u, sub)
+            constexpr int u = (ID - FZ_E) / 4, sub = (ID - FZ_E) % 4, f = u / 8, m = (u % 8) / 4, g = u % 4;
+            auto lo_pair = [&](uint32_t dh, float x0, float x1) -> uint32_t {
+                uint32_t dl;
+                if constexpr (FZMIX) {
+                    // lo = half(x - float(hi)) in one instruction per value: v_fma_mix{lo,hi}_f16 = half(fma(f16 source, -1.0, f32 source)) into the low / high
+                    // half of the destination (x - float(hi) is exact in f32, so the single rounding is the same as convert, subtract, convert)
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dl) : "v"(dh), "v"(x0));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(dl) : "v"(dh), "v"(x1));
+                } else {
+                    const half2v_t hv = __builtin_bit_cast(half2v_t, dh);
+                    float2v_t rv; rv[0] = x0 - (float)hv[0]; rv[1] = x1 - (float)hv[1];
+                    dl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rv, half2v_t));
+                }
+                return dl;
+            };
+            if constexpr (sub == 0) {                                       // values 0, 1: ReLU (+ the fp16 range), the hi pair
+                z.x0 = __builtin_amdgcn_fmed3f(z.a[m][4 * g], 0.f, 65000.f);
+                z.x1 = __builtin_amdgcn_fmed3f(z.a[m][4 * g + 1], 0.f, 65000.f);
+                float2v_t fv; fv[0] = z.x0; fv[1] = z.x1;
+                z.hq = __builtin_bit_cast(uint32_t, __builtin_convertvector(fv, half2v_t));
+            } else if constexpr (sub == 1) {                                // their lo pair; values 2, 3 leave the accumulators (v_accvgpr_read here, not in sub-unit 2)
+                z.lq = lo_pair(z.hq, z.x0, z.x1);
+                z.x0 = z.a[m][4 * g + 2]; z.x1 = z.a[m][4 * g + 3];
+                asm volatile("" : "+v"(z.x0), "+v"(z.x1));
+            } else if constexpr (sub == 2) {                                // values 2, 3: ReLU, hi pair, lo pair
+                z.x0 = __builtin_amdgcn_fmed3f(z.x0, 0.f, 65000.f);
+                z.x1 = __builtin_amdgcn_fmed3f(z.x1, 0.f, 65000.f);
+                float2v_t fv; fv[0] = z.x0; fv[1] = z.x1;
+                z.dh = __builtin_bit_cast(uint32_t, __builtin_convertvector(fv, half2v_t));
+                z.dl1 = lo_pair(z.dh, z.x0, z.x1);
+            } else {                                                        // the group's two 8-byte stores
                 const uint32_t ah = z.wb ^ (uint32_t)((m * 4 + g) << 4), al = z.wb ^ (uint32_t)((8 + m * 4 + g) << 4);
-                const uint2 vh = make_uint2(z.hq, dh), vl = make_uint2(z.lq, dl);
+                const uint2 vh = make_uint2(z.hq, z.dh), vl = make_uint2(z.lq, z.dl1);
                 if constexpr (!PRO && (FZ_ABL & 2)) { asm volatile("" :: "v"(ah), "v"(vh), "v"(al), "v"(vl)); }
                 else {
                     asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(ah), "v"(vh), "i"(f * 8192) : "memory");
@@ -706,12 +735,16 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
                 constexpr int id = kFzSched.op[L][decltype(KC)::value];
                 if constexpr (id >= 0) fz_op(std::integral_constant<int, id>{}, std::false_type{});
             });
-            if constexpr (kFzSched.op[L][0] >= FZ_EA && spl_dense(L)) {
-                // a register group in a dense step: one MFMA, then four of its instructions in that MFMA's shadow (4 v_accvgpr_read, 4 v_med3, 2 v_cvt_pk +
-                // 2 v_xor; the v_fma_mix pairs and the two stores are inline asm, which the scheduler leaves behind their operands: the fourth shadow)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            constexpr bool has_e = kFzSched.op[L][0] >= FZ_E || kFzSched.op[L][1] >= FZ_E || kFzSched.op[L][2] >= FZ_E || kFzSched.op[L][3] >= FZ_E;
+            if constexpr (has_e && spl_dense(L)) {
+                // behind each of the step's first three MFMAs five of the sub-units' instructions (the v_fma_mix pairs and the stores are inline asm,
+                // which the scheduler leaves behind their operands)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            } else if constexpr (has_e) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
@@ -733,18 +766,17 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
             fz_issue();
             spl_for_each<0, FZ_NOPS>([&](auto IC) {
                 constexpr int pos = decltype(IC)::value;
-                // program order of the chains: per fragment PARK, V, U x 5, T x 5, W x 4, K, M x 4, (EA, EB) x 8
-                constexpr int f = pos < 37 ? 0 : 1, q = pos < 37 ? pos : pos - 36;      // fragment 0: positions 0-36 (with PARK), fragment 1: 37-72
+                // program order of the chains: PARK, then per fragment V, U x 5, T x 5, W x 4, K, M x 4, E x 32
+                constexpr int f = pos < 53 ? 0 : 1, q = pos < 53 ? pos : pos - 52;      // fragment 0: positions 0-52 (with PARK), fragment 1: 53-104
                 constexpr int id = pos == 0 ? FZ_PARK :
                                    q == 1 ? FZ_V + f :
                                    q < 7 ? FZ_U + 5 * f + (q - 2) :
                                    q < 12 ? FZ_T + 5 * f + (q - 7) :
                                    q < 16 ? FZ_W + 4 * f + (q - 12) :
                                    q == 16 ? FZ_K + f :
-                                   q < 21 ? FZ_M + 4 * f + (q - 17) :
-                                   ((q - 21) % 2 == 0 ? FZ_EA + 8 * f + (q - 21) / 2 : FZ_EB + 8 * f + (q - 21) / 2);
+                                   q < 21 ? FZ_M + 4 * f + (q - 17) : FZ_E + 32 * f + (q - 21);
                 fz_op(std::integral_constant<int, id>{}, std::true_type{});
-                if constexpr (id < FZ_EA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (id < FZ_E) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             });
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -896,7 +928,7 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     spl_epi_all<0, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part);       // the last tile's
 }
 
-template <bool C128, bool POOL, bool OUT_F32, bool TRN = false, bool FUSE1A = false, bool FZMIX = false>
+template <bool C128, bool POOL, bool OUT_F32, bool TRN = false, bool FUSE1A = false, bool FZMIX = true>
 static int launch_split(hipStream_t st, const ConvArgs& a, const SplFuse& fz = SplFuse{}) {
     if constexpr (C128 && !POOL && !TRN) {
         // the tile orientation with fewer tiles (OMNI_SPLIT_TRN=0/1 forces one: A/B hook; it fixes the order the taps are summed in)
@@ -910,7 +942,7 @@ static int launch_split(hipStream_t st, const ConvArgs& a, const SplFuse& fz = S
     constexpr int TH = C128 ? 2 : 4;
     const int tiles_x = cdiv(a.W, TRN ? TH : 32), tiles_y = cdiv(a.H, TRN ? 32 : TH), n_cg = a.cout / 64;
     // the tiles of an image that run: all of them, or all but the rectangle the caller already holds (ConvArgs::skip_*, in THIS kernel's tile grid)
-    const bool skip = !C128 && a.skip_ty1 > a.skip_ty0 && a.skip_tx1 > a.skip_tx0;      // (the cin = 128 kernel recomputes a rectangle it is offered: same values)
+    const bool skip = !TRN && a.skip_ty1 > a.skip_ty0 && a.skip_tx1 > a.skip_tx0;       // (a transposed-tile launch recomputes a rectangle it is offered: same values)
     OMNI_REQUIRE(!skip || (a.skip_ty0 >= 0 && a.skip_ty1 <= tiles_y && a.skip_tx0 >= 0 && a.skip_tx1 <= tiles_x), OMNI_ERR_INVALID, "conv_split: skip rectangle outside the tile grid");
     SplSkip sk;
     sk.y0 = skip ? a.skip_ty0 : 0; sk.y1 = skip ? a.skip_ty1 : 0; sk.x0 = skip ? a.skip_tx0 : 0; sk.w = skip ? a.skip_tx1 - a.skip_tx0 : 0;
@@ -992,9 +1024,7 @@ int conv1ab_split_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, 
     fz.gray = gray; fz.gstride = gstride; fz.gbytes = a.batch * a.H * gstride;
     omni_fisheye_mask_rows(a.H, fisheye_mask, &fz.mask_r0, &fz.mask_r1);   // cv::Rect(0, rows*3/4, cols, rows/4)
     fz.w1a_frag = reinterpret_cast<const _Float16*>(w1a_frag); fz.lut_hl = lut_hl;
-    // OMNI_SPLIT_FZ_MIX=0: the build's hi / lo split without v_fma_mix (convert back, subtract, convert): same values, A/B hook
-    static const bool mix = [] { const char* e = getenv("OMNI_SPLIT_FZ_MIX"); return !(e && e[0] == '0'); }();
-    return mix ? launch_split<false, true, false, false, true, true>(st, a, fz) : launch_split<false, true, false, false, true, false>(st, a, fz);
+    return launch_split<false, true, false, false, true>(st, a, fz);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -88,7 +88,7 @@ struct omni_sp {
         void** map = nullptr;                        // the activation buffer
         double frac = 0.0;                           // the rectangle's share of the layer's tiles (omni_sp_stage_tiles_left_out)
     };
-    MaskSkip mskip[5];                       // conv1a (OMNI_PREC_SPLIT only: fused away on the fp16 path), conv1b (+pool), conv2a, conv2b (+pool), conv3a
+    MaskSkip mskip[6];                       // conv1a (OMNI_PREC_SPLIT, unfused, only), conv1b (+pool), conv2a, conv2b (+pool), conv3a, conv3b (+pool; OMNI_PREC_SPLIT only)
     bool mask_skip = false, mask_skip_ready = false, mask_skip_calibrating = false;
     uint8_t* zero_gray = nullptr;
     size_t zero_gray_bytes = 0;
@@ -106,7 +106,7 @@ static int dev_upload(void** dst, const void* src, size_t bytes, hipStream_t st)
 
 // Where every layer's output is constant under the fisheye mask, and the tile rectangle inside it (see omni_sp::MaskSkip): pure integer arithmetic
 // on (H, W) and the kernels' tile shapes; k[0] = conv1a (OMNI_PREC_SPLIT only), k[1..4] = conv1b, conv2a, conv2b, conv3a
-static void sp_mask_skip_rects(int H, int W, bool split, omni_sp::MaskSkip (&ks)[5]) {
+static void sp_mask_skip_rects(int H, int W, bool split, omni_sp::MaskSkip (&ks)[6]) {
     int m0, m1;
     omni_fisheye_mask_rows(H, 1, &m0, &m1);
     int h = H, w = W;
@@ -122,11 +122,12 @@ static void sp_mask_skip_rects(int H, int W, bool split, omni_sp::MaskSkip (&ks)
         k.oh = h; k.ow = w; k.oc = 64;
         k.frac = (double)(k.ty1 - k.ty0) / ((h + 7) / 8);
     }
-    const bool pool[4] = {true, false, true, false};
-    const int chans[4] = {64, 64, 64, 128};
-    const int TH = split ? 4 : CONV_TH, TW = 32;           // the cin = 64 kernels' output tiles (conv_split.hip: 4 x 32, conv.hip: CONV_TH x CONV_TW)
+    const bool pool[5] = {true, false, true, false, true};
+    const int chans[5] = {64, 64, 64, 128, 128};
     static_assert(CONV_TW == 32, "tile width");
-    for (int i = 0; i < 4; ++i) {
+    const int TW = 32;
+    for (int i = 0; i < (split ? 5 : 4); ++i) {            // (conv3b: the split kernel's cin = 128 tiles, 2 x 32; the fp16 register-stationary kernel walks every tile)
+        const int TH = split ? (i == 4 ? 2 : 4) : CONV_TH;  // the kernels' output tiles (conv_split.hip: 4 x 32 / 2 x 32, conv.hip: CONV_TH x CONV_TW)
         a += 1; b -= 1; c += 1; d -= 1;                    // a 3x3 convolution (zero padding is NOT the constant): one pixel in from every side
         omni_sp::MaskSkip& k = ks[1 + i];
         if (b < a || d < c) break;                         // nothing constant from here on
@@ -146,8 +147,8 @@ static int sp_plan_mask_skip(omni_sp* s) {
     if (s->conv_variant != 0 || s->precision == OMNI_PREC_F32) return OMNI_OK;
     { const char* e = getenv(split ? "OMNI_SP_MASK_SKIP_SPLIT" : "OMNI_SP_MASK_SKIP"); if (e && e[0] == '0') return OMNI_OK; }      // = 0: the dense pass (A/B, tests)
     sp_mask_skip_rects(s->H, s->W, split, s->mskip);
-    void** maps[5] = {&s->a1a, &s->a1b, &s->a2a, &s->a2b, &s->a3a};
-    for (int i = 0; i < 5; ++i) {
+    void** maps[6] = {&s->a1a, &s->a1b, &s->a2a, &s->a2b, &s->a3a, &s->a3b};
+    for (int i = 0; i < 6; ++i) {
         omni_sp::MaskSkip& k = s->mskip[i];
         k.map = maps[i];
         if (k.oc == 0) continue;
@@ -374,7 +375,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (use_skip && !s->mask_skip_ready && (rc = sp_calibrate_mask_skip(s, stride))) return rc;
     auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
     auto skip_of = [&](int l, ConvArgs& a) {
-        const int i = l == L1B ? 1 : l == L2A ? 2 : l == L2B ? 3 : l == L3A ? 4 : -1;
+        const int i = l == L1B ? 1 : l == L2A ? 2 : l == L2B ? 3 : l == L3A ? 4 : l == L3B ? 5 : -1;
         if (use_skip && i >= 0) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
     };
     auto conv = [&](int l, const void* in, void* out, const float* bias, int h, int w, int cin, int cout, int ks, bool relu,
@@ -719,8 +720,8 @@ double omni_sp_stage_flops(const omni_sp* s, int stage) {
 }
 
 int omni_sp_mask_skip_plan(int width, int height, int precision, int layer, int* rect, double* frac) {
-    OMNI_REQUIRE(width > 0 && height > 0 && layer >= 0 && layer < 5, OMNI_ERR_INVALID, "bad argument");
-    omni_sp::MaskSkip ks[5];
+    OMNI_REQUIRE(width > 0 && height > 0 && layer >= 0 && layer < 6, OMNI_ERR_INVALID, "bad argument");
+    omni_sp::MaskSkip ks[6];
     if (precision != OMNI_PREC_F32) omni::sp_mask_skip_rects(height, width, precision == OMNI_PREC_SPLIT, ks);
     if (rect) { rect[0] = ks[layer].ty0; rect[1] = ks[layer].ty1; rect[2] = ks[layer].tx0; rect[3] = ks[layer].tx1; }
     if (frac) *frac = ks[layer].ty1 > ks[layer].ty0 ? ks[layer].frac : 0.0;
@@ -729,7 +730,7 @@ int omni_sp_mask_skip_plan(int width, int height, int precision, int layer, int*
 
 double omni_sp_stage_tiles_left_out(const omni_sp* s, int stage) {
     if (!s || !s->mask_skip) return 0.0;
-    const int i = stage == ST_CONV1A ? 0 : stage == ST_CONV1B ? 1 : stage == ST_CONV2A ? 2 : stage == ST_CONV2B ? 3 : stage == ST_CONV3A ? 4 : -1;
+    const int i = stage == ST_CONV1A ? 0 : stage == ST_CONV1B ? 1 : stage == ST_CONV2A ? 2 : stage == ST_CONV2B ? 3 : stage == ST_CONV3A ? 4 : stage == ST_CONV3B ? 5 : -1;
     return i < 0 ? 0.0 : s->mskip[i].frac;
 }
 
