@@ -1,7 +1,7 @@
 """The row-sharded database with the collective INSIDE the library (csrc/shard.hip: ncclAllGather on device buffers, RCCL resolved by
 dlopen, no torch): results must equal the unsharded exact-IP oracle with the same add-before-query order (loop_detector.cpp:89-98).
   * world 1: a real RCCL communicator of one rank in this process (init, two all-gathers per exchange, merge);
-  * world 2 / 4 on ONE GPU: RCCL itself refuses several ranks per device, so OMNI_RCCL_LIB points shard.hip's dlopen at tests/stub_rccl (an
+  * world 2 / 4 / 8 on ONE GPU: RCCL itself refuses several ranks per device, so OMNI_RCCL_LIB points shard.hip's dlopen at tests/stub_rccl (an
     all-gather through a mapped file + hipMemcpy, TEST INFRASTRUCTURE): every line of omni_shard_step_batch_dev / omni_shard_search / the sharded
     key-frame pipeline runs with world > 1 -- global id numbering, owned-row pick, per-query prefix limits across ranks, the merge over W
     lists -- before an 8-GPU node ever sees them;
@@ -80,7 +80,7 @@ def check_against_oracle(world, res, logs):
         assert np.array_equal(z["Is"], Is) and np.allclose(z["Ds"], Ds, rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_multi_rank_exchange_on_one_gpu_equals_unsharded_oracle(world, tmp_path):
     """omni_shard_* with world ranks as world processes on GPU 0 (stub collective): ids, scores, add-before-query order, ntotal == the oracle."""
     res, logs = run_world(world, tmp_path, seed=100 + world, env=stub_env())
