@@ -232,7 +232,7 @@ int         omni_index_search_batch_prefix_dev(omni_index* idx, int nq, const fl
                                                const int64_t* n_limits, float* D_dev, int64_t* I_dev);
 /* row sharding across GPUs: this handle holds rows g with g % world == rank at local slot g / world;
  * search then reports GLOBAL ids (local * world + rank).  Default rank 0, world 1. */
-int         omni_index_set_shard(omni_index* idx, int rank, int world);
+int         omni_index_set_shard(omni_index* idx, int rank, int world);   /* (an fp32 shard gives up its fp16 mirror: its batched searches must not wait on the host) */
 /* host-side merge of per-shard top-k lists (after the all-gather): lists [n_lists][nq][k_each] -> [nq][k_out],
  * same ordering rule (score desc, id asc), entries with I < 0 ignored */
 int         omni_topk_merge(int n_lists, int nq, int k_each, const float* D_lists, const int64_t* I_lists,

@@ -39,7 +39,8 @@ struct ConvArgs {
     const void* zero_page = nullptr;   // omni_ctx::zero_page (the persistent LDS-DMA kernels need it; null = generic kernels only)
     float split_inv = 0.f; // OMNI_PREC_SPLIT: 2^-k of conv_pack_weights_split (the epilogue's factor)
     int variant = 0;       // test hook (OMNI_CONV_V1): 0 = best kernel per layer, 1 = generic kernel everywhere, 2 = v2 persistent kernel,
-                           // 3 = v3 ping-pong kernel without the conv1a fusion    // Tile rectangle [skip_ty0, skip_ty1) x [skip_tx0, skip_tx1) of the CONV_TH x CONV_TW output-tile grid of every image whose results ALREADY
+                           // 3 = v3 ping-pong kernel without the conv1a fusion
+    // Tile rectangle [skip_ty0, skip_ty1) x [skip_tx0, skip_tx1) of the CONV_TH x CONV_TW output-tile grid of every image whose results ALREADY
     // stand in `out` (the caller filled them: see superpoint.hip, "constant region of the fisheye mask"): the persistent cin = 64 fp16 kernel
     // leaves those tiles out of its tile walk; every other kernel ignores the hint and recomputes them (same values).  Empty = nothing to skip.
     int skip_ty0 = 0, skip_ty1 = 0, skip_tx0 = 0, skip_tx1 = 0;

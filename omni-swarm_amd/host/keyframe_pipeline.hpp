@@ -95,6 +95,10 @@ public:
             det_.compute_loop = [this](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) {
                 ++geometry_calls_;
                 if (a.drone_id == cfg_.self_id && b.drone_id == cfg_.self_id) {      // verdict not needed by the detector: deferred to collect_geometry()
+                    // CONTRACT: for a candidate between two frames of the self drone the callback returns false HERE, whatever the verdict will be:
+                    // LoopCandidate::loop of the detector's record stays false and inter_drone_loop_count[{self, self}] is not counted by the detector (the
+                    // reference counts it, loop_detector.cpp:826-827, and never reads it: init mode only exists for OTHER drones, :66-72).  The verdict is
+                    // the edge: edges() / geometry_stats() hold it once the micro-batch's tasks are drained, and drain_geometry() adds the count then.
                     deferred_.push_back({&a, &b, da, db, im});
                     return false;
                 }
@@ -117,9 +121,12 @@ public:
     void drain_geometry() {
         while (!geo_inflight_.empty()) {
             GeoBatch& gb = geo_inflight_.front();
-            for (auto& f : gb.futs) {
-                std::pair<bool, LoopEdge> r = f.get();
-                if (r.first) { geo_.number_edge(r.second); edges_.push_back(r.second); }
+            for (size_t fi = 0; fi < gb.futs.size(); ++fi) {
+                std::pair<bool, LoopEdge> r = gb.futs[fi].get();
+                if (r.first) {
+                    geo_.number_edge(r.second); edges_.push_back(r.second);
+                    if (fi < gb.self_self.size() && gb.self_self[fi]) det_.inter_drone_loop_count[{cfg_.self_id, cfg_.self_id}] += 2;      // what the detector would have counted (:826-827, both orders)
+                }
             }
             if (gb.timed) latencies_ms_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - gb.t_enqueue).count());
             geo_inflight_.pop_front();
@@ -131,8 +138,8 @@ public:
         if (deferred_.empty()) return false;
         struct Prepared { size_t first = 0, count = 0; };
         std::vector<BFMatcherL2X::Pair> pairs;
+        std::vector<int> pair_dim;                                   // descriptor length of every pair (one match_multi call per distinct length)
         std::vector<Prepared> prep(deferred_.size());
-        int pdim = 0;
         const int nd = geo_.MAX_DIRS;
         for (size_t ci = 0; ci < deferred_.size(); ++ci) {
             const FisheyeFrameDescriptor &a = *deferred_[ci].a, &b = *deferred_[ci].b;
@@ -145,15 +152,26 @@ public:
                     const int nx = (int)x.landmarks_2d.size(), ny = (int)y.landmarks_2d.size();
                     if (nx > 0 && ny > 0 && x.feature_descriptor.size() % nx == 0) {
                         const int dim = (int)(x.feature_descriptor.size() / nx);
-                        if (pdim == 0) pdim = dim;
-                        if (dim == pdim && (int)y.feature_descriptor.size() == ny * dim) pairs.push_back({x.feature_descriptor.data(), nx, y.feature_descriptor.data(), ny});
+                        if (dim > 0 && (int)y.feature_descriptor.size() == ny * dim) { pairs.push_back({x.feature_descriptor.data(), nx, y.feature_descriptor.data(), ny}); pair_dim.push_back(dim); }
                     }
                 }
             }
             prep[ci].count = pairs.size() - prep[ci].first;
         }
-        std::vector<std::vector<DMatch>> outs;
-        if (!pairs.empty()) bf_.match_multi(pairs, pdim, outs);
+        std::vector<std::vector<DMatch>> outs(pairs.size());
+        {
+            std::vector<char> done(pairs.size(), 0);
+            for (size_t p0 = 0; p0 < pairs.size(); ++p0) {
+                if (done[p0]) continue;
+                std::vector<BFMatcherL2X::Pair> sub;
+                std::vector<size_t> where;
+                for (size_t p = p0; p < pairs.size(); ++p)
+                    if (!done[p] && pair_dim[p] == pair_dim[p0]) { sub.push_back(pairs[p]); where.push_back(p); done[p] = 1; }
+                std::vector<std::vector<DMatch>> so;
+                bf_.match_multi(sub, pair_dim[p0], so);
+                for (size_t j = 0; j < where.size(); ++j) outs[where[j]] = std::move(so[j]);
+            }
+        }
         using Result = std::pair<bool, LoopEdge>;
         geo_inflight_.emplace_back();
         GeoBatch& gb = geo_inflight_.back();
@@ -163,19 +181,23 @@ public:
         for (size_t ci = 0; ci < deferred_.size(); ++ci) {
             auto mine_p = std::make_shared<std::vector<BFMatcherL2X::Pair>>(pairs.begin() + prep[ci].first, pairs.begin() + prep[ci].first + prep[ci].count);
             auto mine_o = std::make_shared<std::vector<std::vector<DMatch>>>();
+            auto mine_d = std::make_shared<std::vector<int>>(pair_dim.begin() + prep[ci].first, pair_dim.begin() + prep[ci].first + prep[ci].count);
             for (size_t j = 0; j < prep[ci].count; ++j) mine_o->push_back(std::move(outs[prep[ci].first + j]));
             const Deferred c = deferred_[ci];
-            auto work = [g0 = geo_, mine_p, mine_o, pdim, c]() -> Result {      // g0: the parameters, copied on this thread
+            auto work = [g0 = geo_, mine_p, mine_o, mine_d, c]() -> Result {    // g0: the parameters, copied on this thread
                 LoopGeometry g = g0;
                 g.match = [&](const float* q, int nq, const float* t, int nt, int dim, std::vector<DMatch>& out) {
                     for (size_t p = 0; p < mine_p->size(); ++p)
-                        if ((*mine_p)[p].query == q && (*mine_p)[p].train == t && (*mine_p)[p].nq == nq && (*mine_p)[p].nt == nt && pdim == dim) { out = (*mine_o)[p]; return; }
-                    out.clear();                                        // a pair the rule above did not list has no usable descriptors: no matches
+                        if ((*mine_p)[p].query == q && (*mine_p)[p].train == t && (*mine_p)[p].nq == nq && (*mine_p)[p].nt == nt && (*mine_d)[p] == dim) { out = (*mine_o)[p]; return; }
+                    // every pair compute_correspond_features can ask for was listed above (the same rule, whatever its descriptor length); a pair that
+                    // was not has malformed descriptors (a length that is not a multiple of its key-point count): no matches
+                    out.clear();
                 };
                 Result r;
                 r.first = g.compute_loop_core(*c.a, *c.b, c.da, c.db, r.second, c.im);
                 return r;
             };
+            gb.self_self.push_back(c.a->drone_id == cfg_.self_id && c.b->drone_id == cfg_.self_id);
             if (pool_) futs.push_back(pool_->submit(work));
             else { std::promise<Result> pr; pr.set_value(work()); futs.push_back(pr.get_future()); }
         }
@@ -372,8 +394,15 @@ private:
             }
             finish_frame_descriptor(f, stamp, kf_id, pose, cfg_.self_id);             // on_flattened_images (loop_cam.cpp:178-217)
         }
-        for (auto& t : stereo_tasks_) t.get();
-        stereo_tasks_.clear();
+        {   // join the triangulation tasks; if one throws, the others are still joined (they reference this micro-batch's frames) and the list is
+            // emptied before the exception leaves: the next finish() must not meet futures that were already consumed
+            std::exception_ptr first;
+            for (auto& t : stereo_tasks_) {
+                try { t.get(); } catch (...) { if (!first) first = std::current_exception(); }
+            }
+            stereo_tasks_.clear();
+            if (first) std::rethrow_exception(first);
+        }
         int hits = 0, fi = 0;
         for (auto& c : det_.on_images_recv_batch(std::move(frames_), lane.rows_dev)) {
             if (c.found) { ++hits; candidates_.push_back({first_id + fi, c.old_msg_id, c.direction_new, c.direction_old}); }
@@ -398,6 +427,7 @@ private:
     std::vector<double> latencies_ms_;
     struct GeoBatch {                           // the geometry tasks of one micro-batch, in candidate order
         std::vector<std::future<std::pair<bool, LoopEdge>>> futs;
+        std::vector<char> self_self;            // per task: a candidate between two frames of the self drone (the detector did not get its verdict)
         std::vector<FisheyeFrameDescriptor> held;
         std::chrono::steady_clock::time_point t_enqueue;
         bool timed = false;

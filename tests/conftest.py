@@ -13,7 +13,9 @@ omni_loader.load()          # registers omni-swarm_amd/ as `omni_swarm_amd` so t
 
 # fp32 shards answer batched searches through their fp16 mirror only from 32768 rows on (below, the exact kernels are as fast); the tests want
 # that path -- mirror pass, exact re-scoring, certificate, fallback -- on their small databases too (read once by libomni_hip.so)
-os.environ.setdefault("OMNI_INDEX_MIRROR_MIN_ROWS", "0")
+# (OMNI_TEST_PRODUCTION_DEFAULTS=1 leaves the production threshold in place: tests/test_gpu_index.py re-runs its batched-search cases that way in a subprocess)
+if os.environ.get("OMNI_TEST_PRODUCTION_DEFAULTS") != "1":
+    os.environ.setdefault("OMNI_INDEX_MIRROR_MIN_ROWS", "0")
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

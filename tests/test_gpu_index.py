@@ -1,5 +1,7 @@
 """GPU parity: omni_index_* (HIP) vs the exact-IP oracle (faiss::IndexFlatIP semantics, loop_detector.cpp:166,213).
 Bar: ids bit-exact, scores within 1e-5 relative (fp32 dot products in a different association order)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -332,9 +334,28 @@ def test_batch_prefix_search_equals_one_prefix_search_per_query(omni, ctx, stora
         assert np.array_equal(I[j], Ir[0]) and np.allclose(D[j], Dr[0], rtol=1e-5, atol=2e-6)
     if storage == "f32" and nq >= 4:
         served, fallbacks = idx.cert_stats()
-        assert served == nq and fallbacks <= 1, (served, fallbacks)        # random rows: the certificate holds (the empty prefix is trivially exact)
+        if os.environ.get("OMNI_INDEX_MIRROR_MIN_ROWS") == "0":
+            assert served == nq and fallbacks <= 1, (served, fallbacks)    # random rows: the certificate holds (the empty prefix is trivially exact)
+        else:
+            assert served == 0                                             # production threshold: 5 003 rows stay on the exact many-query scan
     for p in (rows_dev, buf, one):
         ctx.free(p)
+
+
+def test_batched_fp32_search_with_the_production_mirror_threshold():
+    """The suite sets OMNI_INDEX_MIRROR_MIN_ROWS=0 so that its small databases go through the fp16 mirror + certificate; what ships answers a batch over
+    fewer than 32 768 fp32 rows with the exact many-query scan (ip_scan_rows_kernel), and with OMNI_INDEX_MIRROR=0 every batch.  The same cases, in
+    subprocesses with those settings (the library reads them once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({}, {"OMNI_INDEX_MIRROR": "0"}):
+        env = {k: v for k, v in os.environ.items() if k != "OMNI_INDEX_MIRROR_MIN_ROWS"}
+        env.update(extra, OMNI_TEST_PRODUCTION_DEFAULTS="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_index.py"), "-m", "gpu", "-q", "-x", "-k",
+                            "batch_prefix_search and f32"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-1000:])
+        assert "4 passed" in r.stdout, r.stdout[-500:]
 
 
 def test_fp32_batch_search_certificate_falls_back_to_the_exact_scan_on_near_ties(omni, ctx, tmp_path):
