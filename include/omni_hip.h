@@ -316,9 +316,15 @@ typedef struct omni_cam_result {      /* pointers into the handle's pinned host 
     const int*   match_down;  /* [n_dirs][max_num]  key-point index in the down image (cv::DMatch::trainIdx) */
     const float* match_dist;  /* [n_dirs][max_num] */
     const int*   n_matches;   /* [n_dirs] */
+    int n_images;             /* 2*n_dirs (omni_cam_create) or n_dirs (omni_cam_create_mono): the leading dimension of kps_xy / n_kps / desc / scores */
 } omni_cam_result;
 omni_cam* omni_cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_dirs, int max_num,
                           int global_dim, int bf_mode);
+/* CameraConfig::PINHOLE_DEPTH (loop_cam.cpp:190-194; generate_gray_depth_image_descriptor :231-339; launch/realsense.launch): ONE camera per
+ * image -- SuperPoint and MobileNetVLAD on each of the n_images images, no up/down match (n_matches = 0, the match arrays unused), the arrays
+ * of omni_cam_result sized [n_images].  sp with max_batch >= n_images, vlad with max_batch >= n_images.  The landmarks come from the depth
+ * image on the host (host/loop_geometry.hpp fill_depth_landmarks); pass fisheye_mask = 0 to the enqueue calls (:536 masks STEREO_FISHEYE only). */
+omni_cam* omni_cam_create_mono(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_images, int max_num, int global_dim);
 void      omni_cam_destroy(omni_cam* cam);
 int       omni_cam_enqueue_dev(omni_cam* cam, const uint8_t* gray_dev, int stride, int fisheye_mask);   /* no host sync */
 /* same with the images in HOST memory, image i at gray_host + i*stride*height (the reference hands every engine call a host cv::Mat

@@ -34,7 +34,7 @@ SYMBOLS = [
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
-    "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
+    "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_create_mono", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
     "omni_shard_unique_id", "omni_shard_library_path", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait",
     "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
@@ -57,7 +57,7 @@ class _CamResult(C.Structure):
     _fields_ = [("n_dirs", C.c_int), ("max_num", C.c_int), ("desc_dim", C.c_int), ("global_dim", C.c_int),
                 ("kps_xy", C.POINTER(C.c_float)), ("n_kps", C.POINTER(C.c_int)), ("desc", C.POINTER(C.c_float)),
                 ("scores", C.POINTER(C.c_float)), ("global_desc", C.POINTER(C.c_float)), ("match_up", C.POINTER(C.c_int)),
-                ("match_down", C.POINTER(C.c_int)), ("match_dist", C.POINTER(C.c_float)), ("n_matches", C.POINTER(C.c_int))]
+                ("match_down", C.POINTER(C.c_int)), ("match_dist", C.POINTER(C.c_float)), ("n_matches", C.POINTER(C.c_int)), ("n_images", C.c_int)]
 
 
 class _VladWeights(C.Structure):
@@ -151,6 +151,7 @@ def lib():
     sig("omni_bf_match_batched_dev", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, C.c_int64,
                                                _vp, _vp, _vp, _vp, _vp])
     sig("omni_cam_create", _vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
+    sig("omni_cam_create_mono", _vp, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int])
     sig("omni_cam_destroy", None, [_vp])
     sig("omni_cam_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int])
     sig("omni_cam_enqueue_host", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
@@ -747,9 +748,13 @@ class Cam:
     """omni_cam: one key frame's CNN + matching work as a single asynchronous unit (LoopCam::on_flattened_images,
     loop_cam.cpp:178-229).  wait() returns numpy VIEWS of the handle's pinned host block (valid until the next enqueue)."""
 
-    def __init__(self, sp: SuperPoint, vlad, n_dirs: int, global_dim: int, bf_mode: int = BF_OPENCV):
-        self.sp, self.vlad, self.n = sp, vlad, n_dirs
-        self.h = lib().omni_cam_create(sp.ctx.h, sp.h, vlad.ctx.h, vlad.h, n_dirs, sp.max_num, global_dim, bf_mode)
+    def __init__(self, sp: SuperPoint, vlad, n_dirs: int, global_dim: int, bf_mode: int = BF_OPENCV, mono: bool = False):
+        """mono: CameraConfig::PINHOLE_DEPTH -- one camera per image (omni_cam_create_mono): n_dirs images, no up/down match"""
+        self.sp, self.vlad, self.n, self.cams = sp, vlad, n_dirs, (1 if mono else 2)
+        if mono:
+            self.h = lib().omni_cam_create_mono(sp.ctx.h, sp.h, vlad.ctx.h, vlad.h, n_dirs, sp.max_num, global_dim)
+        else:
+            self.h = lib().omni_cam_create(sp.ctx.h, sp.h, vlad.ctx.h, vlad.h, n_dirs, sp.max_num, global_dim, bf_mode)
         if not self.h:
             raise OmniError(f"omni_cam_create failed: {lib().omni_last_error().decode()}")
         sp.ctx._adopt(self)
@@ -771,16 +776,16 @@ class Cam:
         _check(lib().omni_cam_enqueue_dev(self.h, gray_dev, stride, int(fisheye_mask)))
 
     def enqueue_host(self, gray_host: np.ndarray, fisheye_mask: bool = True):
-        """gray_host [2*n_dirs][H][W] u8, ideally pinned (Context.host_alloc); must stay untouched until wait() returns."""
-        assert gray_host.dtype == np.uint8 and gray_host.ndim == 3 and gray_host.shape[0] == 2 * self.n and gray_host.flags.c_contiguous
+        """gray_host [2*n_dirs][H][W] u8 ([n_dirs] for a mono handle), ideally pinned (Context.host_alloc); must stay untouched until wait() returns."""
+        assert gray_host.dtype == np.uint8 and gray_host.ndim == 3 and gray_host.shape[0] == self.cams * self.n and gray_host.flags.c_contiguous
         _check(lib().omni_cam_enqueue_host(self.h, gray_host.ctypes.data_as(_vp), gray_host.shape[2], gray_host.shape[2], gray_host.shape[1],
                                            int(fisheye_mask)))
 
     def wait(self) -> dict:
         r = self._res
         _check(lib().omni_cam_wait(self.h, C.byref(r)))
-        n, m, d, g = r.n_dirs, r.max_num, r.desc_dim, r.global_dim
+        n, m, d, g, ni = r.n_dirs, r.max_num, r.desc_dim, r.global_dim, r.n_images
         A = np.ctypeslib.as_array
-        return {"kps_xy": A(r.kps_xy, (2 * n, m, 2)), "n_kps": A(r.n_kps, (2 * n,)), "desc": A(r.desc, (2 * n, m, d)),
-                "scores": A(r.scores, (2 * n, m)), "global_desc": A(r.global_desc, (n, g)), "match_up": A(r.match_up, (n, m)),
+        return {"kps_xy": A(r.kps_xy, (ni, m, 2)), "n_kps": A(r.n_kps, (ni,)), "desc": A(r.desc, (ni, m, d)),
+                "scores": A(r.scores, (ni, m)), "global_desc": A(r.global_desc, (n, g)), "match_up": A(r.match_up, (n, m)),
                 "match_down": A(r.match_down, (n, m)), "match_dist": A(r.match_dist, (n, m)), "n_matches": A(r.n_matches, (n,))}

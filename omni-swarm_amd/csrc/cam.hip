@@ -14,7 +14,8 @@ struct omni_cam {
     omni_sp* sp = nullptr;
     omni_vlad* vlad = nullptr;
     omni_ctx *c1 = nullptr, *c2 = nullptr;
-    int n = 0, M = 0, D = 0, out_dim = 0, bf_mode = 0, W = 0, H = 0;   // W x H: the size the SuperPoint handle (and MobileNetVLAD) was created for
+    int n = 0, cams = 2, M = 0, D = 0, out_dim = 0, bf_mode = 0, W = 0, H = 0;   // cams: 2 = up + down camera per direction, 1 = one camera (no stereo match)
+      // W x H: the size the SuperPoint handle (and MobileNetVLAD) was created for
     int *d_qidx = nullptr, *d_tidx = nullptr, *d_nm = nullptr;
     float* d_dist = nullptr;
     const float *kps_dev = nullptr, *desc_dev = nullptr, *sc_dev = nullptr, *g_dev = nullptr;
@@ -30,23 +31,36 @@ struct omni_cam {
 
 extern "C" {
 
+static omni_cam* cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_dirs, int cams, int max_num, int global_dim, int bf_mode);
+
 omni_cam* omni_cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_dirs, int max_num, int global_dim,
                           int bf_mode) {
+    return cam_create(sp_ctx, sp, vlad_ctx, vlad, n_dirs, 2, max_num, global_dim, bf_mode);
+}
+
+// CameraConfig::PINHOLE_DEPTH (loop_cam.cpp:190-194, generate_gray_depth_image_descriptor :231-339): ONE camera per image, both networks on every
+// image, no up/down match; the landmarks come from the depth image on the host (loop_geometry.hpp fill_depth_landmarks)
+omni_cam* omni_cam_create_mono(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_images, int max_num, int global_dim) {
+    return cam_create(sp_ctx, sp, vlad_ctx, vlad, n_images, 1, max_num, global_dim, 0);
+}
+
+static omni_cam* cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, omni_vlad* vlad, int n_dirs, int cams, int max_num, int global_dim,
+                            int bf_mode) {
     if (!sp_ctx || !sp || !vlad_ctx || !vlad) { omni::set_error("null handle"); return nullptr; }
     if (n_dirs < 1 || n_dirs > 64 || max_num < 1 || max_num > 1024 || global_dim < 1) { omni::set_error("bad n_dirs/max_num/global_dim"); return nullptr; }
     if (sp_ctx->device != vlad_ctx->device) { omni::set_error("SuperPoint and MobileNetVLAD contexts are on different devices"); return nullptr; }
     (void)hipSetDevice(sp_ctx->device);
     omni_cam* c = new omni_cam();
-    c->sp = sp; c->vlad = vlad; c->c1 = sp_ctx; c->c2 = vlad_ctx; c->n = n_dirs; c->M = max_num; c->D = omni_sp_desc_dim(sp);
+    c->sp = sp; c->vlad = vlad; c->c1 = sp_ctx; c->c2 = vlad_ctx; c->n = n_dirs; c->cams = cams; c->M = max_num; c->D = omni_sp_desc_dim(sp);
     c->out_dim = global_dim; c->bf_mode = bf_mode;
     (void)omni_sp_image_size(sp, &c->W, &c->H);
-    const size_t n = n_dirs, M = max_num, D = c->D;
+    const size_t n = n_dirs, M = max_num, D = c->D, ni = (size_t)cams * n;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
-    c->off_kps = o; o += al(2 * n * M * 2 * 4);
-    c->off_n = o;   o += al(2 * n * 4);
-    c->off_desc = o; o += al(2 * n * M * D * 4);
-    c->off_sc = o;  o += al(2 * n * M * 4);
+    c->off_kps = o; o += al(ni * M * 2 * 4);
+    c->off_n = o;   o += al(ni * 4);
+    c->off_desc = o; o += al(ni * M * D * 4);
+    c->off_sc = o;  o += al(ni * M * 4);
     c->off_g = o;   o += al(n * (size_t)global_dim * 4);
     c->off_q = o;   o += al(n * M * 4);
     c->off_t = o;   o += al(n * M * 4);
@@ -92,11 +106,11 @@ int omni_cam_enqueue_dev(omni_cam* c, const uint8_t* gray_dev, int stride, int f
 int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask) {
     OMNI_REQUIRE(c && gray_host, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(width > 0 && height > 0 && stride >= width, OMNI_ERR_INVALID, "bad image geometry %dx%d stride %d", width, height, stride);
-    // the networks read 2n images of THEIR size from the staging buffer: any other size would run them past its end
+    // the networks read cams * n images of THEIR size from the staging buffer: any other size would run them past its end
     OMNI_REQUIRE(width == c->W && height == c->H, OMNI_ERR_INVALID, "omni_cam_enqueue_host: images are %dx%d but the networks were created for %dx%d", width, height, c->W, c->H);
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->c1->device);
-    const size_t need = (size_t)2 * c->n * width * height;
+    const size_t need = (size_t)c->cams * c->n * width * height;
     if (c->d_gray_bytes < need) {
         (void)hipStreamSynchronize(c->c1->stream);
         (void)hipStreamSynchronize(c->c2->stream);
@@ -108,7 +122,7 @@ int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int
     // the reference uploads one image per engine call and blocks (tensorrt_generic.cpp:58-75); here the key frame's 2n images go up as one
     // asynchronous copy on the SuperPoint stream (pinned source: the copy engine runs it next to the other pipelines' kernels) and the
     // MobileNetVLAD stream waits for it on the device
-    OMNI_HIP_TRY(hipMemcpy2DAsync(c->d_gray, (size_t)width, gray_host, (size_t)stride, (size_t)width, (size_t)2 * c->n * height,
+    OMNI_HIP_TRY(hipMemcpy2DAsync(c->d_gray, (size_t)width, gray_host, (size_t)stride, (size_t)width, (size_t)c->cams * c->n * height,
                                   hipMemcpyHostToDevice, c->c1->stream));
     OMNI_HIP_TRY(hipEventRecord(c->e_up, c->c1->stream));
     OMNI_HIP_TRY(hipStreamWaitEvent(c->c2->stream, c->e_up, 0));
@@ -116,25 +130,28 @@ int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int
 }
 
 static int cam_enqueue_locked(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask) {
-    const int n = c->n, M = c->M, D = c->D;
+    const int n = c->n, M = c->M, D = c->D, ni = c->cams * c->n;
     int rc;
     // images 0..n-1 = "up" (main) camera of each direction, n..2n-1 = "down" camera (loop_cam.cpp:350-351)
-    if ((rc = omni_sp_enqueue_dev(c->sp, gray_dev, stride, 2 * n, fisheye_mask))) return rc;
+    if ((rc = omni_sp_enqueue_dev(c->sp, gray_dev, stride, ni, fisheye_mask))) return rc;
     if ((rc = omni_vlad_enqueue_dev(c->vlad, gray_dev, stride, n, fisheye_mask))) return rc;       // main camera only (:553-556)
     // match_HFNet_local_features: up = query, down = train (:147-150); pair p = direction p
-    if ((rc = omni_bf_match_batched_dev(c->c1, n, M, D, c->bf_mode, c->desc_dev, (int64_t)M * D, c->n_dev,
+    if (c->cams == 2 &&
+        (rc = omni_bf_match_batched_dev(c->c1, n, M, D, c->bf_mode, c->desc_dev, (int64_t)M * D, c->n_dev,
                                         c->desc_dev + (size_t)n * M * D, (int64_t)M * D, c->n_dev + n, c->d_qidx, c->d_tidx, c->d_dist, c->d_nm)))
         return rc;
     hipStream_t s1 = c->c1->stream, s2 = c->c2->stream;
     char* h = c->host;
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_kps, c->kps_dev, (size_t)2 * n * M * 2 * 4, hipMemcpyDeviceToHost, s1));
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_n, c->n_dev, (size_t)2 * n * 4, hipMemcpyDeviceToHost, s1));
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_desc, c->desc_dev, (size_t)2 * n * M * D * 4, hipMemcpyDeviceToHost, s1));
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_sc, c->sc_dev, (size_t)2 * n * M * 4, hipMemcpyDeviceToHost, s1));
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_q, c->d_qidx, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_t, c->d_tidx, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_d, c->d_dist, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
-    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_nm, c->d_nm, (size_t)n * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_kps, c->kps_dev, (size_t)ni * M * 2 * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_n, c->n_dev, (size_t)ni * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_desc, c->desc_dev, (size_t)ni * M * D * 4, hipMemcpyDeviceToHost, s1));
+    OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_sc, c->sc_dev, (size_t)ni * M * 4, hipMemcpyDeviceToHost, s1));
+    if (c->cams == 2) {                                                       // (one camera: n_matches stays 0, as the block was zeroed at creation)
+        OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_q, c->d_qidx, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
+        OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_t, c->d_tidx, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
+        OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_d, c->d_dist, (size_t)n * M * 4, hipMemcpyDeviceToHost, s1));
+        OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_nm, c->d_nm, (size_t)n * 4, hipMemcpyDeviceToHost, s1));
+    }
     OMNI_HIP_TRY(hipEventRecord(c->e1, s1));
     OMNI_HIP_TRY(hipMemcpyAsync(h + c->off_g, c->g_dev, (size_t)n * c->out_dim * 4, hipMemcpyDeviceToHost, s2));
     OMNI_HIP_TRY(hipEventRecord(c->e2, s2));
@@ -151,7 +168,7 @@ int omni_cam_wait(omni_cam* c, omni_cam_result* out) {
     OMNI_HIP_TRY(hipEventSynchronize(c->e2));
     c->pending = false;
     const char* h = c->host;
-    out->n_dirs = c->n; out->max_num = c->M; out->desc_dim = c->D; out->global_dim = c->out_dim;
+    out->n_dirs = c->n; out->max_num = c->M; out->desc_dim = c->D; out->global_dim = c->out_dim; out->n_images = c->cams * c->n;
     out->kps_xy = reinterpret_cast<const float*>(h + c->off_kps);
     out->n_kps = reinterpret_cast<const int*>(h + c->off_n);
     out->desc = reinterpret_cast<const float*>(h + c->off_desc);

@@ -35,6 +35,31 @@ omni_pipeline* omni_pipeline_create(int device, const char* sp_weights, const ch
     } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
+// CameraConfig::PINHOLE_DEPTH (launch/realsense.launch; BASELINE.json configs[0]): one gray image + one depth image per key frame, pinhole model
+// fx fy cx cy, landmarks where depth_near < depth < depth_far (metres).  The other arguments as omni_pipeline_create; micro-batch s of run() is
+// [microbatch][height][width] u8; the depth images come in through omni_pipeline_set_depth.
+omni_pipeline* omni_pipeline_create_pinhole_depth(int device, const char* sp_weights, const char* pca_comp_csv, const char* pca_mean_csv, const char* vlad_weights,
+                                                  int width, int height, float thres, int max_num, int precision, int microbatch, int pipelines, int storage,
+                                                  int self_id, double inner_product_thres, double init_mode_product_thres, int match_index_dist, int min_loop_num,
+                                                  int min_direction_loop, int geometry, double fx, double fy, double cx, double cy, double depth_near,
+                                                  double depth_far, int accept_min_3d_pts) {
+    try {
+        omni::KeyframePipeline::Config c;
+        c.device = device; c.sp_weights = sp_weights; c.pca_comp = pca_comp_csv ? pca_comp_csv : ""; c.pca_mean = pca_mean_csv ? pca_mean_csv : "";
+        c.vlad_weights = vlad_weights; c.width = width; c.height = height; c.thres = thres; c.max_num = max_num; c.precision = precision;
+        c.microbatch = microbatch; c.pipelines = pipelines; c.storage = storage; c.self_id = self_id;
+        c.inner_product_thres = inner_product_thres; c.init_mode_product_thres = init_mode_product_thres; c.match_index_dist = match_index_dist;
+        c.min_loop_num = min_loop_num; c.min_direction_loop = min_direction_loop; c.geometry = geometry != 0;
+        c.camera_configuration = 2; c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy; c.depth_near = depth_near; c.depth_far = depth_far; c.accept_min_3d_pts = accept_min_3d_pts;
+        return new omni_pipeline{new omni::KeyframePipeline(c)};
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+// depth images (u16 millimetres, [n][height][width]) of key frames first_msg_id .. first_msg_id + n - 1; BORROWED until the run that uses them returns
+int omni_pipeline_set_depth(omni_pipeline* h, int64_t first_msg_id, int64_t n, const uint16_t* depth) {
+    try { h->p->set_depth(first_msg_id, depth, n); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 void omni_pipeline_destroy(omni_pipeline* h) {
     if (!h) return;
     delete h->p;

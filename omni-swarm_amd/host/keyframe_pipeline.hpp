@@ -72,11 +72,22 @@ public:
         bool geometry = false;
         double fx = 300, fy = 300, cx = 300, cy = 240, triangle_thres = 0.006, stereo_baseline = 0.10;
         int accept_min_3d_pts = 50;
+        // CameraConfig (loop_defines.h:111-116): STEREO_FISHEYE = 1 -- a key frame is 4 directions x (up, down) flattened views, the bottom quarter of
+        // every view blanked; PINHOLE_DEPTH = 2 (launch/realsense.launch, BASELINE.json configs[0]: 640 x 480) -- a key frame is ONE gray image, not
+        // blanked, plus its 16-bit depth image in millimetres (set_depth), MAX_DIRS = 1 (swarm_loop.cpp:279-280), the query image is direction 0
+        // (loop_detector.cpp:252-258) and the landmarks are read from the depth image (loop_cam.cpp:260-304)
+        int camera_configuration = 1;
+        double depth_near = 0.3, depth_far = 7.0;       // DEPTH_NEAR_THRES / DEPTH_FAR_THRES (swarm_loop.cpp:243-244)
+        bool mono() const { return camera_configuration == 2; }
+        int dirs() const { return mono() ? 1 : 4; }
     };
 
     explicit KeyframePipeline(const Config& c) : cfg_(c), index_ctx_(c.device), det_(index_ctx_, c.self_id, c.storage) {
         det_.INNER_PRODUCT_THRES = c.inner_product_thres; det_.INIT_MODE_PRODUCT_THRES = c.init_mode_product_thres;
         det_.MATCH_INDEX_DIST = c.match_index_dist; det_.MIN_LOOP_NUM = c.min_loop_num; det_.MIN_DIRECTION_LOOP = c.min_direction_loop;
+        if (c.camera_configuration != 1 && c.camera_configuration != 2) throw std::runtime_error("KeyframePipeline: camera_configuration must be 1 (STEREO_FISHEYE) or 2 (PINHOLE_DEPTH)");
+        det_.stereo_fisheye = !c.mono();
+        geo_.MAX_DIRS = c.dirs();
         for (int p = 0; p < c.pipelines; ++p) lanes_.push_back(std::make_unique<Lane>(c, c.microbatch));
         if (c.geometry) {
             geo_.self_id = c.self_id; geo_.MIN_LOOP_NUM = c.min_loop_num; geo_.MIN_DIRECTION_LOOP = c.min_direction_loop;
@@ -224,6 +235,13 @@ public:
     // extrinsics of the virtual pinhole views of the stacked fisheye pair: direction d looks along the body x axis rotated by 90 deg * d,
     // the up / down cameras sit +- baseline/2 along body z (camera axes: x right, y down, z forward)
     geom::Pose view_extrinsic(int direction, bool up) const {
+        if (cfg_.mono()) {                                  // the one forward-looking camera, at the body origin
+            geom::Mat3 R;
+            R.m[0][0] = 0;  R.m[0][1] = 0;  R.m[0][2] = 1;
+            R.m[1][0] = -1; R.m[1][1] = 0;  R.m[1][2] = 0;
+            R.m[2][0] = 0;  R.m[2][1] = -1; R.m[2][2] = 0;
+            return {{0, 0, 0}, geom::quat_from_R(R)};
+        }
         const double yaw = M_PI / 2 * direction, c = std::cos(yaw), s = std::sin(yaw);
         geom::Mat3 R;            // Rz(yaw) * [[0,0,1],[-1,0,0],[0,-1,0]]
         R.m[0][0] = s;  R.m[0][1] = 0;  R.m[0][2] = c;
@@ -233,6 +251,11 @@ public:
     }
 
     LoopDetectorCore& detector() { return det_; }
+
+    // PINHOLE_DEPTH: the depth images (u16 millimetres, height x width, rows packed) of key frames msg_id = first_msg_id .. first_msg_id + n - 1,
+    // image i at depth + i * width * height.  Borrowed: they must stay valid until the run() that consumes them returns.  A key frame without
+    // one gets no landmarks.
+    void set_depth(int64_t first_msg_id, const uint16_t* depth, int64_t n) { depth_base_ = first_msg_id; depth_ = depth; depth_n_ = n; }
 
     // N > 1 GPUs, one process per GPU: the database becomes one row-sharded index over all ranks (omni_shard_*, RCCL inside libomni_hip.so).
     // Collective: every rank attaches with rank 0's unique id.  Each micro-batch is then one exchange unit (two ncclAllGather) and a key
@@ -247,16 +270,17 @@ public:
     ~KeyframePipeline() { if (shard_) omni_shard_destroy(shard_); }
     int64_t db_rows() const { return shard_ ? omni_shard_ntotal(shard_) : det_.local_index.ntotal + det_.remote_index.ntotal; }
 
-    // bulk pre-load of the key-frame database: rows [n][4096], 4 consecutive rows = the 4 directions of one earlier key frame
+    // bulk pre-load of the key-frame database: rows [n][4096], dirs() consecutive rows = the directions of one earlier key frame
     void preload(const float* rows, int64_t n) {
         if (shard_) { check(omni_shard_preload_local(shard_, rows, n, n * world_), "omni_shard_preload_local"); return; }    // this rank's rows
         const int64_t base = det_.local_index.ntotal;
         for (int64_t s = 0; s < n; s += 4096) det_.local_index.add(std::min<int64_t>(4096, n - s), rows + s * 4096);
-        for (int64_t i = 0; i < n; ++i) { det_.imgid2fisheye[(int)(base + i)] = -((base + i) / 4) - 1; det_.imgid2dir[(int)(base + i)] = (int)((base + i) % 4); }
+        const int nd = cfg_.dirs();
+        for (int64_t i = 0; i < n; ++i) { det_.imgid2fisheye[(int)(base + i)] = -((base + i) / nd) - 1; det_.imgid2dir[(int)(base + i)] = (int)((base + i) % nd); }
     }
 
     // n_keyframes key frames through the whole hot path.  pool[e] = one micro-batch of images in (pinned) host memory,
-    // [up cameras of the MB frames (4 each) | down cameras of the MB frames], u8, rows packed; micro-batch s uses pool[(first_slot + s) %
+    // [up cameras of the MB frames (4 each) | down cameras of the MB frames] (PINHOLE_DEPTH: the MB gray images), u8, rows packed; micro-batch s uses pool[(first_slot + s) %
     // n_pool].  When n_keyframes is not a multiple of the micro-batch the last rem frames run as their own, smaller unit from `tail`
     // (same layout for rem frames): EXACTLY n_keyframes key frames are processed.  from_host: upload inside the loop
     // (omni_cam_enqueue_host); otherwise the pool entries are device pointers.  Returns the number of loop candidates found.
@@ -271,8 +295,8 @@ public:
             const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
             if (pend_lane_ == lane) check(omni_shard_rows_consumed(shard_), "omni_shard_rows_consumed");      // its row buffer is the exchange's input
             lane->t_enqueue = std::chrono::steady_clock::now();
-            if (from_host) lane->cam.enqueue_host(src, cfg_.width, true);
-            else lane->cam.enqueue_dev(src, cfg_.width, true);
+            if (from_host) lane->cam.enqueue_host(src, cfg_.width, !cfg_.mono());       // loop_cam.cpp:536: only STEREO_FISHEYE blanks rows
+            else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
             pending.emplace_back(lane, first_msg_id + (int64_t)s * MB);
             if (pending.size() >= lanes_.size()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         }
@@ -307,9 +331,9 @@ private:
     struct Lane {                                      // one micro-batch in flight: its own streams, networks and result block
         Lane(const Config& c, int mb_)
             : mb(mb_), sp_ctx(c.device), vlad_ctx(c.device),
-              sp(sp_ctx, c.sp_weights, c.pca_comp, c.pca_mean, c.width, c.height, c.thres, c.max_num, false, c.precision, 8 * mb_),
-              vlad(vlad_ctx, c.vlad_weights, c.width, c.height, false, 4 * mb_),
-              cam(sp_ctx, sp, vlad_ctx, vlad, 4 * mb_, c.max_num, c.width, c.height) {
+              sp(sp_ctx, c.sp_weights, c.pca_comp, c.pca_mean, c.width, c.height, c.thres, c.max_num, false, c.precision, (c.mono() ? 1 : 8) * mb_),
+              vlad(vlad_ctx, c.vlad_weights, c.width, c.height, false, c.dirs() * mb_),
+              cam(sp_ctx, sp, vlad_ctx, vlad, c.dirs() * mb_, c.max_num, c.width, c.height, c.mono()) {
             check(omni_vlad_dev_output(vlad.handle(), &rows_dev), "omni_vlad_dev_output");
         }
         void sync() { check(omni_ctx_sync(sp_ctx.get()), "sync"); check(omni_ctx_sync(vlad_ctx.get()), "sync"); }
@@ -331,7 +355,7 @@ private:
         check(omni_shard_step_wait(shard_, D_.data(), I_.data()), "omni_shard_step_wait");
         int hits = 0;
         for (int m = 0; m < mb; ++m) {
-            const int64_t nt = pend_base_ + (int64_t)(m + 1) * world_ * 4;          // ntotal as of this key frame's step
+            const int64_t nt = pend_base_ + (int64_t)(m + 1) * world_ * cfg_.dirs();          // ntotal as of this key frame's step
             for (int j = 0; j < k; ++j) {
                 const int64_t id = I_[(size_t)m * k + j];
                 if (id >= 0 && id <= nt - cfg_.match_index_dist && D_[(size_t)m * k + j] > cfg_.inner_product_thres) { ++hits; break; }
@@ -355,11 +379,11 @@ private:
             // collected when the NEXT micro-batch gets here (or at the end of run()): meanwhile the host enqueues the next CNN unit
             int hits = collect_exchange();
             const int k = LoopDetectorCore::SEARCH_NEAREST_NUM + cfg_.match_index_dist;
-            check(omni_shard_step_enqueue(shard_, lane.mb, 4, lane.rows_dev, 1, k), "omni_shard_step_enqueue");
+            check(omni_shard_step_enqueue(shard_, lane.mb, cfg_.dirs(), lane.rows_dev, cfg_.mono() ? 0 : 1, k), "omni_shard_step_enqueue");
             pend_lane_ = &lane; pend_mb_ = lane.mb; pend_base_ = omni_shard_ntotal(shard_);
             return hits;
         }
-        const int n = r.n_dirs, M = r.max_num, D = r.desc_dim;
+        const int n = r.n_dirs, M = r.max_num, D = r.desc_dim, nd = cfg_.dirs();
         frames_.resize(lane.mb);
         const int G = r.global_dim;
         for (int m = 0; m < lane.mb; ++m) {
@@ -368,14 +392,19 @@ private:
             const double stamp = (double)kf_id;
             const PoseMsg pose = (kf_id >= pose_base_ && kf_id < pose_base_ + (int64_t)poses_.size()) ? poses_[(size_t)(kf_id - pose_base_)] : PoseMsg{};
             f.prevent_adding_db = false;
-            f.images.resize(4);
-            for (int d = 0; d < 4; ++d) {
-                const int i = 4 * m + d;                                            // image i of the up cameras
+            f.images.resize(nd);
+            for (int d = 0; d < nd; ++d) {
+                const int i = nd * m + d;                                           // image i of the up cameras
                 ImageDescriptor& im = f.images[d];
                 // extractor_img_desc_deepnet (loop_cam.cpp:525-585) + the stamps of generate_stereo_image_descriptor (:362-374)
                 fill_image_descriptor(im, r.kps_xy + (size_t)i * M * 2, r.n_kps[i], r.desc + (size_t)i * M * D, D, r.global_desc + (size_t)i * G, G, lift64_);
                 stamp_image_descriptor(im, stamp, cfg_.self_id, to_msg(view_extrinsic(d, true)), pose, kf_id);
-                if (cfg_.geometry) {
+                if (cfg_.geometry && cfg_.mono()) {
+                    // generate_gray_depth_image_descriptor's landmarks (loop_cam.cpp:260-304): read from the depth image under each key point
+                    const bool have = depth_ && kf_id >= depth_base_ && kf_id < depth_base_ + depth_n_;
+                    if (have) fill_depth_landmarks(im, depth_ + (size_t)(kf_id - depth_base_) * cfg_.width * cfg_.height, cfg_.width, cfg_.width, cfg_.height, cfg_.depth_near,
+                                                   cfg_.depth_far, cfg_.accept_min_3d_pts, lift64_);
+                } else if (cfg_.geometry) {
                     // the stereo half of generate_stereo_image_descriptor (loop_cam.cpp:341-454): the down image of this direction, triangulation
                     // (one task per direction on the geometry pool: ~170 SVD triangulations each; joined before the frames reach the detector)
                     if (downs_.size() < (size_t)4 * lane.mb) downs_.resize((size_t)4 * lane.mb);
@@ -444,6 +473,8 @@ private:
     std::vector<Candidate> candidates_;
     std::vector<PoseMsg> poses_;
     int64_t pose_base_ = 0;
+    const uint16_t* depth_ = nullptr;           // PINHOLE_DEPTH: borrowed depth images (set_depth)
+    int64_t depth_base_ = 0, depth_n_ = 0;
     int geometry_calls_ = 0;
     std::vector<std::unique_ptr<Lane>> lanes_;
     std::map<int, std::unique_ptr<Lane>> tail_lanes_;

@@ -6,6 +6,7 @@
 //   LoopGeometry::compute_loop                               :627-836  the LoopEdge the back end consumes (visualisation left out)
 //   LoopGeometry::check_loop_odometry_consistency            :295-315  Mahalanobis gate against the ego-motion trajectory (pluggable source)
 //   fill_stereo_landmarks                                    loop_cam.cpp:397-444 on the messages of one direction
+//   fill_depth_landmarks                                     loop_cam.cpp:260-304 (PINHOLE_DEPTH: landmarks from the depth image)
 //   fill_image_descriptor / stamp_image_descriptor / finish_frame_descriptor   loop_cam.cpp:525-585, 362-374, 178-217: the messages themselves
 //
 // The descriptor matcher is a callback: omni::BFMatcherL2X (the HIP matcher, bit-identical to cv::BFMatcher's cross-check semantics) in the
@@ -90,6 +91,39 @@ inline int fill_stereo_landmarks(ImageDescriptor& up, ImageDescriptor& down, con
                                              n_matches, triangle_thres, l3u, fu, l3d, fd);
     for (size_t i = 0; i < l3u.size(); ++i) { up.landmarks_3d[i] = {(float)l3u[i].x, (float)l3u[i].y, (float)l3u[i].z}; up.landmarks_flag[i] = fu[i]; }
     for (size_t i = 0; i < l3d.size(); ++i) { down.landmarks_3d[i] = {(float)l3d[i].x, (float)l3d[i].y, (float)l3d[i].z}; down.landmarks_flag[i] = fd[i]; }
+    return count;
+}
+
+// generate_gray_depth_image_descriptor's landmarks (loop_cam.cpp:260-304; CameraConfig::PINHOLE_DEPTH, the camera mode of launch/realsense.launch):
+// every key point whose depth-image value (u16 millimetres, `depth` with `depth_stride` ELEMENTS per row, depth_w x depth_h) lies strictly between
+// depth_near and depth_far (metres; swarm_loop.cpp:252-253: 0.3 / 10.0) gets landmarks_3d = pose_drone * camera_extrinsic * (lifted pixel * depth) and
+// flag 1; the message must carry pose_drone and camera_extrinsic (stamp_image_descriptor).  As in the reference: nothing at all unless the image has MORE
+// than accept_min_3d_pts key points (:266-270); the pixel gate is the reference's literal 640 x 480 with INCLUSIVE upper bounds (:280); the depth is read at
+// the pixel cv::Mat::at<ushort>(Point2f) addresses, i.e. the coordinates rounded half to even (cv::Point_<int>(Point_<float>) = saturate_cast = cvRound).
+// Deviation: a key point the gate lets through but which lies outside THIS depth image (x = 640 on a 640-wide image: the reference reads past the row)
+// gets no landmark.  `lift` = cam->liftProjective (camodocal is un-vendored: the camera model stays with the caller), applied to the pixel in double
+// (:289) and divided by z (:291).  Returns the number of landmarks set (count_3d).
+inline int fill_depth_landmarks(ImageDescriptor& im, const uint16_t* depth, int depth_stride, int depth_w, int depth_h, double depth_near, double depth_far,
+                                int accept_min_3d_pts, const std::function<geom::Vec2(const Point2f&)>& lift) {
+    im.landmarks_3d.assign(im.landmarks_2d.size(), Point3f{});
+    im.landmarks_flag.assign(im.landmarks_2d.size(), 0);
+    if ((int)im.landmarks_2d.size() <= accept_min_3d_pts) return 0;
+    const geom::Pose pose_cam = to_pose(im.pose_drone) * to_pose(im.camera_extrinsic);
+    int count = 0;
+    for (size_t i = 0; i < im.landmarks_2d.size(); ++i) {
+        const Point2f pt = im.landmarks_2d[i];
+        if (pt.x < 0 || pt.x > 640 || pt.y < 0 || pt.y > 480) continue;
+        const long px = std::lrint((double)pt.x), py = std::lrint((double)pt.y);
+        if (px < 0 || px >= depth_w || py < 0 || py >= depth_h) continue;
+        const double dep = depth[(size_t)py * depth_stride + (size_t)px] / 1000.0;
+        if (dep > depth_near && dep < depth_far) {
+            const geom::Vec2 n = lift(pt);
+            const geom::Vec3 w = pose_cam.pos + pose_cam.att * geom::Vec3{n.x * dep, n.y * dep, dep};     // Swarm::Pose * point
+            im.landmarks_3d[i] = {(float)w.x, (float)w.y, (float)w.z};
+            im.landmarks_flag[i] = 1;
+            ++count;
+        }
+    }
     return count;
 }
 

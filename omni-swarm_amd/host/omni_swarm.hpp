@@ -244,13 +244,15 @@ namespace omni {
 //   vlad_ctx; a second Context = a second HIP stream lets the two networks overlap).
 class LoopCamHIP {
 public:
+    // mono: CameraConfig::PINHOLE_DEPTH (loop_cam.cpp:190-194) -- n_dirs images of ONE camera each, no up/down match (omni_cam_create_mono)
     LoopCamHIP(Context& sp_ctx, Swarm::SuperPointHIP& superpoint_net, Context& vlad_ctx, Swarm::MobileNetVLADHIP& netvlad_net, int n_dirs,
-               int max_num, int width, int height)
-        : ctx_(sp_ctx), n_(n_dirs), w_(width), h_img_(height) {
-        h_ = omni_cam_create(sp_ctx.get(), superpoint_net.handle(), vlad_ctx.get(), netvlad_net.handle(), n_dirs, max_num, netvlad_net.out_dim(),
-                             OMNI_BF_OPENCV);
+               int max_num, int width, int height, bool mono = false)
+        : ctx_(sp_ctx), n_(n_dirs), ni_(mono ? n_dirs : 2 * n_dirs), w_(width), h_img_(height) {
+        h_ = mono ? omni_cam_create_mono(sp_ctx.get(), superpoint_net.handle(), vlad_ctx.get(), netvlad_net.handle(), n_dirs, max_num, netvlad_net.out_dim())
+                  : omni_cam_create(sp_ctx.get(), superpoint_net.handle(), vlad_ctx.get(), netvlad_net.handle(), n_dirs, max_num, netvlad_net.out_dim(),
+                                    OMNI_BF_OPENCV);
         if (!h_) throw std::runtime_error(std::string("omni_cam_create: ") + omni_last_error());
-        gray_dev_ = static_cast<uint8_t*>(omni_dev_alloc(sp_ctx.get(), (size_t)2 * n_dirs * width * height));
+        gray_dev_ = static_cast<uint8_t*>(omni_dev_alloc(sp_ctx.get(), (size_t)ni_ * width * height));
         if (!gray_dev_) { omni_cam_destroy(h_); throw std::runtime_error(std::string("omni_dev_alloc: ") + omni_last_error()); }
     }
     ~LoopCamHIP() { omni_cam_destroy(h_); omni_dev_free(ctx_.get(), gray_dev_); if (pinned_) omni_host_free(pinned_); }
@@ -260,8 +262,8 @@ public:
     // images[0..n_dirs) = up cameras, images[n_dirs..2*n_dirs) = down cameras; each H rows of `stride` bytes (u8 gray).
     // Uploads and enqueues; returns at once.  fisheye_mask zeroes rows [3H/4, H) (loop_cam.cpp:536-539).
     void enqueue(const uint8_t* const* images, int stride, bool fisheye_mask = true) {
-        stage_.resize((size_t)2 * n_ * w_ * h_img_);
-        for (int i = 0; i < 2 * n_; ++i)
+        stage_.resize((size_t)ni_ * w_ * h_img_);
+        for (int i = 0; i < ni_; ++i)
             for (int y = 0; y < h_img_; ++y) std::memcpy(stage_.data() + ((size_t)i * h_img_ + y) * w_, images[i] + (size_t)y * stride, w_);
         check(omni_memcpy_h2d(ctx_.get(), gray_dev_, stage_.data(), stage_.size()), "LoopCamHIP upload");
         check(omni_cam_enqueue_dev(h_, gray_dev_, w_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_dev");
@@ -269,9 +271,9 @@ public:
     // same, without blocking: the images are packed into a pinned block owned by this object and go up as ONE asynchronous copy in front of
     // the kernels (omni_cam_enqueue_host); the host is free again as soon as the memcpy into the pinned block is done
     void enqueue_async(const uint8_t* const* images, int stride, bool fisheye_mask = true) {
-        const size_t bytes = (size_t)2 * n_ * w_ * h_img_;
+        const size_t bytes = (size_t)ni_ * w_ * h_img_;
         if (!pinned_) { pinned_ = static_cast<uint8_t*>(omni_host_alloc(bytes)); if (!pinned_) throw std::runtime_error(std::string("omni_host_alloc: ") + omni_last_error()); }
-        for (int i = 0; i < 2 * n_; ++i)
+        for (int i = 0; i < ni_; ++i)
             for (int y = 0; y < h_img_; ++y) std::memcpy(pinned_ + ((size_t)i * h_img_ + y) * w_, images[i] + (size_t)y * stride, w_);
         check(omni_cam_enqueue_host(h_, pinned_, w_, w_, h_img_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_host");
     }
@@ -293,7 +295,7 @@ private:
     omni_cam* h_ = nullptr;
     uint8_t* gray_dev_ = nullptr;
     uint8_t* pinned_ = nullptr;
-    int n_, w_, h_img_;
+    int n_, ni_, w_, h_img_;                  // ni_: images per unit (2 per direction, or 1: mono)
     std::vector<uint8_t> stage_;
 };
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
            "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync",
-           "omni_pipeline_set_poses", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
+           "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
 _lib = None
 
 
@@ -32,6 +32,9 @@ def lib():
         L.omni_pipeline_create.restype = C.c_void_p
         L.omni_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.omni_pipeline_create_pinhole_depth.restype = C.c_void_p
+        L.omni_pipeline_create_pinhole_depth.argtypes = L.omni_pipeline_create.argtypes + [C.c_double] * 6 + [C.c_int]
+        L.omni_pipeline_set_depth.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.omni_pipeline_geometry_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.omni_pipeline_destroy.argtypes = [C.c_void_p]
         L.omni_pipeline_destroy.restype = None
@@ -58,14 +61,28 @@ def _err(what):
 class KeyframePipeline:
     def __init__(self, device: int, sp_weights_path: str, pca_comp_csv: str, pca_mean_csv: str, vlad_weights_path: str, width=600, height=480,
                  thres=0.02, max_num=200, precision=capi.PREC_F16, microbatch=8, pipelines=2, storage=capi.STORE_F32, self_id=1,
-                 inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3, geometry=False):
+                 inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3, geometry=False, pinhole_depth=None):
+        """pinhole_depth: None = CameraConfig::STEREO_FISHEYE (4 directions x up/down views per key frame); a dict(fx, fy, cx, cy, depth_near, depth_far,
+        accept_min_3d_pts) = CameraConfig::PINHOLE_DEPTH (launch/realsense.launch): one gray image + one depth image (set_depth) per key frame"""
         self.microbatch = microbatch
-        self.h = lib().omni_pipeline_create(device, sp_weights_path.encode(), pca_comp_csv.encode(), pca_mean_csv.encode(),
-                                            vlad_weights_path.encode(), width, height, thres, max_num, precision, microbatch, pipelines, storage,
-                                            self_id, inner_product_thres, init_mode_product_thres, match_index_dist, min_loop_num,
-                                            min_direction_loop, int(geometry))
+        common = (device, sp_weights_path.encode(), pca_comp_csv.encode(), pca_mean_csv.encode(), vlad_weights_path.encode(), width, height, thres, max_num,
+                  precision, microbatch, pipelines, storage, self_id, inner_product_thres, init_mode_product_thres, match_index_dist, min_loop_num,
+                  min_direction_loop, int(geometry))
+        if pinhole_depth is None:
+            self.h = lib().omni_pipeline_create(*common)
+        else:
+            d = pinhole_depth
+            self.h = lib().omni_pipeline_create_pinhole_depth(*common, d["fx"], d["fy"], d["cx"], d["cy"], d.get("depth_near", 0.3), d.get("depth_far", 7.0),
+                                                              d.get("accept_min_3d_pts", 50))
+        self._depth = None
         if not self.h:
             raise _err("omni_pipeline_create")
+
+    def set_depth(self, first_msg_id: int, depth: np.ndarray):
+        """depth [n][H][W] u16 millimetres of key frames first_msg_id .. first_msg_id + n - 1 (kept alive by this object)"""
+        self._depth = np.ascontiguousarray(depth, np.uint16)
+        if lib().omni_pipeline_set_depth(self.h, first_msg_id, self._depth.shape[0], self._depth.ctypes.data):
+            raise _err("omni_pipeline_set_depth")
 
     def close(self):
         if getattr(self, "h", None):

@@ -117,3 +117,23 @@ def room_keyframe(place: int, height: int = 480, width: int = 600, revisit: int 
         rng = np.random.default_rng(BASE_SEED + 7_000_000 + 1000 * place + revisit)
         out = np.clip(np.rint(out.astype(np.float32) + rng.normal(0, noise_sigma, out.shape)), 0, 255).astype(np.uint8)
     return out
+
+
+# ---- key frames of a PINHOLE_DEPTH camera (launch/realsense.launch: one 640 x 480 gray image + one depth image) -------------------------------
+DEPTH_STEP_M = (2.0, 3.5)    # the wall in front of the camera has a step: its left half is 2.0 m away, its right half 3.5 m
+
+
+def depth_keyframe(place: int, height: int = 480, width: int = 640, revisit: int = 0, noise_sigma: float = 0.0):
+    """(gray u8 [H][W], depth u16 millimetres [H][W]) of a forward-looking camera in front of a textured, fronto-parallel wall with a step
+    (DEPTH_STEP_M): the landmarks are not coplanar.  One pixel in 16 of the depth image has no return (0), as a real depth camera's does.
+    `revisit` > 0 with `noise_sigma` > 0: the same place seen again, with sensor noise on the gray image and +- 2 mm on the depth."""
+    gray = image_u8(90_000 + place, height, width, n_shapes=260)
+    depth = np.empty((height, width), np.uint16)
+    depth[:, :width // 2] = int(DEPTH_STEP_M[0] * 1000)
+    depth[:, width // 2:] = int(DEPTH_STEP_M[1] * 1000)
+    rng = np.random.default_rng(BASE_SEED + 9_000_000 + 1000 * place + revisit)
+    if revisit > 0 and noise_sigma > 0:
+        gray = np.clip(np.rint(gray.astype(np.float32) + rng.normal(0, noise_sigma, gray.shape)), 0, 255).astype(np.uint8)
+        depth = (depth.astype(np.int32) + rng.integers(-2, 3, depth.shape)).astype(np.uint16)
+    depth[rng.integers(0, 16, depth.shape) == 0] = 0
+    return gray, depth

@@ -3,6 +3,8 @@
 An independent restatement (LAPACK SVD / eigh instead of the product's hand-written Jacobi sweeps) of
     triangulatePoint                       /root/reference/swarm_loop/src/loop_cam.cpp:73-106
     the up/down triangulation loop         loop_cam.cpp:397-444
+    landmarks from the depth image         loop_cam.cpp:260-304 (CameraConfig::PINHOLE_DEPTH; pinned to the reference text through tests/cpp/loopfront_pin.cpp,
+                                           tests/test_geometry_cpu.py::test_pinhole_depth_keyframe_is_pinned_to_the_reference_text)
     cv::findHomography(RANSAC, 3) mask     as used at swarm_loop/src/loop_detector.cpp:589-598 (OpenCV 3.4 ptsetreg.cpp / fundam.cpp)
     cv::solvePnPRansac(K = I)              as used at loop_detector.cpp:390-391: cv::RNG driven RANSAC over EPnP models of 5 points (OpenCV 3.4
                                            epnp.cpp restated) + solvePnP(ITERATIVE) on the inliers (DLT start + LM refit)
@@ -134,6 +136,32 @@ def stereo_landmarks(pose_drone, ext_up, ext_down, norm_up, norm_down, ids_up, i
         l3u[iu], fu[iu], l3d[idn], fd[idn] = X, 1, X, 1
         count += 1
     return count, l3u, fu, l3d, fd
+
+
+def depth_landmarks(pose_drone, ext, kps_xy, lift, depth_mm, near, far, accept_min_3d_pts):
+    """generate_gray_depth_image_descriptor's loop (loop_cam.cpp:266-304): kps_xy float32 pixels, lift(xy) -> normalised point, depth_mm u16 [H][W].
+    -> (count, landmarks_3d f64 [n][3], flags u8 [n]).  cv::Mat::at<ushort>(Point2f) reads pixel (lrint(y), lrint(x)): round half to even."""
+    n = len(kps_xy)
+    l3, fl = np.zeros((n, 3)), np.zeros(n, np.uint8)
+    if n <= accept_min_3d_pts:
+        return 0, l3, fl
+    pc = pmul(pose_drone, ext)
+    R = qR(pc[1])
+    count = 0
+    for i in range(n):
+        x, y = float(kps_xy[i][0]), float(kps_xy[i][1])
+        if x < 0 or x > 640 or y < 0 or y > 480:                     # the literal gate of :276 (whatever the image size)
+            continue
+        px, py = int(np.rint(x)), int(np.rint(y))
+        if not (0 <= px < depth_mm.shape[1] and 0 <= py < depth_mm.shape[0]):
+            continue                                                 # (the reference reads whatever lies there; the product skips the key point)
+        dep = float(depth_mm[py, px]) / 1000.0
+        if near < dep < far:
+            nx, ny = lift(np.array([[x, y]]))[0]
+            l3[i] = R @ (np.array([nx, ny, 1.0]) * dep) + pc[0]
+            fl[i] = 1
+            count += 1
+    return count, l3, fl
 
 
 # ---- cv::RNG + RANSAC driver (OpenCV 3.4 modules/calib3d/src/ptsetreg.cpp) ----------------------------------------------------------------------

@@ -94,6 +94,7 @@ inline geometry_msgs::Pose toROSPose(const Pose_t& p) {
 }  // namespace swarm_msgs
 
 #define CV_8U 0
+#define CV_16U 2
 #define CV_32F 5
 #define CV_64F 6
 #define CV_32S 4
@@ -101,9 +102,10 @@ inline geometry_msgs::Pose toROSPose(const Pose_t& p) {
 #define CV_FONT_HERSHEY_SIMPLEX 0
 
 namespace cv {
-enum { NORM_L2 = 4, COLOR_GRAY2BGR = 8 };
+enum { NORM_L2 = 4, COLOR_GRAY2BGR = 8, FONT_HERSHEY_SIMPLEX = 0 };
 struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float a, float b) : x(a), y(b) {} };
 inline Point2f operator+(const Point2f& a, const Point2f& b) { return Point2f(a.x + b.x, a.y + b.y); }
+inline Point2f operator-(const Point2f& a, const Point2f& b) { return Point2f(a.x - b.x, a.y - b.y); }
 struct Point3f { float x, y, z; Point3f() : x(0), y(0), z(0) {} Point3f(float a, float b, float c) : x(a), y(b), z(c) {} };
 struct DMatch { int queryIdx, trainIdx; float distance; DMatch() : queryIdx(-1), trainIdx(-1), distance(0) {} DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), distance(d) {} };
 struct Scalar { double v0; Scalar(double a = 0, double = 0, double = 0, double = 0) : v0(a) {} };
@@ -118,7 +120,7 @@ public:
     Mat(int r, int c, int type) { create(r, c, type); }
     Mat(int r, int c, int type, void* user) { create(r, c, type); if (r > 0 && c > 0) std::memcpy(data, user, (size_t)r * c * esz); }     // (a copy: the views are read-only here)
     void create(int r, int c, int type) {
-        rows = r; cols = c; esz = type == CV_64F ? 8 : (type == CV_8U ? 1 : 4);
+        rows = r; cols = c; esz = type == CV_64F ? 8 : (type == CV_8U ? 1 : (type == CV_16U ? 2 : 4));
         step = (size_t)c * esz;
         buf = std::make_shared<std::vector<unsigned char>>((size_t)r * c * esz + 8, 0);
         data = buf->data();
@@ -136,6 +138,8 @@ public:
     }
     template <typename T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + (size_t)r * step + (size_t)c * esz); }
     template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + (size_t)r * step + (size_t)c * esz); }
+    // Mat::at(Point pt) with a Point2f argument: cv::Point_<int>(const Point_<float>&) = saturate_cast<int> = cvRound (round half to even), then row pt.y, column pt.x
+    template <typename T> const T& at(Point2f p) const { return at<T>((int)std::lrint((double)p.y), (int)std::lrint((double)p.x)); }
     bool empty() const { return rows == 0 || cols == 0; }
     int channels() const { return 1; }
     Mat clone() const {

@@ -55,6 +55,7 @@ struct Mat {
     Mat<C, R> transpose() const { Mat<C, R> o; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) o.d[j][i] = d[i][j]; return o; }
     Mat operator-() const { Mat o; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) o.d[i][j] = -d[i][j]; return o; }
     Mat operator-(const Mat& b) const { Mat o; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) o.d[i][j] = d[i][j] - b.d[i][j]; return o; }
+    Mat operator*(double s) const { Mat o; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) o.d[i][j] = d[i][j] * s; return o; }
     RowRef<R, C> row(int i) { return RowRef<R, C>{*this, i}; }
     template <int N> ColsRef<R, C, N> leftCols() { return ColsRef<R, C, N>{*this, 0}; }
     template <int N> ColsRef<R, C, N> rightCols() { return ColsRef<R, C, N>{*this, C - N}; }
@@ -127,6 +128,7 @@ public:
     Eigen::Quaterniond att() const { return Eigen::Quaterniond(p.att); }
     Eigen::Vector3d pos() const { return Eigen::Vector3d(p.pos.x, p.pos.y, p.pos.z); }
     friend Pose operator*(Pose a, Pose b) { return Pose(a.p * b.p); }
+    Eigen::Vector3d operator*(const Eigen::Vector3d& v) const { const omni::geom::Vec3 o = p.pos + p.att * omni::geom::Vec3{v.x(), v.y(), v.z()}; return Eigen::Vector3d(o.x, o.y, o.z); }
 };
 }  // namespace Swarm
 
@@ -134,7 +136,7 @@ public:
 struct StereoFrame {                             // swarm_msgs / VINS FlattenImages as generate_stereo_image_descriptor reads it
     ros::Time stamp;
     int64_t keyframe_id = 0;
-    std::vector<cv::Mat> left_images, right_images;
+    std::vector<cv::Mat> left_images, right_images, depth_images;
     std::vector<geometry_msgs::Pose> left_extrisincs, right_extrisincs;
     geometry_msgs::Pose pose_drone;
 };

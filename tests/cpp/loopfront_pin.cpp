@@ -51,7 +51,7 @@ public:
                                     std::vector<int>& ids_up, std::vector<int>& ids_down);
     ImageDescriptor_t extractor_img_desc_deepnet(ros::Time stamp, cv::Mat img, bool superpoint_mode);
     ImageDescriptor_t generate_stereo_image_descriptor(const StereoFrame& msg, cv::Mat& img, const int& vcam_id, cv::Mat& _show);
-    ImageDescriptor_t generate_gray_depth_image_descriptor(const StereoFrame&, cv::Mat&, const int&, cv::Mat&) { std::abort(); }
+    ImageDescriptor_t generate_gray_depth_image_descriptor(const StereoFrame& msg, cv::Mat& img, const int& vcam_id, cv::Mat& _show);
     FisheyeFrameDescriptor_t on_flattened_images(const StereoFrame& msg, std::vector<cv::Mat>& imgs);
 };
 
@@ -61,6 +61,7 @@ double TRIANGLE_THRES;                           // (defined next to its rospara
 #include REF_LOOPCAM_TRI                         // loop_cam.cpp:73-106    triangulatePoint
 #include REF_LOOPCAM_MATCH                       // loop_cam.cpp:141-175   match_HFNet_local_features
 #include REF_LOOPCAM_FRAME                       // loop_cam.cpp:178-229   on_flattened_images
+#include REF_LOOPCAM_DEPTH                       // loop_cam.cpp:231-339   generate_gray_depth_image_descriptor (CameraConfig::PINHOLE_DEPTH)
 #include REF_LOOPCAM_STEREO                      // loop_cam.cpp:341-523   generate_stereo_image_descriptor
 #include REF_LOOPCAM_EXTRACT                     // loop_cam.cpp:525-634   extractor_img_desc_deepnet
 
@@ -110,6 +111,87 @@ int main() {
     };
     std::string cmd;
     while (std::cin >> cmd) {
+        if (cmd == "depthframe") {
+            // One PINHOLE_DEPTH key frame (the camera mode of launch/realsense.launch): ONE gray image + its depth image.  Product: fill_image_descriptor,
+            // stamp_image_descriptor, fill_depth_landmarks, finish_frame_descriptor; reference: on_flattened_images -> generate_gray_depth_image_descriptor
+            // -> extractor_img_desc_deepnet (no rows are blanked in this mode: loop_cam.cpp:536 only masks STEREO_FISHEYE).
+            int H, W, gdim, accept_min, self_id; long long kf_id; double stamp, dnear, dfar; PinholeCam cam; unsigned seed;
+            std::cin >> H >> W >> gdim >> accept_min >> dnear >> dfar >> self_id >> kf_id >> stamp >> cam.fx >> cam.fy >> cam.cx >> cam.cy >> seed;
+            const og::Pose pd = read_pose(), ext = read_pose();
+            Net nt;
+            int n; std::cin >> n;
+            nt.kps.resize(n); nt.desc.resize((size_t)n * 64);
+            for (auto& k : nt.kps) std::cin >> k.x >> k.y;
+            for (auto& v : nt.desc) std::cin >> v;
+            nt.gdesc.resize(gdim);
+            for (auto& v : nt.gdesc) std::cin >> v;
+            std::vector<unsigned char> pix((size_t)H * W);
+            for (auto& v : pix) { seed = seed * 1664525u + 1013904223u; v = (unsigned char)(1 + (seed >> 24) % 255); }
+            // depth in millimetres: a quarter of the pixels 0 (no return), the rest spread from 0.1 m to 14 m -- both thresholds are crossed; the key points'
+            // own pixels get values right at, just below and just above the two thresholds in turn
+            std::vector<unsigned short> dep((size_t)H * W);
+            for (auto& v : dep) { seed = seed * 1664525u + 1013904223u; v = (seed >> 30) == 0 ? 0 : (unsigned short)(100 + (seed >> 8) % 13900); }
+            const unsigned short edge[6] = {(unsigned short)std::lrint(dnear * 1000), (unsigned short)(std::lrint(dnear * 1000) + 1), (unsigned short)(std::lrint(dnear * 1000) - 1),
+                                            (unsigned short)std::lrint(dfar * 1000), (unsigned short)(std::lrint(dfar * 1000) - 1), (unsigned short)(std::lrint(dfar * 1000) + 1)};
+            for (size_t i = 0; i < nt.kps.size(); i += 3) {
+                const long px = std::lrint((double)nt.kps[i].x), py = std::lrint((double)nt.kps[i].y);
+                if (px >= 0 && px < W && py >= 0 && py < H) dep[(size_t)py * W + px] = edge[(i / 3) % 6];
+            }
+            const std::function<og::Vec2(const omni::Point2f&)> lift = [&](const omni::Point2f& p) { return og::Vec2{((double)p.x - cam.cx) / cam.fx, ((double)p.y - cam.cy) / cam.fy}; };
+            omni::FisheyeFrameDescriptor pf;
+            pf.images.resize(1);
+            {
+                omni::ImageDescriptor& im = pf.images[0];
+                std::vector<float> kx;
+                for (auto& k : nt.kps) { kx.push_back(k.x); kx.push_back(k.y); }
+                omni::fill_image_descriptor(im, kx.data(), (int)nt.kps.size(), nt.desc.data(), 64, nt.gdesc.data(), gdim, lift);
+                omni::stamp_image_descriptor(im, stamp, self_id, omni::to_msg(ext), omni::to_msg(pd), kf_id);
+                const int c3 = omni::fill_depth_landmarks(im, dep.data(), W, W, H, dnear, dfar, accept_min, lift);
+                std::printf("PROD COUNT3D %d\n", c3);
+            }
+            omni::finish_frame_descriptor(pf, stamp, kf_id, omni::to_msg(pd), self_id);
+            std::printf("PROD FRAME ts %.9f image_num %d msg_id %lld pose %.17g %.17g landmark_num %d drone %d\n", pf.timestamp, pf.image_num, (long long)pf.msg_id, pf.pose_drone.position[0],
+                        pf.pose_drone.quat_wxyz[0], pf.landmark_num, pf.drone_id);
+            {
+                const omni::ImageDescriptor& im = pf.images[0];
+                print_image("PROD", 0, im, im.direction, im.drone_id, (long long)im.frame_id, im.timestamp, im.camera_extrinsic.position[0], im.camera_extrinsic.quat_wxyz[0],
+                            im.pose_drone.position[0], im.image_desc.size(), fsum(im.image_desc), fsum(im.feature_descriptor));
+            }
+            std::printf("PROD PIX %llu\n", (unsigned long long)checksum(pix.data(), H, W, (size_t)W));       // no rows blanked in this mode
+            ACCEPT_MIN_3D_PTS = accept_min; LOWER_CAM_AS_MAIN = false; OUTPUT_RAW_SUPERPOINT_DESC = false; DEPTH_NEAR_THRES = dnear; DEPTH_FAR_THRES = dfar;
+            LoopCam lc;
+            lc.cam = &cam; lc.self_id = self_id; lc.camera_configuration = CameraConfig::PINHOLE_DEPTH;
+            StereoFrame msg;
+            msg.stamp = ros::Time(stamp); msg.keyframe_id = kf_id; msg.pose_drone = to_ros(pd);
+            msg.left_images.push_back(cv::Mat(H, W, CV_8U, pix.data()));
+            msg.depth_images.push_back(cv::Mat(H, W, CV_16U, dep.data()));
+            msg.left_extrisincs.push_back(to_ros(ext));
+            int sp_calls = 0, vlad_calls = 0;
+            uint64_t seen_sp = 0, seen_vlad = 0;
+            lc.superpoint_net.fn = [&](const cv::Mat& img, std::vector<cv::Point2f>& kps, std::vector<float>& desc) {
+                ++sp_calls; seen_sp = checksum(img.data, img.rows, img.cols, img.step);
+                kps.clear();
+                for (auto& k : nt.kps) kps.push_back(cv::Point2f(k.x, k.y));
+                desc = nt.desc;
+            };
+            lc.netvlad_net.fn = [&](const cv::Mat& img) { ++vlad_calls; seen_vlad = checksum(img.data, img.rows, img.cols, img.step); return nt.gdesc; };
+            std::vector<cv::Mat> imgs;
+            const FisheyeFrameDescriptor_t rf = lc.on_flattened_images(msg, imgs);
+            int rc3 = 0;
+            for (auto fl : rf.images[0].landmarks_flag) rc3 += fl ? 1 : 0;
+            std::printf("REF COUNT3D %d\n", rc3);
+            std::printf("REF FRAME ts %.9f image_num %d msg_id %lld pose %.17g %.17g landmark_num %d drone %d\n", rf.timestamp.sec + 1e-9 * rf.timestamp.nsec, (int)rf.image_num,
+                        (long long)rf.msg_id, rf.pose_drone.position[0], rf.pose_drone.orientation[0], (int)rf.landmark_num, (int)rf.drone_id);
+            {
+                const ImageDescriptor_t& im = rf.images[0];
+                print_image("REF", 0, im, im.direction, im.drone_id, (long long)im.frame_id, im.timestamp.sec + 1e-9 * im.timestamp.nsec, im.camera_extrinsic.position[0],
+                            im.camera_extrinsic.orientation[0], im.pose_drone.position[0], im.image_desc.size(), fsum(im.image_desc), fsum(im.feature_descriptor));
+                if (im.image_desc_size != (int)im.image_desc.size() || im.feature_descriptor_size != (int)im.feature_descriptor.size() || im.image_size != 0) std::printf("REF SIZES-DIFFER 0\n");
+            }
+            std::printf("REF PIX %llu\n", (unsigned long long)checksum(msg.left_images[0].data, H, W, msg.left_images[0].step));
+            std::printf("REF CALLS %d %d SEEN %llu %llu\n", sp_calls, vlad_calls, (unsigned long long)seen_sp, (unsigned long long)seen_vlad);
+            continue;
+        }
         if (cmd != "frame") { std::fprintf(stderr, "unknown command %s\n", cmd.c_str()); return 2; }
         int H, W, n_dirs, gdim, accept_min, self_id; long long kf_id; double stamp, thres; PinholeCam cam; unsigned seed;
         std::cin >> H >> W >> n_dirs >> gdim >> accept_min >> thres >> self_id >> kf_id >> stamp >> cam.fx >> cam.fy >> cam.cx >> cam.cy >> seed;

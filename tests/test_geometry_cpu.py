@@ -461,3 +461,71 @@ def test_keyframe_messages_and_mask_rows_are_pinned_to_the_reference_text(front_
         assert kfc == ["KF-COUNT", "1"]
         cases += 1
     assert cases == 5
+
+
+def test_pinhole_depth_keyframe_is_pinned_to_the_reference_text(front_pin_exe):
+    """CameraConfig::PINHOLE_DEPTH (launch/realsense.launch, BASELINE.json configs[0]: ONE 640 x 480 gray image + its 16-bit depth image per key frame):
+    fill_image_descriptor + stamp_image_descriptor + fill_depth_landmarks + finish_frame_descriptor against the reference's own
+    on_flattened_images -> generate_gray_depth_image_descriptor (loop_cam.cpp:231-339) compiled from its text: the same stamps, key points, lifted
+    points; a landmark exactly where the depth under the ROUNDED pixel lies strictly inside (DEPTH_NEAR_THRES, DEPTH_FAR_THRES) -- the harness puts
+    depths at, one millimetre under and one over both thresholds below every third key point -- and none at all when the image has at most
+    ACCEPT_MIN_3D_PTS key points; the image is NOT blanked in this mode and both networks run once on it."""
+    rng = np.random.default_rng(404)
+    cases = 0
+    for (H, W), n, accept_min, gdim, near, far in (((480, 640), 200, 50, 8, 0.3, 7.0), ((480, 640), 50, 50, 4, 0.3, 7.0), ((480, 640), 51, 50, 4, 0.5, 3.0),
+                                                   ((120, 160), 90, 10, 3, 1.0, 12.0), ((480, 640), 0, 50, 2, 0.3, 7.0)):
+        kf_id, stamp, self_id = 5000 + cases, 91.5 + cases, 2
+        # key points as the detector reports them: integer pixels in [0, W) x [0, H); a few half-way values to exercise the rounding of cv::Mat::at(Point2f)
+        kps = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], 1).astype(np.float32)
+        if n > 8:
+            kps[1] += np.float32(0.25); kps[2] -= np.float32(0.25)
+            kps[3] = (0, 0); kps[4] = (W - 1, H - 1)
+            kps[1] = np.clip(kps[1], 0, [W - 1, H - 1]); kps[2] = np.clip(kps[2], 0, [W - 1, H - 1])
+        desc = rng.standard_normal((n, 64)).astype(np.float32)
+        gdesc = rng.standard_normal(gdim).astype(np.float32)
+        q = rng.standard_normal(4); q /= np.linalg.norm(q)
+        pose = dict(pos=rng.standard_normal(3) * 3, quat=q)
+        e = np.array([0.5, -0.5, 0.5, -0.5]) + rng.standard_normal(4) * 0.01; e /= np.linalg.norm(e)
+        ext = dict(pos=rng.standard_normal(3) * 0.1, quat=e)
+        fp = lambda p: " ".join(repr(float(v)) for v in list(p["pos"]) + list(p["quat"]))
+        seed = int(rng.integers(1, 2 ** 31))
+        text = (f"depthframe {H} {W} {gdim} {accept_min} {near!r} {far!r} {self_id} {kf_id} {stamp!r} {F} {F} {W / 2} {H / 2} {seed} {fp(pose)} {fp(ext)}\n"
+                f"{n} {fmt(kps)} {fmt(desc)}\n{fmt(gdesc)}")
+        out = [ln for ln in run(front_pin_exe, text) if ln and ln[0] in ("PROD", "REF")]
+        prod = [ln[1:] for ln in out if ln[0] == "PROD"]
+        ref = [ln[1:] for ln in out if ln[0] == "REF"]
+        assert not any(ln[0] == "SIZES-DIFFER" for ln in ref)
+        assert prod[0][0] == ref[0][0] == "COUNT3D" and prod[0] == ref[0], (prod[0], ref[0])
+        count3d = int(prod[0][1])
+        assert (count3d == 0) == (n <= accept_min), (n, accept_min, count3d)
+        assert n <= accept_min or 0 < count3d < n                                                # both outcomes occur (a quarter of the depth image is 0)
+        assert prod[1] == ref[1] and prod[1][0] == "FRAME"
+        assert prod[1][prod[1].index("image_num") + 1] == "1" and prod[1][prod[1].index("landmark_num") + 1] == str(n)
+        p, r = prod[2], ref[2]
+        cp, cr = p.index(":"), r.index(":")
+        assert p[:cp] == r[:cr], (p[:cp], r[:cr])
+        assert p[p.index("dir") + 1] == "0" and p[p.index("gd") + 1] == str(gdim)
+        a, b = np.array(p[cp + 1:], np.float64).reshape(-1, 8), np.array(r[cr + 1:], np.float64).reshape(-1, 8)
+        assert np.array_equal(a[:, :5], b[:, :5])                                                # pixels, float-lifted points, FLAGS: the same landmarks chosen
+        assert int(a[:, 4].sum()) == count3d
+        assert np.abs(a[:, 5:] - b[:, 5:]).max(initial=0) <= 1e-6 * max(1.0, np.abs(b[:, 5:]).max(initial=0))
+        # the oracle's restatement (oracle/geometry_ref.py depth_landmarks) on the harness's depth image (its LCG, replayed here)
+        st, dep = seed, np.empty(H * W, np.uint16)
+        for _ in range(H * W):
+            st = (st * 1664525 + 1013904223) & 0xFFFFFFFF                                        # (the gray image's draws come first)
+        for i in range(H * W):
+            st = (st * 1664525 + 1013904223) & 0xFFFFFFFF
+            dep[i] = 0 if (st >> 30) == 0 else 100 + (st >> 8) % 13900
+        dep = dep.reshape(H, W)
+        e_mm = [round(near * 1000), round(near * 1000) + 1, round(near * 1000) - 1, round(far * 1000), round(far * 1000) - 1, round(far * 1000) + 1]
+        for i in range(0, n, 3):
+            dep[int(np.rint(kps[i, 1])), int(np.rint(kps[i, 0]))] = e_mm[(i // 3) % 6]
+        lift = lambda xy: np.stack([(xy[:, 0] - W / 2) / F, (xy[:, 1] - H / 2) / F], 1)
+        oc, ol3, ofl = G.depth_landmarks((pose["pos"], pose["quat"]), (ext["pos"], ext["quat"]), kps, lift, dep, near, far, accept_min)
+        assert oc == count3d and np.array_equal(ofl, a[:, 4].astype(np.uint8))
+        assert np.abs(ol3 - a[:, 5:]).max(initial=0) <= 1e-6 * max(1.0, np.abs(ol3).max(initial=0))
+        assert prod[3] == ref[3] and prod[3][0] == "PIX"                                         # nothing blanked
+        calls = ref[4]
+        assert calls[:3] == ["CALLS", "1", "1"] and calls[4] == calls[5] == prod[3][1]           # SuperPoint and MobileNetVLAD: once each, on the untouched image
+        cases += 1
+    assert cases == 5
