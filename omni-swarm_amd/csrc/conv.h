@@ -122,6 +122,12 @@ int convdb_sparse_sample(hipStream_t stream, const omni_ctx* ctx, const void* in
 int conv_c128_sparse(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, const void* w_packed, const float* bias, int Hc, int Wc,
                      int g32_first, int W, int H, int max_num, const float* kps_xy, const int* n_kps, void* out_f16, int out_cstride, int batch);
 
+// OMNI_PREC_SPLIT: convDa (3x3, 128 input channels, ReLU) at the coarse cells around the key points only, from the split-64 frames of conv4b, with the
+// fused heads layer's packed weights / split_inv / bias (convDa = g32_first 8): compact rows [image][key point][corner][256] fp32, bit-identical to
+// the dense layer's values at those cells (conv_split.hip)
+int conv_split_c128_sparse(hipStream_t stream, const omni_ctx* ctx, const void* a4b, const void* w_packed, const float* bias, float split_inv, int Hc, int Wc,
+                           int g32_first, int W, int H, int max_num, const float* kps_xy, const int* n_kps, float* out, int batch);
+
 // test hook: NHWC (fp16 or fp32) -> NCHW fp32
 int nhwc_any_to_nchw_f32(hipStream_t stream, int precision_of_in, const void* in, float* out, int batch, int C, int HW);
 

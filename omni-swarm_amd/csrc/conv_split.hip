@@ -1013,6 +1013,222 @@ int conv_split(hipStream_t st, const ConvArgs& a) {
 
 float conv_split_act_scale() { return SPL_ACT_SCALE; }
 
+// ==================================================================================================================================================
+// convDa in OMNI_PREC_SPLIT ONLY at the coarse cells around the key points (superpoint.ipynb:183: computeDescriptors reads cDa at the four cells
+// around each key point and nowhere else -- <= 800 of 4 500 cells; the fp16 path's conv3x3_c128_sparse_kernel, conv.hip, with split operands).
+// Same weights, same wave roles and the SAME order of summation as the dense cin = 128 kernel above, so the values are bit-identical to the
+// dense layer's at those cells (tests/test_gpu_superpoint.py::test_fp32_sparse_descriptor_head_is_bit_identical_to_the_dense_map_path):
+//   workgroup = 64 output channels (a quarter of convDa's 256; blockIdx & 3) x a stream of tiles; tile = the 32 corner cells of 8 key points;
+//   wave (co, part) = 32 output channels x input block `part` (64 channels), its 36 wh + 36 wl fragments in 288 registers; per cell the dense
+//   kernel sums (tap column outer, tap row inner [transposed tiles: row outer, column inner], per tap: hi fragments kq = 0..3 against wh then wl,
+//   lo fragments against wh) into a zero accumulator, the pair's two halves of K meet through LDS, v = fmaf(own + partner, inv, bias), ReLU.
+// A cell's 3 x 3 x 128-channel neighbourhood is 4.6 KB of split-64 activations (the zero frame makes every tap a plain read): 147 KB per tile
+// does not fit twice, so the taps stream through LDS in three CHUNKS of one outer index (3 taps x 512 B per cell, 48.5 KB per buffer, two
+// buffers): thread = (cell, eighth) fetches 12 16-byte pieces of the next chunk into registers behind the 36 MFMAs of the current one.
+// out: compact rows [image][key point][corner][256] fp32 (what sp_gather_cells_kernel made from the dense map); cells outside the map / beyond
+// n_kps are not written, tiles without key points are not walked.
+#define SSP_CELL_BYTES 1552                       // 3 taps x 512 B + 16: an odd number of 16-byte slots, conflict-free fragment reads
+#define SSP_BUF_BYTES (32 * SSP_CELL_BYTES)       // 49 664
+#define SSP_XCH_OFF (2 * SSP_BUF_BYTES)
+#define SSP_SMEM (2 * SSP_BUF_BYTES + 8192)
+#define SSP_KP 8                                  // key points per tile (CSP_KP of conv.hip)
+
+// step S of a chunk (tap slot i = S / 8, fragment kg = S % 8): fragment S + 2 issued, S waited for, its MFMAs (the rs_steps pattern)
+template <int S, int O>
+__device__ __forceinline__ void ssp_steps(uint32_t base, const half8_t (&wreg)[72], floatx16& acc, half8_t (&fb)[3]) {
+    if constexpr (S < 24) {
+        constexpr int i = S / 8, kg = S % 8, kq = kg & 3, t = (i * 3 + O) * 4 + kq;
+        if constexpr (S + 2 < 24) {
+            constexpr int i2 = (S + 2) / 8, kg2 = (S + 2) % 8;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[(S + 2) % 3]) : "v"(base), "i"(i2 * 512 + kg2 * 32));
+        }
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fb[S % 3]) : "i"((S + 2 < 24) ? 2 : (S + 1 < 24 ? 1 : 0)));
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[t], fb[S % 3], acc, 0, 0, 0);
+        if constexpr (kg < 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[36 + t], fb[S % 3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ssp_steps<S + 1, O>(base, wreg, acc, fb);
+    }
+}
+
+template <bool TRN>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_split_c128_sparse_kernel(const char* __restrict__ in /* split-64 frames [B][Hf][Wf][2][256 B] */, const _Float16* __restrict__ wp, const float* __restrict__ bias,
+                                 float inv, int Hc, int Wc, int g32_first, int W, int H, int max_num, const float* __restrict__ kps_xy,
+                                 const int* __restrict__ n_kps, float* __restrict__ out, int tiles_per_img, int n_tiles) {
+    extern __shared__ __attribute__((aligned(256))) char smem_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co = wave & 1, part = wave >> 1;
+    const int n = lane & 31, hh = lane >> 5;
+    const int quarter = blockIdx.x & 3, wg = blockIdx.x >> 2, nwg = gridDim.x >> 2;
+    const int g32 = g32_first + quarter * 2 + co;
+    half8_t wreg[72];
+    {
+        const _Float16* wbase = wp + ((int64_t)g32 * 2 + part) * (2 * 36 * 512) + lane * 8;
+#pragma unroll
+        for (int s = 0; s < 72; ++s) {
+            const int hl = s / 36, tk = (s % 36) / 4, kq = s % 4;
+            const int tap = TRN ? (tk % 3) * 3 + tk / 3 : tk;
+            wreg[s] = *reinterpret_cast<const half8_t*>(wbase + ((hl * 9 + tap) * 4 + kq) * 512);
+        }
+    }
+    float4 bs[2];                                   // the two register groups this wave finishes: channels 32 g32 + 16 part + 8 gg + 4 hh + (0..3)
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) bs[gg] = *reinterpret_cast<const float4*>(bias + g32 * 32 + 16 * part + 8 * gg + 4 * hh);
+    const int Wf = split_frame_w(Wc), Hf = split_frame_h(Hc);
+    const int64_t img_bytes = (int64_t)Hf * Wf * 512;
+    const int64_t row_bytes = (int64_t)Wf * 512;
+    const float fW = (float)W, fH = (float)H, fWc = (float)Wc, fHc = (float)Hc;
+    // corner cell `slot` of tile t -> (image, key point, cell x, cell y); false: no such key point / outside the map (sample_corner's arithmetic)
+    auto cell_of = [&](int t, int slot, int& b, int& kp, int& cx, int& cy) __attribute__((always_inline)) -> bool {
+        b = t / tiles_per_img;
+        kp = (t - b * tiles_per_img) * SSP_KP + (slot >> 2);
+        cx = cy = 0;
+        if (kp >= n_kps[b]) return false;
+        const float kx = kps_xy[((int64_t)b * max_num + kp) * 2 + 0], ky = kps_xy[((int64_t)b * max_num + kp) * 2 + 1];
+        const float gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, kx), fW), 1.0f);
+        const float gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, ky), fH), 1.0f);
+        const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), fWc), 1.0f), 2.0f);
+        const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), fHc), 1.0f), 2.0f);
+        cx = (int)floorf(ix) + (slot & 1); cy = (int)floorf(iy) + ((slot >> 1) & 1);
+        return cx >= 0 && cx < Wc && cy >= 0 && cy < Hc;
+    };
+    // the workgroup's tiles: t = wg, wg + nwg, ... without the tiles that hold no key point (uniform: n_kps is read by every thread alike)
+    auto next_tile = [&](int t) __attribute__((always_inline)) -> int {
+        while (t < n_tiles) {
+            const int b = t / tiles_per_img;
+            if ((t - b * tiles_per_img) * SSP_KP < n_kps[b]) break;
+            t += nwg;
+        }
+        return t;
+    };
+    // gather: thread = (cell tid >> 3, eighth tid & 7): pieces j * 8 + eighth, j < 12, of the cell's 96 16-byte pieces of a chunk (tap slot j >> 2,
+    // bytes ((j & 3) * 8 + eighth) * 16 of the pixel's 512).  Named registers (as an array indexed in unrolled loops hipcc keeps them in scratch)
+    const int gcell = tid >> 3, gpart = tid & 7;
+    uint4 s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11;
+    const char* fsrc = in;                          // the cell's own pixel in the frame (a cell that does not exist: pixel (1, 1) of image 0 -- read, never used)
+#define SSP_SRC(O, J) (fsrc + (TRN ? ((O) - 1) * row_bytes + (((J) >> 2) - 1) * 512 : (((J) >> 2) - 1) * row_bytes + ((O) - 1) * 512) + (((J) & 3) * 8 + gpart) * 16)
+#define SSP_FETCH(O)                                                                                                          \
+    {                                                                                                                          \
+        s0 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 0)); s1 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 1));             \
+        s2 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 2)); s3 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 3));             \
+        s4 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 4)); s5 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 5));             \
+        s6 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 6)); s7 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 7));             \
+        s8 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 8)); s9 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 9));             \
+        s10 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 10)); s11 = *reinterpret_cast<const uint4*>(SSP_SRC(O, 11));         \
+    }
+#define SSP_DST(J) (pdst + ((J) >> 2) * 512 + ((J) & 3) * 128)
+#define SSP_PARK(WHICH)                                                                                                       \
+    {                                                                                                                          \
+        char* pdst = smem_raw + (WHICH) * SSP_BUF_BYTES + gcell * SSP_CELL_BYTES + gpart * 16;                                 \
+        *reinterpret_cast<uint4*>(SSP_DST(0)) = s0; *reinterpret_cast<uint4*>(SSP_DST(1)) = s1; *reinterpret_cast<uint4*>(SSP_DST(2)) = s2;    \
+        *reinterpret_cast<uint4*>(SSP_DST(3)) = s3; *reinterpret_cast<uint4*>(SSP_DST(4)) = s4; *reinterpret_cast<uint4*>(SSP_DST(5)) = s5;    \
+        *reinterpret_cast<uint4*>(SSP_DST(6)) = s6; *reinterpret_cast<uint4*>(SSP_DST(7)) = s7; *reinterpret_cast<uint4*>(SSP_DST(8)) = s8;    \
+        *reinterpret_cast<uint4*>(SSP_DST(9)) = s9; *reinterpret_cast<uint4*>(SSP_DST(10)) = s10; *reinterpret_cast<uint4*>(SSP_DST(11)) = s11; \
+    }
+    auto aim = [&](int t) __attribute__((always_inline)) {          // fsrc := the gather cell of tile t
+        int b, kp, cx, cy;
+        const bool ok = cell_of(t, gcell, b, kp, cx, cy);
+        fsrc = ok ? in + b * img_bytes + (cy + 1) * row_bytes + (int64_t)(cx + 1) * 512 : in + row_bytes + 512;
+    };
+    float4* const xch_mine = reinterpret_cast<float4*>(smem_raw + SSP_XCH_OFF) + ((co * 2 + part) * 2) * 64 + lane;
+    const float4* const xch_theirs = reinterpret_cast<const float4*>(smem_raw + SSP_XCH_OFF) + ((co * 2 + (part ^ 1)) * 2) * 64 + lane;
+
+    int t = next_tile(wg);
+    if (t < n_tiles) { aim(t); SSP_FETCH(0) SSP_PARK(0) }
+    __syncthreads();
+    int cur = 0;
+    while (t < n_tiles) {
+        const int tn = next_tile(t + nwg);
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // one chunk: the next chunk's pieces into registers, this chunk's 36 MFMAs, the pieces into the other buffer, barrier
+#define SSP_CHUNK(O, FETCH_NEXT)                                                                                              \
+        {                                                                                                                      \
+            FETCH_NEXT                                                                                                         \
+            const uint32_t base = lds0 + cur * SSP_BUF_BYTES + n * SSP_CELL_BYTES + part * 256 + hh * 16;                      \
+            half8_t fb[3];                                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0]) : "v"(base), "i"(0));                                   \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1]) : "v"(base), "i"(32));                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                                 \
+            ssp_steps<0, O>(base, wreg, acc, fb);                                                                              \
+        }
+        SSP_CHUNK(0, SSP_FETCH(1))
+        SSP_PARK(cur ^ 1)
+        __syncthreads();
+        cur ^= 1;
+        SSP_CHUNK(1, SSP_FETCH(2))
+        SSP_PARK(cur ^ 1)
+        __syncthreads();
+        cur ^= 1;
+        SSP_CHUNK(2, if (tn < n_tiles) { aim(tn); SSP_FETCH(0) })
+        // the pair's hand-over: this wave finishes register groups 2 part, 2 part + 1 and gives the partner the other two
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const int r0 = 4 * (2 * (1 - part) + gg);
+            xch_mine[gg * 64] = part == 0 ? make_float4(acc[8 + 4 * gg], acc[9 + 4 * gg], acc[10 + 4 * gg], acc[11 + 4 * gg])
+                                          : make_float4(acc[4 * gg], acc[1 + 4 * gg], acc[2 + 4 * gg], acc[3 + 4 * gg]);
+            (void)r0;
+        }
+        if (tn < n_tiles) SSP_PARK(cur ^ 1)
+        __syncthreads();
+        cur ^= 1;
+        {
+            int b, kp, cx, cy;
+            const bool ok = cell_of(t, n, b, kp, cx, cy);
+            if (ok) {
+                float* op = out + (((int64_t)b * max_num + kp) * 4 + (n & 3)) * 256 + (g32 - g32_first) * 32 + 16 * part + 4 * hh;
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const float4 p4 = xch_theirs[gg * 64];
+                    const float a0 = part == 0 ? acc[4 * gg] : acc[8 + 4 * gg], a1 = part == 0 ? acc[4 * gg + 1] : acc[9 + 4 * gg];
+                    const float a2 = part == 0 ? acc[4 * gg + 2] : acc[10 + 4 * gg], a3 = part == 0 ? acc[4 * gg + 3] : acc[11 + 4 * gg];
+                    float4 x;
+                    x.x = fmaxf(fmaf(a0 + p4.x, inv, bs[gg].x), 0.f); x.y = fmaxf(fmaf(a1 + p4.y, inv, bs[gg].y), 0.f);
+                    x.z = fmaxf(fmaf(a2 + p4.z, inv, bs[gg].z), 0.f); x.w = fmaxf(fmaf(a3 + p4.w, inv, bs[gg].w), 0.f);
+                    *reinterpret_cast<float4*>(op + 8 * gg) = x;
+                }
+            }
+        }
+        t = tn;
+    }
+#undef SSP_SRC
+#undef SSP_FETCH
+#undef SSP_DST
+#undef SSP_PARK
+#undef SSP_CHUNK
+}
+
+// a4b: split-64 frames of the Hc x Wc x 128 map; w_packed / split_inv / bias: the FUSED heads layer's (convPa | convDa, cout 512: convDa = g32 8..15);
+// out: [batch][max_num][4][256] fp32
+int conv_split_c128_sparse(hipStream_t st, const omni_ctx* ctx, const void* a4b, const void* w_packed, const float* bias, float split_inv, int Hc, int Wc,
+                           int g32_first, int W, int H, int max_num, const float* kps_xy, const int* n_kps, float* out, int batch) {
+    const int tiles_per_img = cdiv(max_num, SSP_KP), n_tiles = tiles_per_img * batch;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int groups = cus / 4;                                                // four workgroups (channel quarters) per tile stream
+    if (groups > n_tiles) groups = n_tiles;
+    if (groups < 1) groups = 1;
+    OMNI_REQUIRE((int64_t)batch * split_frame_h(Hc) * split_frame_w(Wc) * 512 < (1ll << 40), OMNI_ERR_INVALID, "conv_split_c128_sparse: map too large");
+    // the orientation launch_split picks for the dense layer of this shape (it fixes the order the taps are summed in)
+    static const int force = [] { const char* e = getenv("OMNI_SPLIT_TRN"); return e ? atoi(e) : -1; }();
+    const int plain = cdiv(Wc, 32) * cdiv(Hc, 2), trn = cdiv(Hc, 32) * cdiv(Wc, 2);
+    const bool use_trn = force == 1 || (force < 0 && trn < plain);
+    const float inv = split_inv / SPL_ACT_SCALE;
+    auto launch = [&](auto kfn) -> int {
+        static DynSmemState attr;
+        OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)kfn, SSP_SMEM));
+        hipLaunchKernelGGL(kfn, dim3(4 * groups), dim3(256), SSP_SMEM, st, (const char*)a4b, (const _Float16*)w_packed, bias, inv, Hc, Wc, g32_first, W, H, max_num,
+                           kps_xy, n_kps, out, tiles_per_img, n_tiles);
+        OMNI_LAUNCH_CHECK();
+        return OMNI_OK;
+    };
+    return use_trn ? launch(conv3x3_split_c128_sparse_kernel<true>) : launch(conv3x3_split_c128_sparse_kernel<false>);
+}
+
 // conv1a (from the u8 image, built tile by tile inside the kernel) + conv1b + ReLU + 2x2 max-pool in one launch; a = the conv1b layer (a.in unused)
 int conv1ab_split_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const void* w1a_frag, const uint32_t* lut_hl) {
     OMNI_REQUIRE(a.ksize == 3 && a.cin == 64 && a.cout % 64 == 0 && a.pool && !a.out_f32 && a.H % 2 == 0 && a.W % 8 == 0, OMNI_ERR_INVALID, "conv1ab_split_fused: bad layer shape");

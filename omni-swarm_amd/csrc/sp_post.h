@@ -50,6 +50,9 @@ struct SpSparseDesc {
     // do not look at neighbours).
     const float* cda_f32 = nullptr; const void* wdb_f32 = nullptr; float* cx = nullptr; float* cy = nullptr;
     int n_cu = 0; const void* zero_page = nullptr;
+    // OMNI_PREC_SPLIT: convDa itself only at those cells (conv_split_c128_sparse) -- a4b_split: conv4b's split-64 frames; the rows land in cx directly
+    // (cda_f32 is then not read); da_w / da_bias / da_g32_first as above, da_inv = the fused heads layer's split_inv
+    const void* a4b_split = nullptr; float da_inv = 0.f;
 };
 
 // semi: [B][H][W] f32 probability map; desc_nhwc: [B][H/8][W/8][256] f32 (channel-normalised coarse descriptors; unused when sparse.in_f16 is set)

@@ -500,13 +500,19 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
         int rc = convdb_sparse_sample(stream, sparse.ctx, sparse.in_f16, sparse.in_cstride, sparse.wfrag, sparse.bias, p.width, p.height, p.max_num,
                                       b.kps_xy, b.n_kps, b.raw_desc, batch, false);
         if (rc) return rc;
-    } else if (sparse.cda_f32) {
+    } else if (sparse.cda_f32 || sparse.a4b_split) {
         // exact-f32 descriptor head only where the sampler reads: gather the cells -> the SAME 1x1 convolution kernel and per-cell norm the dense
         // map uses, on [8][N / 8] pixels instead of [batch][Hc][Wc] -> sample the compact rows
         const int64_t n_rows = (((int64_t)batch * p.max_num * 4) + 7) & ~(int64_t)7;
-        hipLaunchKernelGGL(sp_gather_cells_kernel, dim3(p.max_num, batch), dim3(256), 0, stream, sparse.cda_f32, sparse.in_cstride, p.width, p.height, p.max_num,
-                           b.kps_xy, b.n_kps, sparse.cx);
-        OMNI_LAUNCH_CHECK();
+        if (sparse.a4b_split) {
+            int rc = conv_split_c128_sparse(stream, sparse.ctx, sparse.a4b_split, sparse.da_w, sparse.da_bias, sparse.da_inv, p.height / 8, p.width / 8,
+                                            sparse.da_g32_first, p.width, p.height, p.max_num, b.kps_xy, b.n_kps, sparse.cx, batch);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(sp_gather_cells_kernel, dim3(p.max_num, batch), dim3(256), 0, stream, sparse.cda_f32, sparse.in_cstride, p.width, p.height, p.max_num,
+                               b.kps_xy, b.n_kps, sparse.cx);
+            OMNI_LAUNCH_CHECK();
+        }
         ConvArgs a;
         a.in = sparse.cx; a.out = sparse.cy; a.w_packed = sparse.wdb_f32; a.bias = sparse.bias; a.batch = 1; a.H = 8; a.W = (int)(n_rows / 8); a.cin = 256;
         a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false; a.out_f32 = true; a.in_cstride = 256; a.n_cu = sparse.n_cu; a.zero_page = sparse.zero_page;

@@ -47,6 +47,7 @@ struct omni_sp {
     bool sparse_desc = true;
     bool sparse_da = true;                   // ... and convDa itself only there too (conv_c128_sparse); OMNI_SP_SPARSE_DA=0: convDa stays dense
     void* headsP = nullptr;                  // [B][Hc][Wc][256] cPa alone (sparse_da passes)
+    bool heads_full = true;                  // `heads` holds the fused layer of the last pass (false: OMNI_PREC_SPLIT ran cPa alone + convDa at the key points)
     void* da_compact = nullptr;              // [B][max_num][4][256] fp16: cDa at the corner cells of the key points
     float *cx32 = nullptr, *cy32 = nullptr;  // fp32 paths: the gathered cDa rows / their convDb + norm, [ceil8(B * max_num * 4)][256] each
     bool dense_valid = false, dense_possible = false;   // `draw` holds / `heads` can still produce the dense map of the last forward pass
@@ -297,7 +298,10 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         const size_t rows = ((B * (size_t)s->max_num * 4) + 7) & ~(size_t)7;
         OMNI_HIP_TRY(hipMalloc((void**)&s->cx32, rows * 256 * 4));
         OMNI_HIP_TRY(hipMalloc((void**)&s->cy32, rows * 256 * 4));
+        OMNI_HIP_TRY(hipMemsetAsync(s->cx32, 0, rows * 256 * 4, st));          // rows of key points that do not exist are never written (and never read back)
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
     }
+    if (s->precision == OMNI_PREC_SPLIT) OMNI_HIP_TRY(hipMalloc(&s->headsP, B * (H / 8) * (W / 8) * 256 * 4));     // cPa alone, fp32 (sparse convDa passes)
     OMNI_HIP_TRY(hipMalloc((void**)&s->draw, B * (H / 8) * (W / 8) * 256 * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->semi, B * H * W * 4));
     OMNI_HIP_TRY(hipMalloc((void**)&s->gray_stage, B * H * W));
@@ -424,11 +428,12 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const bool sparse = s->precision == OMNI_PREC_F16 && s->conv_variant == 0 && s->sparse_desc && run_post;
     // fp32 / split paths: the exact-f32 convDb + norm likewise only at the cells around the key points (sp_post.hip), the dense map on demand
     const bool sparse32 = s->precision != OMNI_PREC_F16 && s->conv_variant == 0 && s->sparse_desc && run_post && s->cx32;
-    const bool sparse_da = sparse && s->sparse_da && s->headsP;
+    const bool sparse_da32 = sparse32 && P == OMNI_PREC_SPLIT && s->sparse_da && s->headsP;      // convDa itself at those cells only (conv_split_c128_sparse)
+    const bool sparse_da = (sparse && s->sparse_da && s->headsP) || sparse_da32;
     // the detector branch needs cPa everywhere; cDa (output channels 256-511 of the fused heads layer) is only read around the key points
     const void* cpa = sparse_da ? s->headsP : s->heads;
     const int cpa_stride = sparse_da ? 256 : 512;
-    if (sparse_da) { if ((rc = conv(LPA, s->a4b, s->headsP, s->bias_heads, H / 8, W / 8, 128, 256, 3, true, false, false))) return rc; }
+    if (sparse_da) { if ((rc = conv(LPA, s->a4b, s->headsP, s->bias_heads, H / 8, W / 8, 128, 256, 3, true, false, P == OMNI_PREC_SPLIT))) return rc; }
     else if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, P == OMNI_PREC_SPLIT))) return rc;
     if ((rc = mark())) return rc;
     if (s->conv_variant == 1) { if ((rc = detector_head(st, PH, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
@@ -438,6 +443,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
                                         s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
     s->dense_valid = !sparse && !sparse32; s->dense_possible = true; s->last_batch = batch;
+    s->heads_full = !sparse_da32;
     if (sparse || sparse32) {
         // nothing here: convDb runs inside the post-processing, at the key points only
     } else if (s->precision == OMNI_PREC_F16 && s->conv_variant == 0) {
@@ -458,7 +464,8 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (run_post) {
         SpSparseDesc sd;
         if (sparse) { sd.ctx = s->ctx; sd.in_f16 = (const char*)s->heads + (size_t)256 * s->esz; sd.in_cstride = 512; sd.wfrag = s->wDbFrag; sd.bias = s->bias[LDB]; }
-        if (sparse_da) { sd.a4b = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_compact = s->da_compact; }
+        if (sparse_da32) { sd.ctx = s->ctx; sd.a4b_split = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_inv = s->winv[LPA]; }
+        else if (sparse_da) { sd.a4b = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_compact = s->da_compact; }
         if (sparse32) {
             sd.cda_f32 = reinterpret_cast<const float*>(s->heads) + 256; sd.in_cstride = 512; sd.wdb_f32 = s->wpk[LDB]; sd.bias = s->bias[LDB];
             sd.cx = s->cx32; sd.cy = s->cy32; sd.n_cu = s->ctx->prop.multiProcessorCount; sd.zero_page = s->ctx->zero_page;
@@ -475,6 +482,14 @@ static int sp_make_dense(omni_sp* s) {
     hipStream_t st = s->ctx->stream;
     int rc;
     if (s->precision != OMNI_PREC_F16) {       // the heads layer's fp32 output is still in HBM: dense convDb + norm from it
+        if (!s->heads_full) {                  // (OMNI_PREC_SPLIT with convDa at the key points only: the fused layer over every cell first)
+            ConvArgs h;
+            h.in = s->a4b; h.out = s->heads; h.w_packed = s->wpk[LPA]; h.bias = s->bias_heads; h.batch = s->last_batch; h.H = s->Hc; h.W = s->Wc; h.cin = 128;
+            h.cout = 512; h.ksize = 3; h.relu = true; h.pool = false; h.out_f32 = true; h.split_inv = s->winv[LPA];
+            h.n_cu = s->ctx->prop.multiProcessorCount; h.zero_page = s->ctx->zero_page; h.variant = s->conv_variant;
+            if ((rc = conv_split(st, h))) return rc;
+            s->heads_full = true;
+        }
         ConvArgs a;
         a.in = (const char*)s->heads + (size_t)256 * 4; a.out = s->draw; a.w_packed = s->wpk[LDB]; a.bias = s->bias[LDB];
         a.batch = s->last_batch; a.H = s->Hc; a.W = s->Wc; a.cin = 256; a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false;
