@@ -49,7 +49,9 @@ def sp_flop_executed(precision, max_num, conv_stages_only=False, left_out_flop=0
     post-processing stage; left_out_flop: the FLOP of the tiles a fisheye-masked pass leaves out of the tile walk -- the constant region of the mask,
     csrc/superpoint.hip sp_plan_mask_skip -- summed from the library's own per-stage figures, omni_sp_stage_flops x omni_sp_stage_tiles_left_out)."""
     sparse_db = precision == "f16" and os.environ.get("OMNI_SP_SPARSE_DESC", "1") != "0"
-    sparse_da = sparse_db and os.environ.get("OMNI_SP_SPARSE_DA", "1") != "0"
+    # convDa at the key points only: the fp16 path (conv_c128_sparse) and, since round 4, OMNI_PREC_SPLIT (conv_split_c128_sparse); the exact-f32 path keeps
+    # the dense convDa.  (The fp32 / split convDb is sparse too, but not part of SP_FLOP_PER_IMAGE's matrix-core figure in those modes.)
+    sparse_da = precision in ("f16", "split") and os.environ.get("OMNI_SP_SPARSE_DESC", "1") != "0" and os.environ.get("OMNI_SP_SPARSE_DA", "1") != "0"
     cells = 0 if conv_stages_only else min(4 * max_num, SP_CELLS)
     f = SP_FLOP_PER_IMAGE - left_out_flop
     if sparse_db:

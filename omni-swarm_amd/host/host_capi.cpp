@@ -88,6 +88,24 @@ int omni_pipeline_run(omni_pipeline* h, int n_keyframes, int64_t first_msg_id, c
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// the streaming intake (omni::KeyframePipeline::push_keyframe / flush): one key frame as SwarmLoop::VIOKF_callback hands it on -- images[0..n_images) host
+// pointers (up cameras, then down cameras; PINHOLE_DEPTH: the one gray image), pose7 = position xyz + quaternion wxyz, depth (PINHOLE_DEPTH, may be
+// NULL) borrowed until the key frame's unit is finished.  *hits += loop candidates found by the units the call finished.
+int omni_pipeline_push_keyframe(omni_pipeline* h, const uint8_t* const* images, int stride, int64_t msg_id, double stamp, const double* pose7,
+                                int prevent_adding_db, const uint16_t* depth, int* hits) {
+    try {
+        omni::KeyframePipeline::KeyframeIn k;
+        k.images = images; k.stride = stride; k.msg_id = msg_id; k.stamp = stamp; k.prevent_adding_db = prevent_adding_db != 0; k.depth = depth;
+        if (pose7) { for (int i = 0; i < 3; ++i) k.pose_drone.position[i] = pose7[i]; for (int i = 0; i < 4; ++i) k.pose_drone.quat_wxyz[i] = pose7[3 + i]; }
+        const int n = h->p->push_keyframe(k);
+        if (hits) *hits += n;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+int omni_pipeline_flush(omni_pipeline* h, int* hits) {
+    try { const int n = h->p->flush(); if (hits) *hits += n; return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 // allocates whatever a later omni_pipeline_run(h, n_keyframes, ...) would allocate on first use (the unit for a partial micro-batch)
 int omni_pipeline_prepare(omni_pipeline* h, int n_keyframes) {
     try { h->p->prepare(n_keyframes); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }

@@ -285,6 +285,7 @@ public:
     // (same layout for rem frames): EXACTLY n_keyframes key frames are processed.  from_host: upload inside the loop
     // (omni_cam_enqueue_host); otherwise the pool entries are device pointers.  Returns the number of loop candidates found.
     int run(int n_keyframes, int64_t first_msg_id, const uint8_t* const* pool, int n_pool, int first_slot, const uint8_t* tail, bool from_host) {
+        if (open_ || !stream_pending_.empty()) throw std::runtime_error("run: key frames pushed through push_keyframe are still open -- flush() first");
         const int MB = cfg_.microbatch;
         const int full = n_keyframes / MB, rem = n_keyframes % MB;
         Lane* tail_lane = rem ? prepare(n_keyframes) : nullptr;
@@ -295,6 +296,7 @@ public:
             const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
             if (pend_lane_ == lane) check(omni_shard_rows_consumed(shard_), "omni_shard_rows_consumed");      // its row buffer is the exchange's input
             lane->t_enqueue = std::chrono::steady_clock::now();
+            lane->meta.clear();
             if (from_host) lane->cam.enqueue_host(src, cfg_.width, !cfg_.mono());       // loop_cam.cpp:536: only STEREO_FISHEYE blanks rows
             else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
             pending.emplace_back(lane, first_msg_id + (int64_t)s * MB);
@@ -314,9 +316,77 @@ public:
 
     void sync() { for (auto& l : lanes_) l->sync(); for (auto& t : tail_lanes_) t.second->sync(); check(omni_ctx_sync(index_ctx_.get()), "sync"); }
 
+    // one key frame as SwarmLoop::VIOKF_callback hands it on (swarm_loop.cpp:140-170): the flattened views -- images[0..dirs) = up cameras, images[dirs..2*dirs)
+    // = down cameras (PINHOLE_DEPTH: the one gray image), each height rows of `stride` bytes -- the key-frame id and stamp (StereoFrame::keyframe_id,
+    // ::stamp), VIO's pose, and prevent_adding_db (:156: a non-key frame that moved less than min_movement_keyframe is matched but not added);
+    // depth: PINHOLE_DEPTH's 16-bit depth image (rows packed), borrowed until the key frame's unit is finished
+    struct KeyframeIn {
+        const uint8_t* const* images = nullptr; int stride = 0;
+        int64_t msg_id = 0; double stamp = 0; PoseMsg pose_drone; bool prevent_adding_db = false;
+        const uint16_t* depth = nullptr;
+    };
 private:
+    struct SlotMeta { int64_t msg_id = 0; double stamp = 0; PoseMsg pose; bool prevent_adding_db = false; const uint16_t* depth = nullptr; };
     struct Lane;
 public:
+    // The streaming intake (what a ROS callback calls per key frame; KeyframeIntake::extract in keyframe_intake.hpp): the images are packed into the
+    // open micro-batch's pinned block and the call returns; the `microbatch`-th key frame sends the unit to the GPU (one upload, SuperPoint,
+    // MobileNetVLAD, up/down match, one download) and, when `pipelines` units are in flight, finishes the oldest (detector, geometry).  Returns the
+    // loop candidates found by the units this call finished.  The reference handles one key frame at a time, synchronously (tensorrt_generic.cpp:58-75).
+    int push_keyframe(const KeyframeIn& k) {
+        if (shard_) throw std::runtime_error("push_keyframe: the sharded database is driven through run()");
+        const int MB = cfg_.microbatch, nd = cfg_.dirs(), cams = cfg_.mono() ? 1 : 2;
+        const size_t img = (size_t)cfg_.width * cfg_.height;
+        if (!open_) {
+            // round robin over the lanes; at most pipelines - 1 units are in flight here (see below), so this lane is free
+            open_ = lanes_[next_lane_++ % lanes_.size()].get();
+            open_->meta.clear();
+            if (!open_->stage) {
+                open_->stage_bytes = (size_t)cams * nd * MB * img;
+                open_->stage = static_cast<uint8_t*>(omni_host_alloc(open_->stage_bytes));
+                if (!open_->stage) throw std::runtime_error(std::string("omni_host_alloc: ") + omni_last_error());
+            }
+            open_->t_enqueue = std::chrono::steady_clock::now();
+        }
+        const int m = (int)open_->meta.size();
+        for (int c = 0; c < cams; ++c)
+            for (int d = 0; d < nd; ++d) {
+                uint8_t* dst = open_->stage + ((size_t)c * nd * MB + (size_t)nd * m + d) * img;
+                const uint8_t* src = k.images[c * nd + d];
+                for (int y = 0; y < cfg_.height; ++y) std::memcpy(dst + (size_t)y * cfg_.width, src + (size_t)y * k.stride, (size_t)cfg_.width);
+            }
+        SlotMeta sm; sm.msg_id = k.msg_id; sm.stamp = k.stamp; sm.pose = k.pose_drone; sm.prevent_adding_db = k.prevent_adding_db; sm.depth = k.depth;
+        open_->meta.push_back(sm);
+        int hits = carried_hits_; carried_hits_ = 0;
+        if ((int)open_->meta.size() == MB) {
+            open_->cam.enqueue_host(open_->stage, cfg_.width, !cfg_.mono());
+            stream_pending_.push_back(open_);
+            open_ = nullptr;
+            while (stream_pending_.size() >= lanes_.size()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
+        }
+        return hits;
+    }
+    // everything pushed so far through the detector (and the geometry stage): a partial micro-batch runs as its own, smaller unit
+    int flush() {
+        int hits = carried_hits_; carried_hits_ = 0;
+        Lane* tail = nullptr;
+        if (open_ && !open_->meta.empty()) {
+            const int MB = cfg_.microbatch, nd = cfg_.dirs(), rem = (int)open_->meta.size();
+            const size_t img = (size_t)cfg_.width * cfg_.height;
+            tail = prepare(rem);
+            if (!cfg_.mono()) std::memmove(open_->stage + (size_t)nd * rem * img, open_->stage + (size_t)nd * MB * img, (size_t)nd * rem * img);      // the down block moves up behind rem up blocks
+            tail->meta = open_->meta;
+            tail->t_enqueue = open_->t_enqueue;
+            tail->cam.enqueue_host(open_->stage, cfg_.width, !cfg_.mono());
+            open_->meta.clear();
+        }
+        while (!stream_pending_.empty()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
+        if (tail) { hits += finish_timed(*tail, 0); tail->meta.clear(); }
+        open_ = nullptr;
+        drain_geometry();
+        return hits;
+    }
+
     // creates (once) the smaller unit a run of n_keyframes needs for its trailing n_keyframes % microbatch key frames, so that the first
     // timed run does not pay for it
     Lane* prepare(int n_keyframes) {
@@ -339,6 +409,10 @@ private:
         void sync() { check(omni_ctx_sync(sp_ctx.get()), "sync"); check(omni_ctx_sync(vlad_ctx.get()), "sync"); }
         std::chrono::steady_clock::time_point t_enqueue;
         int mb;
+        std::vector<SlotMeta> meta;                    // streaming intake (push_keyframe): what each key frame of the unit came with; empty = run()'s numbering
+        uint8_t* stage = nullptr;                      // pinned block the streaming intake packs the unit's images into
+        size_t stage_bytes = 0;
+        ~Lane() { if (stage) omni_host_free(stage); }
         Context sp_ctx, vlad_ctx;
         Swarm::SuperPointHIP sp;
         Swarm::MobileNetVLADHIP vlad;
@@ -388,10 +462,12 @@ private:
         const int G = r.global_dim;
         for (int m = 0; m < lane.mb; ++m) {
             FisheyeFrameDescriptor& f = frames_[m];
-            const int64_t kf_id = first_id + m;
-            const double stamp = (double)kf_id;
-            const PoseMsg pose = (kf_id >= pose_base_ && kf_id < pose_base_ + (int64_t)poses_.size()) ? poses_[(size_t)(kf_id - pose_base_)] : PoseMsg{};
-            f.prevent_adding_db = false;
+            const bool streamed = !lane.meta.empty();
+            const int64_t kf_id = streamed ? lane.meta[m].msg_id : first_id + m;
+            const double stamp = streamed ? lane.meta[m].stamp : (double)kf_id;
+            const PoseMsg pose = streamed ? lane.meta[m].pose
+                                          : (kf_id >= pose_base_ && kf_id < pose_base_ + (int64_t)poses_.size()) ? poses_[(size_t)(kf_id - pose_base_)] : PoseMsg{};
+            f.prevent_adding_db = streamed && lane.meta[m].prevent_adding_db;
             f.images.resize(nd);
             for (int d = 0; d < nd; ++d) {
                 const int i = nd * m + d;                                           // image i of the up cameras
@@ -401,8 +477,8 @@ private:
                 stamp_image_descriptor(im, stamp, cfg_.self_id, to_msg(view_extrinsic(d, true)), pose, kf_id);
                 if (cfg_.geometry && cfg_.mono()) {
                     // generate_gray_depth_image_descriptor's landmarks (loop_cam.cpp:260-304): read from the depth image under each key point
-                    const bool have = depth_ && kf_id >= depth_base_ && kf_id < depth_base_ + depth_n_;
-                    if (have) fill_depth_landmarks(im, depth_ + (size_t)(kf_id - depth_base_) * cfg_.width * cfg_.height, cfg_.width, cfg_.width, cfg_.height, cfg_.depth_near,
+                    const bool have = streamed ? lane.meta[m].depth != nullptr : (depth_ && kf_id >= depth_base_ && kf_id < depth_base_ + depth_n_);
+                    if (have) fill_depth_landmarks(im, streamed ? lane.meta[m].depth : depth_ + (size_t)(kf_id - depth_base_) * cfg_.width * cfg_.height, cfg_.width, cfg_.width, cfg_.height, cfg_.depth_near,
                                                    cfg_.depth_far, cfg_.accept_min_3d_pts, lift64_);
                 } else if (cfg_.geometry) {
                     // the stereo half of generate_stereo_image_descriptor (loop_cam.cpp:341-454): the down image of this direction, triangulation
@@ -434,7 +510,7 @@ private:
         }
         int hits = 0, fi = 0;
         for (auto& c : det_.on_images_recv_batch(std::move(frames_), lane.rows_dev)) {
-            if (c.found) { ++hits; candidates_.push_back({first_id + fi, c.old_msg_id, c.direction_new, c.direction_old}); }
+            if (c.found) { ++hits; candidates_.push_back({lane.meta.empty() ? first_id + fi : lane.meta[(size_t)fi].msg_id, c.old_msg_id, c.direction_new, c.direction_old}); }
             ++fi;
         }
         // the previous micro-batch's tasks ran while this one's CNN unit was waited for; this one's run until the next gets here.  The tasks
@@ -478,6 +554,10 @@ private:
     int geometry_calls_ = 0;
     std::vector<std::unique_ptr<Lane>> lanes_;
     std::map<int, std::unique_ptr<Lane>> tail_lanes_;
+    Lane* open_ = nullptr;                      // streaming intake: the micro-batch being filled
+    std::deque<Lane*> stream_pending_;          // ... and the units in flight, oldest first
+    size_t next_lane_ = 0;
+    int carried_hits_ = 0;
     std::vector<FisheyeFrameDescriptor> frames_;
     std::unique_ptr<IndexFlatIP> shard_index_;
     omni_shard* shard_ = nullptr;

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
            "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync",
-           "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
+           "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_push_keyframe", "omni_pipeline_flush", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
 _lib = None
 
 
@@ -35,6 +35,9 @@ def lib():
         L.omni_pipeline_create_pinhole_depth.restype = C.c_void_p
         L.omni_pipeline_create_pinhole_depth.argtypes = L.omni_pipeline_create.argtypes + [C.c_double] * 6 + [C.c_int]
         L.omni_pipeline_set_depth.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.omni_pipeline_push_keyframe.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_void_p,
+                                                  C.POINTER(C.c_int)]
+        L.omni_pipeline_flush.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.omni_pipeline_geometry_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.omni_pipeline_destroy.argtypes = [C.c_void_p]
         L.omni_pipeline_destroy.restype = None
@@ -115,6 +118,32 @@ class KeyframePipeline:
         hits = C.c_int(0)
         if lib().omni_pipeline_run(self.h, n_keyframes, first_msg_id, arr, len(pool_ptrs), first_slot, tail_ptr, int(from_host), C.byref(hits)):
             raise _err("omni_pipeline_run")
+        return hits.value
+
+    def push_keyframe(self, images, msg_id: int, stamp: float, pose7=None, prevent_adding_db: bool = False, depth: np.ndarray = None) -> int:
+        """The streaming intake: one key frame (images: list of u8 arrays [H][W], up cameras then down cameras; PINHOLE_DEPTH: one) with its id, stamp,
+        odometry pose and prevent_adding_db flag (swarm_loop.cpp:140-170); returns the loop candidates found by the units this call finished.  The
+        images are copied before the call returns; a depth image must stay alive until flush()."""
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+        arr = (C.c_void_p * len(imgs))(*[i.ctypes.data for i in imgs])
+        p7 = None
+        if pose7 is not None:
+            p7v = np.ascontiguousarray(pose7, np.float64).reshape(7)
+            p7 = p7v.ctypes.data_as(C.POINTER(C.c_double))
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.uint16)
+            self._depths = getattr(self, "_depths", []) + [depth]
+        hits = C.c_int(0)
+        if lib().omni_pipeline_push_keyframe(self.h, arr, imgs[0].shape[1], msg_id, float(stamp), p7, int(prevent_adding_db),
+                                             depth.ctypes.data if depth is not None else None, C.byref(hits)):
+            raise _err("omni_pipeline_push_keyframe")
+        return hits.value
+
+    def flush(self) -> int:
+        hits = C.c_int(0)
+        if lib().omni_pipeline_flush(self.h, C.byref(hits)):
+            raise _err("omni_pipeline_flush")
+        self._depths = []
         return hits.value
 
     def prepare(self, n_keyframes: int):

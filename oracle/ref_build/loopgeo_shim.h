@@ -75,6 +75,7 @@ struct FisheyeFrameDescriptor_t {
     int64_t msg_id = 0;
     Pose_t pose_drone;
     int32_t landmark_num = 0, drone_id = 0;
+    bool prevent_adding_db = false;               // (FisheyeFrameDescriptor_t.lcm: set by SwarmLoop::VIOKF_callback, swarm_loop.cpp:156)
 };
 struct Vector3Cov { double x = 0, y = 0, z = 0; };
 struct LoopEdge {                                 // the ROS message, as compute_loop fills it (:789-811)

@@ -529,3 +529,65 @@ def test_pinhole_depth_keyframe_is_pinned_to_the_reference_text(front_pin_exe):
         assert calls[:3] == ["CALLS", "1", "1"] and calls[4] == calls[5] == prod[3][1]           # SuperPoint and MobileNetVLAD: once each, on the untouched image
         cases += 1
     assert cases == 5
+
+
+@pytest.fixture(scope="module")
+def ingest_pin_exe():
+    exe = os.path.join(ROOT, "oracle", "_ref", "ingest_pin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ingest_pin is built from /root/reference, which is absent here")
+    return exe
+
+
+def test_keyframe_intake_is_pinned_to_the_reference_text(ingest_pin_exe):
+    """omni::KeyframeIntake (host/keyframe_intake.hpp) next to SwarmLoop's own intake compiled from its text (find_images_raw, odometry_callback,
+    odometry_keyframe_callback, VIOnonKF_callback, VIOKF_callback, pub_node_frame: swarm_loop.cpp:32-53, 100-187) on jittered streams: camera frames
+    at ~20 Hz of which some never arrive (drops), an odometry message per frame stamped within +-0.4 ms of it (a few off by more than the 1 ms window,
+    a few duplicated), VIO key-frame poses every ~0.35-2.5 s (faster than max_freq allows: the rate limit bites), silent stretches longer than
+    nonkeyframe_waitsec (the non-key-frame path: first frame after 1 s, later ones after the wait, prevent_adding_db when the drone moved less than
+    min_movement_keyframe), frames on which the networks report no landmark (they do not count as key frames).  Both sides must extract the same
+    frames with the same poses, deliver the same ones with the same prevent_adding_db flag and node_frame, miss the same key-frame poses, and end in the
+    same state (received_image, last_invoke, last_kftime, frames left in the queue)."""
+    rng = np.random.default_rng(2024)
+    cases = 0
+    for max_freq, min_move, waitsec, duration, speed in ((1.0, 0.3, 5.0, 60.0, 0.05), (2.0, 0.3, 3.0, 45.0, 0.5), (0.5, 1.0, 5.0, 90.0, 0.02),
+                                                         (1.0, 0.3, 5.0, 30.0, 0.0), (10.0, 0.05, 1.5, 20.0, 1.0)):
+        events, t, idx = [], 1600000000.0 + 100 * cases, 0
+        pos = np.zeros(3)
+        next_kf = t + rng.uniform(1.5, 8.0)                       # the first VIO key frame comes late: the non-key-frame path starts the stream
+        quiet_from, quiet_to = t + duration * 0.45, t + duration * 0.45 + waitsec * 2.2        # a stretch without VIO key frames
+        while t < 1600000000.0 + 100 * cases + duration:
+            t += 0.05 + rng.uniform(-0.004, 0.004)
+            pos = pos + speed * 0.05 * np.array([1.0, 0.3, 0.0]) + rng.normal(0, 0.002, 3)
+            arrived = rng.random() > 0.08                         # 8 % of the camera frames are lost
+            if arrived:
+                events.append(f"I {float(t)!r} {idx} {0 if rng.random() < 0.07 else int(rng.integers(30, 800))}")
+                idx += 1
+            r = rng.random()
+            ot = t + (rng.uniform(-4e-4, 4e-4) if r > 0.05 else rng.choice([-1, 1]) * rng.uniform(1.6e-3, 4e-3))       # 5 %: outside the 1 ms window
+            is_kf = t >= next_kf and not (quiet_from < t < quiet_to)
+            pose = " ".join(repr(float(v)) for v in pos)
+            if is_kf:
+                events.append(f"K {float(ot)!r} {pose}")
+                next_kf = t + rng.uniform(0.35, 2.5)
+                if rng.random() < 0.1:
+                    events.append(f"K {float(ot)!r} {pose}")        # a repeated key-frame pose: its frame is gone
+            else:
+                events.append(f"O {float(ot)!r} {pose}")
+        text = f"{max_freq!r} {min_move!r} {waitsec!r} {len(events)}\n" + "\n".join(events)
+        out = [ln for ln in run(ingest_pin_exe, text) if ln and ln[0] in ("PROD", "REF")]
+        prod = [ln[1:] for ln in out if ln[0] == "PROD"]
+        ref = [ln[1:] for ln in out if ln[0] == "REF"]
+        assert not any(ln[0] == "SINKS-DIFFER" for ln in ref)      # the network, the detector and the node_frame topic got the same frames
+        assert prod == ref, (cases, [p for p, r in zip(prod, ref) if p != r][:3], len(prod), len(ref))
+        kinds = [ln[0] for ln in ref]
+        n_ext, n_del, n_miss = kinds.count("EXTRACT"), kinds.count("DELIVER"), kinds.count("MISS")
+        assert n_ext >= 5 and n_miss >= 1 and kinds[-1] == "STATE"
+        if cases < 3:
+            assert n_del < n_ext                                   # frames without landmarks were extracted and not delivered
+        prevented = sum(int(ln[2]) for ln in ref if ln[0] == "DELIVER")
+        if speed == 0.0:
+            assert prevented >= 1                                  # a hovering drone: non-key frames are matched but not added
+        assert all(ln[3] == "1" for ln in ref if ln[0] == "DELIVER")
+        cases += 1
+    assert cases == 5

@@ -187,6 +187,20 @@ def test_cpp_host_loop_equals_python_host_loop(omni, ctx, tmp_path):
     calls, edges = pg.geometry_stats()
     assert hits_geo == hits_cpp and calls >= 16 and 0 <= edges <= calls
     pg.close()
+    # the same 36 key frames one by one through the streaming intake (push_keyframe + flush after the 20th and at the end: the partial unit of 4)
+    pst = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THR, MAXN, c.PREC_F16, MB, 2, c.STORE_F32, 1, 0.3, 0.2, 5, 30, 3)
+    pst.preload(db)
+    hits_st = 0
+    for i in range(36):
+        blk, m = ((pins[0], i) if i < 8 else (pins[1], i - 8) if i < 16 else (pins[2], i - 16)) if i < 20 else ((pins[0], i - 20) if i < 28 else (pins[1], i - 28))
+        mb = 4 if blk is pins[2] else 8
+        views = [blk[4 * m + d] for d in range(4)] + [blk[4 * mb + 4 * m + d] for d in range(4)]
+        hits_st += pst.push_keyframe(views, i, float(i))
+        if i == 19:
+            hits_st += pst.flush()
+    hits_st += pst.flush()
+    assert hits_st == hits_cpp and pst.db_rows == rows_cpp
+    pst.close()
     # and with the database behind omni_shard_* (a one-rank RCCL group: ncclAllGather of rows and of top-k lists inside the library): the
     # recency + threshold rule on global ids finds the same candidates
     ps = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THR, MAXN, c.PREC_F16, MB, 2, c.STORE_F32,

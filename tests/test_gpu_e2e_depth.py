@@ -81,6 +81,21 @@ def test_pinhole_depth_images_to_loop_edges_equal_the_oracle_chain_and_the_groun
     pl.close()
     for p in pins:
         ctx.host_free(p)
+    # the same key frames one at a time through the streaming intake (push_keyframe: what a ROS callback calls; the stamp is the key frame's own,
+    # the last micro-batch is flushed as a partial one): the same candidates and the same edges
+    ps = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THR, MAXN, c.PREC_SPLIT, 3, 2, c.STORE_F32, 1,
+                                   PARAMS["inner_product_thres"], PARAMS["init_mode_product_thres"], PARAMS["match_index_dist"], PARAMS["min_loop_num"],
+                                   PARAMS["min_direction_loop"], geometry=True,
+                                   pinhole_depth=dict(fx=FX, fy=FY, cx=CX, cy=CY, depth_near=NEAR, depth_far=FAR, accept_min_3d_pts=ACCEPT_MIN))
+    hits_s = 0
+    for i, (gray, depth) in enumerate(frames):
+        hits_s += ps.push_keyframe([gray], i, float(i), np.concatenate([plan[i][3][0], plan[i][3][1]]), False, depth=depth)
+    hits_s += ps.flush()                                                      # 16 key frames in micro-batches of 3: five full units and one of 1
+    cand_s, edges_s = ps.candidates(), ps.edges()
+    assert ps.db_rows == rows
+    ps.close()
+    assert hits_s == hits and np.array_equal(cand_s, cand)
+    assert np.array_equal(edges_s[:, :5], edges[:, :5]) and np.abs(edges_s[:, 5:] - edges[:, 5:]).max(initial=0) < 1e-9
     # ---- the oracle chain ------------------------------------------------------------------------------------------------------------------------
     geo, ref_edges = {}, []
     bf = lambda a, b: M.bf_match(a, b, 0)
