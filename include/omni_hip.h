@@ -71,6 +71,16 @@ typedef struct omni_flatten omni_flatten;
 int         omni_abi_version(void);
 const char* omni_last_error(void);
 
+/* ---- configuration: EVERY switch of the library is an entry of one table (csrc/config.h): environment variable, default, valid range, class
+ * (0 = variant: another kernel for the same results -- A/B measurements, bit-identity tests; 1 = tuning threshold; 2 = debug / timing ablation;
+ * 3 = test fault injection; 4 = string), one line of documentation.  Handles resolve the table when they are created (a value outside its range
+ * fails the creation); nothing else reads the environment.  The defaults ARE the production path (tests/test_config_cpu.py). */
+int omni_config_count(void);
+int omni_config_describe(int i, const char** env, int* def, int* lo, int* hi, int* cls, const char** doc);
+/* what a handle created NOW would see for option `env` (defaults overridden by the current environment); OMNI_ERR_INVALID on an unknown name or
+ * on any option holding a value outside its range */
+int omni_config_value(const char* env, int* value);
+
 /* ---- context: one per GPU/stream; owns a HIP stream, scratch and timers -------------------------------------
  * replaces TensorRTInferenceGeneric's cudaStreamCreate / cudaMalloc plumbing (tensorrt_generic.cpp:14-36,99-120) */
 omni_ctx* omni_ctx_create(int device_id);

@@ -34,7 +34,7 @@ SYMBOLS = [
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
-    "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_cam_create", "omni_cam_create_mono", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
+    "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_config_count", "omni_config_describe", "omni_config_value", "omni_cam_create", "omni_cam_create_mono", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait",
     "omni_shard_unique_id", "omni_shard_library_path", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait",
     "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
@@ -160,6 +160,9 @@ def lib():
     sig("omni_flatten_destroy", None, [_vp])
     sig("omni_flatten_out_bytes", C.c_int64, [_vp])
     sig("omni_flatten_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp])
+    sig("omni_config_count", C.c_int, [])
+    sig("omni_config_describe", C.c_int, [C.c_int, C.POINTER(C.c_char_p), _ip, _ip, _ip, _ip, C.POINTER(C.c_char_p)])
+    sig("omni_config_value", C.c_int, [C.c_char_p, _ip])
     sig("omni_shard_unique_id", C.c_int, [C.c_char_p])
     sig("omni_shard_library_path", C.c_int, [C.c_char_p, C.c_int])
     sig("omni_shard_create", _vp, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p])
@@ -631,6 +634,24 @@ def sp_mask_skip_plan(width: int, height: int, precision: int, layer: int):
     frac = C.c_double()
     _check(lib().omni_sp_mask_skip_plan(width, height, precision, layer, rect, C.byref(frac)))
     return tuple(rect), frac.value
+
+
+def config_table() -> list:
+    """csrc/config.h's table: [{env, default, lo, hi, cls, doc}] (cls: 0 variant, 1 tuning, 2 debug, 3 test, 4 string)"""
+    out = []
+    for i in range(lib().omni_config_count()):
+        env, doc = C.c_char_p(), C.c_char_p()
+        d, lo, hi, cls = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(lib().omni_config_describe(i, C.byref(env), C.byref(d), C.byref(lo), C.byref(hi), C.byref(cls), C.byref(doc)))
+        out.append({"env": env.value.decode(), "default": d.value, "lo": lo.value, "hi": hi.value, "cls": cls.value, "doc": doc.value.decode()})
+    return out
+
+
+def config_value(env: str) -> int:
+    """what a handle created now would see for this option"""
+    v = C.c_int()
+    _check(lib().omni_config_value(env.encode(), C.byref(v)))
+    return v.value
 
 
 def shard_library_path() -> str:

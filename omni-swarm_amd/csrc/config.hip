@@ -1,0 +1,122 @@
+// config.hip -- the table behind config.h and its C entry points (include/omni_hip.h: omni_config_*)
+#include "config.h"
+
+#include <cerrno>
+#include <climits>
+#include <cstdlib>
+
+namespace omni {
+
+const CfgOption kCfgOptions[CFG_COUNT] = {
+    // ---- SuperPoint ---------------------------------------------------------------------------------------------------------------------------------
+    {"OMNI_CONV_V1", 0, 0, 3, CFG_VARIANT, "fp16 3x3 layers: 0 = production (conv1a fused into the ping-pong conv1b, register-stationary cin=128); 1 = generic kernel, 2 = persistent LDS-DMA kernel, "
+                                           "3 = ping-pong without the conv1a fusion -- 1-3 exist only in the test build of the library (lib_test/)"},
+    {"OMNI_CONV_RS", 1, 0, 1, CFG_VARIANT, "cin=128 fp16 layers on the register-stationary kernel (0: generic kernel)"},
+    {"OMNI_RS_TRN", -1, -1, 1, CFG_VARIANT, "register-stationary kernel: tile orientation, -1 = the one with fewer tiles, 0 = plain, 1 = transposed"},
+    {"OMNI_DET16", 1, 0, 1, CFG_VARIANT, "fp16 detector head on v_mfma_f32_32x32x16_f16 (0: the fp32-operand MFMA kernel)"},
+    {"OMNI_SP_SPARSE_DESC", 1, 0, 1, CFG_VARIANT, "convDb + descriptor norm only at the cells around the key points (0: dense descriptor map)"},
+    {"OMNI_SP_SPARSE_DA", 1, 0, 1, CFG_VARIANT, "convDa only at those cells too (fp16 and OMNI_PREC_SPLIT; 0: dense convDa)"},
+    {"OMNI_SP_MASK_SKIP", 1, 0, 1, CFG_VARIANT, "fp16: the tiles inside the constant region of the fisheye mask are left out of the tile walk (0: every tile)"},
+    {"OMNI_SP_MASK_SKIP_SPLIT", 1, 0, 1, CFG_VARIANT, "the same for OMNI_PREC_SPLIT"},
+    {"OMNI_SPLIT_FUSE1A", 1, 0, 1, CFG_VARIANT, "OMNI_PREC_SPLIT: conv1a built inside the conv1b kernel from the u8 image (0: separate exact-f32 conv1a pass)"},
+    {"OMNI_SPLIT_TRN", -1, -1, 1, CFG_VARIANT, "OMNI_PREC_SPLIT cin=128 kernel: tile orientation, as OMNI_RS_TRN"},
+    {"OMNI_SP_PROFILE_MASK", 0, 0, 1, CFG_TUNING, "omni_sp_profile times the stages with the fisheye mask on (what the key-frame pipeline runs)"},
+    {"OMNI_PP_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the ping-pong conv kernel on stderr"},
+    {"OMNI_PP_DBG", 0, 0, 255, CFG_DEBUG, "ping-pong conv kernel timing ablations (WRONG results)"},
+    {"OMNI_RS_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the register-stationary kernel"},
+    {"OMNI_SPLIT_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the split-precision kernel"},
+    {"OMNI_SPLIT_DBG", 0, 0, 3, CFG_DEBUG, "split-precision kernel timing ablations: 1 = no stores, 2 = every DMA reads tile 0 (WRONG results)"},
+    // ---- MobileNetVLAD ------------------------------------------------------------------------------------------------------------------------------
+    {"OMNI_VLAD_BIG", 0, 0, 128, CFG_TUNING, "64 / 128: the 64- / 128-pixel tiles of the unfused block kernel (measured slower at 600x480)"},
+    {"OMNI_VLAD_STEM_FUSE", 1, 0, 1, CFG_VARIANT, "stem + block 0 in one kernel (0: two kernels)"},
+    {"OMNI_VLAD_UNFUSED", 0, 0, 1, CFG_VARIANT, "1: every block as expand / depthwise / project launches"},
+    {"OMNI_VLAD_MFMA", 1, 0, 1, CFG_VARIANT, "late blocks' 1x1 convolutions on the matrix cores"},
+    {"OMNI_VLAD_SBLOCK", 1, 0, 1, CFG_VARIANT, "fused split-fp16 block kernel (vlad_s.hip)"},
+    {"OMNI_VLAD_MBLOCK_PX", 2048, 0, 1 << 24, CFG_TUNING, "fused matrix-core block kernel for blocks of at most this many input pixels per image (0 disables)"},
+    {"OMNI_VLAD_MFMA_PX", 0, 0, 1 << 24, CFG_TUNING, "> 0: matrix-core 1x1 convolutions for blocks of at most this many input pixels per image (default 2048)"},
+    {"OMNI_VLAD_FC_MFMA", 1, 0, 1, CFG_VARIANT, "the final FC on the matrix cores (0: VALU kernel)"},
+    {"OMNI_VLAD_MBLOCK_CPW", 0, 0, 64, CFG_TUNING, "hidden-layer split of the matrix-core block kernel: chunks per workgroup (0 = no split; measured: does not pay)"},
+    {"OMNI_VLAD_SB_LDSPAD", 0, 0, 160 * 1024, CFG_DEBUG, "extra LDS bytes per workgroup of the split block kernel (occupancy A/B)"},
+    {"OMNI_VLAD_SB_PERSIST", 1, 0, 16, CFG_VARIANT, "split block kernel: 0 = one tile per workgroup, N >= 1 = N x (CUs x resident workgroups) persistent workgroups"},
+    {"OMNI_VLAD_SB_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the split block kernel"},
+    {"OMNI_VLAD_SB_DBG", 0, 0, 255, CFG_DEBUG, "split block kernel timing ablations (WRONG results)"},
+    // ---- index -----------------------------------------------------------------------------------------------------------------------------------------
+    {"OMNI_SCAN_ROWS_MIN", 4, 1, 1 << 20, CFG_TUNING, "fp32 scan: from this many queries on, the rows-stationary kernel"},
+    {"OMNI_MQ_ROT", 1, 0, 1, CFG_VARIANT, "matrix-core multi-query scan: rotated query fragments"},
+    {"OMNI_MQ_MIN", 4, 0, 1 << 20, CFG_TUNING, "queries from which an fp16 shard is searched on the matrix cores (1 = always, 0 = never)"},
+    {"OMNI_INDEX_MIRROR", 1, 0, 1, CFG_VARIANT, "fp32 index: fp16 mirror + certificate for batched searches (0: exact scans only)"},
+    {"OMNI_INDEX_MIRROR_MIN_ROWS", 32768, 0, INT_MAX, CFG_TUNING, "the mirror is used from this many rows on"},
+    {"OMNI_INDEX_CERT_FAIL", 0, 0, 1, CFG_TEST, "1: every certificate fails (exercises the exact fallback)"},
+    // ---- host loop -------------------------------------------------------------------------------------------------------------------------------------
+    {"OMNI_GEOMETRY_THREADS", -1, -1, 1024, CFG_TUNING, "threads of the geometric-verification pool (-1: min(16, cores / 2); 0: inline)"},
+    {"OMNI_GEOMETRY_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's geometry tasks run while the next unit is waited for (0: drained at once)"},
+    // ---- strings ---------------------------------------------------------------------------------------------------------------------------------------
+    {"OMNI_RCCL_LIB", 0, 0, 0, CFG_STRING, "path of the RCCL library omni_shard dlopens (default: librccl.so next to torch, then the loader's search path)"},
+};
+
+static int parse_one(const CfgOption& o, int* out, bool* bad) {
+    *out = o.def; *bad = false;
+    if (o.cls == CFG_STRING) return 0;
+    const char* e = getenv(o.env);
+    if (!e || !e[0]) return 0;
+    errno = 0;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (errno || end == e || *end != '\0' || v < o.lo || v > o.hi) { *bad = true; return 0; }
+    *out = (int)v;
+    return 1;
+}
+
+int config_resolve(Config* out) {
+    for (int i = 0; i < CFG_COUNT; ++i) {
+        bool bad;
+        parse_one(kCfgOptions[i], &out->v[i], &bad);
+        OMNI_REQUIRE(!bad, OMNI_ERR_INVALID, "%s=%s: expected an integer in [%d, %d] (%s)", kCfgOptions[i].env, getenv(kCfgOptions[i].env), kCfgOptions[i].lo, kCfgOptions[i].hi,
+                     kCfgOptions[i].doc);
+    }
+    return OMNI_OK;
+}
+
+const Config& config_process() {
+    static const Config c = [] {
+        Config q;
+        for (int i = 0; i < CFG_COUNT; ++i) {
+            bool bad;
+            parse_one(kCfgOptions[i], &q.v[i], &bad);
+            if (bad) fprintf(stderr, "libomni_hip: %s=%s ignored: expected an integer in [%d, %d]\n", kCfgOptions[i].env, getenv(kCfgOptions[i].env), kCfgOptions[i].lo, kCfgOptions[i].hi);
+        }
+        return q;
+    }();
+    return c;
+}
+
+}  // namespace omni
+
+extern "C" {
+
+int omni_config_count(void) { return omni::CFG_COUNT; }
+
+int omni_config_describe(int i, const char** env, int* def, int* lo, int* hi, int* cls, const char** doc) {
+    OMNI_REQUIRE(i >= 0 && i < omni::CFG_COUNT, OMNI_ERR_INVALID, "omni_config_describe: option %d of %d", i, (int)omni::CFG_COUNT);
+    const omni::CfgOption& o = omni::kCfgOptions[i];
+    if (env) *env = o.env;
+    if (def) *def = o.def;
+    if (lo) *lo = o.lo;
+    if (hi) *hi = o.hi;
+    if (cls) *cls = o.cls;
+    if (doc) *doc = o.doc;
+    return OMNI_OK;
+}
+
+int omni_config_value(const char* env, int* value) {
+    OMNI_REQUIRE(env && value, OMNI_ERR_INVALID, "null argument");
+    omni::Config c;
+    const int rc = omni::config_resolve(&c);
+    if (rc) return rc;
+    for (int i = 0; i < omni::CFG_COUNT; ++i)
+        if (!strcmp(omni::kCfgOptions[i].env, env)) { *value = c.v[i]; return OMNI_OK; }
+    omni::set_error("omni_config_value: no option named %s", env);
+    return OMNI_ERR_INVALID;
+}
+
+}  // extern "C"

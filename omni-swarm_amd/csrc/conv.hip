@@ -1,4 +1,5 @@
 // SuperPoint convolution kernels for gfx950 (see conv.h for the design summary and reference map).
+#include "config.h"
 #include "conv.h"
 
 namespace omni {
@@ -260,6 +261,7 @@ conv_mfma_kernel(const T* __restrict__ in, void* __restrict__ out_v, const T* __
 // FUSE1A: halo buffers without the DMA tail padding, + conv1a's bias, the u8 -> (hi, lo) half table and four 240-byte image patches
 #define PP_SMEM_FUSED (C64_W_BYTES + 2 * C64_PIX * 128 + 256 + 256 + 1024 + 960)
 
+#ifdef OMNI_TEST_VARIANTS          // the v2 kernel: a bit-identity reference of the test build (lib_test/), not part of the shipped library
 template <bool POOL>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_c64_f16_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
@@ -403,6 +405,7 @@ static int launch_conv_c64(hipStream_t st, const ConvArgs& a, int n_cu) {
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
+#endif  // OMNI_TEST_VARIANTS
 
 // ---------------------------------------------------------------------------------------------------------------
 // v3 "ping-pong" kernel for the same layers (fp16, 3x3, 64 input channels).  Why: in v2 one wave per SIMD does everything
@@ -951,7 +954,7 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
     fzz.magic_tx = magic(tiles_x);
     fzz.magic_bw = magic(fzz.skip_bw);
     // OMNI_PP_TRACE=1 (debug): s_memtime stamps of workgroup 0's phases 2-5 for the layers without the conv1a fusion (conv1ab_fused prints its own)
-    static const bool want_trace = [] { const char* e = getenv("OMNI_PP_TRACE"); return e && e[0] == '1'; }();
+    static const bool want_trace = config_process()[CFG_PP_TRACE] != 0;
     static unsigned long long* trace_dev = nullptr;
     if (want_trace && !FUSE1A) {
         if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
@@ -978,7 +981,7 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
 template <bool POOL>
 static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
     // OMNI_PP_DBG: timing ablations only (WRONG results): bit 0 no DMA, bit 1 no epilogue, bits 2-3: 1 no fragment reads, 2 no B reads, 3 no A reads
-    static const int dbg = [] { const char* e = getenv("OMNI_PP_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = config_process()[CFG_PP_DBG];
     switch (dbg >> 2) {
         case 1: return launch_conv_pp_abl<POOL, 1>(st, a, n_cu, dbg & 3);
         case 2: return launch_conv_pp_abl<POOL, 2>(st, a, n_cu, dbg & 3);
@@ -1198,7 +1201,7 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     if (per_cg > total) per_cg = total;
     OMNI_REQUIRE(a.zero_page, OMNI_ERR_INVALID, "conv: ConvArgs.zero_page is not set");
     const char* zero_page = reinterpret_cast<const char*>(a.zero_page);
-    static const bool want_trace = [] { const char* e = getenv("OMNI_RS_TRACE"); return e && e[0] == '1'; }();
+    static const bool want_trace = config_process()[CFG_RS_TRACE] != 0;
     static unsigned long long* trace_dev = nullptr;
     if (want_trace) {
         if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
@@ -1225,7 +1228,7 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
 
 // the tile orientation launch_conv_rs picks for a non-pooled H x W layer (it fixes the order the taps are summed in)
 bool conv_rs_transposed(int H, int W) {
-    static const int force = [] { const char* e = getenv("OMNI_RS_TRN"); return e ? atoi(e) : -1; }();
+    static const int force = config_process()[CFG_RS_TRN];
     const int plain = cdiv(W, RS_TW) * cdiv(H, RS_TH), trn = cdiv(W, RS_TH) * cdiv(H, RS_TW);
     return force == 1 || (force < 0 && trn < plain);
 }
@@ -1409,14 +1412,14 @@ int conv1ab_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gs
     fz.gray = gray; fz.gstride = gstride;
     omni_fisheye_mask_rows(a.H, fisheye_mask, &fz.mask_r0, &fz.mask_r1);   // cv::Rect(0, rows*3/4, cols, rows/4)
     fz.w1a_frag = w1a_frag; fz.bias1a = bias1a; fz.lut_hl = lut_hl; fz.trace = nullptr;
-    static const bool want_trace = [] { const char* e = getenv("OMNI_PP_TRACE"); return e && e[0] == '1'; }();
+    static const bool want_trace = config_process()[CFG_PP_TRACE] != 0;
     static unsigned long long* trace_dev = nullptr;
     if (want_trace) {
         if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
         OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * 8, st));
         fz.trace = trace_dev;
     }
-    static const int dbg = [] { const char* e = getenv("OMNI_PP_DBG"); return e ? atoi(e) : 0; }();   // timing ablations only
+    static const int dbg = config_process()[CFG_PP_DBG];   // timing ablations only
     const int rc = launch_conv_pp_abl<true, 0, true>(st, a, a.n_cu, dbg, fz);
     if (want_trace && rc == OMNI_OK) {
         unsigned long long h[64];
@@ -1469,15 +1472,22 @@ int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {
     OMNI_REQUIRE(!(a.pool && a.ksize == 1), OMNI_ERR_INVALID, "1x1 + pool not instantiated");
     if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 64 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 64) && a.n_cu > 0 && a.zero_page &&
         a.variant != 1) {
+#ifdef OMNI_TEST_VARIANTS
         if (a.variant == 2) return a.pool ? launch_conv_c64<true>(st, a, a.n_cu) : launch_conv_c64<false>(st, a, a.n_cu);
+#endif
         return a.pool ? launch_conv_pp<true>(st, a, a.n_cu) : launch_conv_pp<false>(st, a, a.n_cu);
     }
-    static const bool no_rs = [] { const char* e = getenv("OMNI_CONV_RS"); return e && e[0] == '0'; }();     // A/B hook
+    static const bool no_rs = config_process()[CFG_CONV_RS] == 0;     // A/B hook
     if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 128 && a.cout % 128 == 0 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 128) &&
         a.n_cu > 0 && a.zero_page && a.variant == 0 && !no_rs && (!a.pool || a.H % 2 == 0))
         return a.pool ? launch_conv_rs<true>(st, a, a.n_cu) : launch_conv_rs<false>(st, a, a.n_cu);
     if (precision == OMNI_PREC_F16) {
+#ifdef OMNI_TEST_VARIANTS              // the generic kernel on the fp16 3x3 layers (OMNI_CONV_V1=1): the other bit-identity reference of the test build
         if (a.ksize == 3) return a.pool ? launch_conv<_Float16, 3, true>(st, a) : launch_conv<_Float16, 3, false>(st, a);
+#else
+        OMNI_REQUIRE(a.ksize != 3, OMNI_ERR_INVALID, "conv_mfma: no production fp16 kernel for a 3x3 layer with cin=%d cout=%d in_cstride=%d (the generic one is only built into the test library)",
+                     a.cin, a.cout, a.in_cstride);
+#endif
         return launch_conv<_Float16, 1, false>(st, a);
     } else {
         if (a.ksize == 3) return a.pool ? launch_conv<float, 3, true>(st, a) : launch_conv<float, 3, false>(st, a);

@@ -26,6 +26,7 @@
 //   cin = 128 (conv3b, conv4a, conv4b, convPa|convDa): tile = 2 rows x 32 pixels x 64 output channels; wave = (32 output
 //             channels, 64-channel block of the input): K is split over the two waves of a pair, whose partial accumulators
 //             meet through 16 KB of LDS (each wave finishes half of the pair's registers); halo 4 x 34 pixels x 2 blocks.
+#include "config.h"
 #include "conv.h"
 #include <type_traits>
 
@@ -932,7 +933,7 @@ template <bool C128, bool POOL, bool OUT_F32, bool TRN = false, bool FUSE1A = fa
 static int launch_split(hipStream_t st, const ConvArgs& a, const SplFuse& fz = SplFuse{}) {
     if constexpr (C128 && !POOL && !TRN) {
         // the tile orientation with fewer tiles (OMNI_SPLIT_TRN=0/1 forces one: A/B hook; it fixes the order the taps are summed in)
-        static const int force = [] { const char* e = getenv("OMNI_SPLIT_TRN"); return e ? atoi(e) : -1; }();
+        static const int force = config_process()[CFG_SPLIT_TRN];
         const int plain = cdiv(a.W, 32) * cdiv(a.H, 2), trn = cdiv(a.H, 32) * cdiv(a.W, 2);
         if (force == 1 || (force < 0 && trn < plain)) return launch_split<C128, POOL, OUT_F32, true>(st, a);
     }
@@ -958,8 +959,8 @@ static int launch_split(hipStream_t st, const ConvArgs& a, const SplFuse& fz = S
     if (per_cg < 1) per_cg = 1;
     if (per_cg > total) per_cg = total;
     const float inv = a.out_f32 ? a.split_inv / SPL_ACT_SCALE : a.split_inv;
-    static const bool want_trace = [] { const char* e = getenv("OMNI_SPLIT_TRACE"); return e && e[0] == '1'; }();
-    static const int dbg = [] { const char* e = getenv("OMNI_SPLIT_DBG"); return e ? atoi(e) : 0; }();
+    static const bool want_trace = config_process()[CFG_SPLIT_TRACE] != 0;
+    static const int dbg = config_process()[CFG_SPLIT_DBG];
     static unsigned long long* trace_dev = nullptr;
     if (want_trace) {
         if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 128 * 8));
@@ -1214,7 +1215,7 @@ int conv_split_c128_sparse(hipStream_t st, const omni_ctx* ctx, const void* a4b,
     if (groups < 1) groups = 1;
     OMNI_REQUIRE((int64_t)batch * split_frame_h(Hc) * split_frame_w(Wc) * 512 < (1ll << 40), OMNI_ERR_INVALID, "conv_split_c128_sparse: map too large");
     // the orientation launch_split picks for the dense layer of this shape (it fixes the order the taps are summed in)
-    static const int force = [] { const char* e = getenv("OMNI_SPLIT_TRN"); return e ? atoi(e) : -1; }();
+    static const int force = config_process()[CFG_SPLIT_TRN];
     const int plain = cdiv(Wc, 32) * cdiv(Hc, 2), trn = cdiv(Hc, 32) * cdiv(Wc, 2);
     const bool use_trn = force == 1 || (force < 0 && trn < plain);
     const float inv = split_inv / SPL_ACT_SCALE;

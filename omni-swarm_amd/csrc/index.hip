@@ -12,6 +12,7 @@
 //               instruction and stalled on the L1 tag rate at 4.8 TB/s).
 // Search = one streaming scan kernel (HBM-bound: dim*sizeof(elem) bytes per row, read exactly once)
 // that writes one 64-bit sortable key per (query,row), then the exact hierarchical top-k of topk.h.
+#include "config.h"
 #include "common.h"
 #include "topk.h"
 #include <sys/stat.h>
@@ -625,7 +626,7 @@ static int launch_scan(hipStream_t st, const omni_index* ix, int64_t n, int qb, 
     int grid = (int)(want < (int64_t)cus * 8 ? want : (int64_t)cus * 8);
     if (grid < 1) grid = 1;
     size_t smem = (size_t)qb * ix->dim * sizeof(float);
-    static const int rows_min_qb = getenv("OMNI_SCAN_ROWS_MIN") ? atoi(getenv("OMNI_SCAN_ROWS_MIN")) : 4;
+    static const int rows_min_qb = config_process()[CFG_SCAN_ROWS_MIN];
     if (!f16 && qb >= rows_min_qb && qb >= 4) {
         constexpr int R = 4;
         int64_t want_g = cdiv64(cdiv64(n, R), SCAN_WAVES);
@@ -685,7 +686,7 @@ static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, con
     // one workgroup per CU (128 KB of LDS each) walking 512-row blocks b, b + grid, ...
     const int64_t blocks = cdiv64(tiles, MQ_WAVES * MQ_RT);
     const int64_t grid = blocks < cus ? blocks : cus;
-    static const int rotate = getenv("OMNI_MQ_ROT") ? atoi(getenv("OMNI_MQ_ROT")) : 1;
+    static const int rotate = config_process()[CFG_MQ_ROT];
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(MQ_THREADS), MQ_SMEM, st, reinterpret_cast<const _Float16*>(db_t16 ? db_t16 : ix->db),
                        n, ix->dim, ix->mq_q.as<char>(), ix->mq_inv.as<float>(), nq, keys, key_stride, rotate, lim);
     OMNI_LAUNCH_CHECK();
@@ -694,8 +695,8 @@ static int launch_scan_mq(hipStream_t st, omni_index* ix, int64_t n, int nq, con
 
 // number of queries from which an fp16 shard is searched on the matrix cores (OMNI_MQ_MIN overrides: 1 = always, 0 = never)
 static int mq_min_queries() {
-    const char* e = getenv("OMNI_MQ_MIN");
-    int v = e ? atoi(e) : 4;
+    Config c;                                         // (read per call: tests switch it between searches of one process)
+    const int v = config_resolve(&c) == OMNI_OK ? c[CFG_MQ_MIN] : kCfgOptions[CFG_MQ_MIN].def;
     return v <= 0 ? (1 << 30) : v;
 }
 
@@ -780,7 +781,7 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
     const int kp = k + 24 > 2 * k ? k + 24 : 2 * k;                 // candidates per query
     // (small databases stay on the exact kernels: their scans are launch-bound, the mirror's extra launches and its host check would cost more
     // than the halved HBM traffic saves -- OMNI_INDEX_MIRROR_MIN_ROWS, default 32768)
-    static const int64_t mirror_min_rows = [] { const char* e = getenv("OMNI_INDEX_MIRROR_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)32768; }();
+    static const int64_t mirror_min_rows = config_process()[CFG_INDEX_MIRROR_MIN_ROWS];
     if (n >= mirror_min_rows && n > 0 && ix->storage == OMNI_STORE_F32 && ix->db16 && nq >= mq_min_queries() && nq <= MQ_NQ && kp <= TOPK_SEL_MAX_K) {
         if ((rc = ix->cert_keys.ensure((size_t)nq * kp * 8))) return rc;
         if ((rc = ix->cert_flags.ensure((size_t)MQ_NQ * 4))) return rc;
@@ -803,7 +804,7 @@ static int search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* 
         OMNI_HIP_TRY(hipStreamSynchronize(st));
         ix->cert_searches += nq;
         const int* fl = ix->hflags.as<int>();
-        static const bool force_fallback = [] { const char* e = getenv("OMNI_INDEX_CERT_FAIL"); return e && e[0] == '1'; }();      // test hook
+        static const bool force_fallback = config_process()[CFG_INDEX_CERT_FAIL] != 0;      // test hook
         // the uncertified queries, together, through the exact scan (blocks of <= 8 queries per pass over the fp32 rows: what every batch
         // cost before the mirror existed)
         GatherIdx gi;
@@ -871,7 +872,7 @@ omni_index* omni_index_create(omni_ctx* ctx, int dim, int storage, int64_t initi
     if (hipEventCreate(&ix->scan0) != hipSuccess || hipEventCreate(&ix->scan1) != hipSuccess) {
         omni::set_error("hipEventCreate failed"); delete ix; return nullptr;
     }
-    static const bool mirror_on = [] { const char* e = getenv("OMNI_INDEX_MIRROR"); return !(e && e[0] == '0'); }();
+    static const bool mirror_on = omni::config_process()[omni::CFG_INDEX_MIRROR] != 0;
     if (storage == OMNI_STORE_F32 && mirror_on) {
         if (hipMalloc((void**)&ix->norm_max, 4) != hipSuccess || hipMemsetAsync(ix->norm_max, 0, 4, ctx->stream) != hipSuccess) {
             omni::set_error("hipMalloc failed"); omni_index_destroy(ix); return nullptr;

@@ -42,7 +42,7 @@ RcclApi& rccl() {
         // bundle their own libamdhip64 / libhsa-runtime64 / librccl next to /opt/rocm's), and an RCCL whose HSA runtime is not the initialised
         // one fails ncclCommInitRank with "no ROCm-capable device is detected".  So: first the librccl in the directory the loaded
         // libamdhip64 came from, then the default search.
-        // OMNI_RCCL_LIB: an explicit library path first (tests point it at tests/stub_rccl, which lets several ranks share one GPU)
+        // OMNI_RCCL_LIB (the one string option of config.h's table): an explicit library path first (tests point it at tests/stub_rccl, which lets several ranks share one GPU)
         if (const char* forced = getenv("OMNI_RCCL_LIB")) {
             if (forced[0]) {
                 api.so = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);

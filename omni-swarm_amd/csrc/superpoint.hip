@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "config.h"
 #include "conv.h"
 #include "sp_post.h"
 
@@ -29,6 +30,7 @@ const char* kStageNames[OMNI_SP_NUM_STAGES] = {
 
 struct omni_sp {
     omni_ctx* ctx = nullptr;
+    omni::Config cfg;                        // the switches as they stood when the handle was created (config.h)
     int W = 0, H = 0, Hc = 0, Wc = 0, max_num = 0, max_batch = 0, precision = 0, pca_dim = 0, desc_dim = 256;
     float thres = 0.f;
     size_t esz = 4;
@@ -146,7 +148,7 @@ static int sp_plan_mask_skip(omni_sp* s) {
     s->mask_skip = false;
     const bool split = s->precision == OMNI_PREC_SPLIT;
     if (s->conv_variant != 0 || s->precision == OMNI_PREC_F32) return OMNI_OK;
-    { const char* e = getenv(split ? "OMNI_SP_MASK_SKIP_SPLIT" : "OMNI_SP_MASK_SKIP"); if (e && e[0] == '0') return OMNI_OK; }      // = 0: the dense pass (A/B, tests)
+    if (!s->cfg[split ? CFG_SP_MASK_SKIP_SPLIT : CFG_SP_MASK_SKIP]) return OMNI_OK;       // = 0: the dense pass (A/B, tests)
     sp_mask_skip_rects(s->H, s->W, split, s->mskip);
     void** maps[6] = {&s->a1a, &s->a1b, &s->a2a, &s->a2b, &s->a3a, &s->a3b};
     for (int i = 0; i < 6; ++i) {
@@ -188,12 +190,9 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         std::vector<uint16_t> w16(2 * 2 * 16 * 64 * 8);
         detector_pack_weights16(t.data(), w16.data());
         if ((rc = dev_upload(&s->wPbA16, w16.data(), w16.size() * 2, st))) return rc;
-        const char* e16 = getenv("OMNI_DET16");
-        s->det16 = !(e16 && e16[0] == '0');
-        const char* esd = getenv("OMNI_SP_SPARSE_DESC");
-        s->sparse_desc = !(esd && esd[0] == '0');
-        const char* esa = getenv("OMNI_SP_SPARSE_DA");
-        s->sparse_da = s->sparse_desc && !(esa && esa[0] == '0');
+        s->det16 = s->cfg[CFG_DET16] != 0;
+        s->sparse_desc = s->cfg[CFG_SP_SPARSE_DESC] != 0;
+        s->sparse_da = s->sparse_desc && s->cfg[CFG_SP_SPARSE_DA] != 0;
     }
     {
         std::vector<float> bh(512);
@@ -219,8 +218,7 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         uint32_t lh[256];
         conv1a_make_split_lut(lh);
         if ((rc = dev_upload((void**)&s->lut_hl, lh, sizeof(lh), st))) return rc;
-        const char* e = getenv("OMNI_SPLIT_FUSE1A");
-        s->split_fuse1a = !(e && e[0] == '0');
+        s->split_fuse1a = s->cfg[CFG_SPLIT_FUSE1A] != 0;
     }
     if (s->precision == OMNI_PREC_F16) {
         std::vector<uint16_t> fr(2048);
@@ -565,7 +563,15 @@ omni_sp* omni_sp_create(omni_ctx* ctx, const omni_sp_weights* w, const float* pc
     s->ctx = ctx; s->W = width; s->H = height; s->Hc = height / 8; s->Wc = width / 8; s->thres = thres; s->max_num = max_num;
     s->max_batch = max_batch; s->precision = precision; s->esz = precision == OMNI_PREC_F16 ? 2 : 4;
     s->pca_dim = pca_comp ? pca_dim : 0; s->desc_dim = pca_comp ? pca_dim : 256;
-    { const char* e = getenv("OMNI_CONV_V1"); s->conv_variant = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0; }
+    if (omni::config_resolve(&s->cfg) != OMNI_OK) { delete s; return nullptr; }
+    s->conv_variant = s->cfg[omni::CFG_CONV_V1];
+#ifndef OMNI_TEST_VARIANTS
+    if (s->conv_variant != 0) {
+        omni::set_error("OMNI_CONV_V1=%d: the reference variants of the fp16 convolutions are only built into the test library (omni-swarm_amd/lib_test/, make -C omni-swarm_amd test-variants)", s->conv_variant);
+        delete s;
+        return nullptr;
+    }
+#endif
     if (omni::sp_init(s, w, pca_comp, pca_mean) != OMNI_OK) { omni_sp_destroy(s); return nullptr; }
     return s;
 }
@@ -750,7 +756,7 @@ double omni_sp_stage_tiles_left_out(const omni_sp* s, int stage) {
 }
 
 int omni_sp_profile(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms) {
-    static const int prof_mask = [] { const char* e = getenv("OMNI_SP_PROFILE_MASK"); return (e && e[0] == '1') ? 1 : 0; }();   // stage times with the fisheye mask on (as the key-frame pipeline runs)
+    const int prof_mask = s ? s->cfg[omni::CFG_SP_PROFILE_MASK] : 0;   // stage times with the fisheye mask on (as the key-frame pipeline runs)
     OMNI_REQUIRE(s && gray_dev && stage_ms && reps >= 1, OMNI_ERR_INVALID, "bad argument");
     OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
     std::lock_guard<std::mutex> lk(s->mu);

@@ -9,6 +9,7 @@
 // The net is ~0.34 GMAC/image (1.4 % of SuperPoint) so it is written as plain fp32 NHWC kernels: an LDS-tiled
 // pointwise (1x1) conv, a depthwise 3x3, a stem conv, the NetVLAD aggregation and an HBM-bound FC that reads the
 // 58.7 MB weight matrix once per batch.
+#include "config.h"
 #include "common.h"
 #include "vlad_h.h"
 
@@ -27,6 +28,7 @@ struct VladFusedBlock {      // one inverted-residual block = [expand] + depthwi
 
 struct omni_vlad {
     omni_ctx* ctx = nullptr;
+    omni::Config cfg;                         // the switches as they stood when the handle was created (config.h)
     bool sblock = true;                       // blocks with an sblob run on vlad_sblock_kernel (OMNI_VLAD_SBLOCK=0 disables: A/B and parity tests)
     int prec = OMNI_PREC_F32;                 // OMNI_PREC_F16: blocks with an hblob run on vlad_hblock_kernel (omni_vlad_set_precision)
     bool fused = false;                       // every block has a fused kernel (OMNI_VLAD_UNFUSED=1 forces the layer-by-layer path)
@@ -757,8 +759,7 @@ static int vlad_block(hipStream_t st, int cin, const VladBlockArgs& a) {
     // (measured: 128- / 64-pixel tiles are SLOWER for the 300x240 / 150x120 blocks -- 54 -> 70 us, 38 -> 46 us: their LDS footprint
     // halves the resident workgroups and with them the latency hiding; kept instantiated for other image sizes only)
     // OMNI_VLAD_BIG=64|128 re-enables them for A/B at other batch sizes (numerics do not depend on the tile size)
-    const char* be = getenv("OMNI_VLAD_BIG");
-    const int big = be ? atoi(be) : 0; (void)px;
+    const int big = config_process()[CFG_VLAD_BIG]; (void)px;
 #define VB(CI, CPV, T) if (cin == CI && cp == CPV) return launch_vlad_block<CI, CPV, T>(st, a)
     if (big == 128) { VB(16, 8, 128); VB(8, 8, 128); VB(16, 16, 128); }
     if (big >= 64) { VB(16, 8, 64); VB(8, 8, 64); VB(8, 16, 64); VB(16, 16, 64); }
@@ -1149,8 +1150,7 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
     const VladLayerDev& S = v->layers[0];
     int cur = 0, rc;
     size_t first = 0;
-    const char* sf = getenv("OMNI_VLAD_STEM_FUSE");                      // "0": stem and block 0 as two kernels (A/B and parity tests)
-    const bool stem_fuse = !(sf && sf[0] == '0');
+    const bool stem_fuse = v->cfg[omni::CFG_VLAD_STEM_FUSE] != 0;           // 0: stem and block 0 as two kernels (A/B and parity tests)
     const VladFusedBlock* B0 = v->blocks.empty() ? nullptr : &v->blocks[0];
     if (stem_fuse && B0 && S.cout == 16 && S.stride == 2 && !B0->expand && !B0->res && B0->cin == 16 && B0->hid == 16 && B0->cout == 8 &&
         B0->stride == 1) {
@@ -1180,6 +1180,7 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
             sa.in = v->buf[cur]; sa.out = v->buf[(cur + 1) % 3]; sa.blob = B.sblob; sa.bp = B.bp;
             sa.Hi = B.hin; sa.Wi = B.win; sa.Ho = B.hout; sa.Wo = B.wout; sa.cin = B.cin; sa.hid = B.hid; sa.cout = B.cout; sa.res = B.res; sa.batch = batch;
             sa.n_cu = v->ctx->prop.multiProcessorCount > 0 ? v->ctx->prop.multiProcessorCount : 256; sa.trace = nullptr; sa.dbg = 0;
+            sa.persist = v->cfg[omni::CFG_VLAD_SB_PERSIST];
             if ((rc = launch_vlad_sblock(st, sa, B.stride))) return rc;
             cur = (cur + 1) % 3;
             continue;
@@ -1292,6 +1293,7 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     omni_vlad* v = new omni_vlad();
+    if (omni::config_resolve(&v->cfg) != OMNI_OK) { delete v; return nullptr; }
     v->ctx = ctx; v->W = width; v->H = height; v->max_batch = max_batch; v->K = w->n_clusters; v->Dm = w->feat_dim; v->out_dim = w->out_dim;
     int h = height, wd = width, c = 0;
     size_t max_elems = 0;
@@ -1391,22 +1393,17 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
             v->blocks.push_back(B);
             i += 2;
         }
-        const char* env = getenv("OMNI_VLAD_UNFUSED");
-        v->fused = fusable && !(env && env[0] == '1');
-        const char* env2 = getenv("OMNI_VLAD_MFMA");
-        v->mfma_late = !(env2 && env2[0] == '0');
+        v->fused = fusable && !v->cfg[omni::CFG_VLAD_UNFUSED];
+        v->mfma_late = v->cfg[omni::CFG_VLAD_MFMA] != 0;
         // fused matrix-core block kernel for blocks whose input has at most this many pixels per image (0 disables).  Measured at 32 images
         // (profiles/r02_vlad32_*): the ten 38x30 / 19x15 blocks take 451 us on it vs 502 us as three launches each; on the 75x60 ... 300x240
         // blocks it is slower than the fp32-VALU fused kernel (one 8x8 tile per workgroup keeps 47-108 KB of LDS: 1-2 workgroups per CU
         // and every phase of a chunk is a dependent chain behind a barrier -- waves wait 50 % of their life, MFMA-busy 14-18 %).  A
         // split-fp16 variant (v_mfma_f32_32x32x16_f16, hi/lo operands: 5x less matrix time) measured SLOWER still (60 us per block): the
         // matrix pipe is not what bounds these blocks, the per-workgroup latency chain is.
-        const char* env6 = getenv("OMNI_VLAD_SBLOCK");
-        v->sblock = !(env6 && env6[0] == '0');
-        const char* env5 = getenv("OMNI_VLAD_MBLOCK_PX");
-        v->mblock_max_px = env5 ? atoi(env5) : 2048;
-        const char* env4 = getenv("OMNI_VLAD_MFMA_PX");
-        if (env4 && atoi(env4) > 0) v->mfma_max_px = atoi(env4);
+        v->sblock = v->cfg[omni::CFG_VLAD_SBLOCK] != 0;
+        v->mblock_max_px = v->cfg[omni::CFG_VLAD_MBLOCK_PX];
+        if (v->cfg[omni::CFG_VLAD_MFMA_PX] > 0) v->mfma_max_px = v->cfg[omni::CFG_VLAD_MFMA_PX];
     }
     if (ok) {
         v->hf = h; v->wf = wd; v->buf_elems = max_elems * max_batch;
@@ -1417,8 +1414,7 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
              !omni::upload(&v->clusters, w->clusters, n_in, st) && !omni::upload(&v->fc_w, w->fc_w, n_in * v->out_dim, st) &&
              !omni::upload(&v->fc_b, w->fc_b, v->out_dim, st);
         {   // FC on the matrix cores: W [out][n_in] -> [out / 32][n_in / 4][32 rows][4] (vlad_fc_mfma_kernel); OMNI_VLAD_FC_MFMA=0 keeps the VALU kernel
-            const char* ef = getenv("OMNI_VLAD_FC_MFMA");
-            const bool want = !(ef && ef[0] == '0') && v->fused;
+            const bool want = v->cfg[omni::CFG_VLAD_FC_MFMA] != 0 && v->fused;
             if (ok && want && v->out_dim % 32 == 0 && n_in % (4 * 2 * FCM_KY * 4) == 0) {
                 const size_t groups = n_in / 4;
                 std::vector<float> pk(n_in * (size_t)v->out_dim);
@@ -1430,8 +1426,7 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
             }
         }
         {   // scratch of the hidden-layer split (OMNI_VLAD_MBLOCK_CPW = chunks per workgroup; 0 = no split)
-            const char* ec = getenv("OMNI_VLAD_MBLOCK_CPW");
-            v->mb_cpw = ec ? atoi(ec) : 0;             // measured: splitting does not pay (same total issue-bound work + a reduce launch per block)
+            v->mb_cpw = v->cfg[omni::CFG_VLAD_MBLOCK_CPW];             // measured: splitting does not pay (same total issue-bound work + a reduce launch per block)
             size_t need = 0, max_tiles = 0;
             for (auto& B : v->blocks) {
                 if (!B.mblob || B.hin * B.win > v->mblock_max_px) continue;

@@ -31,6 +31,7 @@ struct VladSBlockArgs {
     unsigned m_img, m_tx;            // ceil(2^32 / tiles per image), ceil(2^32 / tiles per row): set by the launcher
     int dbg;                         // OMNI_VLAD_SB_DBG (timing ablations only, WRONG results): bit 0 no result stores, bit 1 no input prefetch
     unsigned long long* trace;       // OMNI_VLAD_SB_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
+    int persist;                     // OMNI_VLAD_SB_PERSIST as the handle saw it: 0 = one tile per workgroup, N >= 1 = N x (CUs x resident workgroups) persistent workgroups (read by the launcher only)
 };
 bool vlad_sblock_supported(int cin, int hid, int cout, int stride);
 size_t vlad_sblock_blob_bytes(int cin, int hid, int cout);

@@ -16,6 +16,7 @@
 //     there -- the zero padding of the depthwise conv -- without mask code;
 //   * weights are pre-packed in MFMA fragment order and fetched straight into registers one phase ahead of their use;
 //   * LDS rows are odd multiples of 16 bytes (conflict-free ds_read_b128 fragment reads); two barriers per chunk.
+#include "config.h"
 #include "common.h"
 #include "vlad_h.h"
 
@@ -401,7 +402,7 @@ void vlad_sblock_pack(int cin, int hid, int cout, const float* we, const float* 
 template <int STRIDE, int CIN, int NT>
 static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
     using C = SBlockCfg<STRIDE, CIN, NT>;
-    static const size_t pad = [] { const char* e = getenv("OMNI_VLAD_SB_LDSPAD"); return e ? (size_t)atoi(e) : 0; }();   // A/B hook: occupancy
+    static const size_t pad = (size_t)config_process()[CFG_VLAD_SB_LDSPAD];   // A/B hook: occupancy
     const size_t smem = C::smem(a.hid) + pad;
     OMNI_REQUIRE(smem <= 160 * 1024, OMNI_ERR_CAPACITY, "vlad_sblock: %zu B of LDS for hid=%d", smem, a.hid);
     auto kfn = vlad_sblock_kernel<STRIDE, CIN, NT>;
@@ -416,14 +417,14 @@ static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
     // OMNI_VLAD_SB_PERSIST (A/B hook): 0 = one tile per workgroup, N >= 1 = N x (CUs x resident workgroups per CU) workgroups
-    static const int persist = [] { const char* e = getenv("OMNI_VLAD_SB_PERSIST"); return e ? atoi(e) : 1; }();
+    const int persist = a.persist;                               // (the handle's snapshot of the table)
     const int64_t cap = (int64_t)a.n_cu * per_cu * (persist > 0 ? persist : 1);
     const int grid = (!persist || tiles < cap) ? tiles : (int)cap;
-    static const bool want_trace = [] { const char* e = getenv("OMNI_VLAD_SB_TRACE"); return e && e[0] == '1'; }();
+    static const bool want_trace = config_process()[CFG_VLAD_SB_TRACE] != 0;
     static unsigned long long* trace_dev = nullptr;
     VladSBlockArgs at = a;
     at.trace = nullptr;
-    static const int dbg = [] { const char* e = getenv("OMNI_VLAD_SB_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = config_process()[CFG_VLAD_SB_DBG];
     at.dbg = dbg;
     {   // sb_div()'s reciprocals
         const unsigned d_img = (unsigned)(cdiv(a.Wo, 8) * cdiv(a.Ho, C::TH)), d_tx = (unsigned)cdiv(a.Wo, 8);

@@ -99,8 +99,9 @@ public:
             // the init-mode counters of REMOTE drones (inter_drone_loop_count, loop_detector.cpp:66-72,826-827): candidates between two frames
             // of the self drone are deferred, anything else is verified on the spot.
             {
-                const char* e = getenv("OMNI_GEOMETRY_THREADS");
-                int nt = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+                int nt = -1;                                            // (the library's one table of switches: csrc/config.h)
+                check(omni_config_value("OMNI_GEOMETRY_THREADS", &nt), "omni_config_value");
+                if (nt < 0) nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
                 if (nt > 0) pool_ = std::make_unique<TaskPool>(nt);
             }
             det_.compute_loop = [this](const FisheyeFrameDescriptor& a, const FisheyeFrameDescriptor& b, int da, int db, bool im) {
@@ -539,7 +540,7 @@ private:
     };
     std::deque<GeoBatch> geo_inflight_;         // (declared before the pool: outlives its threads)
     bool geo_left_in_flight_ = false;
-    bool async_geometry_ = !(getenv("OMNI_GEOMETRY_ASYNC") && atoi(getenv("OMNI_GEOMETRY_ASYNC")) == 0);
+    bool async_geometry_ = [] { int v = 1; check(omni_config_value("OMNI_GEOMETRY_ASYNC", &v), "omni_config_value"); return v != 0; }();
     std::unique_ptr<TaskPool> pool_;
     std::vector<ImageDescriptor> downs_;        // the down-camera halves of the micro-batch being finished
     std::vector<std::future<void>> stereo_tasks_;

@@ -13,6 +13,8 @@ Tolerances (north_star: key points bit-exact after the fixed NMS ordering, descr
                 candidates -- SURVEY.md section 7 "Hard parts").  The same gates at the benchmarked launch shape (64 images, threshold
                 0.02): tests/test_gpu_bench_shape.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -193,11 +195,30 @@ def test_fp32_sparse_descriptor_head_is_bit_identical_to_the_dense_map_path(omni
         assert np.array_equal(res["1"][2][0][1], res["1"][0][nb - 1][1])
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TEST_LIB = os.path.join(ROOT, "omni-swarm_amd", "lib_test", "libomni_hip.so")
+
+
 def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, monkeypatch):
     """The cin=64 kernels (v3 8-wave ping-pong, v2 persistent LDS-DMA) and the generic kernel accumulate K in the same
     order: same bits.  Odd sizes exercise border tiles, partial tiles and workgroups with a single tile.
     OMNI_CONV_V1: 3 = ping-pong without the conv1a fusion, 1 = generic kernels, 2 = v2, 0 = default (conv1a fused into conv1b,
-    cin=128 layers on the register-stationary kernel)."""
+    cin=128 layers on the register-stationary kernel).
+    The reference variants 1-3 are NOT in the shipped library (csrc/config.h: a handle created with OMNI_CONV_V1 != 0 fails loudly); they are compiled
+    into omni-swarm_amd/lib_test/libomni_hip.so (make -C omni-swarm_amd test-variants, part of build()), which this test loads in a subprocess."""
+    if os.path.abspath(os.environ.get("OMNI_LIB", "")) != TEST_LIB:
+        monkeypatch.setenv("OMNI_CONV_V1", "1")
+        with pytest.raises(omni.capi.OmniError, match="test library"):
+            omni.capi.SuperPoint(ctx, S.synth_weights(0), None, None, 96, 64, 0.015, 50, omni.capi.PREC_F16, 1)
+        monkeypatch.delenv("OMNI_CONV_V1")
+        assert os.path.exists(TEST_LIB), "omni-swarm_amd/lib_test/libomni_hip.so is missing: run __graft_entry__.build()"
+        import subprocess
+        import sys
+        env = dict(os.environ, OMNI_LIB=TEST_LIB)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "persistent_kernels_are_bit_identical"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "1 passed" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+        return
     weights = S.synth_weights(0)
     for (h, w, nb) in ((480, 600, 2), (72, 104, 1), (208, 400, 3)):
         imgs = np.stack([synth.image_u8(30 + i, h, w) for i in range(nb)])

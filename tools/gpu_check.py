@@ -171,8 +171,7 @@ def _():
     comp, mean = synth.pca()
     imgs = np.stack([synth.image_u8(i, 480, 600) for i in range(8)])
     gdev = ctx.to_device(imgs)
-    for prec, pname, v1 in ((c.PREC_F16, "f16", "0"), (c.PREC_F16, "f16-generic-kernel", "1"), (c.PREC_F32, "f32", "0")):
-        os.environ["OMNI_CONV_V1"] = v1
+    for prec, pname in ((c.PREC_F16, "f16"), (c.PREC_SPLIT, "split"), (c.PREC_F32, "f32")):
         sp = c.SuperPoint(ctx, weights, comp, mean, 600, 480, 0.015, 200, prec, 8)
         sp.profile(gdev, 600, 8, 2)
         prof = sp.profile(gdev, 600, 8, 5)
