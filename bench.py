@@ -32,6 +32,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the key-frame pipeline's five streams must not share a hardware queue (csrc/ctx.hip: libomni_hip.so asks for 8 when it is loaded; here as well, because
+# torch may initialise the HIP runtime before the library is loaded -- the runtime reads the variable once)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("OMNI_HW_QUEUES", "8") if os.environ.get("OMNI_HW_QUEUES", "8") != "0" else "4")
 os.environ.setdefault("OMNI_SP_PROFILE_MASK", "1")      # omni_sp_profile: stage times with the fisheye mask on, as the key-frame pipeline runs the network
 
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
@@ -116,7 +119,10 @@ def parse():
     ap.add_argument("--min-time", type=float, default=1.0, help="repeat the timed region of --steps key frames until this many seconds were timed; the median region is reported")
     ap.add_argument("--db-keyframes", type=int, default=1000, help="key frames pre-loaded in the index (x4 rows) for the throughput loop")
     ap.add_argument("--match-db-rows", type=int, default=100_000, help="index rows for the p50 loop-match measurement (node total)")
-    ap.add_argument("--pipelines", type=int, default=2, help="micro-batches in flight per GPU (separate HIP streams)")
+    ap.add_argument("--pipelines", type=int, default=0,
+                    help="micro-batches (units) in flight per GPU, each with its own HIP streams; 0 = by measurement (round 4, profiles/r04*): 4 for f16 -- the small-grid "
+                         "kernels of a unit's tail (NMS, descriptor sampling, the matcher, MobileNetVLAD's last blocks) leave CUs idle that the next units' kernels fill: "
+                         "2215 -> 2476 kf/s -- and 2 for the fp32-class modes, whose time is all in CU-filling convolutions (no gain from depth, only latency)")
     ap.add_argument("--microbatch", type=int, default=8,
                     help="consecutive key frames enqueued together (one SuperPoint launch over 8*MB images, one MobileNetVLAD launch over 4*MB): "
                          "the low-resolution layers of both nets are launch/latency-bound at one key frame")
@@ -292,7 +298,7 @@ def main():
 
     def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False, ptrs=None, mb=None, pipelines=None):
         mb = mb or MB
-        pipelines = pipelines or args.pipelines
+        pipelines = pipelines or args.pipelines or (4 if precision == capi.PREC_F16 else 2)
         ptrs = ptrs or (pool_ptrs if mb == MB else [pinned_batch(1000 * rank + 50_000 + 8 * mb * p, mb).ctypes.data for p in range(2)])
         pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, mb,
                                        pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
@@ -313,6 +319,7 @@ def main():
         def run(n):
             if state["calls"] == (1 if warmup > 0 else 0):
                 pl.latencies_ms(reset=True)                    # the warm-up's micro-batches do not count
+                pl.host_times(reset=True)
             state["calls"] += 1
             t = tail if n == steps else wtail
             state["hits"] += pl.run(n, state["id"], ptrs, state["slot"], None if t is None else t.ctypes.data, True)
@@ -322,6 +329,7 @@ def main():
         out = summarize(dts, steps)
         lat = pl.latencies_ms()
         out.update(db_rows_start=db_rows, db_rows_end=int(pl.db_rows), loop_candidates_found=state["hits"])
+        out["host_ms_per_microbatch"] = pl.host_times()
         if len(lat):
             out["keyframe_latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
                                           "micro_batches": int(len(lat)), "keyframes_in_flight": mb * pipelines,
@@ -336,7 +344,7 @@ def main():
     # ---- the Python host loop (N > 1, --host python, and the `python_host` comparison leg) -----------------------------------------
     class PythonLoop:
         def __init__(self, precision):
-            self.ctxs = [capi.Context(local_rank) for _ in range(args.pipelines)]
+            self.ctxs = [capi.Context(local_rank) for _ in range(args.pipelines or 2)]
             self.prec = precision
             self.cams = [frontend.LoopCam(c, sp_w, comp, mean, vl_w, vl_specs, vl_shape, W, H, THRES, MAXN, precision, n_dirs=4 * MB) for c in self.ctxs]
             self.tail_cam = None
@@ -452,7 +460,7 @@ def main():
     if world == 1:
         if cpp_host and args.geometry_steps > 0:
             n = max(MB, args.geometry_steps // MB * MB)
-            with_geometry = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, n, MB * args.pipelines, min(args.min_time, 0.5), geometry=True,
+            with_geometry = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, n, MB * (args.pipelines or 4), min(args.min_time, 0.5), geometry=True,
                                     ptrs=[a.ctypes.data for a in room_pool()])
             with_geometry.update(steps=n, note="same loop + the host geometry stage per candidate (lifting, up/down triangulation, BF + homography-RANSAC "
                                                "mask, PnP-RANSAC; f64, host) on key frames of a RENDERED scene (synth.room_keyframe: a stereo rig in textured "
@@ -460,19 +468,19 @@ def main():
         if cpp_host and args.python_steps > 0:
             pyloop = PythonLoop(prec)
             n = max(MB, args.python_steps // MB * MB)
-            python_host = summarize(timed_regions(pyloop.run, pyloop.sync, n, MB * args.pipelines, min(args.min_time, 0.5)), n)
+            python_host = summarize(timed_regions(pyloop.run, pyloop.sync, n, MB * (args.pipelines or 4), min(args.min_time, 0.5)), n)
             python_host["steps"] = n
         if args.f32_steps > 0 and args.precision == "f16":
             n = max(MB, args.f32_steps // MB * MB)
             if cpp_host:
-                value_f32 = cpp_leg(capi.PREC_F32, capi.STORE_F32, 4 * args.db_keyframes, n, MB * args.pipelines, 0.0)
+                value_f32 = cpp_leg(capi.PREC_F32, capi.STORE_F32, 4 * args.db_keyframes, n, MB * (args.pipelines or 4), 0.0)
             else:
                 l32 = PythonLoop(capi.PREC_F32)
-                value_f32 = summarize(timed_regions(l32.run, l32.sync, n, MB * args.pipelines, 0.0), n)
+                value_f32 = summarize(timed_regions(l32.run, l32.sync, n, MB * (args.pipelines or 4), 0.0), n)
             value_f32.update(steps=n, dtype="f32", note="OMNI_PREC_F32: exact-f32 MFMA network (key points identical to the fp32 oracle), same workload")
         if args.parity_steps > 0 and args.precision == "f16" and cpp_host:
             n = max(MB, args.parity_steps // MB * MB)
-            value_parity = cpp_leg(capi.PREC_SPLIT, capi.STORE_F32, 4 * args.db_keyframes, n, MB * args.pipelines, min(args.min_time, 0.5))
+            value_parity = cpp_leg(capi.PREC_SPLIT, capi.STORE_F32, 4 * args.db_keyframes, n, MB * (args.pipelines or 4), min(args.min_time, 0.5))
             value_parity.update(steps=n, dtype="f16 x3 (split hi+lo operands, fp32-class)",
                                 note="OMNI_PREC_SPLIT: the SAME workload and host loop with SuperPoint's 3x3 convolutions on the fp16 matrix cores at fp32-class "
                                      "accuracy (every operand a (hi, lo) pair of halfs, three MFMA terms per product; heads in exact f32; MobileNetVLAD is "
@@ -492,7 +500,7 @@ def main():
             db100k = {"db_keyframes": args.big_db_keyframes, "db_rows": 4 * args.big_db_keyframes, "steps": n,
                       "note": "same key-frame loop, every key frame's query scans the whole database (one pass per micro-batch, per-query row limits)"}
             for name, st in (("f16_rows", capi.STORE_F16), ("f32_rows", capi.STORE_F32)):
-                db100k[name] = cpp_leg(prec, st, 4 * args.big_db_keyframes, n, MB * args.pipelines, min(args.min_time, 0.5))
+                db100k[name] = cpp_leg(prec, st, 4 * args.big_db_keyframes, n, MB * (args.pipelines or 4), min(args.min_time, 0.5))
 
     # ---- roofline of the dominant kernel (conv1b + pool, 43 % of the FLOPs): HIP events on the kernel's own stream --
     # same launch shape as in the timed loop: one micro-batch = 8 * MB images per launch (HIP events between the stages, on the
@@ -649,10 +657,11 @@ def main():
             "dtype": {"f16": "f16", "f32": "f32", "split": "f16 x3 (split operands)"}[args.precision], "data": "synthetic",
             "repeats": main_leg["repeats"], "ms_per_step_minmax": main_leg["ms_per_step_minmax"],
             "keyframe_latency_ms": main_leg.get("keyframe_latency_ms"),
+            "host_ms_per_microbatch": main_leg.get("host_ms_per_microbatch"),
             "config": {"workload": "configs[1]: reference-faithful fisheye key frame = upload of 8 images + 8 SuperPoint + 4 MobileNetVLAD(assumed arch) "
                                    "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query + results to host; "
                                    f"{args.db_keyframes}-keyframe DB ({4 * args.db_keyframes} rows); seeded synthetic weights",
-                       "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": args.pipelines,
+                       "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": args.pipelines or (4 if prec == capi.PREC_F16 else 2),
                        "keyframes_per_microbatch": MB, "host_loop": ("c++ (host/keyframe_pipeline.hpp)" + (" + omni_shard (RCCL inside libomni_hip.so)" if world > 1 else "")) if cpp_host else
                                     "python" + (" + torch.distributed exchange" if world > 1 else ""),
                        "image_upload": "inside the timed region (pinned host -> HBM, one async copy per micro-batch)",

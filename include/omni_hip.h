@@ -84,6 +84,14 @@ int omni_config_value(const char* env, int* value);
 /* ---- context: one per GPU/stream; owns a HIP stream, scratch and timers -------------------------------------
  * replaces TensorRTInferenceGeneric's cudaStreamCreate / cudaMalloc plumbing (tensorrt_generic.cpp:14-36,99-120) */
 omni_ctx* omni_ctx_create(int device_id);
+/* the same with the context's stream at the device's highest stream priority: for short, latency-bound work the host waits on (the detector's
+ * searches) next to streams that keep every CU busy -- its kernels get the next free CUs instead of queueing behind whole launches */
+omni_ctx* omni_ctx_create_priority(int device_id, int high_priority);
+/* everything enqueued on `later`'s stream from now on runs after everything enqueued on `earlier`'s stream so far (an event on the device: the
+ * host does not wait).  E.g. a network's stream behind the detector's, whose appends still read the network's output buffer. */
+int       omni_ctx_order_after(omni_ctx* later, omni_ctx* earlier);
+/* device -> PINNED host memory on the context's stream, without waiting: omni_ctx_sync() (or any later synchronising call) completes it */
+int       omni_memcpy_d2h_async(omni_ctx* ctx, void* dst_pinned, const void* src, size_t bytes);
 void      omni_ctx_destroy(omni_ctx* ctx);
 int       omni_ctx_sync(omni_ctx* ctx);
 void*     omni_ctx_stream(omni_ctx* ctx);                 /* hipStream_t, for callers that enqueue their own work */

@@ -25,7 +25,7 @@ VLAD_KINDS = {"conv3x3": 0, "pw_relu6": 1, "dw3x3_relu6": 2, "pw_linear": 3, "pw
 
 # every symbol include/omni_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "omni_abi_version", "omni_last_error", "omni_ctx_create", "omni_ctx_destroy", "omni_ctx_sync", "omni_ctx_stream",
+    "omni_abi_version", "omni_last_error", "omni_ctx_create", "omni_ctx_create_priority", "omni_ctx_order_after", "omni_memcpy_d2h_async", "omni_ctx_destroy", "omni_ctx_sync", "omni_ctx_stream",
     "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_image_size", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
@@ -91,6 +91,9 @@ def lib():
     sig("omni_abi_version", C.c_int, [])
     sig("omni_last_error", C.c_char_p, [])
     sig("omni_ctx_create", _vp, [C.c_int])
+    sig("omni_ctx_create_priority", _vp, [C.c_int, C.c_int])
+    sig("omni_ctx_order_after", C.c_int, [_vp, _vp])
+    sig("omni_memcpy_d2h_async", C.c_int, [_vp, _vp, _vp, C.c_size_t])
     sig("omni_ctx_destroy", None, [_vp])
     sig("omni_ctx_sync", C.c_int, [_vp])
     sig("omni_ctx_stream", _vp, [_vp])
@@ -196,11 +199,11 @@ def _pf(a):
 class Context:
     """One HIP stream + scratch on one GPU (omni_ctx)."""
 
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, high_priority: bool = False):
         import weakref
         self.device_id = device_id
         self._children = weakref.WeakSet()      # handles created on this context: closed before the context is (their destroy uses its stream)
-        self.h = lib().omni_ctx_create(device_id)
+        self.h = lib().omni_ctx_create_priority(device_id, 1) if high_priority else lib().omni_ctx_create(device_id)
         if not self.h:
             raise OmniError(f"omni_ctx_create failed: {lib().omni_last_error().decode()}")
 

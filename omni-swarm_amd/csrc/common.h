@@ -60,10 +60,21 @@ struct DevBuf {
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return OMNI_OK;
+        // hipFree waits for the WHOLE device to go idle: a buffer whose need creeps up with the database (the key lists of a scan: 8 bytes per row per
+        // query) must not be reallocated at every micro-batch -- that made the host wait for the key-frame unit in flight each time it enqueued a search
+        // (2.7 ms of a 3.8 ms cycle, round 4).  Grow by half at least: a handful of reallocations over a database's life.
+        size_t want = bytes + bytes / 2;
+        if (want < need) want = need;
+        want = (want + 4095) & ~(size_t)4095;
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
-        OMNI_HIP_TRY(hipMalloc(&p, need));
-        bytes = need;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            want = need;                                    // no room for the slack: the exact size
+            OMNI_HIP_TRY(hipMalloc(&p, want));
+        }
+        bytes = want;
         return OMNI_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -76,10 +87,12 @@ struct HostBuf {
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return OMNI_OK;
+        size_t want = bytes + bytes / 2;                    // (as DevBuf: hipHostFree synchronises too)
+        if (want < need) want = need;
         if (p) (void)hipHostFree(p);
         p = nullptr; bytes = 0;
-        OMNI_HIP_TRY(hipHostMalloc(&p, need, hipHostMallocDefault));
-        bytes = need;
+        OMNI_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        bytes = want;
         return OMNI_OK;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
@@ -94,6 +107,7 @@ struct omni_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_order = nullptr;     // omni_ctx_order_after: marks this stream's position for another stream to wait on
     hipDeviceProp_t prop;
     std::mutex mu;
     // 64 KB of zeros in HBM, never written after creation: the LDS-DMA source of convolution halo pixels outside the image.  A lane reads the

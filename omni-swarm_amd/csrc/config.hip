@@ -50,6 +50,11 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     // ---- host loop -------------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_GEOMETRY_THREADS", -1, -1, 1024, CFG_TUNING, "threads of the geometric-verification pool (-1: min(16, cores / 2); 0: inline)"},
     {"OMNI_GEOMETRY_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's geometry tasks run while the next unit is waited for (0: drained at once)"},
+    {"OMNI_DETECTOR_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's detector step (appends, searches) is enqueued and collected one unit later (0: the host waits for it on the spot)"},
+    {"OMNI_PIPELINE_ONE_STREAM", 0, 0, 1, CFG_VARIANT, "a unit's MobileNetVLAD launches behind its SuperPoint launches on one stream (0: next to them on a second stream)"},
+    // ---- runtime ---------------------------------------------------------------------------------------------------------------------------------------
+    {"OMNI_HW_QUEUES", 8, 0, 64, CFG_TUNING, "hardware queues asked of the HIP runtime when the library is loaded (GPU_MAX_HW_QUEUES, unless already set): the pipeline's five "
+                                            "streams must not share one; 0 = the runtime's default of 4"},
     // ---- strings ---------------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_RCCL_LIB", 0, 0, 0, CFG_STRING, "path of the RCCL library omni_shard dlopens (default: librccl.so next to torch, then the loader's search path)"},
 };

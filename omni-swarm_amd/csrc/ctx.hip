@@ -1,7 +1,10 @@
 // Context, device memory and timer entry points of the C ABI (include/omni_hip.h).
 // Replaces the cudaStreamCreate / cudaMalloc / cudaMallocHost plumbing of the reference's
 // TensorRTInferenceGeneric (swarm_loop/src/tensorrt_generic.cpp:14-36,99-120).
+#include "config.h"
 #include "common.h"
+
+#include <cstdlib>
 
 namespace omni {
 static thread_local char g_err[512] = "";
@@ -13,12 +16,33 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace omni
 
+// The key-frame pipeline keeps five streams busy (two units in flight x (SuperPoint, MobileNetVLAD) + the detector's); the HIP runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and two streams on one queue run strictly one after the other: the detector's search
+// of micro-batch k then sits behind the MobileNetVLAD kernels of micro-batch k + 1, the host waits for it, and the GPU idles 15 % of the time
+// (rocprofv3 kernel trace of round 4).  The runtime reads the variable when it initialises: ask for 8 queues when this library is loaded,
+// unless the process already chose (OMNI_HW_QUEUES=0 leaves the runtime's default).
+namespace {
+struct HwQueues {
+    HwQueues() {
+        const int n = omni::config_process()[omni::CFG_HW_QUEUES];
+        if (n > 0) { char v[16]; snprintf(v, sizeof(v), "%d", n); setenv("GPU_MAX_HW_QUEUES", v, 0); }
+    }
+} g_hw_queues;
+}  // namespace
+
+static omni_ctx* ctx_create(int device_id, bool high_priority);
+
 extern "C" {
 
 int omni_abi_version(void) { return OMNI_ABI_VERSION; }
 const char* omni_last_error(void) { return omni::g_err; }
 
-omni_ctx* omni_ctx_create(int device_id) {
+omni_ctx* omni_ctx_create(int device_id) { return ctx_create(device_id, false); }
+omni_ctx* omni_ctx_create_priority(int device_id, int high_priority) { return ctx_create(device_id, high_priority != 0); }
+
+}  // extern "C"
+
+static omni_ctx* ctx_create(int device_id, bool high_priority) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -29,8 +53,10 @@ omni_ctx* omni_ctx_create(int device_id) {
     if (device_id < 0 || device_id >= n) { omni::set_error("device_id %d out of range [0,%d)", device_id, n); return nullptr; }
     omni_ctx* c = new omni_ctx();
     c->device = device_id;
+    int least = 0, greatest = 0;                 // (numerically lower = higher priority)
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&c->prop, device_id) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        (high_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) ||
+        (high_priority ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || c->ensure_zero_page() != OMNI_OK ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
         omni::set_error("failed to initialise HIP context on device %d", device_id);
@@ -40,6 +66,8 @@ omni_ctx* omni_ctx_create(int device_id) {
     return c;
 }
 
+extern "C" {
+
 void omni_ctx_destroy(omni_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -48,6 +76,7 @@ void omni_ctx_destroy(omni_ctx* c) {
     if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -107,6 +136,21 @@ int omni_memcpy_d2h(omni_ctx* c, void* dst, const void* src, size_t bytes) {
     OMNI_REQUIRE(c && dst && src, OMNI_ERR_INVALID, "null argument");
     OMNI_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     OMNI_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OMNI_OK;
+}
+
+int omni_memcpy_d2h_async(omni_ctx* c, void* dst_pinned, const void* src, size_t bytes) {
+    OMNI_REQUIRE(c && dst_pinned && src, OMNI_ERR_INVALID, "null argument");
+    OMNI_HIP_TRY(hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return OMNI_OK;
+}
+
+int omni_ctx_order_after(omni_ctx* later, omni_ctx* earlier) {
+    OMNI_REQUIRE(later && earlier && later->device == earlier->device, OMNI_ERR_INVALID, "omni_ctx_order_after: two contexts of one device");
+    if (later == earlier) return OMNI_OK;
+    if (!earlier->ev_order) OMNI_HIP_TRY(hipEventCreateWithFlags(&earlier->ev_order, hipEventDisableTiming));
+    OMNI_HIP_TRY(hipEventRecord(earlier->ev_order, earlier->stream));
+    OMNI_HIP_TRY(hipStreamWaitEvent(later->stream, earlier->ev_order, 0));
     return OMNI_OK;
 }
 

@@ -176,6 +176,9 @@ int omni_fisheye_maps(const double* mei, int img_width, double fov_deg, int cam_
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// omni::KeyframePipeline::host_times: the host thread's milliseconds per unit in {enqueue, wait for the GPU, build messages, detector step, geometry hand-over}
+int omni_pipeline_host_times(omni_pipeline* h, double* out5, int reset) { return h->p->host_times(out5, reset != 0); }
+
 int omni_pipeline_sync(omni_pipeline* h) {
     try { h->p->sync(); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -82,7 +82,7 @@ public:
         int dirs() const { return mono() ? 1 : 4; }
     };
 
-    explicit KeyframePipeline(const Config& c) : cfg_(c), index_ctx_(c.device), det_(index_ctx_, c.self_id, c.storage) {
+    explicit KeyframePipeline(const Config& c) : cfg_(c), index_ctx_(c.device, true), det_(index_ctx_, c.self_id, c.storage) {
         det_.INNER_PRODUCT_THRES = c.inner_product_thres; det_.INIT_MODE_PRODUCT_THRES = c.init_mode_product_thres;
         det_.MATCH_INDEX_DIST = c.match_index_dist; det_.MIN_LOOP_NUM = c.min_loop_num; det_.MIN_DIRECTION_LOOP = c.min_direction_loop;
         if (c.camera_configuration != 1 && c.camera_configuration != 2) throw std::runtime_error("KeyframePipeline: camera_configuration must be 1 (STEREO_FISHEYE) or 2 (PINHOLE_DEPTH)");
@@ -217,6 +217,15 @@ public:
         return true;
     }
     int geometry_calls() const { return geometry_calls_; }
+    // where the host thread's time goes, per unit (micro-batch), in milliseconds since the last reset: [0] enqueue (upload + launches), [1] waiting for
+    // the unit's results, [2] building the frame messages (+ stereo landmarks), [3] the detector step (index appends / searches, one GPU round trip),
+    // [4] geometry hand-over; returns the number of units.  The loop runs at the GPU's pace while [1] > 0: the host then waits for the GPU, not the GPU for it.
+    int host_times(double out[5], bool reset) {
+        for (int i = 0; i < 5; ++i) out[i] = host_units_ ? host_ms_[i] / host_units_ : 0.0;
+        const int n = host_units_;
+        if (reset) { for (double& v : host_ms_) v = 0; host_units_ = 0; }
+        return n;
+    }
     const std::vector<LoopEdge>& edges() const { return edges_; }
     // every loop candidate the detector returned (query_fisheyeframe_from_database found an old frame), in key-frame order
     struct Candidate { int64_t new_msg_id, old_msg_id; int dir_new, dir_old; };
@@ -300,11 +309,13 @@ public:
             lane->meta.clear();
             if (from_host) lane->cam.enqueue_host(src, cfg_.width, !cfg_.mono());       // loop_cam.cpp:536: only STEREO_FISHEYE blanks rows
             else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
+            host_ms_[0] += since(lane->t_enqueue);
             pending.emplace_back(lane, first_msg_id + (int64_t)s * MB);
             if (pending.size() >= lanes_.size()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         }
         while (!pending.empty()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         hits += collect_exchange();
+        hits += collect_detector();
         drain_geometry();
         return hits;
     }
@@ -384,6 +395,7 @@ public:
         while (!stream_pending_.empty()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
         if (tail) { hits += finish_timed(*tail, 0); tail->meta.clear(); }
         open_ = nullptr;
+        hits += collect_detector();
         drain_geometry();
         return hits;
     }
@@ -403,8 +415,9 @@ private:
         Lane(const Config& c, int mb_)
             : mb(mb_), sp_ctx(c.device), vlad_ctx(c.device),
               sp(sp_ctx, c.sp_weights, c.pca_comp, c.pca_mean, c.width, c.height, c.thres, c.max_num, false, c.precision, (c.mono() ? 1 : 8) * mb_),
-              vlad(vlad_ctx, c.vlad_weights, c.width, c.height, false, c.dirs() * mb_),
-              cam(sp_ctx, sp, vlad_ctx, vlad, c.dirs() * mb_, c.max_num, c.width, c.height, c.mono()) {
+              one_stream(cfg_int("OMNI_PIPELINE_ONE_STREAM") != 0),
+              vlad(one_stream ? sp_ctx : vlad_ctx, c.vlad_weights, c.width, c.height, false, c.dirs() * mb_),
+              cam(sp_ctx, sp, one_stream ? sp_ctx : vlad_ctx, vlad, c.dirs() * mb_, c.max_num, c.width, c.height, c.mono()) {
             check(omni_vlad_dev_output(vlad.handle(), &rows_dev), "omni_vlad_dev_output");
         }
         void sync() { check(omni_ctx_sync(sp_ctx.get()), "sync"); check(omni_ctx_sync(vlad_ctx.get()), "sync"); }
@@ -416,6 +429,8 @@ private:
         ~Lane() { if (stage) omni_host_free(stage); }
         Context sp_ctx, vlad_ctx;
         Swarm::SuperPointHIP sp;
+        bool one_stream;                               // MobileNetVLAD behind SuperPoint on ONE stream (OMNI_PIPELINE_ONE_STREAM) instead of next to it on its own
+        Context& vlad_stream_ctx() { return one_stream ? sp_ctx : vlad_ctx; }
         Swarm::MobileNetVLADHIP vlad;
         LoopCamHIP cam;
         const float* rows_dev = nullptr;
@@ -439,16 +454,42 @@ private:
         return hits;
     }
     int finish_timed(Lane& lane, int64_t first_id) {
-        geo_left_in_flight_ = false;
         const int hits = finish(lane, first_id);
-        if (!geo_left_in_flight_)                                   // (otherwise drain_geometry() records it, when the micro-batch's last edge is in)
-            latencies_ms_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lane.t_enqueue).count());
+        if (shard_) latencies_ms_.push_back(since(lane.t_enqueue));       // (the local path records a unit's latency when its detector step is collected)
+        return hits;
+    }
+    // The detector step of the unit whose batch was begun last: LoopDetectorCore::end_images_batch waits for the copy of its result lists -- enqueued one
+    // unit ago, so it ran behind the CNN kernels of the unit that is in flight and the host does not wait here -- and replays the rules; then the unit's
+    // geometry.  (The host used to wait for the searches right where it enqueued them: on a GPU kept busy by the next unit's kernels that round trip took
+    // 2.9 ms of a 3.8 ms cycle, the next unit was enqueued late and the GPU idled 15 % of the time -- host_times(), DESIGN.md.)
+    int collect_detector() {
+        if (!det_pending_.active) return 0;
+        auto t_a = std::chrono::steady_clock::now();
+        int hits = 0, fi = 0;
+        for (auto& c : det_.end_images_batch()) {
+            if (c.found) { ++hits; candidates_.push_back({det_pending_.ids[(size_t)fi], c.old_msg_id, c.direction_new, c.direction_old}); }
+            ++fi;
+        }
+        det_pending_.active = false;
+        host_ms_[3] += since(t_a);
+        t_a = std::chrono::steady_clock::now();
+        // the previous micro-batch's tasks ran meanwhile; this one's run until the next is collected.  The tasks reference this micro-batch's frames:
+        // those moved into the database live there (std::map: stable), the others are handed over
+        drain_geometry();
+        const bool left = start_geometry(&det_.held_frames(), &det_pending_.t_enqueue);
+        if (!async_geometry_) drain_geometry();
+        det_.held_frames().clear();
+        if (!left) latencies_ms_.push_back(since(det_pending_.t_enqueue));        // (otherwise drain_geometry() records it, when the micro-batch's last edge is in)
+        host_ms_[4] += since(t_a);
         return hits;
     }
     // the micro-batch's key frames reach the detector in order, as one batch; rows and queries are taken from MobileNetVLAD's output
     // buffer in HBM ([4*mb][4096], key-frame major) -- wait() has synchronised with the MobileNetVLAD stream
     int finish(Lane& lane, int64_t first_id) {
+        auto t_a = std::chrono::steady_clock::now();
         const omni_cam_result r = lane.cam.wait();
+        host_ms_[1] += since(t_a); ++host_units_;
+        t_a = std::chrono::steady_clock::now();
         if (shard_) {
             // the exchange of THIS micro-batch is enqueued (two collectives, the scan, the copy of the lists: no host wait) and its results are
             // collected when the NEXT micro-batch gets here (or at the end of run()): meanwhile the host enqueues the next CNN unit
@@ -509,17 +550,20 @@ private:
             stereo_tasks_.clear();
             if (first) std::rethrow_exception(first);
         }
-        int hits = 0, fi = 0;
-        for (auto& c : det_.on_images_recv_batch(std::move(frames_), lane.rows_dev)) {
-            if (c.found) { ++hits; candidates_.push_back({lane.meta.empty() ? first_id + fi : lane.meta[(size_t)fi].msg_id, c.old_msg_id, c.direction_new, c.direction_old}); }
-            ++fi;
-        }
-        // the previous micro-batch's tasks ran while this one's CNN unit was waited for; this one's run until the next gets here.  The tasks
-        // reference this micro-batch's frames: those moved into the database live there (std::map: stable), the others are handed over
-        drain_geometry();
-        geo_left_in_flight_ = start_geometry(&frames_, &lane.t_enqueue);
-        if (!async_geometry_) { drain_geometry(); }
+        host_ms_[2] += since(t_a);
+        t_a = std::chrono::steady_clock::now();
+        int hits = collect_detector();                                          // the unit before this one
+        t_a = std::chrono::steady_clock::now();
+        det_pending_.ids.resize((size_t)lane.mb);
+        for (int m = 0; m < lane.mb; ++m) det_pending_.ids[(size_t)m] = lane.meta.empty() ? first_id + m : lane.meta[(size_t)m].msg_id;
+        det_pending_.t_enqueue = lane.t_enqueue;
+        det_.begin_images_batch(std::move(frames_), lane.rows_dev);             // appends + searches + the copy of the lists: enqueued, not waited for
+        det_pending_.active = true;
         frames_.clear();
+        // the appends and the query gather read MobileNetVLAD's output buffer: the lane's next unit must not overwrite it before they have
+        check(omni_ctx_order_after(lane.vlad_stream_ctx().get(), index_ctx_.get()), "omni_ctx_order_after");
+        host_ms_[3] += since(t_a);
+        if (!async_detector_) hits += collect_detector();                       // OMNI_DETECTOR_ASYNC=0: wait for it here, as before (A/B)
         return hits;
     }
 
@@ -539,7 +583,8 @@ private:
         bool timed = false;
     };
     std::deque<GeoBatch> geo_inflight_;         // (declared before the pool: outlives its threads)
-    bool geo_left_in_flight_ = false;
+    struct DetPending { bool active = false; std::vector<int64_t> ids; std::chrono::steady_clock::time_point t_enqueue; } det_pending_;
+    bool async_detector_ = [] { int v = 1; check(omni_config_value("OMNI_DETECTOR_ASYNC", &v), "omni_config_value"); return v != 0; }();
     bool async_geometry_ = [] { int v = 1; check(omni_config_value("OMNI_GEOMETRY_ASYNC", &v), "omni_config_value"); return v != 0; }();
     std::unique_ptr<TaskPool> pool_;
     std::vector<ImageDescriptor> downs_;        // the down-camera halves of the micro-batch being finished
@@ -555,6 +600,10 @@ private:
     int geometry_calls_ = 0;
     std::vector<std::unique_ptr<Lane>> lanes_;
     std::map<int, std::unique_ptr<Lane>> tail_lanes_;
+    double host_ms_[5] = {0, 0, 0, 0, 0};
+    int host_units_ = 0;
+    static int cfg_int(const char* name) { int v = 0; check(omni_config_value(name, &v), "omni_config_value"); return v; }
+    static double since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
     Lane* open_ = nullptr;                      // streaming intake: the micro-batch being filled
     std::deque<Lane*> stream_pending_;          // ... and the units in flight, oldest first
     size_t next_lane_ = 0;

@@ -42,7 +42,8 @@ inline void check(int rc, const char* what) {
 // ---- shared context (one HIP stream); the reference creates one cudaStream per runner (tensorrt_generic.cpp:103) ----
 class Context {
 public:
-    explicit Context(int device_id = 0) : h_(omni_ctx_create(device_id)) {
+    // high_priority: the stream of short work the host waits on (the detector's searches) next to streams that keep the whole GPU busy
+    explicit Context(int device_id = 0, bool high_priority = false) : h_(high_priority ? omni_ctx_create_priority(device_id, 1) : omni_ctx_create(device_id)) {
         if (!h_) throw std::runtime_error(std::string("omni_ctx_create: ") + omni_last_error());
     }
     ~Context() { omni_ctx_destroy(h_); }
@@ -411,7 +412,7 @@ public:
 
     LoopDetectorCore(Context& ctx, int self_id, int storage = OMNI_STORE_F32)
         : self_id(self_id), local_index(ctx, 4096, storage), remote_index(ctx, 4096, storage), ctx_(ctx) {}
-    ~LoopDetectorCore() { if (batch_buf_) omni_dev_free(ctx_.get(), batch_buf_); }
+    ~LoopDetectorCore() { if (batch_buf_) omni_dev_free(ctx_.get(), batch_buf_); if (raw_pinned_) omni_host_free(raw_pinned_); }
 
     int database_size() const { return replaying_ ? (int)(sim_local_ + sim_remote_) : (int)(local_index.ntotal + remote_index.ntotal); }
 
@@ -423,23 +424,70 @@ public:
     // (e.g. MobileNetVLAD's output buffer): rows are appended and queried from there, the host copies are not read.
     // rvalue overload: frames that enter the database are MOVED into it (the const& overload copies them, 270 KB per fisheye key frame)
     std::vector<LoopCandidate> on_images_recv_batch(std::vector<FisheyeFrameDescriptor>&& frames, const float* rows_dev = nullptr) {
-        movable_ = &frames;
-        try { auto out = on_images_recv_batch(static_cast<const std::vector<FisheyeFrameDescriptor>&>(frames), rows_dev); movable_ = nullptr; return out; }
-        catch (...) { movable_ = nullptr; throw; }
+        begin_images_batch(std::move(frames), rows_dev);
+        return end_images_batch();
     }
     std::vector<LoopCandidate> on_images_recv_batch(const std::vector<FisheyeFrameDescriptor>& frames_in, const float* rows_dev = nullptr) {
+        begin_batch(&frames_in, false, rows_dev);
+        return end_images_batch();
+    }
+    // The same in two halves, for a host loop that must not wait for the GPU here (KeyframePipeline): begin_images_batch plans the batch, enqueues the
+    // appends, the prefix searches and the copy of the result lists into a pinned block, and returns; end_images_batch waits for that copy (long done
+    // when it is called one micro-batch later), replays the decision rules and returns the candidates.  One batch at a time; the frames are owned
+    // by the detector in between (those that enter the database are moved into it by end_images_batch, the others stay in held_frames() until the
+    // next begin).  rows_dev must stay untouched until the appends and searches have read it: order the producer's stream behind ctx's
+    // (omni_ctx_order_after) before it writes the buffer again.
+    void begin_images_batch(std::vector<FisheyeFrameDescriptor>&& frames, const float* rows_dev = nullptr) {
+        if (pb_.active) throw std::logic_error("begin_images_batch: the previous batch was not ended");
+        pb_.owned = std::move(frames);
+        begin_batch(&pb_.owned, true, rows_dev);
+    }
+    bool batch_pending() const { return pb_.active; }
+    std::vector<FisheyeFrameDescriptor>& held_frames() { return pb_.owned; }
+
+private:
+    struct BatchSearch { IndexFlatIP* index; size_t row; int max_index; int64_t n_limit; };
+    struct PendingBatch {
+        bool active = false, movable = false;
+        std::vector<FisheyeFrameDescriptor> owned, cleaned;
+        const std::vector<FisheyeFrameDescriptor>* frames = nullptr;
+        std::vector<BatchSearch> searches;
+        std::vector<std::pair<size_t, size_t>> where;            // byte offsets of I and D per search
+        size_t need = 0;
+        bool any_add = false;
+        int64_t start_local = 0, start_remote = 0;
+        float* own_rows = nullptr;
+    } pb_;
+    char* raw_pinned_ = nullptr;
+    size_t raw_pinned_bytes_ = 0;
+    void rollback_batch() {
+        // a failed append / search / copy: take the rows of this batch out again so that row ids, the id maps and the recency rule of every
+        // later frame stay what they were (the Python twin's _rollback)
+        (void)omni_index_truncate(local_index.handle(), pb_.start_local);
+        (void)omni_index_truncate(remote_index.handle(), pb_.start_remote);
+        local_index.ntotal = omni_index_ntotal(local_index.handle());
+        remote_index.ntotal = omni_index_ntotal(remote_index.handle());
+        if (pb_.own_rows) { omni_dev_free(ctx_.get(), pb_.own_rows); pb_.own_rows = nullptr; }
+        row_ids_.clear(); deferred_.clear();
+        pb_.active = false;
+    }
+    void begin_batch(const std::vector<FisheyeFrameDescriptor>* frames_in, bool movable, const float* rows_dev) {
+        if (pb_.active) throw std::logic_error("on_images_recv_batch: a batch begun with begin_images_batch is still open");
         // host rows are read as 4096 floats each: an image whose global descriptor has another length (a malformed or other-version packet
         // that got past LoopNet) counts as an image without landmarks -- the reference would read past the vector (loop_detector.cpp:166-170)
-        std::vector<FisheyeFrameDescriptor> cleaned;
+        pb_.cleaned.clear();
+        pb_.movable = movable;
         if (!rows_dev) {
             bool bad = false;
-            for (auto& f : frames_in) bad = bad || malformed(f);
-            if (bad) { cleaned = frames_in; for (auto& f : cleaned) sanitise(f); movable_ = nullptr; }
+            for (auto& f : *frames_in) bad = bad || malformed(f);
+            if (bad) { pb_.cleaned = *frames_in; for (auto& f : pb_.cleaned) sanitise(f); pb_.movable = false; }
         }
-        const std::vector<FisheyeFrameDescriptor>& frames = cleaned.empty() ? frames_in : cleaned;
+        pb_.frames = pb_.cleaned.empty() ? frames_in : &pb_.cleaned;
+        const std::vector<FisheyeFrameDescriptor>& frames = *pb_.frames;
         struct Add { IndexFlatIP* index; size_t row; };
-        struct Search { IndexFlatIP* index; size_t row; int max_index; int64_t n_limit; };
-        std::vector<Add> adds; std::vector<Search> searches;
+        std::vector<Add> adds;
+        std::vector<BatchSearch>& searches = pb_.searches;
+        searches.clear();
         int64_t sim_local = local_index.ntotal, sim_remote = remote_index.ntotal;
         std::set<int> nodes = all_nodes;
         row_ids_.clear();
@@ -472,19 +520,20 @@ public:
             }
         }
         // enqueue: rows to HBM unless they are there already, appends, prefix searches, one result copy
-        float* own_rows = nullptr;
+        pb_.own_rows = nullptr;
         if (!rows_dev && (!adds.empty() || !searches.empty())) {
             std::vector<float> stage(total_rows * 4096, 0.f);
             size_t r = 0;
             for (auto& f : frames) for (auto& img : f.images) { if (img.image_desc.size() == 4096) std::memcpy(&stage[r * 4096], img.image_desc.data(), 4096 * 4); ++r; }
-            own_rows = static_cast<float*>(omni_dev_alloc(ctx_.get(), stage.size() * 4));
-            if (!own_rows) throw std::runtime_error(std::string("omni_dev_alloc: ") + omni_last_error());
-            check(omni_memcpy_h2d(ctx_.get(), own_rows, stage.data(), stage.size() * 4), "on_images_recv_batch upload");
-            rows_dev = own_rows;
+            pb_.own_rows = static_cast<float*>(omni_dev_alloc(ctx_.get(), stage.size() * 4));
+            if (!pb_.own_rows) throw std::runtime_error(std::string("omni_dev_alloc: ") + omni_last_error());
+            check(omni_memcpy_h2d(ctx_.get(), pb_.own_rows, stage.data(), stage.size() * 4), "on_images_recv_batch upload");
+            rows_dev = pb_.own_rows;
         }
-        const int64_t start_local = local_index.ntotal, start_remote = remote_index.ntotal;
-        std::vector<char> raw;
-        std::vector<std::pair<size_t, size_t>> where(searches.size(), {SIZE_MAX, SIZE_MAX});     // byte offsets of I and D per search
+        pb_.start_local = local_index.ntotal; pb_.start_remote = remote_index.ntotal;
+        pb_.where.assign(searches.size(), {SIZE_MAX, SIZE_MAX});
+        pb_.active = true;
+        pb_.any_add = !adds.empty();
         try {
         for (size_t a = 0; a < adds.size();) {                                    // consecutive rows of one index go in as one append
             size_t b = a + 1;
@@ -508,7 +557,7 @@ public:
             c->js.push_back(j);
         }
         for (auto& c : chunks) { c.off_i = need; c.off_d = need + c.js.size() * c.k * 8; need += c.js.size() * c.k * 12; }
-        raw.resize(need);
+        pb_.need = need;
         if (need) {
             if (batch_buf_bytes_ < need) {
                 if (batch_buf_) omni_dev_free(ctx_.get(), batch_buf_);
@@ -516,52 +565,57 @@ public:
                 if (!batch_buf_) throw std::runtime_error(std::string("omni_dev_alloc: ") + omni_last_error());
                 batch_buf_bytes_ = need;
             }
+            if (raw_pinned_bytes_ < need) {
+                if (raw_pinned_) omni_host_free(raw_pinned_);
+                raw_pinned_ = static_cast<char*>(omni_host_alloc(need));
+                if (!raw_pinned_) { raw_pinned_bytes_ = 0; throw std::runtime_error(std::string("omni_host_alloc: ") + omni_last_error()); }
+                raw_pinned_bytes_ = need;
+            }
             for (auto& c : chunks) {
                 std::vector<int64_t> rows_idx, limits;
                 for (size_t pos = 0; pos < c.js.size(); ++pos) {
-                    const Search& sj = searches[c.js[pos]];
+                    const BatchSearch& sj = searches[c.js[pos]];
                     rows_idx.push_back((int64_t)sj.row); limits.push_back(sj.n_limit);
-                    where[c.js[pos]] = {c.off_i + pos * c.k * 8, c.off_d + pos * c.k * 4};
+                    pb_.where[c.js[pos]] = {c.off_i + pos * c.k * 8, c.off_d + pos * c.k * 4};
                 }
                 check(omni_index_search_batch_prefix_dev(c.index->handle(), (int)c.js.size(), rows_dev, rows_idx.data(), c.k, limits.data(),
                                                          reinterpret_cast<float*>(batch_buf_ + c.off_d), reinterpret_cast<int64_t*>(batch_buf_ + c.off_i)),
                       "omni_index_search_batch_prefix_dev");
             }
-            check(omni_memcpy_d2h(ctx_.get(), raw.data(), batch_buf_, need), "on_images_recv_batch fetch");   // the only synchronisation
-        } else if (!adds.empty()) {
-            check(omni_ctx_sync(ctx_.get()), "omni_ctx_sync");
+            check(omni_memcpy_d2h_async(ctx_.get(), raw_pinned_, batch_buf_, need), "on_images_recv_batch fetch");      // (end_images_batch waits for it)
         }
-        } catch (...) {
-            // a failed append / search / copy: take the rows of this batch out again so that row ids, the id maps and the recency rule of every
-            // later frame stay what they were (the Python twin's _rollback)
-            (void)omni_index_truncate(local_index.handle(), start_local);
-            (void)omni_index_truncate(remote_index.handle(), start_remote);
-            local_index.ntotal = omni_index_ntotal(local_index.handle());
-            remote_index.ntotal = omni_index_ntotal(remote_index.handle());
-            if (own_rows) omni_dev_free(ctx_.get(), own_rows);
-            row_ids_.clear(); deferred_.clear();
-            throw;
-        }
+        } catch (...) { rollback_batch(); throw; }
+    }
+
+public:
+    std::vector<LoopCandidate> end_images_batch() {
+        if (!pb_.active) throw std::logic_error("end_images_batch without a batch");
+        const std::vector<FisheyeFrameDescriptor>& frames = *pb_.frames;
+        try {
+            if (pb_.need || pb_.any_add || pb_.own_rows) check(omni_ctx_sync(ctx_.get()), "omni_ctx_sync");      // the only synchronisation
+        } catch (...) { rollback_batch(); throw; }
         deferred_.clear();
-        for (size_t j = 0; j < searches.size(); ++j) {
-            const Search& sj = searches[j];
+        for (size_t j = 0; j < pb_.searches.size(); ++j) {
+            const BatchSearch& sj = pb_.searches[j];
             Deferred d; d.ntotal = sj.n_limit;
             const int k = SEARCH_NEAREST_NUM + sj.max_index;
             d.D.assign(k, -3.402823466e+38f); d.I.assign(k, -1);
-            if (where[j].first != SIZE_MAX) {
-                std::memcpy(d.I.data(), raw.data() + where[j].first, (size_t)k * 8);
-                std::memcpy(d.D.data(), raw.data() + where[j].second, (size_t)k * 4);
+            if (pb_.where[j].first != SIZE_MAX) {
+                std::memcpy(d.I.data(), raw_pinned_ + pb_.where[j].first, (size_t)k * 8);
+                std::memcpy(d.D.data(), raw_pinned_ + pb_.where[j].second, (size_t)k * 4);
             }
             deferred_.push_back(std::move(d));
         }
-        if (own_rows) omni_dev_free(ctx_.get(), own_rows);
+        if (pb_.own_rows) { omni_dev_free(ctx_.get(), pb_.own_rows); pb_.own_rows = nullptr; }
+        pb_.active = false;
         // replay the decision rules frame by frame on the fetched results
-        replaying_ = true; sim_local_ = start_local; sim_remote_ = start_remote; next_deferred_ = next_row_id_ = 0;
+        replaying_ = true; sim_local_ = pb_.start_local; sim_remote_ = pb_.start_remote; next_deferred_ = next_row_id_ = 0;
         std::vector<LoopCandidate> out;
+        std::vector<FisheyeFrameDescriptor>* movable = pb_.movable ? &pb_.owned : nullptr;
         try {
-            for (size_t fi = 0; fi < frames.size(); ++fi) { move_src_ = movable_ ? &(*movable_)[fi] : nullptr; out.push_back(on_image_recv(frames[fi])); }
+            for (size_t fi = 0; fi < frames.size(); ++fi) { move_src_ = movable ? &(*movable)[fi] : nullptr; out.push_back(on_image_recv(frames[fi])); }
             move_src_ = nullptr;
-        } catch (...) { replaying_ = false; throw; }
+        } catch (...) { replaying_ = false; move_src_ = nullptr; throw; }
         replaying_ = false;
         if (next_deferred_ != deferred_.size() || next_row_id_ != row_ids_.size()) throw std::logic_error("on_images_recv_batch: plan and replay diverged");
         return out;
@@ -632,7 +686,6 @@ private:
     size_t next_deferred_ = 0, next_row_id_ = 0;
     char* batch_buf_ = nullptr;
     size_t batch_buf_bytes_ = 0;
-    std::vector<FisheyeFrameDescriptor>* movable_ = nullptr;      // set by the rvalue overload of on_images_recv_batch
     FisheyeFrameDescriptor* move_src_ = nullptr;
     int add_image(const ImageDescriptor& img) {                                   // :164-173
         if (replaying_) {                                                         // on_images_recv_batch: already appended, in this order

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
            "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync",
-           "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_push_keyframe", "omni_pipeline_flush", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
+           "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_push_keyframe", "omni_pipeline_flush", "omni_pipeline_host_times", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
 _lib = None
 
 
@@ -38,6 +38,7 @@ def lib():
         L.omni_pipeline_push_keyframe.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_void_p,
                                                   C.POINTER(C.c_int)]
         L.omni_pipeline_flush.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.omni_pipeline_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.omni_pipeline_geometry_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.omni_pipeline_destroy.argtypes = [C.c_void_p]
         L.omni_pipeline_destroy.restype = None
@@ -145,6 +146,12 @@ class KeyframePipeline:
             raise _err("omni_pipeline_flush")
         self._depths = []
         return hits.value
+
+    def host_times(self, reset: bool = True) -> dict:
+        """the host thread's milliseconds per unit (micro-batch): enqueue, wait_gpu, messages, detector, geometry; `units` = how many were averaged"""
+        out = (C.c_double * 5)()
+        n = lib().omni_pipeline_host_times(self.h, out, int(reset))
+        return dict(zip(("enqueue", "wait_gpu", "messages", "detector", "geometry"), [round(v, 4) for v in out]), units=n)
 
     def prepare(self, n_keyframes: int):
         if lib().omni_pipeline_prepare(self.h, n_keyframes):
