@@ -527,9 +527,10 @@ def main():
         t = c1b["ms"] * 1e-3
         pk = PEAK_F32_TFLOPS if precision == "f32" else PEAK_F16_TFLOPS
         split = precision == "split"
-        trace = rocprof_trace("conv3x3_split_kernelILb0ELb1ELb0" if split else "conv3x3_c64_pp_kernelILb1ELi0ELb1")
+        trace = rocprof_trace("conv3x3_split_kernelILb0ELb1ELb0ELb0ELb1" if split else "conv3x3_c64_pp_kernelILb1ELi0ELb1")
         return {"bound": "mfma",
-                "kernel": ("conv3x3_split_kernel<cin 64, POOL> = conv1b 3x3 64->64 + ReLU + maxpool2 with split (hi, lo) fp16 operands: three MFMA terms per product" if split else
+                "kernel": ("conv3x3_split_kernel<cin 64, POOL, FUSE1A> = conv1a (built tile by tile from the u8 image, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 with split "
+                           "(hi, lo) fp16 operands: three MFMA terms per product; FLOP counted for conv1b only" if split else
                            "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 in one launch; "
                            "FLOP counted for conv1b only"),
                 "achieved": round(executed / t / 1e12, 1), "peak": pk, "unit": "TFLOP/s", "frac": round(executed / t / 1e12 / pk, 4),
@@ -539,7 +540,7 @@ def main():
                 "rocprof_trace": trace,
                 "rocprof_trace_note": "median launch duration of the same kernel under rocprofv3 --kernel-trace (committed summary); frac recomputed from it = "
                                       + (str(round(executed / (trace["median_us"] * 1e-6) / 1e12 / pk, 4)) if trace else "n/a: no trace committed yet"),
-                **(traffic_fields("conv3x3_split_kernel<cin64,POOL> (conv1b: the larger half of the launches)", True, n_img) if split else
+                **(traffic_fields("conv3x3_split_kernel<cin64,POOL,FUSE1A> (conv1b)", True, n_img) if split else
                    traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", precision == "f16", n_img))}
 
     roofline = conv1b_roofline(prof, args.precision)

@@ -32,14 +32,13 @@ def main(tag, images):
         "ip_scan_mq_kernel": lambda n: "ip_scan_mq_kernel" in n,
         "vlad_mblock_kernel": lambda n: "vlad_mblock_kernel" in n,
         "vlad_fc_mfma_kernel": lambda n: "vlad_fc_mfma_kernel" in n,
-        # OMNI_PREC_SPLIT: conv1b and conv2b share one instantiation (cin 64, pool): conv1b's launches are the ones that move the most bytes
-        "conv3x3_split_kernel<cin64,POOL> (conv1b: the larger half of the launches)": lambda n: "conv3x3_split_kernelILb0ELb1ELb0" in n,
+        # OMNI_PREC_SPLIT: conv1b = the FUSE1A instantiation <C128 = 0, POOL = 1, OUT_F32 = 0, TRN = 0, FUSE1A = 1> (conv1a is built inside it from the u8 image)
+        "conv3x3_split_kernel<cin64,POOL,FUSE1A> (conv1b)": lambda n: "conv3x3_split_kernelILb0ELb1ELb0ELb0ELb1" in n,
+        "conv3x3_split_c128_sparse_kernel (convDa at the key points)": lambda n: "conv3x3_split_c128_sparse_kernel" in n,
     }
     for key, m in kernels.items():
         rd = mean_by(f"gpurun_out/{tag}_pmc3", "FETCH_SIZE", m)
         wr = mean_by(f"gpurun_out/{tag}_pmc4", "WRITE_SIZE", m)
-        if "larger half" in key:
-            rd, wr = sorted(rd)[len(rd) // 2:], sorted(wr)[len(wr) // 2:]
         if rd and wr:
             r, w = sum(rd) / len(rd) * 1024 * 2, sum(wr) / len(wr) * 1024
             out[key] = {"read_bytes": round(r), "write_bytes": round(w), "bytes_per_launch": round(r + w), "dispatches": len(rd)}
