@@ -298,7 +298,8 @@ def main():
 
     def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False, ptrs=None, mb=None, pipelines=None):
         mb = mb or MB
-        pipelines = pipelines or args.pipelines or (4 if precision == capi.PREC_F16 else 2)
+        # units in flight: not more than the region holds (the driver times regions of 20 key frames = 2.5 micro-batches)
+        pipelines = pipelines or args.pipelines or (min(4, max(2, -(-steps // mb))) if precision == capi.PREC_F16 else 2)
         ptrs = ptrs or (pool_ptrs if mb == MB else [pinned_batch(1000 * rank + 50_000 + 8 * mb * p, mb).ctypes.data for p in range(2)])
         pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, mb,
                                        pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)

@@ -350,7 +350,12 @@ int       omni_cam_enqueue_dev(omni_cam* cam, const uint8_t* gray_dev, int strid
  * owned by the handle, then the work of omni_cam_enqueue_dev.  gray_host should be pinned (omni_host_alloc) and must stay untouched
  * until omni_cam_wait returns. */
 int       omni_cam_enqueue_host(omni_cam* cam, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask);
-int       omni_cam_wait(omni_cam* cam, omni_cam_result* out);                                          /* two event waits */
+int       omni_cam_wait(omni_cam* cam, omni_cam_result* out);
+/* Units in flight, oldest first: whatever is enqueued on `later` from now on starts behind the CONVOLUTION STACK of `earlier`'s last enqueue (an event
+ * on the device; the host does not wait).  Without it the units' CU-filling kernels take turns, every unit finishes late and together; with it the
+ * oldest unit finishes first while the next one's convolutions run under its small-grid tail (NMS, descriptor sampling, matcher).
+ * streams: 1 = `later`'s SuperPoint stream waits, 2 = its MobileNetVLAD stream too, 0 = no-op. */
+int       omni_cam_order_after(omni_cam* later, omni_cam* earlier, int streams);                                          /* two event waits */
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,18 @@ static int cam_enqueue_locked(omni_cam* c, const uint8_t* gray_dev, int stride, 
     return OMNI_OK;
 }
 
+int omni_cam_order_after(omni_cam* later, omni_cam* earlier, int streams) {
+    OMNI_REQUIRE(later && earlier, OMNI_ERR_INVALID, "null argument");
+    if (later == earlier || streams <= 0) return OMNI_OK;
+    OMNI_REQUIRE(later->c1->device == earlier->c1->device, OMNI_ERR_INVALID, "omni_cam_order_after: two units of one device");
+    (void)hipSetDevice(later->c1->device);
+    hipEvent_t ev = omni_sp_convs_event(earlier->sp);
+    OMNI_REQUIRE(ev, OMNI_ERR_INVALID, "omni_cam_order_after: no event");
+    OMNI_HIP_TRY(hipStreamWaitEvent(later->c1->stream, ev, 0));          // (an event that was never recorded does not block)
+    if (streams >= 2 && later->c2 != later->c1) OMNI_HIP_TRY(hipStreamWaitEvent(later->c2->stream, ev, 0));
+    return OMNI_OK;
+}
+
 int omni_cam_wait(omni_cam* c, omni_cam_result* out) {
     OMNI_REQUIRE(c && out, OMNI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mu);

@@ -101,6 +101,8 @@ struct HostBuf {
 
 }  // namespace omni
 
+extern "C" hipEvent_t omni_sp_convs_event(omni_sp* s);      // internal (superpoint.hip -> cam.hip): recorded behind a pass's convolution stack
+
 #define OMNI_ZERO_PAGE_BYTES 65536
 
 struct omni_ctx {

@@ -52,6 +52,9 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_GEOMETRY_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's geometry tasks run while the next unit is waited for (0: drained at once)"},
     {"OMNI_DETECTOR_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's detector step (appends, searches) is enqueued and collected one unit later (0: the host waits for it on the spot)"},
     {"OMNI_PIPELINE_ONE_STREAM", 0, 0, 1, CFG_VARIANT, "a unit's MobileNetVLAD launches behind its SuperPoint launches on one stream (0: next to them on a second stream)"},
+    {"OMNI_PIPELINE_FIFO", -1, -1, 2, CFG_VARIANT, "units in flight run oldest first: a unit's SuperPoint stream (1) / both its streams (2) start behind the convolution stack of the unit "
+                                                   "enqueued before it; 0: the units' kernels take turns; -1: by measurement (round 4) -- 1 for the fp32-class precisions, whose time is all "
+                                                   "CU-filling convolutions (+2-4 %), 0 for fp16, whose small-grid tails the next units' kernels fill (-5 % when chained)"},
     // ---- runtime ---------------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_HW_QUEUES", 8, 0, 64, CFG_TUNING, "hardware queues asked of the HIP runtime when the library is loaded (GPU_MAX_HW_QUEUES, unless already set): the pipeline's five "
                                             "streams must not share one; 0 = the runtime's default of 4"},

@@ -73,6 +73,7 @@ struct omni_sp {
     omni::HostBuf hstage;
     omni::DevBuf dense_tmp;
     hipEvent_t ev[OMNI_SP_NUM_STAGES + 1] = {};
+    hipEvent_t ev_convs = nullptr;           // recorded behind the last CU-filling kernel of a pass (the detector head): what omni_cam_order_after waits for
     int conv_variant = 0;                    // OMNI_CONV_V1=1: generic conv kernel everywhere, 2: v2 persistent kernel (A/B and debugging)
     // The constant region of the fisheye mask (fp16 path; OMNI_SP_MASK_SKIP=0 switches it off).  LoopCam blanks rows [3H/4, 3H/4 + H/4) of every image before the
     // network sees it (loop_cam.cpp:536-539): a few pixels inside that band -- one per 3x3 convolution, doubling with every pool -- every
@@ -323,6 +324,7 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     s->pb.pca_compT = s->pca_compT;
     s->pb.pca_mean = s->pca_mean;
     for (int i = 0; i <= OMNI_SP_NUM_STAGES; ++i) OMNI_HIP_TRY(hipEventCreate(&s->ev[i]));
+    OMNI_HIP_TRY(hipEventCreateWithFlags(&s->ev_convs, hipEventDisableTiming));
     OMNI_HIP_TRY(hipStreamSynchronize(st));
     return sp_plan_mask_skip(s);
 }
@@ -440,6 +442,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     } else if ((rc = detector_head_mfma(st, PH, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
                                         s->ctx->prop.multiProcessorCount))) return rc;
     if ((rc = mark())) return rc;
+    OMNI_HIP_TRY(hipEventRecord(s->ev_convs, st));        // the convolution stack and the detector head are enqueued: what follows are small grids
     s->dense_valid = !sparse && !sparse32; s->dense_possible = true; s->last_batch = batch;
     s->heads_full = !sparse_da32;
     if (sparse || sparse32) {
@@ -589,6 +592,7 @@ void omni_sp_destroy(omni_sp* s) {
     for (auto& k : s->mskip) if (k.vec) (void)hipFree(k.vec);
     s->hstage.release(); s->dense_tmp.release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->ev_convs) (void)hipEventDestroy(s->ev_convs);
     delete s;
 }
 
@@ -719,6 +723,9 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
     omni::set_error("unknown layer '%s'", name);
     return OMNI_ERR_INVALID;
 }
+
+// (internal, cam.hip) the event a pass records behind its convolution stack
+hipEvent_t omni_sp_convs_event(omni_sp* s) { return s ? s->ev_convs : nullptr; }
 
 const char* omni_sp_stage_name(int stage) { return (stage >= 0 && stage < OMNI_SP_NUM_STAGES) ? kStageNames[stage] : ""; }
 

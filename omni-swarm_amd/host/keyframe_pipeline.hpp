@@ -307,6 +307,7 @@ public:
             if (pend_lane_ == lane) check(omni_shard_rows_consumed(shard_), "omni_shard_rows_consumed");      // its row buffer is the exchange's input
             lane->t_enqueue = std::chrono::steady_clock::now();
             lane->meta.clear();
+            chain(lane);
             if (from_host) lane->cam.enqueue_host(src, cfg_.width, !cfg_.mono());       // loop_cam.cpp:536: only STEREO_FISHEYE blanks rows
             else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
             host_ms_[0] += since(lane->t_enqueue);
@@ -371,6 +372,7 @@ public:
         open_->meta.push_back(sm);
         int hits = carried_hits_; carried_hits_ = 0;
         if ((int)open_->meta.size() == MB) {
+            chain(open_);
             open_->cam.enqueue_host(open_->stage, cfg_.width, !cfg_.mono());
             stream_pending_.push_back(open_);
             open_ = nullptr;
@@ -389,6 +391,7 @@ public:
             if (!cfg_.mono()) std::memmove(open_->stage + (size_t)nd * rem * img, open_->stage + (size_t)nd * MB * img, (size_t)nd * rem * img);      // the down block moves up behind rem up blocks
             tail->meta = open_->meta;
             tail->t_enqueue = open_->t_enqueue;
+            chain(tail);
             tail->cam.enqueue_host(open_->stage, cfg_.width, !cfg_.mono());
             open_->meta.clear();
         }
@@ -602,6 +605,13 @@ private:
     std::map<int, std::unique_ptr<Lane>> tail_lanes_;
     double host_ms_[5] = {0, 0, 0, 0, 0};
     int host_units_ = 0;
+    // units in flight run oldest first (omni_cam_order_after): the unit about to be enqueued starts behind the convolution stack of the one enqueued last
+    Lane* last_enqueued_ = nullptr;
+    int fifo_streams_ = [this] { const int v = cfg_int("OMNI_PIPELINE_FIFO"); return v >= 0 ? v : (cfg_.precision == OMNI_PREC_F16 ? 0 : 1); }();
+    void chain(Lane* lane) {
+        if (fifo_streams_ > 0 && last_enqueued_ && last_enqueued_ != lane) lane->cam.order_after(last_enqueued_->cam, fifo_streams_);
+        last_enqueued_ = lane;
+    }
     static int cfg_int(const char* name) { int v = 0; check(omni_config_value(name, &v), "omni_config_value"); return v; }
     static double since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
     Lane* open_ = nullptr;                      // streaming intake: the micro-batch being filled

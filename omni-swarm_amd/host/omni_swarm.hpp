@@ -285,6 +285,8 @@ public:
     void enqueue_dev(const uint8_t* gray_dev, int stride, bool fisheye_mask = true) {      // images already in HBM
         check(omni_cam_enqueue_dev(h_, gray_dev, stride, fisheye_mask ? 1 : 0), "omni_cam_enqueue_dev");
     }
+    // the next enqueue on this object starts behind the convolution stack of `earlier`'s last one (omni_cam_order_after)
+    void order_after(LoopCamHIP& earlier, int streams) { check(omni_cam_order_after(h_, earlier.h_, streams), "omni_cam_order_after"); }
     // blocks until the key frame is done; pointers stay valid until the next enqueue on this object
     omni_cam_result wait() {
         omni_cam_result r{};
