@@ -9,7 +9,7 @@ EXTRA="$*"
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-db-keyframes 0 --parity-steps 0 --c5-rows 0 $EXTRA"
+LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-db-keyframes 0 --parity-steps 0 --c5-rows 0 --long-region-steps 0 $EXTRA"
 BENCH="python bench.py --steps 40 --warmup 8 --min-time 0 $LEGS"
 BENCH_PMC="python bench.py --steps 8 --warmup 8 --min-time 0 --match-db-rows 100000 $LEGS"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ${TAG} -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.err

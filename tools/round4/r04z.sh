@@ -12,7 +12,7 @@ echo "t=$(( $(date +%s) - T0 ))s"
 timeout 900 python bench.py > $OUT/r04z_bench.json 2> $OUT/r04z_bench.err; echo "bench rc=$?"
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/r04z_bench_driver_style.json 2> $OUT/r04z_bench_driver_style.err; echo "bench driver-style rc=$?"
 echo "t=$(( $(date +%s) - T0 ))s"
-LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-db-keyframes 0 --parity-steps 0 --c5-rows 0"
+LEGS="--no-cpu-baseline --f32-steps 0 --python-steps 0 --geometry-steps 0 --big-db-keyframes 0 --parity-steps 0 --c5-rows 0 --long-region-steps 0"
 timeout 400 rocprofv3 --kernel-trace -d $OUT/r04z_trace -o r04z -- python bench.py --steps 200 --warmup 32 --min-time 0 $LEGS > $OUT/r04z_bench_under_rocprof.json 2> $OUT/r04z_trace.err
 python tools/pipeline_busy.py $(ls $OUT/r04z_trace/*_results.db $OUT/r04z_trace/*/*_results.db 2>/dev/null | head -1) "r04z: HEAD, bench.py --steps 200 --warmup 32 (f16, 4 units in flight), under rocprofv3 --kernel-trace" > $OUT/r04z_pipeline_busy.json 2>> $OUT/r04z_trace.err
 cat $OUT/r04z_pipeline_busy.json
