@@ -302,8 +302,16 @@ def main():
         # units in flight: not more than the region holds (the driver times regions of 20 key frames = 2.5 micro-batches)
         pipelines = pipelines or args.pipelines or (min(4, max(2, -(-steps // mb))) if precision == capi.PREC_F16 else 2)
         ptrs = ptrs or (pool_ptrs if mb == MB else [pinned_batch(1000 * rank + 50_000 + 8 * mb * p, mb).ctypes.data for p in range(2)])
+        # units oldest-first (omni_cam_order_after): in a region that drains (fewer than 8 micro-batches) the first unit then finishes early and the host's
+        # work on it overlaps the rest (+7-11 % at 20 key frames, profiles/r04ab_short_regions.log); a loop that never drains is faster with the units'
+        # kernels taking turns for fp16 (-5 % when chained) -- the library's default (-1) picks by precision, the bench also by region length
+        fifo_was = os.environ.get("OMNI_PIPELINE_FIFO")
+        if fifo_was is None and steps < 8 * mb:
+            os.environ["OMNI_PIPELINE_FIFO"] = "1"
         pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, mb,
                                        pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
+        if fifo_was is None:
+            os.environ.pop("OMNI_PIPELINE_FIFO", None)
         gen = RowFactory(7 + rank)
         if world > 1:
             pl.attach_shard(rank, world, shard_uid())

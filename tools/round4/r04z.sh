@@ -24,7 +24,7 @@ import json
 for f in ("$OUT/r04z_bench.json", "$OUT/r04z_bench_driver_style.json"):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
-        print(f, "value", d["value"], "parity", (d.get("value_parity") or {}).get("value"), "geom", (d.get("with_geometry") or {}).get("value"), "f32", (d.get("value_f32") or {}).get("value"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+        print(f, "value", d["value"], "parity", (d.get("value_parity") or {}).get("value"), "geom", (d.get("with_geometry") or {}).get("value"), "f32", (d.get("value_f32") or {}).get("value"), "cpu", (d.get("cpu_baseline") or {}).get("value"), "long_regions", (d.get("value_long_regions") or {}).get("value"))
         print(" db100k", {k: v.get("value") for k, v in (d.get("db100k") or {}).items()}, "c5", (d.get("c5_shard") or {}).get("value"), "python", (d.get("python_host") or {}).get("value"), "loop_match", d["loop_match"]["p50_ms"])
         print(" host", d.get("host_ms_per_microbatch"), "lat", d.get("keyframe_latency_ms", {}).get("p50"))
         print(" roofline", {k: d["roofline"][k] for k in ("achieved", "frac", "frac_algorithmic", "launch_ms", "tiles_left_out", "traffic")}, d["roofline"]["rocprof_trace_note"][-12:], (d["roofline"]["rocprof_trace"] or {}).get("median_us"))
