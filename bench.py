@@ -340,6 +340,8 @@ def main():
         lat = pl.latencies_ms()
         out.update(db_rows_start=db_rows, db_rows_end=int(pl.db_rows), loop_candidates_found=state["hits"])
         out["host_ms_per_microbatch"] = pl.host_times()
+        out["pipelines"] = pipelines
+        out["units_oldest_first"] = os.environ.get("OMNI_PIPELINE_FIFO") or ("1 (short regions)" if steps < 8 * mb else ("0" if precision == capi.PREC_F16 else "1") + " (library default)")
         if len(lat):
             out["keyframe_latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
                                           "micro_batches": int(len(lat)), "keyframes_in_flight": mb * pipelines,
@@ -681,7 +683,7 @@ def main():
             "config": {"workload": "configs[1]: reference-faithful fisheye key frame = upload of 8 images + 8 SuperPoint + 4 MobileNetVLAD(assumed arch) "
                                    "images 600x480 + 4 up/down BF matches + <=4 index inserts + top-k query + results to host; "
                                    f"{args.db_keyframes}-keyframe DB ({4 * args.db_keyframes} rows); seeded synthetic weights",
-                       "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": args.pipelines or (4 if prec == capi.PREC_F16 else 2),
+                       "images_per_keyframe": KF_IMAGES, "superpoint_thres": THRES, "max_num": MAXN, "pipelines_per_gpu": main_leg.get("pipelines", args.pipelines), "units_oldest_first": main_leg.get("units_oldest_first"),
                        "keyframes_per_microbatch": MB, "host_loop": ("c++ (host/keyframe_pipeline.hpp)" + (" + omni_shard (RCCL inside libomni_hip.so)" if world > 1 else "")) if cpp_host else
                                     "python" + (" + torch.distributed exchange" if world > 1 else ""),
                        "image_upload": "inside the timed region (pinned host -> HBM, one async copy per micro-batch)",
