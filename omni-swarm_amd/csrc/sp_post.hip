@@ -80,24 +80,25 @@ sp_cand_kernel(const float* __restrict__ semi, int W, int H, float thres, int* _
             if (cmask & (1u << e)) s_list[pos++] = (unsigned short)(((py + 4) << 8) | (px0 + e + 4));
     }
     __syncthreads();
-    // 2. masks: one wave per candidate, lane = window position (lanes 0-39 carry a mask bit), two ballots per candidate
+    // 2. masks: one THREAD per candidate, the 40 + 40 window positions in registers' worth of independent LDS reads (round 4: the first version ran one
+    // wave per candidate -- lane = window position, two ballots -- and its serial loop of dependent LDS round trips was the kernel's time: 84 us per 64 images)
     int* out = cand + (int64_t)b * hw;
     uint64_t* mo = masks + (int64_t)b * hw * 2;
-    const int bit_k = (lane < 36) ? (lane / 9 - 4) : 0;
-    const int bit_j = (lane < 36) ? (lane - (bit_k + 4) * 9 - 4) : (lane - 40);
-    const bool bit_on = lane < 40;
-    for (int ci = wave; ci < total; ci += 4) {
+    for (int ci = tid; ci < total; ci += 256) {
         const int cy = s_list[ci] >> 8, cx = s_list[ci] & 255;
         const float c0 = tile[cy][cx];
-        const float ve = bit_on ? tile[cy + bit_k][cx + bit_j] : NEG_SENTINEL;
-        const float vl = bit_on ? tile[cy - bit_k][cx - bit_j] : NEG_SENTINEL;
-        const uint64_t m0 = __ballot(ve > c0), m1 = __ballot(vl > c0);
-        if (lane == 0) {
-            const int pos = s_base + ci;
-            out[pos] = (ty0 + cy - 4) * W + tx0 + cx - 4;
-            mo[2 * (int64_t)pos] = m0;
-            mo[2 * (int64_t)pos + 1] = m1;
+        uint32_t e_lo = 0, e_hi = 0, l_lo = 0, l_hi = 0;              // bits 0-31 / 32-39 of the earlier and the later mask
+#pragma unroll
+        for (int i = 0; i < 40; ++i) {
+            const int k = (i < 36) ? (i / 9 - 4) : 0;
+            const int j = (i < 36) ? (i - (k + 4) * 9 - 4) : (i - 40);
+            const uint32_t be = tile[cy + k][cx + j] > c0 ? 1u : 0u, bl = tile[cy - k][cx - j] > c0 ? 1u : 0u;
+            if (i < 32) { e_lo |= be << i; l_lo |= bl << i; } else { e_hi |= be << (i - 32); l_hi |= bl << (i - 32); }
         }
+        const int pos = s_base + ci;
+        out[pos] = (ty0 + cy - 4) * W + tx0 + cx - 4;
+        mo[2 * (int64_t)pos] = ((uint64_t)e_hi << 32) | e_lo;
+        mo[2 * (int64_t)pos + 1] = ((uint64_t)l_hi << 32) | l_lo;
     }
 }
 
