@@ -15,6 +15,9 @@ namespace omni {
 
 #define CONV_TH 8          // output tile rows  (4 waves x 2 rows)
 #define CONV_TW 32         // output tile cols  (2 fragments x 16)
+#define RS_TH 6            // the register-stationary cin = 128 kernel's output tile (plain orientation): 6 rows x 32 columns
+#define RS_TW 32
+struct RsSkip { int act, n_above, n_upto, y0, y1, x0, w, bw; };      // conv3x3_c128_rs_kernel: the tiles of an image that run (ConvArgs::skip_*)
 #define CONV_COUT_TILE 64  // output channels per workgroup (2 fragments x 32)
 #define CONV_CIN_CHUNK 64  // input channels staged per pass
 

@@ -1006,8 +1006,7 @@ static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
 // ---------------------------------------------------------------------------------------------------------------
 #define CSP_KP 8                                  // key points per tile of the sparse descriptor kernels (32 corner cells)
 bool conv_rs_transposed(int H, int W);
-#define RS_TH 6
-#define RS_TW 32
+// (RS_TH x RS_TW = 6 x 32: conv.h)
 #define RS_ITH (RS_TH + 2)
 #define RS_ITW (RS_TW + 2)
 #define RS_PIX (RS_ITH * RS_ITW)                 // 272 halo pixels
@@ -1052,7 +1051,8 @@ __global__ void __launch_bounds__(256, 1)
 conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
                        const float* __restrict__ bias, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu,
                        const char* __restrict__ zero_page /* OMNI_ZERO_PAGE_BYTES of zeros: DMA source of the halo pixels outside the image */,
-                       unsigned long long* trace /* OMNI_RS_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr */) {
+                       unsigned long long* trace /* OMNI_RS_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr */,
+                       RsSkip sk /* ConvArgs::skip_* in this kernel's tile grid (plain tiles only): the tiles that run */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1061,7 +1061,7 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
     const bool tr = trace != nullptr && blockIdx.x == 0 && tid == 0;
     int tk = 0;
     const int cg = blockIdx.x % n_cg, wg = blockIdx.x / n_cg, nwg = gridDim.x / n_cg;
-    const int tiles_per_img = tiles_x * tiles_y;
+    const int tiles_per_img = sk.act;              // (the tiles that run: all of them unless a rectangle is left out)
     const int total = batch * tiles_per_img;
     const int g32 = cg * 4 + wave;                 // this wave's group of 32 output channels
 
@@ -1079,10 +1079,21 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
     float* const bias_lds = reinterpret_cast<float*>(smem_raw + 2 * RS_BUF_BYTES);
     if (tid < 128) bias_lds[tid] = bias[cg * 128 + tid];
 
+    // tile t = (image, index r among the image's tiles that run): the tile rows above the rectangle, the tiles left and right of it in its own rows,
+    // the tile rows below (tests/test_mask_skip_cpu.py walks this arithmetic over every rectangle of several grids)
     auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
         b = t / tiles_per_img;
-        const int r = t - b * tiles_per_img;
-        ty0 = (r / tiles_x) * (TRN ? RS_TW : RS_TH); tx0 = (r % tiles_x) * (TRN ? RS_TH : RS_TW);
+        int r = t - b * tiles_per_img, ry, rx;
+        if (r < sk.n_above || r >= sk.n_upto) {
+            int base = 0;
+            if (r >= sk.n_upto) { r -= sk.n_upto; base = sk.y1; }
+            ry = r / tiles_x; rx = r - ry * tiles_x; ry += base;
+        } else {
+            r -= sk.n_above;
+            const int q = r / sk.bw, c = r - q * sk.bw;
+            ry = sk.y0 + q; rx = c < sk.x0 ? c : c + sk.w;
+        }
+        ty0 = ry * (TRN ? RS_TW : RS_TH); tx0 = rx * (TRN ? RS_TH : RS_TW);
     };
     // DMA: 68 wave-instructions of 1 KiB per tile, wave w issues pieces 17 w .. 17 w + 16 into buffer `which`.  Buffer-addressed: the
     // descriptor is the image, so halo rows above / below it are out of range (the offset wraps negative or passes the image's bytes) and
@@ -1195,7 +1206,17 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     auto kfn = conv3x3_c128_rs_kernel<POOL, TRN>;
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_SMEM));
     const int tiles_x = cdiv(a.W, TRN ? RS_TH : RS_TW), tiles_y = cdiv(a.H, TRN ? RS_TW : RS_TH), n_cg = a.cout / 128;
-    const int total = a.batch * tiles_x * tiles_y;
+    // the tiles of an image that run: all of them, or all but the rectangle the caller already holds (ConvArgs::skip_*, in THIS kernel's 6 x 32 tile grid)
+    const bool skip = !TRN && a.skip_ty1 > a.skip_ty0 && a.skip_tx1 > a.skip_tx0;
+    OMNI_REQUIRE(!skip || (a.skip_ty0 >= 0 && a.skip_ty1 <= tiles_y && a.skip_tx0 >= 0 && a.skip_tx1 <= tiles_x), OMNI_ERR_INVALID, "conv_rs: skip rectangle outside the tile grid");
+    RsSkip sk;
+    sk.y0 = skip ? a.skip_ty0 : 0; sk.y1 = skip ? a.skip_ty1 : 0; sk.x0 = skip ? a.skip_tx0 : 0; sk.w = skip ? a.skip_tx1 - a.skip_tx0 : 0;
+    sk.bw = tiles_x - sk.w;
+    sk.act = tiles_x * tiles_y - (sk.y1 - sk.y0) * sk.w;
+    sk.n_above = skip ? sk.y0 * tiles_x : sk.act;
+    sk.n_upto = sk.n_above + (sk.y1 - sk.y0) * sk.bw;
+    OMNI_REQUIRE(sk.act > 0 && sk.bw > 0, OMNI_ERR_INVALID, "conv_rs: the skip rectangle covers whole tile rows");
+    const int total = a.batch * sk.act;
     int per_cg = n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
     if (per_cg > total) per_cg = total;
@@ -1209,7 +1230,7 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     }
     hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), RS_SMEM, st, reinterpret_cast<const _Float16*>(a.in),
                        reinterpret_cast<_Float16*>(a.out), reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_cg,
-                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, zero_page, want_trace ? trace_dev : nullptr);
+                       tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, zero_page, want_trace ? trace_dev : nullptr, sk);
     OMNI_LAUNCH_CHECK();
     if (want_trace) {
         unsigned long long h[64];

@@ -73,7 +73,7 @@ def test_plan_for_600x480_is_the_one_worked_out_by_hand():
     assert plan(480, 600, SPLIT, 1) == ((91, 119, 1, 18), 28 * 17 / (120 * 19))      # rows 362-478 -> 4-row tile rows 91-118
     assert plan(480, 600, SPLIT, 2) == ((46, 59, 1, 9), 13 * 8 / (60 * 10))          # rows 182-237
     assert plan(480, 600, SPLIT, 5) == ((47, 58, 1, 4), 11 * 3 / (60 * 5))           # conv3b, 120 x 150, 2 x 32 tiles: rows 94-115 x columns 4-145
-    assert plan(480, 600, F16, 5)[1] == 0.0                                          # (the fp16 cin = 128 kernel walks every tile)
+    assert plan(480, 600, F16, 5) == ((16, 19, 1, 4), 3 * 3 / (20 * 5))              # conv3b on the fp16 register-stationary kernel: 6 x 32 tiles, rows 96-113
     for layer in range(6):
         assert plan(64, 96, F16, layer)[1] == 0.0                                    # the band is thinner than a tile row
         assert plan(480, 600, F32, layer)[1] == 0.0
