@@ -348,7 +348,9 @@ public:
     // loop candidates found by the units this call finished.  The reference handles one key frame at a time, synchronously (tensorrt_generic.cpp:58-75).
     int push_keyframe(const KeyframeIn& k) {
         if (shard_) throw std::runtime_error("push_keyframe: the sharded database is driven through run()");
+        if (!k.images || k.stride < cfg_.width) throw std::invalid_argument("push_keyframe: no images / a row stride below the image width");
         const int MB = cfg_.microbatch, nd = cfg_.dirs(), cams = cfg_.mono() ? 1 : 2;
+        for (int i = 0; i < cams * nd; ++i) if (!k.images[i]) throw std::invalid_argument("push_keyframe: a null image pointer");
         const size_t img = (size_t)cfg_.width * cfg_.height;
         if (!open_) {
             // round robin over the lanes; at most pipelines - 1 units are in flight here (see below), so this lane is free
