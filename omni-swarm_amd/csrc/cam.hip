@@ -122,10 +122,15 @@ int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int
     // the reference uploads one image per engine call and blocks (tensorrt_generic.cpp:58-75); here the key frame's 2n images go up as one
     // asynchronous copy on the SuperPoint stream (pinned source: the copy engine runs it next to the other pipelines' kernels) and the
     // MobileNetVLAD stream waits for it on the device
-    OMNI_HIP_TRY(hipMemcpy2DAsync(c->d_gray, (size_t)width, gray_host, (size_t)stride, (size_t)width, (size_t)c->cams * c->n * height,
-                                  hipMemcpyHostToDevice, c->c1->stream));
+    // (two copies for a stereo rig: MobileNetVLAD only reads the up cameras' images -- the first half -- and starts as soon as they are up, while the
+    // down cameras' half is still on the bus; SuperPoint's stream carries both copies and so waits for all of it)
+    const size_t rows_up = (size_t)c->n * height, rows_all = (size_t)c->cams * c->n * height;
+    OMNI_HIP_TRY(hipMemcpy2DAsync(c->d_gray, (size_t)width, gray_host, (size_t)stride, (size_t)width, rows_up, hipMemcpyHostToDevice, c->c1->stream));
     OMNI_HIP_TRY(hipEventRecord(c->e_up, c->c1->stream));
     OMNI_HIP_TRY(hipStreamWaitEvent(c->c2->stream, c->e_up, 0));
+    if (rows_all > rows_up)
+        OMNI_HIP_TRY(hipMemcpy2DAsync(c->d_gray + rows_up * width, (size_t)width, gray_host + rows_up * stride, (size_t)stride, (size_t)width, rows_all - rows_up,
+                                      hipMemcpyHostToDevice, c->c1->stream));
     return cam_enqueue_locked(c, c->d_gray, width, fisheye_mask);
 }
 
