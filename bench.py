@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 # the key-frame pipeline's five streams must not share a hardware queue (csrc/ctx.hip: libomni_hip.so asks for 8 when it is loaded; here as well, because
 # torch may initialise the HIP runtime before the library is loaded -- the runtime reads the variable once)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("OMNI_HW_QUEUES", "8") if os.environ.get("OMNI_HW_QUEUES", "8") != "0" else "4")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process GPU work on this driver: dmabuf IPC only (RCCL fails without it)
 os.environ.setdefault("OMNI_SP_PROFILE_MASK", "1")      # omni_sp_profile: stage times with the fisheye mask on, as the key-frame pipeline runs the network
 
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
@@ -137,7 +138,7 @@ def parse():
     ap.add_argument("--geometry-steps", type=int, default=64, help="key frames of the leg with the geometric verification stage on (with_geometry); 0 = skip")
     ap.add_argument("--python-steps", type=int, default=64, help="key frames of the Python-host leg (python_host); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-keyframes", type=int, default=10, help="key frames timed on the host cores for cpu_baseline (after 2 warm-ups; the median is reported)")
+    ap.add_argument("--cpu-keyframes", type=int, default=20, help="key frames timed on the host cores for cpu_baseline (after 3 warm-ups; the median is reported: SURVEY 8d asks for >= 20)")
     return ap.parse_args()
 
 
@@ -183,11 +184,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
+        # torch.distributed is plumbing here (the 128-byte unique id, barriers, the MAX over ranks): a gloo group.  The data path's collectives are RCCL
+        # inside libomni_hip.so (csrc/shard.hip: ncclAllGather over xGMI on the shard's own stream) -- ONE RCCL user per process, no second communicator
+        # next to it.  OMNI_BENCH_TORCH_NCCL=1 puts torch's side on its nccl backend instead (A/B; both then share one librccl: the
+        # line reports every librccl mapped into the process).
+        torch_nccl = os.environ.get("OMNI_BENCH_TORCH_NCCL", "0") == "1" and not one_gpu
+        if torch_nccl:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        coll_dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)     # where the all_gather payloads live
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        coll_dev = torch.device("cuda", local_rank) if torch_nccl else torch.device("cpu")     # where torch's all_reduce / all_gather payloads live
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import omni_loader
@@ -262,16 +268,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_all(x):
+        """x of every rank, in rank order (a list of floats)"""
+        if dist is None:
+            return [float(x)]
+        out = [torch.zeros(1, device=coll_dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([x], device=coll_dev, dtype=torch.float64))
+        return [float(o.item()) for o in out]
+
+    own = []                                                   # this rank's own seconds per region of the last timed_regions() call
+
     def timed_regions(run, sync, steps, warmup, min_time, max_repeats=200):
         """run(n_steps) processes exactly n_steps key frames.  Warm-up, then regions of `steps` key frames, each bracketed by barrier +
         synchronize on both sides and reduced with MAX over ranks; repeated until min_time seconds are covered; returns the list."""
         if warmup > 0:
             run(warmup)
         dts = []
+        own.clear()
         while True:
             barrier(sync)
             t0 = time.perf_counter()
             run(steps)
+            sync()                                             # this rank's own work done: its own rate (per_rank below), before the others are waited for
+            own.append(time.perf_counter() - t0)
             barrier(sync)
             dts.append(reduce_max(time.perf_counter() - t0))
             if sum(dts) >= min_time or len(dts) >= max_repeats:
@@ -299,19 +318,13 @@ def main():
 
     def cpp_leg(precision, storage, db_rows, steps, warmup, min_time, geometry=False, ptrs=None, mb=None, pipelines=None):
         mb = mb or MB
-        # units in flight: not more than the region holds (the driver times regions of 20 key frames = 2.5 micro-batches)
-        pipelines = pipelines or args.pipelines or (min(4, max(2, -(-steps // mb))) if precision == capi.PREC_F16 else 2)
+        # ONE configuration: the library's defaults, whatever --steps is.  Units in flight: --pipelines, else 0 = the library's default
+        # for the precision (KeyframePipeline::default_pipelines: 4 for fp16, 2 for the fp32-class modes); whether the units run oldest-first is the
+        # library's own rule (KeyframePipeline::run: by precision and by how many units the call holds), not an environment variable set here
+        pipelines = pipelines or args.pipelines or 0
         ptrs = ptrs or (pool_ptrs if mb == MB else [pinned_batch(1000 * rank + 50_000 + 8 * mb * p, mb).ctypes.data for p in range(2)])
-        # units oldest-first (omni_cam_order_after): in a region that drains (fewer than 8 micro-batches) the first unit then finishes early and the host's
-        # work on it overlaps the rest (+7-11 % at 20 key frames, profiles/r04ab_short_regions.log); a loop that never drains is faster with the units'
-        # kernels taking turns for fp16 (-5 % when chained) -- the library's default (-1) picks by precision, the bench also by region length
-        fifo_was = os.environ.get("OMNI_PIPELINE_FIFO")
-        if fifo_was is None and steps < 8 * mb:
-            os.environ["OMNI_PIPELINE_FIFO"] = "1"
         pl = pipeline.KeyframePipeline(local_rank, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THRES, MAXN, precision, mb,
                                        pipelines, storage, 1, QUERY_THRES, INIT_THRES, MATCH_INDEX_DIST, 30, 3, geometry=geometry)
-        if fifo_was is None:
-            os.environ.pop("OMNI_PIPELINE_FIFO", None)
         gen = RowFactory(7 + rank)
         if world > 1:
             pl.attach_shard(rank, world, shard_uid())
@@ -340,8 +353,21 @@ def main():
         lat = pl.latencies_ms()
         out.update(db_rows_start=db_rows, db_rows_end=int(pl.db_rows), loop_candidates_found=state["hits"])
         out["host_ms_per_microbatch"] = pl.host_times()
-        out["pipelines"] = pipelines
-        out["units_oldest_first"] = os.environ.get("OMNI_PIPELINE_FIFO") or ("1 (short regions)" if steps < 8 * mb else ("0" if precision == capi.PREC_F16 else "1") + " (library default)")
+        units, fifo = pl.units()
+        out["pipelines"] = units
+        out["units_oldest_first"] = f"{fifo} (" + ("OMNI_PIPELINE_FIFO" if os.environ.get("OMNI_PIPELINE_FIFO") not in (None, "-1") else
+                                                    "library default: by precision and by the units a run() call holds") + ")"
+        if world > 1:
+            # per rank: its own rate over its own time per region (before the barrier), the database rows it holds, and the device time of the exchange's two
+            # all-gathers (HIP events on the shard's stream inside libomni_hip.so)
+            ex = pl.exchange_us()
+            mine = steps / float(np.median(own)) if own else 0.0
+            out["per_rank_keyframes_per_s"] = [round(v, 2) for v in gather_all(mine)]
+            out["db_rows_per_gpu"] = int(pl.db_rows) // world            # global row g lives on rank g % world: every shard holds ntotal / world rows
+            p50 = lambda a: float(np.median(a)) if len(a) else 0.0
+            out["all_gather_us_p50"] = {"new_rows": [round(v, 1) for v in gather_all(p50(ex[:, 0]))], "topk_lists": [round(v, 1) for v in gather_all(p50(ex[:, 1]))],
+                                        "exchange_units": int(len(ex)),
+                                        "bytes_per_rank": {"new_rows": mb * 4 * 4096 * 4, "topk_lists": mb * world * K_SEARCH * 12}}
         if len(lat):
             out["keyframe_latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
                                           "micro_batches": int(len(lat)), "keyframes_in_flight": mb * pipelines,
@@ -512,6 +538,10 @@ def main():
             c5_mb, c5_pipes = 16, 4
             n = c5_mb * c5_pipes * 2
             c5_shard = cpp_leg(prec, capi.STORE_F16, args.c5_rows, n, c5_mb * c5_pipes, min(args.min_time, 0.5), mb=c5_mb, pipelines=c5_pipes)
+            if args.precision == "f16" and args.parity_steps > 0:
+                c5_split = cpp_leg(capi.PREC_SPLIT, capi.STORE_F16, args.c5_rows, n, c5_mb * c5_pipes, min(args.min_time, 0.5), mb=c5_mb, pipelines=c5_pipes)
+                c5_shard["split"] = {k: c5_split[k] for k in ("value", "ms_per_step", "repeats", "keyframe_latency_ms", "db_rows_end", "loop_candidates_found")}
+                c5_shard["split"]["dtype"] = "f16 x3 (split operands, fp32-class): the same leg in the mode that meets north_star's tolerance"
             c5_shard.update(steps=n, shard_rows=args.c5_rows, keyframes_per_microbatch=c5_mb, pipelines=c5_pipes,
                             note="configs[4] end to end on ONE GPU's share: 64 concurrent key frames against a 500k-row fp16 shard (1/8 of the 4M rows of a "
                                  "1M-key-frame database), the batched search inside the timed loop; the 8-GPU exchange itself is the driver's run")
@@ -521,6 +551,10 @@ def main():
                       "note": "same key-frame loop, every key frame's query scans the whole database (one pass per micro-batch, per-query row limits)"}
             for name, st in (("f16_rows", capi.STORE_F16), ("f32_rows", capi.STORE_F32)):
                 db100k[name] = cpp_leg(prec, st, 4 * args.big_db_keyframes, n, MB * (args.pipelines or 4), min(args.min_time, 0.5))
+            if args.precision == "f16" and args.parity_steps > 0:
+                # north_star's "against a 100k-keyframe DB" in the mode that meets its tolerance: OMNI_PREC_SPLIT, exact fp32 rows
+                db100k["split_f32_rows"] = cpp_leg(capi.PREC_SPLIT, capi.STORE_F32, 4 * args.big_db_keyframes, n, MB * (args.pipelines or 2), min(args.min_time, 0.5))
+                db100k["split_f32_rows"]["dtype"] = "f16 x3 (split operands, fp32-class): key points identical to the fp32 oracle (parity_split)"
 
     # ---- roofline of the dominant kernel (conv1b + pool, 43 % of the FLOPs): HIP events on the kernel's own stream --
     # same launch shape as in the timed loop: one micro-batch = 8 * MB images per launch (HIP events between the stages, on the
@@ -665,15 +699,39 @@ def main():
         cpu, parity, parity_split = cpu_baseline(args.cpu_keyframes, W, H, THRES, MAXN, comp, mean, sp_w, vl_w, vl_specs, vl_shape, capi, ictx, prec)
 
     librccl = None
+    rccl_mapped = None
     if world > 1 and cpp_host:
         try:
             librccl = capi.shard_library_path()
         except Exception as e:                                    # noqa: BLE001
             librccl = f"unavailable: {e}"
+        try:                                                      # every librccl mapped into this process: one path = one RCCL, whoever else loaded it
+            rccl_mapped = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libstub_rccl" in ln})
+        except OSError:
+            rccl_mapped = None
+
+    def gate(par, label):
+        """north_star's tolerance, as a boolean next to the number it qualifies: key-point sets identical on every image of the sample (the fixed NMS
+        ordering makes the index lists bit-exact then), descriptors and the MobileNetVLAD vector within 1e-3 relative"""
+        if par is None:
+            return None
+        a, b = par["images_with_identical_keypoint_set"].split("/")
+        ok = a == b and par["desc64_rel_err_p99"] <= 1e-3 and par["vlad_rel_err_max"] <= 1e-3
+        return {"precision": label, "within_north_star_tolerance": bool(ok), "images_with_identical_keypoint_set": par["images_with_identical_keypoint_set"],
+                "desc64_rel_err_p99": par["desc64_rel_err_p99"], "vlad_rel_err_max": par["vlad_rel_err_max"]}
+    headline_gate = gate(parity, args.precision)
+    split_gate = gate(parity_split, "split") if parity_split is not None else None
     if rank == 0:
         line = {
             "metric": "keyframes/sec (4x fisheye 600x480) + p50 loop-match ms @ 100k-frame DB",
             "value": kfps, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # the honesty gate (VERDICT r4 item 8): is `value` a number INSIDE north_star's tolerance (key-point indices bit-exact, descriptors / VLAD vectors
+            # within 1e-3)?  fp16 -- the reference's own engine precision (launch/realsense.launch:10-11) -- is not; the mode that is runs at
+            # `value_within_north_star_tolerance` (= value_parity.value, OMNI_PREC_SPLIT, same workload and host loop, same run)
+            "within_north_star_tolerance": None if headline_gate is None else headline_gate["within_north_star_tolerance"],
+            "parity_gate": {"headline": headline_gate, "value_parity": split_gate},
+            "value_within_north_star_tolerance": (kfps if (headline_gate or {}).get("within_north_star_tolerance") else
+                                                  (value_parity or {}).get("value") if (split_gate or {}).get("within_north_star_tolerance") else None),
             "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f16": "f16", "f32": "f32", "split": "f16 x3 (split operands)"}[args.precision], "data": "synthetic",
             "repeats": main_leg["repeats"], "ms_per_step_minmax": main_leg["ms_per_step_minmax"],
@@ -693,7 +751,10 @@ def main():
             "gflop_per_keyframe_superpoint": round(sp_flop_executed(args.precision, MAXN, False, left_out_flop) * KF_IMAGES / 1e9, 1),
             "gflop_per_keyframe_superpoint_dense": round(SP_FLOP_PER_IMAGE * KF_IMAGES / 1e9, 1),
             "achieved_tflops_end_to_end": round(kfps * sp_flop_executed(args.precision, MAXN, False, left_out_flop) * KF_IMAGES / 1e12 / world, 1),
-            "rccl_ranks": world if (world > 1 and cpp_host) else (1 if world == 1 else 0), "librccl": librccl,
+            "rccl_ranks": world if (world > 1 and cpp_host) else (1 if world == 1 else 0), "librccl": librccl, "librccl_mapped_in_process": rccl_mapped,
+            "torch_distributed_backend": (dist.get_backend() if dist is not None else None),
+            "per_rank_keyframes_per_s": main_leg.get("per_rank_keyframes_per_s"), "db_rows_per_gpu": main_leg.get("db_rows_per_gpu"),
+            "all_gather_us_p50": main_leg.get("all_gather_us_p50"),
             "roofline": roofline, "roofline_parity": roofline_parity, "roofline_knn": roofline_knn, "roofline_knn_batched": batched, "loop_match": loop_match,
             "db100k": db100k, "with_geometry": with_geometry, "value_f32": value_f32, "value_parity": value_parity, "c5_shard": c5_shard,
             "python_host": python_host, "parity": parity, "parity_split": parity_split, "cpu_baseline": cpu,
@@ -735,8 +796,8 @@ def cpu_baseline(n_kf, W, H, thres, max_num, comp, mean, sp_w, vl_w, vl_specs, v
         match_ref.ip_search_numpy(db, g[1], 10)
         last.update(kps=kps, feats=feats, g=g)
 
-    keyframe()                                  # warm-ups
-    keyframe()
+    for _ in range(3):                          # warm-ups (median of >= 20 after 3)
+        keyframe()
     dts = []
     for _ in range(n_kf):
         t = time.perf_counter()
@@ -745,7 +806,7 @@ def cpu_baseline(n_kf, W, H, thres, max_num, comp, mean, sp_w, vl_w, vl_specs, v
     dt = float(np.median(dts))
     cpu = {"value": round(1.0 / dt, 4), "unit": "keyframes/s", "cores": cores, "kind": "port",
            "sample": f"median of {n_kf} key frames (8 SuperPoint + 4 MobileNetVLAD 600x480, post-processing, 4 BF matches, 1 search over 4000 rows) "
-                     f"after 2 warm-ups (a bounded sample: SURVEY 8d's median of >= 20 would take a minute); torch {torch.__version__} fp32, {cores} threads of {avail} host CPUs",
+                     f"after 3 warm-ups (SURVEY 8d); torch {torch.__version__} fp32, {cores} threads of {avail} host CPUs",
            "ms_per_keyframe": round(dt * 1e3, 1), "ms_per_keyframe_minmax": [round(min(dts) * 1e3, 1), round(max(dts) * 1e3, 1)]}
     # GPU path on the same key frame vs the oracle's outputs
     vl = capi.MobileNetVLAD(ictx, vl_w, vl_specs, *vl_shape, W, H, 4)

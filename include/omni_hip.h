@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OMNI_ABI_VERSION 1
+#define OMNI_ABI_VERSION 2      /* 2: omni_cam_result gained n_images; omni_cam_set_active / omni_cam_ready */
 
 enum {
     OMNI_OK = 0,
@@ -172,7 +172,7 @@ double      omni_sp_stage_flops(const omni_sp* sp, int stage);   /* algorithmic 
  * written once per handle, bit-identical results); 0 when the stage computes every tile */
 double      omni_sp_stage_tiles_left_out(const omni_sp* sp, int stage);
 /* the plan itself (pure arithmetic on the image size and the kernels' tile shapes; no device needed): layer 0 = conv1a (OMNI_PREC_SPLIT only), 1..5 =
- * conv1b, conv2a, conv2b, conv3a, conv3b (OMNI_PREC_SPLIT only); rect = {tile row 0, tile row 1, tile column 0, tile column 1} of the layer's conv-output tile grid (empty = nothing
+ * conv1b, conv2a, conv2b, conv3a, conv3b (both matrix-core precisions); rect = {tile row 0, tile row 1, tile column 0, tile column 1} of the layer's conv-output tile grid (empty = nothing
  * left out), frac = its share of the layer's tiles */
 int         omni_sp_mask_skip_plan(int width, int height, int precision, int layer, int* rect, double* frac);
 
@@ -287,6 +287,9 @@ int         omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* 
 int         omni_shard_step_enqueue(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k);
 int         omni_shard_rows_consumed(omni_shard* s);
 int         omni_shard_step_wait(omni_shard* s, float* D_host, int64_t* I_host);
+/* device time (HIP events on the shard's stream, microseconds) of the two collectives of the exchange omni_shard_step_wait collected last: the all-gather
+ * of every rank's new rows and the all-gather of the per-shard top-k lists (the one exchange step of the path) */
+int         omni_shard_last_exchange_us(omni_shard* s, float* rows_gather_us, float* topk_gather_us);
 /* collective: the same nq <= 64 queries on every rank -> the unsharded index's top-k on every rank */
 int         omni_shard_search(omni_shard* s, int nq, const float* q_host, int k, float* D, int64_t* I);
 
@@ -351,11 +354,17 @@ int       omni_cam_enqueue_dev(omni_cam* cam, const uint8_t* gray_dev, int strid
  * until omni_cam_wait returns. */
 int       omni_cam_enqueue_host(omni_cam* cam, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask);
 int       omni_cam_wait(omni_cam* cam, omni_cam_result* out);
+/* A unit smaller than the handle was created for (a partly filled micro-batch of key frames that must not wait any longer): the next enqueues read
+ * cams * n_dirs images -- the up cameras' first, the down cameras' right behind them -- and every array of omni_cam_result has that leading dimension.
+ * 1 <= n_dirs <= the n_dirs of omni_cam_create; not while a unit is in flight. */
+int       omni_cam_set_active(omni_cam* cam, int n_dirs);
+/* non-blocking: *ready = 1 when omni_cam_wait would return at once (hipEventQuery on the unit's two events), or when nothing is pending */
+int       omni_cam_ready(omni_cam* cam, int* ready);
 /* Units in flight, oldest first: whatever is enqueued on `later` from now on starts behind the CONVOLUTION STACK of `earlier`'s last enqueue (an event
  * on the device; the host does not wait).  Without it the units' CU-filling kernels take turns, every unit finishes late and together; with it the
  * oldest unit finishes first while the next one's convolutions run under its small-grid tail (NMS, descriptor sampling, matcher).
  * streams: 1 = `later`'s SuperPoint stream waits, 2 = its MobileNetVLAD stream too, 0 = no-op. */
-int       omni_cam_order_after(omni_cam* later, omni_cam* earlier, int streams);                                          /* two event waits */
+int       omni_cam_order_after(omni_cam* later, omni_cam* earlier, int streams);
 
 #ifdef __cplusplus
 }

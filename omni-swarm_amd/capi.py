@@ -17,6 +17,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = 0, 1, 2, 3, 4
 PREC_F32, PREC_F16, PREC_SPLIT = 0, 1, 2
 STORE_F32, STORE_F16 = 0, 1
 BF_OPENCV, BF_MUTUAL = 0, 1
+ABI_VERSION = 2               # include/omni_hip.h OMNI_ABI_VERSION: checked when the library is loaded
 SP_NUM_LAYERS = 12
 SP_NUM_STAGES = 16
 SP_LAYER_NAMES = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b",
@@ -34,8 +35,8 @@ SYMBOLS = [
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
-    "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_config_count", "omni_config_describe", "omni_config_value", "omni_cam_create", "omni_cam_create_mono", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait", "omni_cam_order_after",
-    "omni_shard_unique_id", "omni_shard_library_path", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait",
+    "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_config_count", "omni_config_describe", "omni_config_value", "omni_cam_create", "omni_cam_create_mono", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_wait", "omni_cam_order_after", "omni_cam_set_active", "omni_cam_ready",
+    "omni_shard_unique_id", "omni_shard_library_path", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait", "omni_shard_last_exchange_us",
     "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
 
@@ -160,6 +161,8 @@ def lib():
     sig("omni_cam_enqueue_host", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int])
     sig("omni_cam_wait", C.c_int, [_vp, C.POINTER(_CamResult)])
     sig("omni_cam_order_after", C.c_int, [_vp, _vp, C.c_int])
+    sig("omni_cam_set_active", C.c_int, [_vp, C.c_int])
+    sig("omni_cam_ready", C.c_int, [_vp, C.POINTER(C.c_int)])
     sig("omni_flatten_create", _vp, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(_fp)])
     sig("omni_flatten_destroy", None, [_vp])
     sig("omni_flatten_out_bytes", C.c_int64, [_vp])
@@ -177,8 +180,9 @@ def lib():
     sig("omni_shard_step_enqueue", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int])
     sig("omni_shard_rows_consumed", C.c_int, [_vp])
     sig("omni_shard_step_wait", C.c_int, [_vp, _fp, _i64p])
+    sig("omni_shard_last_exchange_us", C.c_int, [_vp, _fp, _fp])
     sig("omni_shard_search", C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp, _i64p])
-    if L.omni_abi_version() != 1:
+    if L.omni_abi_version() != ABI_VERSION:
         raise OmniError("libomni_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -633,7 +637,7 @@ def shard_unique_id() -> bytes:
 
 def sp_mask_skip_plan(width: int, height: int, precision: int, layer: int):
     """((tile row 0, tile row 1, tile column 0, tile column 1), share of the layer's tiles) a fisheye-masked pass leaves out of layer `layer`
-    (0 = conv1a [split only], 1..4 = conv1b, conv2a, conv2b, conv3a): csrc/superpoint.hip, pure arithmetic (no device)."""
+    (0 = conv1a [split only], 1..5 = conv1b, conv2a, conv2b, conv3a, conv3b): csrc/superpoint.hip, pure arithmetic (no device)."""
     rect = (C.c_int * 4)()
     frac = C.c_double()
     _check(lib().omni_sp_mask_skip_plan(width, height, precision, layer, rect, C.byref(frac)))
@@ -776,6 +780,7 @@ class Cam:
     def __init__(self, sp: SuperPoint, vlad, n_dirs: int, global_dim: int, bf_mode: int = BF_OPENCV, mono: bool = False):
         """mono: CameraConfig::PINHOLE_DEPTH -- one camera per image (omni_cam_create_mono): n_dirs images, no up/down match"""
         self.sp, self.vlad, self.n, self.cams = sp, vlad, n_dirs, (1 if mono else 2)
+        self.n_active = n_dirs
         if mono:
             self.h = lib().omni_cam_create_mono(sp.ctx.h, sp.h, vlad.ctx.h, vlad.h, n_dirs, sp.max_num, global_dim)
         else:
@@ -802,9 +807,19 @@ class Cam:
 
     def enqueue_host(self, gray_host: np.ndarray, fisheye_mask: bool = True):
         """gray_host [2*n_dirs][H][W] u8 ([n_dirs] for a mono handle), ideally pinned (Context.host_alloc); must stay untouched until wait() returns."""
-        assert gray_host.dtype == np.uint8 and gray_host.ndim == 3 and gray_host.shape[0] == self.cams * self.n and gray_host.flags.c_contiguous
+        assert gray_host.dtype == np.uint8 and gray_host.ndim == 3 and gray_host.shape[0] == self.cams * self.n_active and gray_host.flags.c_contiguous
         _check(lib().omni_cam_enqueue_host(self.h, gray_host.ctypes.data_as(_vp), gray_host.shape[2], gray_host.shape[2], gray_host.shape[1],
                                            int(fisheye_mask)))
+
+    def set_active(self, n_dirs: int):
+        """a unit of fewer directions than the handle was created for: the next enqueues read cams * n_dirs images (up cameras first, down right behind)"""
+        _check(lib().omni_cam_set_active(self.h, n_dirs))
+        self.n_active = n_dirs
+
+    def ready(self) -> bool:
+        r = C.c_int(0)
+        _check(lib().omni_cam_ready(self.h, C.byref(r)))
+        return bool(r.value)
 
     def wait(self) -> dict:
         r = self._res

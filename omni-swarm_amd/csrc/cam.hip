@@ -14,7 +14,8 @@ struct omni_cam {
     omni_sp* sp = nullptr;
     omni_vlad* vlad = nullptr;
     omni_ctx *c1 = nullptr, *c2 = nullptr;
-    int n = 0, cams = 2, M = 0, D = 0, out_dim = 0, bf_mode = 0, W = 0, H = 0;   // cams: 2 = up + down camera per direction, 1 = one camera (no stereo match)
+    int n = 0, n_cap = 0, cams = 2, M = 0, D = 0, out_dim = 0, bf_mode = 0, W = 0, H = 0;   // cams: 2 = up + down camera per direction, 1 = one camera (no stereo match)
+      // n: directions of the NEXT enqueue (omni_cam_set_active), n_cap: what the handle and its networks were created for
       // W x H: the size the SuperPoint handle (and MobileNetVLAD) was created for
     int *d_qidx = nullptr, *d_tidx = nullptr, *d_nm = nullptr;
     float* d_dist = nullptr;
@@ -51,7 +52,7 @@ static omni_cam* cam_create(omni_ctx* sp_ctx, omni_sp* sp, omni_ctx* vlad_ctx, o
     if (sp_ctx->device != vlad_ctx->device) { omni::set_error("SuperPoint and MobileNetVLAD contexts are on different devices"); return nullptr; }
     (void)hipSetDevice(sp_ctx->device);
     omni_cam* c = new omni_cam();
-    c->sp = sp; c->vlad = vlad; c->c1 = sp_ctx; c->c2 = vlad_ctx; c->n = n_dirs; c->cams = cams; c->M = max_num; c->D = omni_sp_desc_dim(sp);
+    c->sp = sp; c->vlad = vlad; c->c1 = sp_ctx; c->c2 = vlad_ctx; c->n = c->n_cap = n_dirs; c->cams = cams; c->M = max_num; c->D = omni_sp_desc_dim(sp);
     c->out_dim = global_dim; c->bf_mode = bf_mode;
     (void)omni_sp_image_size(sp, &c->W, &c->H);
     const size_t n = n_dirs, M = max_num, D = c->D, ni = (size_t)cams * n;
@@ -173,6 +174,32 @@ int omni_cam_order_after(omni_cam* later, omni_cam* earlier, int streams) {
     OMNI_REQUIRE(ev, OMNI_ERR_INVALID, "omni_cam_order_after: no event");
     OMNI_HIP_TRY(hipStreamWaitEvent(later->c1->stream, ev, 0));          // (an event that was never recorded does not block)
     if (streams >= 2 && later->c2 != later->c1) OMNI_HIP_TRY(hipStreamWaitEvent(later->c2->stream, ev, 0));
+    return OMNI_OK;
+}
+
+// a unit smaller than the handle was created for (a partly filled micro-batch that must not wait any longer): the next enqueues read cams * n_dirs
+// images -- up cameras first, the down cameras right behind them -- and every array of omni_cam_result has that leading dimension
+int omni_cam_set_active(omni_cam* c, int n_dirs) {
+    OMNI_REQUIRE(c, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    OMNI_REQUIRE(n_dirs >= 1 && n_dirs <= c->n_cap, OMNI_ERR_INVALID, "omni_cam_set_active: %d directions, the handle holds 1..%d", n_dirs, c->n_cap);
+    OMNI_REQUIRE(!c->pending, OMNI_ERR_INVALID, "omni_cam_set_active with a unit in flight (omni_cam_wait first)");
+    c->n = n_dirs;
+    return OMNI_OK;
+}
+
+// non-blocking: *ready = 1 when omni_cam_wait would return at once (or nothing is pending)
+int omni_cam_ready(omni_cam* c, int* ready) {
+    OMNI_REQUIRE(c && ready, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    *ready = 1;
+    if (!c->pending) return OMNI_OK;
+    (void)hipSetDevice(c->c1->device);
+    for (hipEvent_t e : {c->e1, c->e2}) {
+        const hipError_t r = hipEventQuery(e);
+        if (r == hipErrorNotReady) { *ready = 0; return OMNI_OK; }
+        if (r != hipSuccess) { omni::set_error("hipEventQuery failed: %s", hipGetErrorString(r)); return OMNI_ERR_HIP; }
+    }
     return OMNI_OK;
 }
 

@@ -16,6 +16,7 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_DET16", 1, 0, 1, CFG_VARIANT, "fp16 detector head on v_mfma_f32_32x32x16_f16 (0: the fp32-operand MFMA kernel)"},
     {"OMNI_SP_SPARSE_DESC", 1, 0, 1, CFG_VARIANT, "convDb + descriptor norm only at the cells around the key points (0: dense descriptor map)"},
     {"OMNI_SP_SPARSE_DA", 1, 0, 1, CFG_VARIANT, "convDa only at those cells too (fp16 and OMNI_PREC_SPLIT; 0: dense convDa)"},
+    {"OMNI_SP_FUSED_CAND", 1, 0, 1, CFG_VARIANT, "getKeyPoints' threshold inside the detector head's epilogue + window masks from the candidate list (0: sp_cand_kernel re-reads the heat map)"},
     {"OMNI_SP_MASK_SKIP", 1, 0, 1, CFG_VARIANT, "fp16: the tiles inside the constant region of the fisheye mask are left out of the tile walk (0: every tile)"},
     {"OMNI_SP_MASK_SKIP_SPLIT", 1, 0, 1, CFG_VARIANT, "the same for OMNI_PREC_SPLIT"},
     {"OMNI_SPLIT_FUSE1A", 1, 0, 1, CFG_VARIANT, "OMNI_PREC_SPLIT: conv1a built inside the conv1b kernel from the u8 image (0: separate exact-f32 conv1a pass)"},
@@ -53,8 +54,9 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_DETECTOR_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's detector step (appends, searches) is enqueued and collected one unit later (0: the host waits for it on the spot)"},
     {"OMNI_PIPELINE_ONE_STREAM", 0, 0, 1, CFG_VARIANT, "a unit's MobileNetVLAD launches behind its SuperPoint launches on one stream (0: next to them on a second stream)"},
     {"OMNI_PIPELINE_FIFO", -1, -1, 2, CFG_VARIANT, "units in flight run oldest first: a unit's SuperPoint stream (1) / both its streams (2) start behind the convolution stack of the unit "
-                                                   "enqueued before it; 0: the units' kernels take turns; -1: by measurement (round 4) -- 1 for the fp32-class precisions, whose time is all "
-                                                   "CU-filling convolutions (+2-4 %), 0 for fp16, whose small-grid tails the next units' kernels fill (-5 % when chained)"},
+                                                   "enqueued before it; 0: the units' kernels take turns; -1: by measurement -- 1 for the fp32-class precisions, whose time is all "
+                                                   "CU-filling convolutions (+2-4 %), and for an fp16 run() of fewer than 8 units (it drains: +7-11 %), 0 for fp16 otherwise, whose small-grid "
+                                                   "tails the next units' kernels fill (-5 % when chained)"},
     // ---- runtime ---------------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_HW_QUEUES", 8, 0, 64, CFG_TUNING, "hardware queues asked of the HIP runtime when the library is loaded (GPU_MAX_HW_QUEUES, unless already set): the pipeline's five "
                                             "streams must not share one; 0 = the runtime's default of 4"},

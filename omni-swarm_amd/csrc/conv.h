@@ -99,13 +99,17 @@ int conv1a_direct(hipStream_t stream, int precision, const uint8_t* gray, int st
 int detector_head(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                   const float* wT, const float* bias, float* semi);
 
+// getKeyPoints' threshold fused into the head's epilogue (superpoint_tensorrt.cpp:167-173): with cand set, every pixel whose probability exceeds thres is
+// appended to its image's candidate list cand[b * hw ...] (counters[b * 4] = the count; zeroed by the launcher) -- SpPostBuffers::cand / ::counters
+struct DetCand { float thres = 0.f; int* cand = nullptr; int* counters = nullptr; int hw = 0; };
+
 // Same on the matrix cores (v_mfma_f32_32x32x2_f32 for the 64 kept channels, VALU for the dustbin); weights packed on the host.
 void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*[16384]*/, float* wdust /*[256]*/);
 void detector_pack_weights16(const float* wT /*[256][65]*/, uint16_t* wA16 /*[32768]: split-fp16 A fragments*/);
 int detector_head_mfma16(hipStream_t stream, const void* in_f16, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
-                         const float* bias, float* semi, int n_cu);
+                         const float* bias, float* semi, int n_cu, const DetCand& dc = DetCand{});
 int detector_head_mfma(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
-                       const float* wA, const float* wdust, const float* bias, float* semi, int n_cu);
+                       const float* wA, const float* wdust, const float* bias, float* semi, int n_cu, const DetCand& dc = DetCand{});
 
 // desc = desc / ||desc||_2 over the 256 channels of every coarse cell (superpoint.ipynb:187-188); fp32 NHWC in place.
 int l2norm_channels(hipStream_t stream, float* desc_nhwc, int64_t n_cells);

@@ -1706,11 +1706,52 @@ int detector_head(hipStream_t st, int precision, const void* in, int in_stride, 
 // into one 16-byte store (channel c = 8 ry + rx: 4 consecutive rx).
 // ---------------------------------------------------------------------------------------------------------------
 #define DETM_THREADS 256
+// getKeyPoints' threshold (superpoint_tensorrt.cpp:167-173: mask = prob > thres; findNonZero) inside the head's epilogue, where the probabilities of a
+// cell's 64 pixels sit in registers: a lane holds 32 of them -- l0 / l1 = rows g / 4 + g of the cell, columns 4 hh + e -- and appends the pixel indices
+// of those above the threshold to ITS IMAGE's candidate list (unordered: NMS2's scan order is encoded by the window masks sp_mask_kernel makes from the
+// list).  One atomic per wave and image: a 32-cell fragment touches at most two images (a map has more than 32 cells).  The values compared are the
+// ones stored into the heat map, so the list equals thresholding that map.
+__device__ __forceinline__ void det_emit_candidates(const float (&p0)[16], const float (&p1)[16], bool valid, int b, int hy, int wx, int hh, int Wpix, int lane,
+                                                    const DetCand& dc) {
+    uint32_t cm = 0;
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cm |= (p0[r] > dc.thres ? 1u : 0u) << r; cm |= (p1[r] > dc.thres ? 1u : 0u) << (16 + r); }
+    }
+    const int cnt = __popc(cm);
+    const int b_first = __shfl(b, 0, 64);                       // (lane 0's cell is always valid: f * 32 < n_cells)
+    int base = 0, excl = 0;
+#pragma unroll 1
+    for (int g = 0; g < 2; ++g) {
+        const bool mine = valid && b == b_first + g;
+        if (__ballot(mine && cnt > 0) == 0ull) continue;       // wave-uniform
+        int incl = mine ? cnt : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        const int total = __shfl(incl, 63, 64);
+        int wave_base = 0;
+        if (lane == 0) wave_base = atomicAdd(&dc.counters[(b_first + g) * 4 + 0], total);
+        wave_base = __shfl(wave_base, 0, 64);
+        if (mine) { base = wave_base; excl = incl - cnt; }
+    }
+    if (cm) {
+        int* out = dc.cand + (int64_t)b * dc.hw + base + excl;
+        const int pix0 = (hy * 8) * Wpix + wx * 8 + 4 * hh;
+        while (cm) {
+            const int i = __ffs(cm) - 1;
+            cm &= cm - 1;
+            // bit i < 16: l0[i] = row (i >> 2), column (i & 3); bit 16 + i: l1[i] = row 4 + (i >> 2)
+            const int ry = ((i & 15) >> 2) + ((i >> 4) << 2), rx = i & 3;
+            *out++ = pix0 + ry * Wpix + rx;
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(DETM_THREADS)
 detector_head_mfma_kernel(const T* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
                           const float* __restrict__ wA /*[2][32][2][32][4] fragment order*/, const float* __restrict__ wdust /*[256]*/,
-                          const float* __restrict__ bias /*[65]*/, float* __restrict__ semi) {
+                          const float* __restrict__ bias /*[65]*/, float* __restrict__ semi, DetCand dc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* wl = reinterpret_cast<float*>(smem_raw);           // [2][32][2][32][4] = 16384 floats
     float* wd = wl + 16384;                                    // [256]
@@ -1781,20 +1822,21 @@ detector_head_mfma_kernel(const T* __restrict__ in, int in_stride, int in_off, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) { l0[r] = expf(l0[r] - mx); l1[r] = expf(l1[r] - mx); sum += l0[r] + l1[r]; }
         sum = sum + __shfl_xor(sum, 32, 64) + expf(dust - mx);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { l0[r] = l0[r] / sum; l1[r] = l1[r] / sum; }
+        const int wx = cell % Wc;
+        const int hy = (cell / Wc) % Hc;
+        const int b = cell / (Wc * Hc);
         if (valid) {
-            const int wx = cell % Wc;
-            const int hy = (cell / Wc) % Hc;
-            const int b = cell / (Wc * Hc);
             float* o = semi + ((int64_t)b * Hc * 8 + hy * 8) * (Wc * 8) + wx * 8 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // channel c = 32 m + 8 g + 4 hh + (r & 3)  ->  row ry = 4 m + g, columns rx = 4 hh + (r & 3)
-                *reinterpret_cast<float4*>(o + (int64_t)g * (Wc * 8)) =
-                    make_float4(l0[4 * g + 0] / sum, l0[4 * g + 1] / sum, l0[4 * g + 2] / sum, l0[4 * g + 3] / sum);
-                *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) =
-                    make_float4(l1[4 * g + 0] / sum, l1[4 * g + 1] / sum, l1[4 * g + 2] / sum, l1[4 * g + 3] / sum);
+                *reinterpret_cast<float4*>(o + (int64_t)g * (Wc * 8)) = make_float4(l0[4 * g + 0], l0[4 * g + 1], l0[4 * g + 2], l0[4 * g + 3]);
+                *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) = make_float4(l1[4 * g + 0], l1[4 * g + 1], l1[4 * g + 2], l1[4 * g + 3]);
             }
         }
+        if (dc.cand) det_emit_candidates(l0, l1, valid, b, hy, wx, hh, Wc * 8, lane, dc);
     }
 }
 
@@ -1809,20 +1851,27 @@ void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*16384*/, f
     for (int k = 0; k < 256; ++k) wdust[k] = wT[(size_t)k * 65 + 64];
 }
 
+// dc.cand != nullptr: the candidate counters of the batch's images are zeroed here, in front of the kernel that fills the lists
+static int det_cand_reset(hipStream_t st, const DetCand& dc, int batch) {
+    if (dc.cand) OMNI_HIP_TRY(hipMemsetAsync(dc.counters, 0, (size_t)batch * 4 * sizeof(int), st));
+    return OMNI_OK;
+}
+
 int detector_head_mfma(hipStream_t st, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
-                       const float* wA, const float* wdust, const float* bias, float* semi, int n_cu) {
+                       const float* wA, const float* wdust, const float* bias, float* semi, int n_cu, const DetCand& dc) {
     const int n_cells = batch * Hc * Wc;
+    { const int rc = det_cand_reset(st, dc, batch); if (rc) return rc; }
     const size_t smem = (size_t)(16384 + 256 + 80) * 4;
     int grid = cdiv(cdiv(n_cells, 32), 4);
     if (n_cu > 0 && grid > n_cu) grid = n_cu;
     if (precision == OMNI_PREC_F16) {
         OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(detector_head_mfma_kernel<_Float16>, dim3(grid), dim3(DETM_THREADS), smem, st, (const _Float16*)in, in_stride, in_off,
-                           n_cells, Hc, Wc, wA, wdust, bias, semi);
+                           n_cells, Hc, Wc, wA, wdust, bias, semi, dc);
     } else {
         OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(detector_head_mfma_kernel<float>, dim3(grid), dim3(DETM_THREADS), smem, st, (const float*)in, in_stride, in_off,
-                           n_cells, Hc, Wc, wA, wdust, bias, semi);
+                           n_cells, Hc, Wc, wA, wdust, bias, semi, dc);
     }
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
@@ -1838,7 +1887,7 @@ int detector_head_mfma(hipStream_t st, int precision, const void* in, int in_str
 __global__ void __launch_bounds__(DETM_THREADS)
 detector_head_mfma16_kernel(const _Float16* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
                             const uint4* __restrict__ wA16 /*[hl 2][m 2][s 16][lane 64] x 8 halfs*/, const float* __restrict__ wdust /*[256]*/,
-                            const float* __restrict__ bias /*[65]*/, float* __restrict__ semi) {
+                            const float* __restrict__ bias /*[65]*/, float* __restrict__ semi, DetCand dc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint4* wl = reinterpret_cast<uint4*>(smem_raw);            // 4096 x 16 B = 64 KB
     float* wd = reinterpret_cast<float*>(wl + 4096);           // [256]
@@ -1901,19 +1950,21 @@ detector_head_mfma16_kernel(const _Float16* __restrict__ in, int in_stride, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) { l0[r] = expf(l0[r] - mx); l1[r] = expf(l1[r] - mx); sum += l0[r] + l1[r]; }
         sum = sum + __shfl_xor(sum, 32, 64) + expf(dust - mx);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { l0[r] = l0[r] / sum; l1[r] = l1[r] / sum; }
+        const int wx = cell % Wc;
+        const int hy = (cell / Wc) % Hc;
+        const int b = cell / (Wc * Hc);
         if (valid) {
-            const int wx = cell % Wc;
-            const int hy = (cell / Wc) % Hc;
-            const int b = cell / (Wc * Hc);
             float* o = semi + ((int64_t)b * Hc * 8 + hy * 8) * (Wc * 8) + wx * 8 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<float4*>(o + (int64_t)g * (Wc * 8)) =
-                    make_float4(l0[4 * g + 0] / sum, l0[4 * g + 1] / sum, l0[4 * g + 2] / sum, l0[4 * g + 3] / sum);
-                *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) =
-                    make_float4(l1[4 * g + 0] / sum, l1[4 * g + 1] / sum, l1[4 * g + 2] / sum, l1[4 * g + 3] / sum);
+                // channel c = 32 m + 8 g + 4 hh + (r & 3)  ->  row ry = 4 m + g, columns rx = 4 hh + (r & 3)
+                *reinterpret_cast<float4*>(o + (int64_t)g * (Wc * 8)) = make_float4(l0[4 * g + 0], l0[4 * g + 1], l0[4 * g + 2], l0[4 * g + 3]);
+                *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) = make_float4(l1[4 * g + 0], l1[4 * g + 1], l1[4 * g + 2], l1[4 * g + 3]);
             }
         }
+        if (dc.cand) det_emit_candidates(l0, l1, valid, b, hy, wx, hh, Wc * 8, lane, dc);
     }
 }
 
@@ -1932,14 +1983,15 @@ void detector_pack_weights16(const float* wT /*[256][65]*/, uint16_t* wA16 /*2*2
 }
 
 int detector_head_mfma16(hipStream_t st, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
-                         const float* bias, float* semi, int n_cu) {
+                         const float* bias, float* semi, int n_cu, const DetCand& dc) {
     const int n_cells = batch * Hc * Wc;
+    { const int rc = det_cand_reset(st, dc, batch); if (rc) return rc; }
     const size_t smem = (size_t)4096 * 16 + (256 + 80) * 4;
     int grid = cdiv(cdiv(n_cells, 32), 4);
     if (n_cu > 0 && grid > 2 * n_cu) grid = 2 * n_cu;         // 66 KB of LDS: two workgroups per CU
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(detector_head_mfma16_kernel, dim3(grid), dim3(DETM_THREADS), smem, st, (const _Float16*)in, in_stride, in_off, n_cells, Hc, Wc,
-                       (const uint4*)wA16, wdust, bias, semi);
+                       (const uint4*)wA16, wdust, bias, semi, dc);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }

@@ -108,6 +108,10 @@ struct omni_shard {
     // one exchange may be in flight (omni_shard_step_enqueue -> omni_shard_step_wait): its shape, the local row count to restore on failure, and
     // two events on the shard's stream: e_rows = the caller's row buffer has been gathered (it may be overwritten), e_done = the lists are on the host
     hipEvent_t e_rows = nullptr, e_done = nullptr;
+    // timing events around the two collectives of the last exchange (omni_shard_last_exchange_us): t[0]..t[1] = the all-gather of the new rows,
+    // t[2]..t[3] = the all-gather of the per-shard top-k lists
+    hipEvent_t t[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
     bool pending = false;
     int pend_F = 0, pend_m = 0, pend_k = 0;
     int64_t pend_local_before = 0;
@@ -148,6 +152,8 @@ omni_shard* omni_shard_create(omni_ctx* ctx, omni_index* local, int dim, int ran
     if (hipEventCreateWithFlags(&s->e_rows, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->e_done, hipEventDisableTiming) != hipSuccess) {
         omni::set_error("hipEventCreate failed"); delete s; return nullptr;
     }
+    for (hipEvent_t& e : s->t)
+        if (hipEventCreate(&e) != hipSuccess) { omni::set_error("hipEventCreate failed"); omni_shard_destroy(s); return nullptr; }
     ncclResult_t r = rccl().CommInitRank(&s->comm, world, id, rank);
     if (r != ncclSuccess) { omni::set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r)); delete s; return nullptr; }
     return s;
@@ -160,6 +166,7 @@ void omni_shard_destroy(omni_shard* s) {
     if (s->comm) (void)rccl().CommDestroy(s->comm);
     if (s->e_rows) (void)hipEventDestroy(s->e_rows);
     if (s->e_done) (void)hipEventDestroy(s->e_done);
+    for (hipEvent_t e : s->t) if (e) (void)hipEventDestroy(e);
     s->all_rows.release(); s->owned.release(); s->send.release(); s->recv.release(); s->qrows.release(); s->hrecv.release(); s->hq.release();
     delete s;
 }
@@ -218,7 +225,10 @@ int omni_shard_step_enqueue(omni_shard* s, int F, int m, const float* rows_dev, 
     if ((rc = s->recv.ensure(list_bytes * W))) return rc;
     if ((rc = s->hrecv.ensure(list_bytes * W))) return rc;
     // 1. every rank's new rows
+    s->timed = false;
+    OMNI_HIP_TRY(hipEventRecord(s->t[0], st));
     OMNI_RCCL_TRY(rccl().AllGather(rows_dev, s->all_rows.p, mine, ncclFloat32, s->comm, st));
+    OMNI_HIP_TRY(hipEventRecord(s->t[1], st));
     OMNI_HIP_TRY(hipEventRecord(s->e_rows, st));                 // rows_dev is free again from here on (stream order)
     // 2. append the rows this rank owns, in global-id order
     hipLaunchKernelGGL(shard_pick_rows_kernel, dim3(F * m), dim3(256), 0, st, s->all_rows.as<float>(), W, F, m, dim, s->rank, s->owned.as<float>());
@@ -245,7 +255,9 @@ int omni_shard_step_enqueue(omni_shard* s, int F, int m, const float* rows_dev, 
                 return rc;
         }
         // 4. the per-shard lists of every query, to everybody, and on to the host
+        OMNI_HIP_TRY(hipEventRecord(s->t[2], st));
         OMNI_RCCL_TRY(rccl().AllGather(s->send.p, s->recv.p, list_bytes, ncclInt8, s->comm, st));
+        OMNI_HIP_TRY(hipEventRecord(s->t[3], st));
         OMNI_HIP_TRY(hipMemcpyAsync(s->hrecv.p, s->recv.p, list_bytes * W, hipMemcpyDeviceToHost, st));
         OMNI_HIP_TRY(hipEventRecord(s->e_done, st));
         return OMNI_OK;
@@ -280,10 +292,24 @@ int omni_shard_step_wait(omni_shard* s, float* D_host, int64_t* I_host) {
         return OMNI_ERR_HIP;
     }
     s->ntotal += (int64_t)F * W * s->pend_m;
+    s->timed = true;
     // 5. merge the lists of MY queries (query f*W + rank)
     std::vector<int> which(F);
     for (int f = 0; f < F; ++f) which[f] = f * W + s->rank;
     return merge_mine(s, s->hrecv.as<char>(), F * W, k, which.data(), F, D_host, I_host);
+}
+
+// device time of the two collectives of the last exchange that omni_shard_step_wait collected (HIP events on the shard's stream, microseconds): the
+// all-gather of every rank's new rows (F * m * dim floats per rank) and the all-gather of the per-shard top-k lists (F * world * k * 12 bytes per rank)
+int omni_shard_last_exchange_us(omni_shard* s, float* rows_gather_us, float* topk_gather_us) {
+    OMNI_REQUIRE(s && rows_gather_us && topk_gather_us, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OMNI_REQUIRE(s->timed, OMNI_ERR_INVALID, "no finished exchange to report");
+    float a = 0, b = 0;
+    OMNI_HIP_TRY(hipEventElapsedTime(&a, s->t[0], s->t[1]));
+    OMNI_HIP_TRY(hipEventElapsedTime(&b, s->t[2], s->t[3]));
+    *rows_gather_us = a * 1e3f; *topk_gather_us = b * 1e3f;
+    return OMNI_OK;
 }
 
 int omni_shard_step_batch_dev(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k, float* D_host, int64_t* I_host) {

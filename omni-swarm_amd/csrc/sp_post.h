@@ -53,6 +53,12 @@ struct SpSparseDesc {
     // OMNI_PREC_SPLIT: convDa itself only at those cells (conv_split_c128_sparse) -- a4b_split: conv4b's split-64 frames; the rows land in cx directly
     // (cda_f32 is then not read); da_w / da_bias / da_g32_first as above, da_inv = the fused heads layer's split_inv
     const void* a4b_split = nullptr; float da_inv = 0.f;
+    // the detector head already thresholded the map (conv.h DetCand): SpPostBuffers::cand / ::counters are filled, only the window masks are to be made
+    // (sp_mask_kernel, one thread per candidate) -- sp_cand_kernel, which re-reads the whole heat map, is not launched
+    bool cand_fused = false;
+    // a heat map that did not come from the head (omni_sp_postprocess_dense): the same two steps as separate kernels -- sp_thresh_kernel makes the lists,
+    // sp_mask_kernel the masks -- so that every edge case of the post-processing tests runs through the kernel the pipeline uses
+    bool cand_from_list = false;
 };
 
 // semi: [B][H][W] f32 probability map; desc_nhwc: [B][H/8][W/8][256] f32 (channel-normalised coarse descriptors; unused when sparse.in_f16 is set)

@@ -102,6 +102,58 @@ sp_cand_kernel(const float* __restrict__ semi, int W, int H, float thres, int* _
     }
 }
 
+// The static part of NMS2 for a candidate list that already exists (the detector head thresholds its own output, conv.hip det_emit_candidates): one THREAD per
+// candidate reads the 80 window positions around it from the heat map -- 9 short row segments, L2 / MALL hits: the map was written by the kernel
+// before -- and writes the same two masks as sp_cand_kernel.  A neighbour counts when it is a candidate with a higher confidence; the candidate's own
+// confidence is above the threshold, so `inside the image and semi > c0` says exactly that.  Loads are unconditional (clamped address + predicate): all
+// 80 of a thread are in flight together.
+// mask = prob > thres; findNonZero (superpoint_tensorrt.cpp:167-173) as a stand-alone kernel: the candidate lists of heat maps the head did not produce
+__global__ void __launch_bounds__(256)
+sp_thresh_kernel(const float* __restrict__ semi, int hw, float thres, int* __restrict__ cand, int* __restrict__ counters) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const float* sm = semi + (int64_t)b * hw;
+    int* cd = cand + (int64_t)b * hw;
+    for (int p0 = blockIdx.x * 256 + (threadIdx.x & ~63); p0 < hw; p0 += gridDim.x * 256) {       // wave-uniform
+        const int p = p0 + lane;
+        const bool c = p < hw && sm[p] > thres;
+        const unsigned long long m = __ballot(c);
+        if (m == 0ull) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&counters[b * 4 + 0], __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (c) cd[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+    }
+}
+
+#define MASK_BLOCKS_PER_IMAGE 32
+__global__ void __launch_bounds__(256)
+sp_mask_kernel(const float* __restrict__ semi, int W, int H, const int* __restrict__ cand, const int* __restrict__ counters, uint64_t* __restrict__ masks) {
+    const int b = blockIdx.y;
+    const int hw = W * H;
+    const int n = counters[b * 4 + 0];
+    const float* sm = semi + (int64_t)b * hw;
+    const int* cd = cand + (int64_t)b * hw;
+    uint64_t* mo = masks + (int64_t)b * hw * 2;
+    for (int ci = blockIdx.x * 256 + threadIdx.x; ci < n; ci += gridDim.x * 256) {
+        const int p = cd[ci];
+        const int y = p / W, x = p - y * W;
+        const float c0 = sm[p];
+        uint32_t e_lo = 0, e_hi = 0, l_lo = 0, l_hi = 0;
+#pragma unroll
+        for (int i = 0; i < 40; ++i) {
+            const int k = (i < 36) ? (i / 9 - 4) : 0;
+            const int j = (i < 36) ? (i - (k + 4) * 9 - 4) : (i - 40);
+            const bool in_e = (y + k >= 0) && (x + j >= 0) && (x + j < W);            // earlier: rows above / same row to the left (k <= 0)
+            const bool in_l = (y - k < H) && (x - j >= 0) && (x - j < W);             // later: the negated offset
+            const float ve = sm[in_e ? p + k * W + j : p], vl = sm[in_l ? p - k * W - j : p];
+            const uint32_t be = (in_e && ve > c0) ? 1u : 0u, bl = (in_l && vl > c0) ? 1u : 0u;
+            if (i < 32) { e_lo |= be << i; l_lo |= bl << i; } else { e_hi |= be << (i - 32); l_hi |= bl << (i - 32); }
+        }
+        mo[2 * (int64_t)ci] = ((uint64_t)e_hi << 32) | e_lo;
+        mo[2 * (int64_t)ci + 1] = ((uint64_t)l_hi << 32) | l_lo;
+    }
+}
+
 __device__ __forceinline__ unsigned st_get(const unsigned* st, int p) { return (st[p >> 4] >> ((p & 15) * 2)) & 3u; }
 // pixel offset of mask bit i (earlier-mask numbering)
 __device__ __forceinline__ int mask_bit_offset(int i, int W) {
@@ -482,9 +534,18 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
     OMNI_REQUIRE(smem <= 160 * 1024, OMNI_ERR_CAPACITY, "image %dx%d too large for the in-LDS NMS state plane", p.width, p.height);
     OMNI_REQUIRE(p.max_num >= 1 && p.max_num <= 1024, OMNI_ERR_CAPACITY, "max_num=%d outside [1,1024]", p.max_num);
     OMNI_REQUIRE(p.dist_thresh == 4, OMNI_ERR_INVALID, "NMS radius %d: the window masks are built for 4 (superpoint_tensorrt.cpp:183)", p.dist_thresh);
-    OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
-    hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(p.width, CT_W) * cdiv(p.height, CT_H), batch), dim3(256), 0, stream, semi, p.width, p.height,
-                       p.thres, b.cand, b.cand_masks, b.counters);
+    if (sparse.cand_fused || sparse.cand_from_list) {
+        if (!sparse.cand_fused) {
+            OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
+            hipLaunchKernelGGL(sp_thresh_kernel, dim3(MASK_BLOCKS_PER_IMAGE, batch), dim3(256), 0, stream, semi, hw, p.thres, b.cand, b.counters);
+            OMNI_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(sp_mask_kernel, dim3(MASK_BLOCKS_PER_IMAGE, batch), dim3(256), 0, stream, semi, p.width, p.height, b.cand, b.counters, b.cand_masks);
+    } else {
+        OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
+        hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(p.width, CT_W) * cdiv(p.height, CT_H), batch), dim3(256), 0, stream, semi, p.width, p.height,
+                           p.thres, b.cand, b.cand_masks, b.counters);
+    }
     OMNI_LAUNCH_CHECK();
     OMNI_HIP_TRY(hipFuncSetAttribute((const void*)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(sp_nms_kernel, dim3(batch), dim3(NMS_THREADS), smem, stream, semi, p.width, p.height, p.max_num, b.cand,

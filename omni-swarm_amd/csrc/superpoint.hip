@@ -44,6 +44,7 @@ struct omni_sp {
     float *wPbA = nullptr, *wPbDust = nullptr; // convPb in MFMA A-fragment order + the dustbin row
     void* wPbA16 = nullptr;                    // convPb as split-fp16 A fragments (detector_head_mfma16_kernel); OMNI_DET16=0 keeps the f32 MFMA head
     bool det16 = true;
+    bool fused_cand = true;                  // getKeyPoints' threshold inside the detector head's epilogue (OMNI_SP_FUSED_CAND)
     // fp16 path: descriptors are computed only at the four coarse cells around each key point (convdb_sparse_sample) and the dense map `draw`
     // is produced on demand (omni_sp_get_dense) -- OMNI_SP_SPARSE_DESC=0 keeps the dense map in every forward pass (A/B, parity tests)
     bool sparse_desc = true;
@@ -192,6 +193,7 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         detector_pack_weights16(t.data(), w16.data());
         if ((rc = dev_upload(&s->wPbA16, w16.data(), w16.size() * 2, st))) return rc;
         s->det16 = s->cfg[CFG_DET16] != 0;
+        s->fused_cand = s->cfg[CFG_SP_FUSED_CAND] != 0;
         s->sparse_desc = s->cfg[CFG_SP_SPARSE_DESC] != 0;
         s->sparse_da = s->sparse_desc && s->cfg[CFG_SP_SPARSE_DA] != 0;
     }
@@ -436,11 +438,15 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (sparse_da) { if ((rc = conv(LPA, s->a4b, s->headsP, s->bias_heads, H / 8, W / 8, 128, 256, 3, true, false, P == OMNI_PREC_SPLIT))) return rc; }
     else if ((rc = conv(LPA, s->a4b, s->heads, s->bias_heads, H / 8, W / 8, 128, 512, 3, true, false, P == OMNI_PREC_SPLIT))) return rc;
     if ((rc = mark())) return rc;
+    // the head thresholds its own output into the candidate lists when the post-processing follows (superpoint_tensorrt.cpp:167-173 inside the epilogue)
+    DetCand dc;
+    const bool cand_fused = run_post && s->fused_cand && s->conv_variant != 1;
+    if (cand_fused) { dc.thres = s->thres; dc.cand = s->pb.cand; dc.counters = s->pb.counters; dc.hw = H * W; }
     if (s->conv_variant == 1) { if ((rc = detector_head(st, PH, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
     else if (P == OMNI_PREC_F16 && s->det16) {
-        if ((rc = detector_head_mfma16(st, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount))) return rc;
+        if ((rc = detector_head_mfma16(st, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount, dc))) return rc;
     } else if ((rc = detector_head_mfma(st, PH, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
-                                        s->ctx->prop.multiProcessorCount))) return rc;
+                                        s->ctx->prop.multiProcessorCount, dc))) return rc;
     if ((rc = mark())) return rc;
     OMNI_HIP_TRY(hipEventRecord(s->ev_convs, st));        // the convolution stack and the detector head are enqueued: what follows are small grids
     s->dense_valid = !sparse && !sparse32; s->dense_possible = true; s->last_batch = batch;
@@ -471,6 +477,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
             sd.cda_f32 = reinterpret_cast<const float*>(s->heads) + 256; sd.in_cstride = 512; sd.wdb_f32 = s->wpk[LDB]; sd.bias = s->bias[LDB];
             sd.cx = s->cx32; sd.cy = s->cy32; sd.n_cu = s->ctx->prop.multiProcessorCount; sd.zero_page = s->ctx->zero_page;
         }
+        sd.cand_fused = cand_fused;
         if ((rc = sp_postprocess(st, post_params(s), s->pb, s->semi, s->draw, batch, sd))) return rc;
     }
     if ((rc = mark())) return rc;
@@ -681,7 +688,9 @@ int omni_sp_postprocess_dense(omni_sp* s, const float* semi_host, const float* d
     OMNI_HIP_TRY(hipMemcpyAsync(s->dense_tmp.p, desc_host, n * 4, hipMemcpyHostToDevice, st));
     if ((rc = omni::nchw_to_nhwc(st, s->dense_tmp.as<float>(), s->draw, batch, 256, s->Hc * s->Wc))) return rc;
     s->dense_valid = true; s->dense_possible = false; s->last_batch = batch;          // `draw` / `semi` now hold the caller's maps
-    if ((rc = omni::sp_postprocess(st, omni::post_params(s), s->pb, s->semi, s->draw, batch))) return rc;
+    omni::SpSparseDesc sd;
+    sd.cand_from_list = s->fused_cand;       // threshold + window masks as the pipeline makes them (OMNI_SP_FUSED_CAND=0: sp_cand_kernel)
+    if ((rc = omni::sp_postprocess(st, omni::post_params(s), s->pb, s->semi, s->draw, batch, sd))) return rc;
     return omni::sp_fetch_locked(s, batch, kps_xy, n_kps, desc, scores);
 }
 

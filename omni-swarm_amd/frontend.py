@@ -60,8 +60,8 @@ class LoopCam:
     def fetch(self) -> dict:
         """Waits for the key frame and returns one FisheyeFrameDescriptor_t's worth of CNN outputs (copies: the pinned
         block is reused by the next enqueue)."""
-        n = self.n_dirs
         r = self.cam.wait()
+        n = r["global_desc"].shape[0]          # the unit's directions: n_dirs, or fewer after Cam.set_active
         nk = r["n_kps"]
         images = []
         for d in range(n):

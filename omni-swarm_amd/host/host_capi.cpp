@@ -102,6 +102,31 @@ int omni_pipeline_push_keyframe(omni_pipeline* h, const uint8_t* const* images, 
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
+// the latency bound of the streaming intake (omni::KeyframePipeline::poll): call it from a timer or after every push; never waits for a CNN unit.
+// *hits += loop candidates found.
+int omni_pipeline_poll(omni_pipeline* h, int* hits) {
+    try { const int n = h->p->poll(); if (hits) *hits += n; return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+// max_wait_ms: a partly filled micro-batch older than this leaves for the GPU at the next push / poll (< 0: only flush() sends it; default 50);
+// dispatch_when_idle: a key frame that arrives while no unit is in flight goes at once, as a unit of one (default on)
+int omni_pipeline_set_latency(omni_pipeline* h, double max_wait_ms, int dispatch_when_idle) {
+    try { h->p->set_latency(max_wait_ms, dispatch_when_idle != 0); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+// units in flight (the `pipelines` argument, or the library's default for the precision when that was <= 0) and how the last run() ordered them
+// (0: the units' kernels take turns; 1 / 2: oldest first, omni_cam_order_after)
+int omni_pipeline_units(omni_pipeline* h, int* units_oldest_first) {
+    if (units_oldest_first) *units_oldest_first = h->p->last_run_fifo();
+    return h->p->pipelines();
+}
+// sharded mode: device microseconds of the two all-gathers of every exchange unit since the last reset, out[i][2] = {new rows, per-shard top-k lists};
+// returns how many exist (writes <= max)
+int omni_pipeline_get_exchange_us(omni_pipeline* h, float* out, int max, int reset) {
+    const auto& v = h->p->exchange_us();
+    const int n = (int)v.size();
+    for (int i = 0; i < n && i < max; ++i) { out[2 * i] = v[(size_t)i].first; out[2 * i + 1] = v[(size_t)i].second; }
+    if (reset) h->p->clear_exchange_us();
+    return n;
+}
 int omni_pipeline_flush(omni_pipeline* h, int* hits) {
     try { const int n = h->p->flush(); if (hits) *hits += n; return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -63,7 +63,7 @@ public:
     struct Config {
         int device = 0, width = 600, height = 480, max_num = 200, precision = OMNI_PREC_F16;
         float thres = 0.02f;
-        int microbatch = 8, pipelines = 2, storage = OMNI_STORE_F32, self_id = 1;
+        int microbatch = 8, pipelines = 0 /* units in flight; <= 0: default_pipelines(precision) */, storage = OMNI_STORE_F32, self_id = 1;
         double inner_product_thres = 0.3, init_mode_product_thres = 0.2;
         int match_index_dist = 5, min_loop_num = 30, min_direction_loop = 3;
         std::string sp_weights, pca_comp, pca_mean, vlad_weights;
@@ -77,12 +77,27 @@ public:
         // blanked, plus its 16-bit depth image in millimetres (set_depth), MAX_DIRS = 1 (swarm_loop.cpp:279-280), the query image is direction 0
         // (loop_detector.cpp:252-258) and the landmarks are read from the depth image (loop_cam.cpp:260-304)
         int camera_configuration = 1;
-        double depth_near = 0.3, depth_far = 7.0;       // DEPTH_NEAR_THRES / DEPTH_FAR_THRES (swarm_loop.cpp:243-244)
+        double depth_near = 0.3, depth_far = 10.0;      // DEPTH_NEAR_THRES / DEPTH_FAR_THRES: the reference's own defaults (swarm_loop.cpp:251-252; launch/realsense.launch sets 0.3 / 100)
+        // The streaming intake's latency bound (push_keyframe / poll).  The reference reports a key frame's loop synchronously (swarm_loop.cpp:140-170); a
+        // micro-batch that only left for the GPU when `microbatch` key frames had arrived would, at the reference's 1 Hz key-frame rate (max_freq), hold a key
+        // frame for seconds.  So: (1) dispatch_when_idle: a key frame that arrives while NO unit is in flight goes to the GPU at once, as a unit of one --
+        // batches only grow while the GPU is busy anyway (adaptive batching: full throughput under load, one frame's compute time when idle);
+        // (2) max_wait_ms: a partly filled micro-batch older than this is sent as it is by the next push_keyframe() or poll() (< 0: never -- only flush()).
+        bool dispatch_when_idle = true;
+        double max_wait_ms = 50.0;
         bool mono() const { return camera_configuration == 2; }
         int dirs() const { return mono() ? 1 : 4; }
     };
 
-    explicit KeyframePipeline(const Config& c) : cfg_(c), index_ctx_(c.device, true), det_(index_ctx_, c.self_id, c.storage) {
+    // units in flight when the caller does not say: fp16's small-grid tails (NMS, sampling, matcher, MobileNetVLAD's last blocks) are filled by the next
+    // units' kernels, so four pay; the fp32-class modes are CU-filling convolutions end to end and gain nothing beyond two
+    static int default_pipelines(int precision) { return precision == OMNI_PREC_F16 ? 4 : 2; }
+    static Config resolved(Config c) { if (c.pipelines <= 0) c.pipelines = default_pipelines(c.precision); return c; }
+    int pipelines() const { return cfg_.pipelines; }
+
+    explicit KeyframePipeline(const Config& c0) : KeyframePipeline(resolved(c0), 0) {}
+private:
+    KeyframePipeline(const Config& c, int) : cfg_(c), index_ctx_(c.device, true), det_(index_ctx_, c.self_id, c.storage) {
         det_.INNER_PRODUCT_THRES = c.inner_product_thres; det_.INIT_MODE_PRODUCT_THRES = c.init_mode_product_thres;
         det_.MATCH_INDEX_DIST = c.match_index_dist; det_.MIN_LOOP_NUM = c.min_loop_num; det_.MIN_DIRECTION_LOOP = c.min_direction_loop;
         if (c.camera_configuration != 1 && c.camera_configuration != 2) throw std::runtime_error("KeyframePipeline: camera_configuration must be 1 (STEREO_FISHEYE) or 2 (PINHOLE_DEPTH)");
@@ -122,6 +137,7 @@ public:
             };
         }
     }
+public:
     // The geometry of every deferred candidate: (1) ONE GPU round trip matches the direction pairs of all of them (compute_correspond_features
     // pairs up to four directions per candidate, loop_detector.cpp:431-537; the matcher is a pure function of its two descriptor sets);
     // (2) one task per candidate on the pool: flag filter, homography-RANSAC masks, PnP-RANSAC + refit, verification (f64), its match() calls
@@ -216,7 +232,11 @@ public:
         deferred_.clear();
         return true;
     }
+    // device time of the two all-gathers of every exchange unit collected so far (microseconds: new rows, per-shard top-k lists); sharded mode only
+    const std::vector<std::pair<float, float>>& exchange_us() const { return exchange_us_; }
+    void clear_exchange_us() { exchange_us_.clear(); }
     int geometry_calls() const { return geometry_calls_; }
+    int last_run_fifo() const { return last_fifo_; }
     // where the host thread's time goes, per unit (micro-batch), in milliseconds since the last reset: [0] enqueue (upload + launches), [1] waiting for
     // the unit's results, [2] building the frame messages (+ stereo landmarks), [3] the detector step (index appends / searches, one GPU round trip),
     // [4] geometry hand-over; returns the number of units.  The loop runs at the GPU's pace while [1] > 0: the host then waits for the GPU, not the GPU for it.
@@ -301,13 +321,21 @@ public:
         Lane* tail_lane = rem ? prepare(n_keyframes) : nullptr;
         std::deque<std::pair<Lane*, int64_t>> pending;
         int hits = 0;
-        for (int s = 0; s < full + (rem ? 1 : 0); ++s) {
+        // units oldest first (omni_cam_order_after)?  OMNI_PIPELINE_FIFO >= 0 decides; the default (-1) does by what this call is given: the fp32-class
+        // modes always (CU-filling convolutions end to end: +2-4 %); fp16 when the run drains before the pipeline is in steady state (fewer than 8
+        // units: the first unit then finishes early and the host's work on it overlaps the rest, +7-11 % at 20 key frames,
+        // profiles/r04ab_short_regions.log), not in a run that keeps the pipeline full (the units' kernels taking turns fill each other's tails: +5 %)
+        const int n_units = full + (rem ? 1 : 0);
+        const int fifo = fifo_cfg_ >= 0 ? fifo_cfg_ : ((cfg_.precision != OMNI_PREC_F16 || n_units < 8) ? 1 : 0);
+        last_fifo_ = fifo;
+        for (int s = 0; s < n_units; ++s) {
             Lane* lane = s < full ? lanes_[s % lanes_.size()].get() : tail_lane;
             const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
             if (pend_lane_ == lane) check(omni_shard_rows_consumed(shard_), "omni_shard_rows_consumed");      // its row buffer is the exchange's input
             lane->t_enqueue = std::chrono::steady_clock::now();
             lane->meta.clear();
-            chain(lane);
+            if (lane->cur != lane->mb) { lane->cam.set_active(cfg_.dirs() * lane->mb); lane->cur = lane->mb; }     // (the streaming intake may have left a partial unit's size)
+            chain(lane, fifo);
             if (from_host) lane->cam.enqueue_host(src, cfg_.width, !cfg_.mono());       // loop_cam.cpp:536: only STEREO_FISHEYE blanks rows
             else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
             host_ms_[0] += since(lane->t_enqueue);
@@ -347,23 +375,30 @@ public:
     // MobileNetVLAD, up/down match, one download) and, when `pipelines` units are in flight, finishes the oldest (detector, geometry).  Returns the
     // loop candidates found by the units this call finished.  The reference handles one key frame at a time, synchronously (tensorrt_generic.cpp:58-75).
     int push_keyframe(const KeyframeIn& k) {
+        std::lock_guard<std::mutex> lk(intake_mu_);
         if (shard_) throw std::runtime_error("push_keyframe: the sharded database is driven through run()");
         if (!k.images || k.stride < cfg_.width) throw std::invalid_argument("push_keyframe: no images / a row stride below the image width");
         const int MB = cfg_.microbatch, nd = cfg_.dirs(), cams = cfg_.mono() ? 1 : 2;
         for (int i = 0; i < cams * nd; ++i) if (!k.images[i]) throw std::invalid_argument("push_keyframe: a null image pointer");
         const size_t img = (size_t)cfg_.width * cfg_.height;
+        int hits = carried_hits_; carried_hits_ = 0;
+        hits += reap_ready();                                   // units the GPU has finished meanwhile (non-blocking): "idle" below is then the truth
         if (!open_) {
-            // round robin over the lanes; at most pipelines - 1 units are in flight here (see below), so this lane is free
-            open_ = lanes_[next_lane_++ % lanes_.size()].get();
-            open_->meta.clear();
-            if (!open_->stage) {
-                open_->stage_bytes = (size_t)cams * nd * MB * img;
-                open_->stage = static_cast<uint8_t*>(omni_host_alloc(open_->stage_bytes));
-                if (!open_->stage) throw std::runtime_error(std::string("omni_host_alloc: ") + omni_last_error());
+            // round robin over the lanes: with fewer than `pipelines` units in flight the next lane is free (a poll() may have sent a partial unit without
+            // finishing the oldest -- it never waits --, so that is made sure of here)
+            while (stream_pending_.size() >= lanes_.size()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
+            Lane* l = lanes_[next_lane_++ % lanes_.size()].get();
+            l->meta.clear();
+            if (!l->stage) {
+                l->stage_bytes = (size_t)cams * nd * MB * img;
+                l->stage = static_cast<uint8_t*>(omni_host_alloc(l->stage_bytes));
+                if (!l->stage) throw std::runtime_error(std::string("omni_host_alloc: ") + omni_last_error());
             }
-            open_->t_enqueue = std::chrono::steady_clock::now();
+            l->t_enqueue = std::chrono::steady_clock::now();
+            open_ = l;
         }
         const int m = (int)open_->meta.size();
+        if (m >= MB) throw std::logic_error("push_keyframe: the open micro-batch is already full");      // (cannot happen: a full unit leaves below, whatever throws)
         for (int c = 0; c < cams; ++c)
             for (int d = 0; d < nd; ++d) {
                 uint8_t* dst = open_->stage + ((size_t)c * nd * MB + (size_t)nd * m + d) * img;
@@ -372,38 +407,44 @@ public:
             }
         SlotMeta sm; sm.msg_id = k.msg_id; sm.stamp = k.stamp; sm.pose = k.pose_drone; sm.prevent_adding_db = k.prevent_adding_db; sm.depth = k.depth;
         open_->meta.push_back(sm);
-        int hits = carried_hits_; carried_hits_ = 0;
-        if ((int)open_->meta.size() == MB) {
-            chain(open_);
-            open_->cam.enqueue_host(open_->stage, cfg_.width, !cfg_.mono());
-            stream_pending_.push_back(open_);
-            open_ = nullptr;
+        const bool full = (int)open_->meta.size() == MB;
+        const bool idle = cfg_.dispatch_when_idle && stream_pending_.empty();
+        const bool aged = cfg_.max_wait_ms >= 0 && since(open_->t_enqueue) >= cfg_.max_wait_ms;
+        if (full || idle || aged) {
+            dispatch_open();
             while (stream_pending_.size() >= lanes_.size()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
         }
         return hits;
     }
-    // everything pushed so far through the detector (and the geometry stage): a partial micro-batch runs as its own, smaller unit
-    int flush() {
+    // The latency bound of the streaming intake, to be called from a timer (or after every push): never waits for a CNN unit.  (1) a partly filled
+    // micro-batch older than Config::max_wait_ms leaves for the GPU as it is; (2) every unit the GPU has finished goes through the detector; (3) when no
+    // unit is in flight any more, the detector step enqueued last (reported one unit later otherwise: OMNI_DETECTOR_ASYNC) and its geometry are
+    // collected -- a short wait for searches that run on an otherwise idle GPU.  Returns the loop candidates found.
+    int poll() {
+        std::lock_guard<std::mutex> lk(intake_mu_);
+        if (shard_) return 0;
         int hits = carried_hits_; carried_hits_ = 0;
-        Lane* tail = nullptr;
-        if (open_ && !open_->meta.empty()) {
-            const int MB = cfg_.microbatch, nd = cfg_.dirs(), rem = (int)open_->meta.size();
-            const size_t img = (size_t)cfg_.width * cfg_.height;
-            tail = prepare(rem);
-            if (!cfg_.mono()) std::memmove(open_->stage + (size_t)nd * rem * img, open_->stage + (size_t)nd * MB * img, (size_t)nd * rem * img);      // the down block moves up behind rem up blocks
-            tail->meta = open_->meta;
-            tail->t_enqueue = open_->t_enqueue;
-            chain(tail);
-            tail->cam.enqueue_host(open_->stage, cfg_.width, !cfg_.mono());
-            open_->meta.clear();
-        }
-        while (!stream_pending_.empty()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
-        if (tail) { hits += finish_timed(*tail, 0); tail->meta.clear(); }
-        open_ = nullptr;
-        hits += collect_detector();
-        drain_geometry();
+        hits += reap_ready();
+        if (open_ && !open_->meta.empty() && cfg_.max_wait_ms >= 0 && since(open_->t_enqueue) >= cfg_.max_wait_ms) dispatch_open();
         return hits;
     }
+    // everything pushed so far through the detector (and the geometry stage): a partial micro-batch runs as its own, smaller unit
+    int flush() {
+        std::lock_guard<std::mutex> lk(intake_mu_);
+        int hits = carried_hits_; carried_hits_ = 0;
+        std::exception_ptr first;
+        try { if (open_ && !open_->meta.empty()) dispatch_open(); } catch (...) { first = std::current_exception(); }
+        open_ = nullptr;
+        while (!stream_pending_.empty()) {
+            Lane* l = stream_pending_.front(); stream_pending_.pop_front();
+            try { hits += finish_timed(*l, 0); } catch (...) { if (!first) first = std::current_exception(); }      // the other units are still finished
+        }
+        try { hits += collect_detector(); drain_geometry(); } catch (...) { if (!first) first = std::current_exception(); }
+        if (first) std::rethrow_exception(first);
+        return hits;
+    }
+    // the streaming intake's settings after construction (what the C entry point omni_pipeline_set_latency sets)
+    void set_latency(double max_wait_ms, bool dispatch_when_idle) { std::lock_guard<std::mutex> lk(intake_mu_); cfg_.max_wait_ms = max_wait_ms; cfg_.dispatch_when_idle = dispatch_when_idle; }
 
     // creates (once) the smaller unit a run of n_keyframes needs for its trailing n_keyframes % microbatch key frames, so that the first
     // timed run does not pay for it
@@ -424,10 +465,12 @@ private:
               vlad(one_stream ? sp_ctx : vlad_ctx, c.vlad_weights, c.width, c.height, false, c.dirs() * mb_),
               cam(sp_ctx, sp, one_stream ? sp_ctx : vlad_ctx, vlad, c.dirs() * mb_, c.max_num, c.width, c.height, c.mono()) {
             check(omni_vlad_dev_output(vlad.handle(), &rows_dev), "omni_vlad_dev_output");
+            cur = mb_;
         }
         void sync() { check(omni_ctx_sync(sp_ctx.get()), "sync"); check(omni_ctx_sync(vlad_ctx.get()), "sync"); }
         std::chrono::steady_clock::time_point t_enqueue;
-        int mb;
+        int mb;                                        // key frames the unit was created for
+        int cur = 0;                                   // ... and of the unit in flight (a partly filled micro-batch of the streaming intake: omni_cam_set_active)
         std::vector<SlotMeta> meta;                    // streaming intake (push_keyframe): what each key frame of the unit came with; empty = run()'s numbering
         uint8_t* stage = nullptr;                      // pinned block the streaming intake packs the unit's images into
         size_t stage_bytes = 0;
@@ -441,6 +484,31 @@ private:
         const float* rows_dev = nullptr;
     };
 
+    // The open unit of the streaming intake leaves for the GPU, full or not (a partial one: the down cameras' block moves up behind the up cameras' and the
+    // unit runs with fewer directions, omni_cam_set_active -- no second set of networks).  Exception-safe: open_ is cleared FIRST, so whatever throws
+    // below the next push starts a fresh unit (a failed unit's key frames are dropped with it: the caller got the exception).
+    void dispatch_open() {
+        Lane* u = open_;
+        open_ = nullptr;
+        const int MB = cfg_.microbatch, nd = cfg_.dirs(), rem = (int)u->meta.size();
+        const size_t img = (size_t)cfg_.width * cfg_.height;
+        try {
+            if (rem < MB && !cfg_.mono()) std::memmove(u->stage + (size_t)nd * rem * img, u->stage + (size_t)nd * MB * img, (size_t)nd * rem * img);
+            if (u->cur != rem) { u->cam.set_active(nd * rem); u->cur = rem; }
+            chain(u, fifo_cfg_ >= 0 ? fifo_cfg_ : (cfg_.precision == OMNI_PREC_F16 ? 0 : 1));
+            u->cam.enqueue_host(u->stage, cfg_.width, !cfg_.mono());
+        } catch (...) { u->meta.clear(); throw; }
+        stream_pending_.push_back(u);
+    }
+    // finishes, oldest first, the units the GPU is done with (never waits for a CNN unit); with nothing left in flight also the detector step enqueued
+    // last and its geometry
+    int reap_ready() {
+        int hits = 0;
+        while (!stream_pending_.empty() && stream_pending_.front()->cam.ready()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
+        if (stream_pending_.empty() && det_pending_.active) { hits += collect_detector(); drain_geometry(); }
+        return hits;
+    }
+
     // waits for the exchange in flight (if any) and applies the reference's rule (loop_detector.cpp:232: recency + threshold) on GLOBAL row ids
     int collect_exchange() {
         if (!pend_lane_) return 0;
@@ -448,6 +516,7 @@ private:
         D_.resize((size_t)mb * k); I_.resize((size_t)mb * k);
         pend_lane_ = nullptr;
         check(omni_shard_step_wait(shard_, D_.data(), I_.data()), "omni_shard_step_wait");
+        { float a = 0, b = 0; if (omni_shard_last_exchange_us(shard_, &a, &b) == OMNI_OK) exchange_us_.push_back({a, b}); }
         int hits = 0;
         for (int m = 0; m < mb; ++m) {
             const int64_t nt = pend_base_ + (int64_t)(m + 1) * world_ * cfg_.dirs();          // ntotal as of this key frame's step
@@ -471,11 +540,11 @@ private:
         if (!det_pending_.active) return 0;
         auto t_a = std::chrono::steady_clock::now();
         int hits = 0, fi = 0;
+        det_pending_.active = false;                     // first: if end_images_batch() throws (its rollback has dropped the batch), the next unit starts clean
         for (auto& c : det_.end_images_batch()) {
             if (c.found) { ++hits; candidates_.push_back({det_pending_.ids[(size_t)fi], c.old_msg_id, c.direction_new, c.direction_old}); }
             ++fi;
         }
-        det_pending_.active = false;
         host_ms_[3] += since(t_a);
         t_a = std::chrono::steady_clock::now();
         // the previous micro-batch's tasks ran meanwhile; this one's run until the next is collected.  The tasks reference this micro-batch's frames:
@@ -500,14 +569,14 @@ private:
             // collected when the NEXT micro-batch gets here (or at the end of run()): meanwhile the host enqueues the next CNN unit
             int hits = collect_exchange();
             const int k = LoopDetectorCore::SEARCH_NEAREST_NUM + cfg_.match_index_dist;
-            check(omni_shard_step_enqueue(shard_, lane.mb, cfg_.dirs(), lane.rows_dev, cfg_.mono() ? 0 : 1, k), "omni_shard_step_enqueue");
-            pend_lane_ = &lane; pend_mb_ = lane.mb; pend_base_ = omni_shard_ntotal(shard_);
+            check(omni_shard_step_enqueue(shard_, lane.cur, cfg_.dirs(), lane.rows_dev, cfg_.mono() ? 0 : 1, k), "omni_shard_step_enqueue");
+            pend_lane_ = &lane; pend_mb_ = lane.cur; pend_base_ = omni_shard_ntotal(shard_);
             return hits;
         }
         const int n = r.n_dirs, M = r.max_num, D = r.desc_dim, nd = cfg_.dirs();
-        frames_.resize(lane.mb);
+        frames_.resize(lane.cur);
         const int G = r.global_dim;
-        for (int m = 0; m < lane.mb; ++m) {
+        for (int m = 0; m < lane.cur; ++m) {
             FisheyeFrameDescriptor& f = frames_[m];
             const bool streamed = !lane.meta.empty();
             const int64_t kf_id = streamed ? lane.meta[m].msg_id : first_id + m;
@@ -530,7 +599,7 @@ private:
                 } else if (cfg_.geometry) {
                     // the stereo half of generate_stereo_image_descriptor (loop_cam.cpp:341-454): the down image of this direction, triangulation
                     // (one task per direction on the geometry pool: ~170 SVD triangulations each; joined before the frames reach the detector)
-                    if (downs_.size() < (size_t)4 * lane.mb) downs_.resize((size_t)4 * lane.mb);
+                    if (downs_.size() < (size_t)4 * lane.cur) downs_.resize((size_t)4 * lane.cur);
                     ImageDescriptor& down = downs_[(size_t)i];
                     down = ImageDescriptor{};
                     const int j = n + i;
@@ -559,8 +628,8 @@ private:
         t_a = std::chrono::steady_clock::now();
         int hits = collect_detector();                                          // the unit before this one
         t_a = std::chrono::steady_clock::now();
-        det_pending_.ids.resize((size_t)lane.mb);
-        for (int m = 0; m < lane.mb; ++m) det_pending_.ids[(size_t)m] = lane.meta.empty() ? first_id + m : lane.meta[(size_t)m].msg_id;
+        det_pending_.ids.resize((size_t)lane.cur);
+        for (int m = 0; m < lane.cur; ++m) det_pending_.ids[(size_t)m] = lane.meta.empty() ? first_id + m : lane.meta[(size_t)m].msg_id;
         det_pending_.t_enqueue = lane.t_enqueue;
         det_.begin_images_batch(std::move(frames_), lane.rows_dev);             // appends + searches + the copy of the lists: enqueued, not waited for
         det_pending_.active = true;
@@ -609,11 +678,13 @@ private:
     int host_units_ = 0;
     // units in flight run oldest first (omni_cam_order_after): the unit about to be enqueued starts behind the convolution stack of the one enqueued last
     Lane* last_enqueued_ = nullptr;
-    int fifo_streams_ = [this] { const int v = cfg_int("OMNI_PIPELINE_FIFO"); return v >= 0 ? v : (cfg_.precision == OMNI_PREC_F16 ? 0 : 1); }();
-    void chain(Lane* lane) {
-        if (fifo_streams_ > 0 && last_enqueued_ && last_enqueued_ != lane) lane->cam.order_after(last_enqueued_->cam, fifo_streams_);
+    int fifo_cfg_ = cfg_int("OMNI_PIPELINE_FIFO");          // >= 0: as asked; -1: run() and the streaming intake decide (see run())
+    int last_fifo_ = 0;                                      // what the last run() used (reported by the bench line)
+    void chain(Lane* lane, int fifo_streams) {
+        if (fifo_streams > 0 && last_enqueued_ && last_enqueued_ != lane) lane->cam.order_after(last_enqueued_->cam, fifo_streams);
         last_enqueued_ = lane;
     }
+    std::mutex intake_mu_;                                   // push_keyframe / poll / flush may come from different threads (a callback and a timer)
     static int cfg_int(const char* name) { int v = 0; check(omni_config_value(name, &v), "omni_config_value"); return v; }
     static double since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
     Lane* open_ = nullptr;                      // streaming intake: the micro-batch being filled
@@ -629,6 +700,7 @@ private:
     int64_t pend_base_ = 0;
     std::vector<float> D_;
     std::vector<int64_t> I_;
+    std::vector<std::pair<float, float>> exchange_us_;
 };
 
 }  // namespace omni

@@ -43,7 +43,11 @@ inline void check(int rc, const char* what) {
 class Context {
 public:
     // high_priority: the stream of short work the host waits on (the detector's searches) next to streams that keep the whole GPU busy
-    explicit Context(int device_id = 0, bool high_priority = false) : h_(high_priority ? omni_ctx_create_priority(device_id, 1) : omni_ctx_create(device_id)) {
+    explicit Context(int device_id = 0, bool high_priority = false) : h_(nullptr) {
+        // a host built against another include/omni_hip.h (struct layouts, entry points) must not run: checked before the first handle exists
+        if (omni_abi_version() != OMNI_ABI_VERSION)
+            throw std::runtime_error("libomni_hip.so has ABI version " + std::to_string(omni_abi_version()) + ", this host was built against " + std::to_string(OMNI_ABI_VERSION));
+        h_ = high_priority ? omni_ctx_create_priority(device_id, 1) : omni_ctx_create(device_id);
         if (!h_) throw std::runtime_error(std::string("omni_ctx_create: ") + omni_last_error());
     }
     ~Context() { omni_ctx_destroy(h_); }
@@ -287,6 +291,10 @@ public:
     }
     // the next enqueue on this object starts behind the convolution stack of `earlier`'s last one (omni_cam_order_after)
     void order_after(LoopCamHIP& earlier, int streams) { check(omni_cam_order_after(h_, earlier.h_, streams), "omni_cam_order_after"); }
+    // a unit of fewer directions than this object was created for (omni_cam_set_active): the next enqueues read cams * n_dirs images
+    void set_active(int n_dirs) { check(omni_cam_set_active(h_, n_dirs), "omni_cam_set_active"); }
+    // non-blocking: would wait() return at once?
+    bool ready() { int r = 0; check(omni_cam_ready(h_, &r), "omni_cam_ready"); return r != 0; }
     // blocks until the key frame is done; pointers stay valid until the next enqueue on this object
     omni_cam_result wait() {
         omni_cam_result r{};

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
            "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync",
-           "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_push_keyframe", "omni_pipeline_flush", "omni_pipeline_host_times", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies"]
+           "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_push_keyframe", "omni_pipeline_flush", "omni_pipeline_host_times", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies",
+           "omni_pipeline_poll", "omni_pipeline_set_latency", "omni_pipeline_units", "omni_pipeline_get_exchange_us"]
 _lib = None
 
 
@@ -38,6 +39,10 @@ def lib():
         L.omni_pipeline_push_keyframe.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_void_p,
                                                   C.POINTER(C.c_int)]
         L.omni_pipeline_flush.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.omni_pipeline_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.omni_pipeline_set_latency.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.omni_pipeline_units.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.omni_pipeline_get_exchange_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
         L.omni_pipeline_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.omni_pipeline_geometry_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.omni_pipeline_destroy.argtypes = [C.c_void_p]
@@ -64,10 +69,11 @@ def _err(what):
 
 class KeyframePipeline:
     def __init__(self, device: int, sp_weights_path: str, pca_comp_csv: str, pca_mean_csv: str, vlad_weights_path: str, width=600, height=480,
-                 thres=0.02, max_num=200, precision=capi.PREC_F16, microbatch=8, pipelines=2, storage=capi.STORE_F32, self_id=1,
+                 thres=0.02, max_num=200, precision=capi.PREC_F16, microbatch=8, pipelines=0, storage=capi.STORE_F32, self_id=1,
                  inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3, geometry=False, pinhole_depth=None):
         """pinhole_depth: None = CameraConfig::STEREO_FISHEYE (4 directions x up/down views per key frame); a dict(fx, fy, cx, cy, depth_near, depth_far,
-        accept_min_3d_pts) = CameraConfig::PINHOLE_DEPTH (launch/realsense.launch): one gray image + one depth image (set_depth) per key frame"""
+        accept_min_3d_pts) = CameraConfig::PINHOLE_DEPTH (launch/realsense.launch): one gray image + one depth image (set_depth) per key frame.
+        pipelines <= 0: the library's default number of units in flight for the precision (4 for fp16, 2 otherwise)"""
         self.microbatch = microbatch
         common = (device, sp_weights_path.encode(), pca_comp_csv.encode(), pca_mean_csv.encode(), vlad_weights_path.encode(), width, height, thres, max_num,
                   precision, microbatch, pipelines, storage, self_id, inner_product_thres, init_mode_product_thres, match_index_dist, min_loop_num,
@@ -76,7 +82,7 @@ class KeyframePipeline:
             self.h = lib().omni_pipeline_create(*common)
         else:
             d = pinhole_depth
-            self.h = lib().omni_pipeline_create_pinhole_depth(*common, d["fx"], d["fy"], d["cx"], d["cy"], d.get("depth_near", 0.3), d.get("depth_far", 7.0),
+            self.h = lib().omni_pipeline_create_pinhole_depth(*common, d["fx"], d["fy"], d["cx"], d["cy"], d.get("depth_near", 0.3), d.get("depth_far", 10.0),
                                                               d.get("accept_min_3d_pts", 50))
         self._depth = None
         if not self.h:
@@ -140,6 +146,24 @@ class KeyframePipeline:
             raise _err("omni_pipeline_push_keyframe")
         return hits.value
 
+    def poll(self) -> int:
+        """The streaming intake's latency bound (call from a timer or after every push; never waits for a CNN unit): sends a partly filled micro-batch
+        older than max_wait_ms, finishes the units the GPU is done with, and -- with nothing left in flight -- collects the last detector step."""
+        hits = C.c_int(0)
+        if lib().omni_pipeline_poll(self.h, C.byref(hits)):
+            raise _err("omni_pipeline_poll")
+        return hits.value
+
+    def set_latency(self, max_wait_ms: float = 50.0, dispatch_when_idle: bool = True):
+        if lib().omni_pipeline_set_latency(self.h, float(max_wait_ms), int(dispatch_when_idle)):
+            raise _err("omni_pipeline_set_latency")
+
+    def units(self):
+        """(units in flight, how the last run() ordered them: 0 = kernels take turns, 1 / 2 = oldest first)"""
+        f = C.c_int(0)
+        n = lib().omni_pipeline_units(self.h, C.byref(f))
+        return n, f.value
+
     def flush(self) -> int:
         hits = C.c_int(0)
         if lib().omni_pipeline_flush(self.h, C.byref(hits)):
@@ -188,6 +212,13 @@ class KeyframePipeline:
         n = lib().omni_pipeline_get_latencies(self.h, None, 0, 0)
         out = np.zeros(max(n, 1), np.float64)
         lib().omni_pipeline_get_latencies(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), n, int(reset))
+        return out[:n]
+
+    def exchange_us(self, reset: bool = True) -> np.ndarray:
+        """sharded mode: [n][2] device microseconds of the two all-gathers (new rows, per-shard top-k lists) of every exchange unit since the last reset"""
+        n = lib().omni_pipeline_get_exchange_us(self.h, None, 0, 0)
+        out = np.zeros((max(n, 1), 2), np.float32)
+        lib().omni_pipeline_get_exchange_us(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), n, int(reset))
         return out[:n]
 
     def sync(self):

@@ -55,6 +55,42 @@ def ip_search_numpy(db: np.ndarray, q: np.ndarray, k: int):
     return D, I
 
 
+def ip_search_blocked(blocks, q: np.ndarray, k: int, extra: int = 32):
+    """The same contract (exact inner-product top-k, descending, ties -> lower row) for databases too big for the scalar C loop: `blocks`
+    yields (first_row, rows[float32]) in any order, each block scored with one BLAS sgemm, its k + extra best per query re-scored in
+    float64 (the sgemm's own summation noise, ~1e-6, is far below the score gap over `extra` ranks of a random database), then merged by
+    (score desc, row asc).  Returns (D float32, I int64, S float64): S = the float64 scores, for the near-tie rule of the caller."""
+    q = np.ascontiguousarray(np.atleast_2d(q), np.float32)
+    nq = q.shape[0]
+    q64 = q.astype(np.float64)
+    cand_s = [[] for _ in range(nq)]
+    cand_i = [[] for _ in range(nq)]
+    for row0, blk in blocks:
+        blk = np.ascontiguousarray(blk, np.float32)
+        n = blk.shape[0]
+        if n == 0:
+            continue
+        s = q @ blk.T                                      # [nq][n] fp32
+        kk = min(n, k + extra)
+        part = np.argpartition(-s, kk - 1, axis=1)[:, :kk] if kk < n else np.tile(np.arange(n), (nq, 1))
+        for qi in range(nq):
+            rows = np.sort(part[qi])
+            cand_s[qi].append(blk[rows].astype(np.float64) @ q64[qi])
+            cand_i[qi].append(rows.astype(np.int64) + int(row0))
+    D = np.full((nq, k), -3.402823466e+38, np.float32)
+    I = np.full((nq, k), -1, np.int64)
+    S = np.full((nq, k), -np.inf, np.float64)
+    for qi in range(nq):
+        if not cand_s[qi]:
+            continue
+        sc, ids = np.concatenate(cand_s[qi]), np.concatenate(cand_i[qi])
+        order = np.lexsort((ids, -sc))[:k]
+        D[qi, :len(order)] = sc[order].astype(np.float32)
+        I[qi, :len(order)] = ids[order]
+        S[qi, :len(order)] = sc[order]
+    return D, I, S
+
+
 def bf_match(q: np.ndarray, t: np.ndarray, mode: int = 0):
     """-> (query_idx, train_idx, distance); mode 0 = OpenCV batchDistance crosscheck, 1 = strict mutual NN."""
     q = np.ascontiguousarray(q, np.float32)

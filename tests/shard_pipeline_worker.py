@@ -67,7 +67,7 @@ def main():
         pl.close()
     net = capi.MobileNetVLAD(ctx, vw, specs, 32, 112, 4096, W, H, 4 * MB)
     g = [net.inference(b[:4 * MB], fisheye_mask=True) for b in blocks]          # [block][4 MB][4096]: the rows the pipeline appended
-    np.savez(out, hits=np.array(hits), rows_total=rows_total, g=np.stack(g))
+    np.savez(out, hits=np.array(hits), rows_total=rows_total, g=np.stack(g), librccl=capi.shard_library_path())
     for p in pins:
         ctx.host_free(p)
 

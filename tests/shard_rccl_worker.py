@@ -45,7 +45,7 @@ def main():
             res_D.append(D[0]); res_I.append(I[0])
     q = base[[3, 17]] + 0.01
     Ds, Is = sw.search(q, k)
-    np.savez(out, D=np.stack(res_D), I=np.stack(res_I), Ds=Ds, Is=Is, ntotal=sw.ntotal)
+    np.savez(out, D=np.stack(res_D), I=np.stack(res_I), Ds=Ds, Is=Is, ntotal=sw.ntotal, librccl=capi.shard_library_path())
     sw.close()
 
 

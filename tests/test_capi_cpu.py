@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(omni):
     assert declared == set(c.SYMBOLS), (declared ^ set(c.SYMBOLS))
     for s in declared:
         assert hasattr(L, s), f"{s} declared in include/omni_hip.h but not exported"
-    assert c.lib().omni_abi_version() == 1
+    assert c.lib().omni_abi_version() == c.ABI_VERSION == 2
 
 
 def test_product_package_never_imports_the_oracle():

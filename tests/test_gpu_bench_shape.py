@@ -238,6 +238,101 @@ def test_cpp_host_loop_equals_python_host_loop(omni, ctx, tmp_path):
         ctx.host_free(p)
 
 
+def test_streaming_intake_latency_bound_poll_idle_dispatch_and_partial_units(omni, ctx, tmp_path):
+    """the streaming intake must not hold a key frame until `microbatch` of them have arrived.  (1) with both rules off nothing leaves before
+    flush(); (2) max_wait_ms: poll() sends a partly filled micro-batch that is older, finishes it without any further push and reports its candidates;
+    (3) dispatch_when_idle: a key frame that meets an idle GPU goes at once as a unit of one; (4) whatever the unit sizes (1, 3, 5, 8 ... through
+    omni_cam_set_active on the SAME networks), rows, candidates and their order equal run() on the same key frames; (5) omni_cam_set_active's range."""
+    import time
+    c = omni.capi
+    from omni_swarm_amd import pipeline, weights
+    w, h, mb = 128, 96, 8
+    sp_w, vw = S.synth_weights(0), V.synth_weights()
+    comp, mean = synth.pca()
+    files = weights.write_pipeline_files(str(tmp_path), sp_w, comp, mean, vw, V.layer_specs(), c.VLAD_KINDS)
+    rng = np.random.default_rng(4)
+    db = rng.standard_normal((200, 4096), dtype=np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    kfs = [[synth.image_u8(8000 + 8 * (m % 10) + i, h, w, n_shapes=60) for i in range(8)] for m in range(20)]        # key frames 10..19 revisit 0..9
+    block = lambda ms: np.stack([kfs[m][i] for m in ms for i in range(4)] + [kfs[m][4 + i] for m in ms for i in range(4)])
+    make = lambda: pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], w, h, 0.015, 100, c.PREC_F16, mb, 2, c.STORE_F32,
+                                             1, 0.3, 0.2, 5, 10, 3)
+    # reference: run() over the same 20 key frames (2 full units + a partial one of 4)
+    pins = []
+    for ms in (range(0, 8), range(8, 16), range(16, 20)):
+        p = ctx.host_alloc((8 * len(ms), h, w), np.uint8)
+        p[:] = block(list(ms))
+        pins.append(p)
+    ref = make()
+    ref.preload(db)
+    hits_ref = ref.run(20, 0, [pins[0].ctypes.data, pins[1].ctypes.data], 0, pins[2].ctypes.data, True)
+    cand_ref, rows_ref = ref.candidates(), ref.db_rows
+    ref.close()
+    assert hits_ref >= 8 and rows_ref == 200 + 80
+
+    def wait_for(pl, rows, hits):
+        t0 = time.time()
+        while pl.db_rows < rows and time.time() - t0 < 20:
+            hits += pl.poll()
+            time.sleep(0.002)
+        return hits + pl.poll()
+
+    pl = make()
+    pl.preload(db)
+    pl.set_latency(-1.0, False)                                   # (1) the old behaviour: only a full unit or flush() leaves
+    hits = 0
+    for m in range(3):
+        hits += pl.push_keyframe(kfs[m], m, float(m))
+    time.sleep(0.05)
+    assert pl.poll() == 0 and pl.db_rows == 200 and len(pl.candidates()) == 0
+    pl.set_latency(20.0, False)                                   # (2) the three key frames are older than 20 ms by now: poll() sends them as a unit of three
+    hits = wait_for(pl, 212, hits)
+    assert pl.db_rows == 212, "poll() did not finish the aged partial unit"
+    pl.set_latency(-1.0, True)                                    # (3) idle GPU: a unit of one, at once; finished by poll() alone
+    hits += pl.push_keyframe(kfs[3], 3, 3.0)
+    hits = wait_for(pl, 216, hits)
+    assert pl.db_rows == 216
+    pl.set_latency(1e9, False)                                    # (4) a unit of five by flush(), then full units and whatever idle dispatch makes of the rest
+    for m in range(4, 9):
+        hits += pl.push_keyframe(kfs[m], m, float(m))
+    hits += pl.flush()
+    assert pl.db_rows == 200 + 36
+    pl.set_latency(50.0, True)                                    # the defaults
+    for m in range(9, 20):
+        hits += pl.push_keyframe(kfs[m], m, float(m))
+    hits += pl.flush()
+    assert pl.db_rows == rows_ref and hits == hits_ref
+    assert np.array_equal(pl.candidates(), cand_ref)
+    assert len(pl.latencies_ms()) >= 5
+    pl.close()
+    # (5) omni_cam_set_active: 1 .. the handle's directions, not with a unit in flight
+    from omni_swarm_amd import frontend
+    cam = frontend.LoopCam(ctx, sp_w, comp, mean, vw, V.layer_specs(), (V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM), w, h, 0.015, 100, c.PREC_F16, n_dirs=8)
+    for bad in (0, 9, -1):
+        with pytest.raises(c.OmniError):
+            cam.cam.set_active(bad)
+    full = ctx.host_alloc((16, h, w), np.uint8)
+    full[:] = block([0, 1])
+    cam.enqueue_host(full)
+    with pytest.raises(c.OmniError):
+        cam.cam.set_active(4)                                     # a unit is in flight
+    while not cam.cam.ready():
+        time.sleep(0.001)
+    two = cam.fetch()
+    cam.cam.set_active(4)
+    one = ctx.host_alloc((8, h, w), np.uint8)
+    one[:] = block([1])
+    cam.enqueue_host(one)
+    got = cam.fetch()
+    for d in range(4):                                            # key frame 1 alone == key frame 1 inside the unit of two (up camera d: image 4 + d there)
+        a, b = two["images"][4 + d], got["images"][d]
+        assert np.array_equal(a["landmarks_2d"], b["landmarks_2d"]) and np.array_equal(a["feature_descriptor"], b["feature_descriptor"])
+        assert np.array_equal(a["image_desc"], b["image_desc"]) and np.array_equal(a["ids_up"], b["ids_up"]) and np.array_equal(a["ids_down"], b["ids_down"])
+    cam.close()
+    for p in pins + [full, one]:
+        ctx.host_free(p)
+
+
 def test_cam_enqueue_host_with_a_row_stride(omni, ctx):
     """omni_cam_enqueue_host from a host block whose rows are padded (stride > width: a cv::Mat ROI / aligned buffer): the 2-D upload packs
     the rows, results equal the packed upload."""

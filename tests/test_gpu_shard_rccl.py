@@ -5,7 +5,10 @@ dlopen, no torch): results must equal the unsharded exact-IP oracle with the sam
     all-gather through a mapped file + hipMemcpy, TEST INFRASTRUCTURE): every line of omni_shard_step_batch_dev / omni_shard_search / the sharded
     key-frame pipeline runs with world > 1 -- global id numbering, owned-row pick, per-query prefix limits across ranks, the merge over W
     lists -- before an 8-GPU node ever sees them;
-  * the real RCCL is covered with world 1 (above); it refuses two ranks on one device."""
+  * the real RCCL is covered with world 1 (above); it refuses two ranks on one device;
+  * SELF-ACTIVATING on a box with >= 2 GPUs (skipped only when the box has one): the same exchange, the sharded pipeline and `bench.py --gpus N` with
+    N = min(8, device count) ranks, one GPU each, over the REAL librccl (xGMI) -- the day an 8-GPU node runs this suite, RCCL with more than one
+    rank is covered without anybody changing a line."""
 import os
 import subprocess
 import sys
@@ -51,12 +54,12 @@ def stub_env():
     return dict(os.environ, OMNI_RCCL_LIB=STUB)
 
 
-def run_world(world, tmp_path, seed, worker="shard_rccl_worker.py", env=None):
-    id_file = str(tmp_path / f"uid{world}")
+def run_world(world, tmp_path, seed, worker="shard_rccl_worker.py", env=None, one_gpu_per_rank=False):
+    id_file = str(tmp_path / f"uid{world}{'m' if one_gpu_per_rank else ''}")
     procs = []
     for r in range(world):
-        out = str(tmp_path / f"w{world}_r{r}.npz")
-        procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), str(r), str(world), "0", id_file, out, str(seed)],
+        out = str(tmp_path / f"w{world}_r{r}{'m' if one_gpu_per_rank else ''}.npz")
+        procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), str(r), str(world), str(r if one_gpu_per_rank else 0), id_file, out, str(seed)],
                                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env), out))
     logs = []
     for p, _ in procs:
@@ -87,18 +90,14 @@ def test_multi_rank_exchange_on_one_gpu_equals_unsharded_oracle(world, tmp_path)
     check_against_oracle(world, res, logs)
 
 
-def test_sharded_pipeline_two_ranks_equals_unsharded_oracle(tmp_path):
-    """The sharded C++ key-frame pipeline, two ranks on GPU 0 (stub collective), toy images: every rank's loop candidates per exchange unit equal
-    the reference's rule (loop_detector.cpp:232: recency + threshold on the row id) applied to the unsharded database in global insertion order
-    (exchange unit -> step -> rank -> direction)."""
-    world, seed, MB, k, mid, thres = 2, 77, 2, 10, 5, 0.3
-    res, logs = run_world(world, tmp_path, seed, worker="shard_pipeline_worker.py", env=stub_env())
+def check_pipeline_against_oracle(world, seed, res, logs):
+    MB, k, mid, thres = 2, 10, 5, 0.3
     assert all(rc == 0 for rc, _ in res), "\n".join(logs)[-3000:]
     z = [np.load(out) for _, out in res]
     rng = np.random.default_rng(seed)
     db = rng.standard_normal((world * 40, 4096)).astype(np.float32)
     db /= np.linalg.norm(db, axis=1, keepdims=True)
-    assert np.allclose(z[0]["g"], z[1]["g"], atol=1e-6)                       # the same blocks on both ranks
+    assert all(np.allclose(z[0]["g"], zr["g"], atol=1e-6) for zr in z[1:])    # the same blocks on every rank
     g = z[0]["g"].reshape(2, MB, 4, 4096)                                     # [block][frame][direction]
     rows = [db]
     n_units = len(z[0]["hits"])
@@ -119,6 +118,71 @@ def test_sharded_pipeline_two_ranks_equals_unsharded_oracle(tmp_path):
         assert int(z[r]["rows_total"]) == len(db) + n_units * MB * world * 4
         assert np.array_equal(z[r]["hits"], exp[r]), (r, z[r]["hits"], exp[r])
     assert exp[:, 1:].sum() >= world * MB * (n_units - 1)                      # from the second unit on every key frame revisits an earlier one
+    return z
+
+
+def test_sharded_pipeline_two_ranks_equals_unsharded_oracle(tmp_path):
+    """The sharded C++ key-frame pipeline, two ranks on GPU 0 (stub collective), toy images: every rank's loop candidates per exchange unit equal
+    the reference's rule (loop_detector.cpp:232: recency + threshold on the row id) applied to the unsharded database in global insertion order
+    (exchange unit -> step -> rank -> direction)."""
+    world, seed = 2, 77
+    res, logs = run_world(world, tmp_path, seed, worker="shard_pipeline_worker.py", env=stub_env())
+    check_pipeline_against_oracle(world, seed, res, logs)
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _real_rccl_env():
+    env = {k: v for k, v in os.environ.items() if k != "OMNI_RCCL_LIB"}         # the library's own search: the librccl next to the HIP runtime
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"                                     # this driver: dmabuf IPC only
+    return env
+
+
+def test_real_rccl_one_gpu_per_rank_exchange_equals_unsharded_oracle(tmp_path):
+    """min(8, device count) ranks, ONE GPU EACH, the real librccl: omni_shard_* == the unsharded oracle.  Skipped only on a one-GPU box."""
+    n = _gpus()
+    if n < 2:
+        pytest.skip(f"{n} GPU on this box: RCCL refuses several ranks per device (the stub cases above cover the multi-rank code on one GPU)")
+    world = min(8, n)
+    res, logs = run_world(world, tmp_path, seed=100 + world, env=_real_rccl_env(), one_gpu_per_rank=True)
+    check_against_oracle(world, res, logs)
+    libs = {str(np.load(out)["librccl"]) for _, out in res}
+    assert len(libs) == 1 and "stub" not in next(iter(libs)) and "rccl" in next(iter(libs)), libs
+
+
+def test_real_rccl_one_gpu_per_rank_sharded_pipeline_equals_unsharded_oracle(tmp_path):
+    """The sharded C++ key-frame pipeline on min(8, device count) GPUs over the real librccl == the reference's rule on the unsharded database."""
+    n = _gpus()
+    if n < 2:
+        pytest.skip(f"{n} GPU on this box")
+    world = min(8, n)
+    res, logs = run_world(world, tmp_path, 77, worker="shard_pipeline_worker.py", env=_real_rccl_env(), one_gpu_per_rank=True)
+    z = check_pipeline_against_oracle(world, 77, res, logs)
+    assert all("stub" not in str(zr["librccl"]) for zr in z)
+
+
+def test_real_rccl_bench_line_on_every_gpu_of_the_box(tmp_path):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one rank per GPU), N = min(8, device count): the line says the exchange ran in
+    libomni_hip.so over the real librccl on N ranks, with per-rank rates and the all-gathers' device time."""
+    import json
+    n = _gpus()
+    if n < 2:
+        pytest.skip(f"{n} GPU on this box")
+    world = min(8, n)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "29531",
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "16", "--warmup", "8", "--min-time", "0", "--match-db-rows", "80000",
+           "--batched-rows", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_real_rccl_env(), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["rccl_ranks"] == world and "stub" not in line["librccl"] and line["torch_distributed_backend"] == "gloo"
+    assert len(line["per_rank_keyframes_per_s"]) == world and min(line["per_rank_keyframes_per_s"]) > 0
+    assert line["all_gather_us_p50"]["exchange_units"] > 0 and len(line["all_gather_us_p50"]["topk_lists"]) == world
+    assert line["db_rows_per_gpu"] > 0 and line["value"] > 0
+    assert line["value"] <= sum(line["per_rank_keyframes_per_s"]) * 1.001             # the job's rate = all key frames / the slowest rank's time
 
 
 def test_sharded_exchange_with_the_real_rccl_equals_unsharded_oracle(tmp_path):

@@ -91,3 +91,43 @@ def test_full_size_frame_from_oracle_net(omni, ctx):
     xy, _, _, _ = P.get_keypoints(semi[0], 0.015, 200)
     _, raw = P.compute_descriptors(desc[0], xy, w, h, comp, mean)
     assert d.shape[1] == 256 and np.abs(d - raw).max() < 2e-5
+
+
+@pytest.mark.parametrize("prec", ["PREC_F16", "PREC_SPLIT", "PREC_F32"])
+def test_threshold_inside_the_detector_head_equals_the_separate_candidate_kernel(omni, ctx, monkeypatch, prec):
+    """getKeyPoints' threshold (superpoint_tensorrt.cpp:167-173) fused into the detector head's epilogue + sp_mask_kernel (one thread per candidate)
+    against sp_cand_kernel re-reading the heat map (OMNI_SP_FUSED_CAND=0; a handle keeps the setting it was created with): identical key points, scores,
+    descriptors -- batches whose 32-cell fragments straddle two images (117 cells per image), activity on every image border, the full-size frame; and
+    the GPU's own heat map through the literal oracle."""
+    c = omni.capi
+    comp, mean = synth.pca()
+    weights = S.synth_weights(0)
+    for (w, h, batch, thr, max_num) in ((104, 72, 3, 0.015, 200), (600, 480, 2, 0.02, 200), (96, 64, 1, 0.5, 30)):
+        imgs = np.stack([synth.image_u8(40 + i, h, w, n_shapes=80 if w > 200 else 40) for i in range(batch)])
+        imgs[:, 0, :] = 255 - imgs[:, 1, :]                               # texture right at the borders: windows that leave the image
+        imgs[:, :, -1] = 255 - imgs[:, :, -2]
+        monkeypatch.setenv("OMNI_SP_FUSED_CAND", "1")
+        fused = c.SuperPoint(ctx, weights, comp, mean, w, h, thr, max_num, getattr(c, prec), batch)
+        monkeypatch.setenv("OMNI_SP_FUSED_CAND", "0")
+        plain = c.SuperPoint(ctx, weights, comp, mean, w, h, thr, max_num, getattr(c, prec), batch)
+        monkeypatch.delenv("OMNI_SP_FUSED_CAND")
+        for mask in (False, True):
+            ra, rb = fused.inference(imgs, fisheye_mask=mask), plain.inference(imgs, fisheye_mask=mask)
+            semi, _ = fused.get_dense(batch)
+            for b in range(batch):
+                assert np.array_equal(ra[b][0], rb[b][0]) and np.array_equal(ra[b][2], rb[b][2]) and np.array_equal(ra[b][1], rb[b][1]), (w, b, mask)
+                xy, conf, _, _ = P.get_keypoints(semi[b], thr, max_num)
+                assert np.array_equal(ra[b][0].astype(np.int32), xy) and np.array_equal(ra[b][2], conf)
+            assert sum(len(r[0]) for r in ra) > 0 or thr > 0.4
+        # a heat map handed in from outside: threshold kernel + mask kernel vs sp_cand_kernel
+        rng = np.random.default_rng(w)
+        semi = (rng.random((h, w)).astype(np.float32) ** 3)
+        semi[:, 0] = rng.random(h) ** 2
+        semi[-1, :] = rng.random(w) ** 2
+        desc = rng.standard_normal((256, h // 8, w // 8)).astype(np.float32)
+        (ka, da, sa), = fused.postprocess_dense(semi, desc)
+        (kb, db, sb), = plain.postprocess_dense(semi, desc)
+        assert np.array_equal(ka, kb) and np.array_equal(sa, sb) and np.array_equal(da, db)
+        xy, conf, _, _ = P.get_keypoints(semi, thr, max_num)
+        assert np.array_equal(ka.astype(np.int32), xy) and np.array_equal(sa, conf)
+        fused.close(); plain.close()

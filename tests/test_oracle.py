@@ -103,6 +103,24 @@ def test_ip_search_c_equals_numpy_and_tie_rule():
     assert (I3[:, 3:] == -1).all() and (D3[:, 3:] < -1e38).all()     # k > n padding (faiss semantics)
 
 
+def test_blocked_ip_search_equals_the_scalar_oracle():
+    """ip_search_blocked (BLAS per block + float64 re-scoring: the oracle of the full-size GPU index tests) == the scalar C loop, incl. ties across
+    blocks -> lower row, k > rows of a block, blocks handed over out of order, and the golden database."""
+    db = synth.global_db(3000, seed=3)
+    db[2900] = db[41]
+    db[1200] = db[41]
+    q, rows = synth.queries_from_db(db, 6, seed=4)
+    q[5] = db[41]
+    Dr, Ir = M.ip_search(db, q, 12)
+    for edges in ([0, 3000], [0, 700, 1400, 3000], [0, 5, 2999, 3000]):
+        blocks = [(a, db[a:b]) for a, b in zip(edges[:-1], edges[1:])]
+        D, I, S = M.ip_search_blocked(iter(blocks[::-1]), q, 12)
+        assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-6, atol=1e-7) and np.allclose(S, Dr, rtol=1e-6, atol=1e-7)
+    assert I[5, :3].tolist() == [41, 1200, 2900]
+    D, I, S = M.ip_search_blocked(iter([(0, db[:4])]), q[:2], 9)
+    assert (I[:, 4:] == -1).all() and (D[:, 4:] < -1e38).all()
+
+
 def test_ip_search_matches_golden(golden):
     g = golden("match.npz")
     db = synth.global_db(3000, seed=3)
