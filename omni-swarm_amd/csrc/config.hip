@@ -21,6 +21,8 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_SP_MASK_SKIP_SPLIT", 1, 0, 1, CFG_VARIANT, "the same for OMNI_PREC_SPLIT"},
     {"OMNI_SPLIT_FUSE1A", 1, 0, 1, CFG_VARIANT, "OMNI_PREC_SPLIT: conv1a built inside the conv1b kernel from the u8 image (0: separate exact-f32 conv1a pass)"},
     {"OMNI_SPLIT_TRN", -1, -1, 1, CFG_VARIANT, "OMNI_PREC_SPLIT cin=128 kernel: tile orientation, as OMNI_RS_TRN"},
+    {"OMNI_CONV_XCD", 1, 0, 1, CFG_VARIANT, "persistent convolution kernels derive (cout group, tile walk) from an XCD-aware block id: the cout groups of a pixel tile and its neighbours "
+                                           "share one L2 (0: plain blockIdx; process-wide, same results either way)"},
     {"OMNI_SP_PROFILE_MASK", 0, 0, 1, CFG_TUNING, "omni_sp_profile times the stages with the fisheye mask on (what the key-frame pipeline runs)"},
     {"OMNI_PP_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the ping-pong conv kernel on stderr"},
     {"OMNI_PP_DBG", 0, 0, 255, CFG_DEBUG, "ping-pong conv kernel timing ablations (WRONG results)"},

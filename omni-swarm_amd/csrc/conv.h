@@ -17,7 +17,7 @@ namespace omni {
 #define CONV_TW 32         // output tile cols  (2 fragments x 16)
 #define RS_TH 6            // the register-stationary cin = 128 kernel's output tile (plain orientation): 6 rows x 32 columns
 #define RS_TW 32
-struct RsSkip { int act, n_above, n_upto, y0, y1, x0, w, bw; };      // conv3x3_c128_rs_kernel: the tiles of an image that run (ConvArgs::skip_*)
+struct RsSkip { int act, n_above, n_upto, y0, y1, x0, w, bw, xcd /* OMNI_CONV_XCD: xcd_block_id() */; };      // conv3x3_c128_rs_kernel: the tiles of an image that run (ConvArgs::skip_*)
 #define CONV_COUT_TILE 64  // output channels per workgroup (2 fragments x 32)
 #define CONV_CIN_CHUNK 64  // input channels staged per pass
 
@@ -99,9 +99,21 @@ int conv1a_direct(hipStream_t stream, int precision, const uint8_t* gray, int st
 int detector_head(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                   const float* wT, const float* bias, float* semi);
 
-// getKeyPoints' threshold fused into the head's epilogue (superpoint_tensorrt.cpp:167-173): with cand set, every pixel whose probability exceeds thres is
-// appended to its image's candidate list cand[b * hw ...] (counters[b * 4] = the count; zeroed by the launcher) -- SpPostBuffers::cand / ::counters
-struct DetCand { float thres = 0.f; int* cand = nullptr; int* counters = nullptr; int hw = 0; };
+// The id a persistent convolution kernel derives its (cout group, tile walk) from, with the XCD placement folded in.  Block b runs on XCD b % 8 (observed,
+// MI355X_MICROARCH.md "Workgroup dispatch"; for speed only -- any placement gives the same results): XCD x gets the contiguous ids [x n/8, (x+1) n/8), so
+// the cout groups of one pixel tile (ids differing by < n_cg) and the tiles next to it sit behind ONE L2 and the input halo is fetched from HBM / MALL once
+// instead of once per cout group and per neighbouring tile (round 4's counters: 3.6-8.2x the algorithmic input on the split cin = 128 layers).
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_block_id(int enable) {
+    const int n = (int)gridDim.x, b = (int)blockIdx.x;
+    return (enable && (n & 7) == 0) ? (b & 7) * (n >> 3) + (b >> 3) : b;
+}
+#endif
+
+// getKeyPoints' threshold fused into the head's epilogue (superpoint_tensorrt.cpp:167-173: mask = prob > thres): with bits set, a lane stores the 32
+// comparisons of its half cell as ONE word, bits[cell * 2 + hh] (SpPostBuffers::cand_bits: bit i = row i >> 2, column 4 hh + (i & 3) of the 8 x 8 cell) --
+// a coalesced 4-byte store, no atomics; sp_mask_kernel turns the bitmap into the candidate lists
+struct DetCand { float thres = 0.f; uint32_t* bits = nullptr; };
 
 // Same on the matrix cores (v_mfma_f32_32x32x2_f32 for the 64 kept channels, VALU for the dustbin); weights packed on the host.
 void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*[16384]*/, float* wdust /*[256]*/);

@@ -570,6 +570,7 @@ struct Fuse1aArgs {
     // rows (skip_bw per row, up to n_upto), the tile rows below it; no rectangle: n_above = n_upto = act_per_img = tiles_per_img
     int act_per_img, n_above, n_upto, skip_y0, skip_y1, skip_x0, skip_w, skip_bw;
     uint32_t magic_bw;            // ceil(2^32 / skip_bw)
+    int xcd;                      // OMNI_CONV_XCD: xcd_block_id() (set by the launcher)
 };
 
 template <bool POOL, int ABL, bool FUSE1A>
@@ -583,7 +584,8 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wl = wave & 3;
     const int n = lane & 31, hh = lane >> 5;
-    const int ct = blockIdx.x % n_ct, wg = blockIdx.x / n_ct, nwg = gridDim.x / n_ct;
+    const int bid = xcd_block_id(fz.xcd);
+    const int ct = bid % n_ct, wg = bid / n_ct, nwg = gridDim.x / n_ct;
     const int total = batch * fz.act_per_img;
     const int n_mine = wg < total ? (total - wg + nwg - 1) / nwg : 0;      // tiles of this workgroup: t_k = wg + k * nwg
 
@@ -953,6 +955,7 @@ static int launch_conv_pp_abl(hipStream_t st, const ConvArgs& a, int n_cu, int d
     fzz.magic_tpi = magic(fzz.act_per_img);
     fzz.magic_tx = magic(tiles_x);
     fzz.magic_bw = magic(fzz.skip_bw);
+    fzz.xcd = config_process()[CFG_CONV_XCD];
     // OMNI_PP_TRACE=1 (debug): s_memtime stamps of workgroup 0's phases 2-5 for the layers without the conv1a fusion (conv1ab_fused prints its own)
     static const bool want_trace = config_process()[CFG_PP_TRACE] != 0;
     static unsigned long long* trace_dev = nullptr;
@@ -1060,7 +1063,8 @@ conv3x3_c128_rs_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ o
     const int n = lane & 31, hh = lane >> 5;
     const bool tr = trace != nullptr && blockIdx.x == 0 && tid == 0;
     int tk = 0;
-    const int cg = blockIdx.x % n_cg, wg = blockIdx.x / n_cg, nwg = gridDim.x / n_cg;
+    const int bid = xcd_block_id(sk.xcd);
+    const int cg = bid % n_cg, wg = bid / n_cg, nwg = gridDim.x / n_cg;
     const int tiles_per_img = sk.act;              // (the tiles that run: all of them unless a rectangle is left out)
     const int total = batch * tiles_per_img;
     const int g32 = cg * 4 + wave;                 // this wave's group of 32 output channels
@@ -1216,6 +1220,7 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     sk.n_above = skip ? sk.y0 * tiles_x : sk.act;
     sk.n_upto = sk.n_above + (sk.y1 - sk.y0) * sk.bw;
     OMNI_REQUIRE(sk.act > 0 && sk.bw > 0, OMNI_ERR_INVALID, "conv_rs: the skip rectangle covers whole tile rows");
+    sk.xcd = config_process()[CFG_CONV_XCD];
     const int total = a.batch * sk.act;
     int per_cg = n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
@@ -1706,45 +1711,17 @@ int detector_head(hipStream_t st, int precision, const void* in, int in_stride, 
 // into one 16-byte store (channel c = 8 ry + rx: 4 consecutive rx).
 // ---------------------------------------------------------------------------------------------------------------
 #define DETM_THREADS 256
-// getKeyPoints' threshold (superpoint_tensorrt.cpp:167-173: mask = prob > thres; findNonZero) inside the head's epilogue, where the probabilities of a
-// cell's 64 pixels sit in registers: a lane holds 32 of them -- l0 / l1 = rows g / 4 + g of the cell, columns 4 hh + e -- and appends the pixel indices
-// of those above the threshold to ITS IMAGE's candidate list (unordered: NMS2's scan order is encoded by the window masks sp_mask_kernel makes from the
-// list).  One atomic per wave and image: a 32-cell fragment touches at most two images (a map has more than 32 cells).  The values compared are the
-// ones stored into the heat map, so the list equals thresholding that map.
-__device__ __forceinline__ void det_emit_candidates(const float (&p0)[16], const float (&p1)[16], bool valid, int b, int hy, int wx, int hh, int Wpix, int lane,
-                                                    const DetCand& dc) {
+// getKeyPoints' threshold (superpoint_tensorrt.cpp:167-173: mask = prob > thres) inside the head's epilogue, where the probabilities of a cell's 64
+// pixels sit in registers: a lane holds 32 of them -- l0 / l1 = rows g / 4 + g of the cell, columns 4 hh + e -- and stores the 32 comparisons as one
+// word of the image's bitmap (bit i = row i >> 2, column i & 3 of its half cell).  The values compared are the ones stored into the heat map, so the
+// bitmap equals thresholding that map.  (A first version appended to the candidate lists right here, one atomic per wave and image: the wave waited
+// ~4 us per fragment for the atomic's return -- the head 71 -> 89 us; the bitmap costs nothing measurable and sp_mask_kernel compacts it.)
+__device__ __forceinline__ void det_emit_candidates(const float (&p0)[16], const float (&p1)[16], bool valid, int cell, int hh, const DetCand& dc) {
+    if (!valid) return;
     uint32_t cm = 0;
-    if (valid) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { cm |= (p0[r] > dc.thres ? 1u : 0u) << r; cm |= (p1[r] > dc.thres ? 1u : 0u) << (16 + r); }
-    }
-    const int cnt = __popc(cm);
-    const int b_first = __shfl(b, 0, 64);                       // (lane 0's cell is always valid: f * 32 < n_cells)
-    int base = 0, excl = 0;
-#pragma unroll 1
-    for (int g = 0; g < 2; ++g) {
-        const bool mine = valid && b == b_first + g;
-        if (__ballot(mine && cnt > 0) == 0ull) continue;       // wave-uniform
-        int incl = mine ? cnt : 0;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-        const int total = __shfl(incl, 63, 64);
-        int wave_base = 0;
-        if (lane == 0) wave_base = atomicAdd(&dc.counters[(b_first + g) * 4 + 0], total);
-        wave_base = __shfl(wave_base, 0, 64);
-        if (mine) { base = wave_base; excl = incl - cnt; }
-    }
-    if (cm) {
-        int* out = dc.cand + (int64_t)b * dc.hw + base + excl;
-        const int pix0 = (hy * 8) * Wpix + wx * 8 + 4 * hh;
-        while (cm) {
-            const int i = __ffs(cm) - 1;
-            cm &= cm - 1;
-            // bit i < 16: l0[i] = row (i >> 2), column (i & 3); bit 16 + i: l1[i] = row 4 + (i >> 2)
-            const int ry = ((i & 15) >> 2) + ((i >> 4) << 2), rx = i & 3;
-            *out++ = pix0 + ry * Wpix + rx;
-        }
-    }
+    for (int r = 0; r < 16; ++r) { cm |= (p0[r] > dc.thres ? 1u : 0u) << r; cm |= (p1[r] > dc.thres ? 1u : 0u) << (16 + r); }
+    dc.bits[(int64_t)cell * 2 + hh] = cm;
 }
 
 template <typename T>
@@ -1836,7 +1813,7 @@ detector_head_mfma_kernel(const T* __restrict__ in, int in_stride, int in_off, i
                 *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) = make_float4(l1[4 * g + 0], l1[4 * g + 1], l1[4 * g + 2], l1[4 * g + 3]);
             }
         }
-        if (dc.cand) det_emit_candidates(l0, l1, valid, b, hy, wx, hh, Wc * 8, lane, dc);
+        if (dc.bits) det_emit_candidates(l0, l1, valid, cell, hh, dc);
     }
 }
 
@@ -1851,16 +1828,9 @@ void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*16384*/, f
     for (int k = 0; k < 256; ++k) wdust[k] = wT[(size_t)k * 65 + 64];
 }
 
-// dc.cand != nullptr: the candidate counters of the batch's images are zeroed here, in front of the kernel that fills the lists
-static int det_cand_reset(hipStream_t st, const DetCand& dc, int batch) {
-    if (dc.cand) OMNI_HIP_TRY(hipMemsetAsync(dc.counters, 0, (size_t)batch * 4 * sizeof(int), st));
-    return OMNI_OK;
-}
-
 int detector_head_mfma(hipStream_t st, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                        const float* wA, const float* wdust, const float* bias, float* semi, int n_cu, const DetCand& dc) {
     const int n_cells = batch * Hc * Wc;
-    { const int rc = det_cand_reset(st, dc, batch); if (rc) return rc; }
     const size_t smem = (size_t)(16384 + 256 + 80) * 4;
     int grid = cdiv(cdiv(n_cells, 32), 4);
     if (n_cu > 0 && grid > n_cu) grid = n_cu;
@@ -1964,7 +1934,7 @@ detector_head_mfma16_kernel(const _Float16* __restrict__ in, int in_stride, int 
                 *reinterpret_cast<float4*>(o + (int64_t)(4 + g) * (Wc * 8)) = make_float4(l1[4 * g + 0], l1[4 * g + 1], l1[4 * g + 2], l1[4 * g + 3]);
             }
         }
-        if (dc.cand) det_emit_candidates(l0, l1, valid, b, hy, wx, hh, Wc * 8, lane, dc);
+        if (dc.bits) det_emit_candidates(l0, l1, valid, cell, hh, dc);
     }
 }
 
@@ -1985,7 +1955,6 @@ void detector_pack_weights16(const float* wT /*[256][65]*/, uint16_t* wA16 /*2*2
 int detector_head_mfma16(hipStream_t st, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
                          const float* bias, float* semi, int n_cu, const DetCand& dc) {
     const int n_cells = batch * Hc * Wc;
-    { const int rc = det_cand_reset(st, dc, batch); if (rc) return rc; }
     const size_t smem = (size_t)4096 * 16 + (256 + 80) * 4;
     int grid = cdiv(cdiv(n_cells, 32), 4);
     if (n_cu > 0 && grid > 2 * n_cu) grid = 2 * n_cu;         // 66 KB of LDS: two workgroups per CU

@@ -176,7 +176,7 @@ struct SplPacked { uint4 a, b; };
 struct SplTileIx { int b, r, ty, tx; };                               // image, index among the image's tiles that run, tile row, tile column
 // ConvArgs::skip_* for this kernel's tile grid: the tiles of an image that run = the tile rows above the rectangle (n_above tiles), the tiles
 // left and right of it in its own rows (bw per row, up to n_upto), the tile rows below; no rectangle: n_above = n_upto = act = tiles_x * tiles_y
-struct SplSkip { int act, n_above, n_upto, y0, y1, x0, w, bw; uint32_t magic_tx, magic_bw; };
+struct SplSkip { int act, n_above, n_upto, y0, y1, x0, w, bw; uint32_t magic_tx, magic_bw; int xcd /* OMNI_CONV_XCD: xcd_block_id() */; };
 struct SplOrg { __amdgpu_buffer_rsrc_t r; uint32_t soff; };           // a halo tile's DMA source: the image's frame + the scalar offset of the halo origin
 typedef float spl_f4 __attribute__((ext_vector_type(4)));
 template <bool C128, bool POOL>
@@ -459,7 +459,8 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co = wave & 1, part = wave >> 1;
     const int n = lane & 31, hh = lane >> 5;
-    const int cg = blockIdx.x % n_cg, wg = blockIdx.x / n_cg, nwg = gridDim.x / n_cg;
+    const int bid = xcd_block_id(sk.xcd);
+    const int cg = bid % n_cg, wg = bid / n_cg, nwg = gridDim.x / n_cg;
     const int tiles_per_img = sk.act;                       // (the tiles that run)
     const int total = batch * tiles_per_img;
     const int g32 = cg * 2 + co;
@@ -954,6 +955,7 @@ static int launch_split(hipStream_t st, const ConvArgs& a, const SplFuse& fz = S
     OMNI_REQUIRE(sk.act > 0, OMNI_ERR_INVALID, "conv_split: the skip rectangle covers the whole image");
     auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };      // exact for n * d < 2^32; 0 = divisor 1
     sk.magic_tx = magic(tiles_x); sk.magic_bw = magic(sk.bw);
+    sk.xcd = config_process()[CFG_CONV_XCD];
     const int total = a.batch * sk.act;
     int per_cg = a.n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;

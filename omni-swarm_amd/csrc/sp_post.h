@@ -16,7 +16,7 @@ struct SpPostParams {
 };
 
 struct SpPostBuffers {      // all device pointers, sized for max_batch images
-    unsigned char* state;   // [B][H*W]            0 none / 1 unknown / 2 alive / 3 dead
+    uint32_t* cand_bits;    // [B][H/8 * W/8][2]   prob > thres as a bitmap: word (cell, hh) = rows 0-7 x columns 4 hh .. 4 hh + 3 of the 8 x 8 cell, bit i = (row i >> 2, column i & 3)
     int* cand;              // [B][H*W]            candidate pixel indices (unordered)
     uint64_t* cand_masks;   // [B][H*W][2]         per candidate: earlier / later higher-confidence window masks
     int* counters;          // [B][4]              n_cand, n_surv, n_iter, spare
@@ -53,11 +53,11 @@ struct SpSparseDesc {
     // OMNI_PREC_SPLIT: convDa itself only at those cells (conv_split_c128_sparse) -- a4b_split: conv4b's split-64 frames; the rows land in cx directly
     // (cda_f32 is then not read); da_w / da_bias / da_g32_first as above, da_inv = the fused heads layer's split_inv
     const void* a4b_split = nullptr; float da_inv = 0.f;
-    // the detector head already thresholded the map (conv.h DetCand): SpPostBuffers::cand / ::counters are filled, only the window masks are to be made
-    // (sp_mask_kernel, one thread per candidate) -- sp_cand_kernel, which re-reads the whole heat map, is not launched
+    // the detector head already thresholded the map (conv.h DetCand): SpPostBuffers::cand_bits is filled; sp_mask_kernel compacts it into the candidate
+    // lists and makes the window masks of the candidates only -- sp_cand_kernel, which re-reads the whole heat map through LDS tiles, is not launched
     bool cand_fused = false;
-    // a heat map that did not come from the head (omni_sp_postprocess_dense): the same two steps as separate kernels -- sp_thresh_kernel makes the lists,
-    // sp_mask_kernel the masks -- so that every edge case of the post-processing tests runs through the kernel the pipeline uses
+    // a heat map that did not come from the head (omni_sp_postprocess_dense): the same two steps as separate kernels -- sp_thresh_kernel makes the bitmap,
+    // sp_mask_kernel lists and masks -- so that every edge case of the post-processing tests runs through the kernel the pipeline uses
     bool cand_from_list = false;
 };
 

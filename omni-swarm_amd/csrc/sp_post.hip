@@ -102,53 +102,103 @@ sp_cand_kernel(const float* __restrict__ semi, int W, int H, float thres, int* _
     }
 }
 
-// The static part of NMS2 for a candidate list that already exists (the detector head thresholds its own output, conv.hip det_emit_candidates): one THREAD per
-// candidate reads the 80 window positions around it from the heat map -- 9 short row segments, L2 / MALL hits: the map was written by the kernel
-// before -- and writes the same two masks as sp_cand_kernel.  A neighbour counts when it is a candidate with a higher confidence; the candidate's own
-// confidence is above the threshold, so `inside the image and semi > c0` says exactly that.  Loads are unconditional (clamped address + predicate): all
-// 80 of a thread are in flight together.
-// mask = prob > thres; findNonZero (superpoint_tensorrt.cpp:167-173) as a stand-alone kernel: the candidate lists of heat maps the head did not produce
+// ---- the same two steps when the detector head has thresholded its own output (conv.hip det_emit_candidates; OMNI_SP_FUSED_CAND) ----------------------
+// cand_bits: word (cell, hh) of an image = the comparisons prob > thres of rows 0-7 x columns 4 hh .. 4 hh + 3 of the 8 x 8 cell, bit i = (row i >> 2,
+// column i & 3).  sp_thresh_kernel makes that bitmap from a heat map the head did not produce (omni_sp_postprocess_dense); sp_mask_kernel turns the
+// bitmap into the candidate lists (one prefix + ONE atomic per workgroup) and makes the two window masks of the candidates -- and of nothing else:
+// sp_cand_kernel stages every pixel of the map through LDS tiles to find the 2 % that are candidates.
 __global__ void __launch_bounds__(256)
-sp_thresh_kernel(const float* __restrict__ semi, int hw, float thres, int* __restrict__ cand, int* __restrict__ counters) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const float* sm = semi + (int64_t)b * hw;
-    int* cd = cand + (int64_t)b * hw;
-    for (int p0 = blockIdx.x * 256 + (threadIdx.x & ~63); p0 < hw; p0 += gridDim.x * 256) {       // wave-uniform
-        const int p = p0 + lane;
-        const bool c = p < hw && sm[p] > thres;
-        const unsigned long long m = __ballot(c);
-        if (m == 0ull) continue;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&counters[b * 4 + 0], __popcll(m));
-        base = __shfl(base, 0, 64);
-        if (c) cd[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+sp_thresh_kernel(const float* __restrict__ semi, int W, int H, float thres, uint32_t* __restrict__ bits) {
+    const int Wc = W >> 3, words = Wc * (H >> 3) * 2;
+    const int b = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= words) return;
+    const int cell = w >> 1, hh = w & 1, cy = cell / Wc, cx = cell - cy * Wc;
+    const float* p = semi + (int64_t)b * W * H + (int64_t)(cy * 8) * W + cx * 8 + 4 * hh;
+    uint32_t cm = 0;
+#pragma unroll
+    for (int ry = 0; ry < 8; ++ry) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)ry * W);
+        cm |= ((v.x > thres ? 1u : 0u) | (v.y > thres ? 2u : 0u) | (v.z > thres ? 4u : 0u) | (v.w > thres ? 8u : 0u)) << (4 * ry);
     }
+    bits[(int64_t)b * words + w] = cm;
 }
 
-#define MASK_BLOCKS_PER_IMAGE 32
+// One workgroup = 256 bitmap words (128 cells) of one image.  (1) popcount, prefix over the workgroup, one atomicAdd on the image's counter; (2) every set
+// bit becomes an entry of the workgroup's candidate list in LDS (so that the mask work is spread evenly over the threads, whatever the cells hold);
+// (3) one THREAD per candidate: the 9 rows of its 9 x 9 window as three ALIGNED 16-byte loads each (the window [x - 4, x + 4] lies inside the three
+// float4 chunks from (x - 4) & ~3 on; chunks and rows outside the image are never loaded and count as "no candidate") -- 27 loads per candidate, all in
+// flight together, instead of 80 scalar ones that each cost a cache-line transaction -- then the same two masks as sp_cand_kernel: a neighbour counts when
+// it is a candidate of higher confidence, and the candidate's own confidence is above the threshold, so `inside the image and semi > c0` says exactly that.
+#define MK_WORDS 256
+#define MK_LIST_CAP (MK_WORDS * 32)
 __global__ void __launch_bounds__(256)
-sp_mask_kernel(const float* __restrict__ semi, int W, int H, const int* __restrict__ cand, const int* __restrict__ counters, uint64_t* __restrict__ masks) {
-    const int b = blockIdx.y;
-    const int hw = W * H;
-    const int n = counters[b * 4 + 0];
+sp_mask_kernel(const float* __restrict__ semi, int W, int H, const uint32_t* __restrict__ bits, int* __restrict__ cand, uint64_t* __restrict__ masks,
+               int* __restrict__ counters) {
+    __shared__ int s_list[MK_LIST_CAP];
+    __shared__ int s_wave_cnt[4];
+    __shared__ int s_base;
+    const int Wc = W >> 3, words = Wc * (H >> 3) * 2, hw = W * H;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x * MK_WORDS + tid;
+    uint32_t cm = w < words ? bits[(int64_t)b * words + w] : 0u;
+    const int mine = __popc(cm);
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    if (lane == 63) s_wave_cnt[wave] = incl;
+    __syncthreads();
+    const int total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    if (total == 0) return;
+    if (tid == 0) s_base = atomicAdd(&counters[b * 4 + 0], total);
+    {
+        int pos = incl - mine;
+        for (int q = 0; q < wave; ++q) pos += s_wave_cnt[q];
+        const int cell = w >> 1, hh = w & 1, cy = cell / Wc, cx = cell - cy * Wc;
+        const int pix0 = (cy * 8) * W + cx * 8 + 4 * hh;
+        while (cm) {
+            const int i = __ffs(cm) - 1;
+            cm &= cm - 1;
+            s_list[pos++] = pix0 + (i >> 2) * W + (i & 3);
+        }
+    }
+    __syncthreads();
     const float* sm = semi + (int64_t)b * hw;
-    const int* cd = cand + (int64_t)b * hw;
-    uint64_t* mo = masks + (int64_t)b * hw * 2;
-    for (int ci = blockIdx.x * 256 + threadIdx.x; ci < n; ci += gridDim.x * 256) {
-        const int p = cd[ci];
+    int* out = cand + (int64_t)b * hw + s_base;
+    uint64_t* mo = masks + ((int64_t)b * hw + s_base) * 2;
+    for (int ci = tid; ci < total; ci += 256) {
+        const int p = s_list[ci];
         const int y = p / W, x = p - y * W;
-        const float c0 = sm[p];
+        const int xa = (x - 4) & ~3;                                 // first column of the three aligned chunks (may be -4: that chunk is outside the image)
+        const int sh = (x - 4) - xa;                                 // window column j (-4..4) = chunk element sh + j + 4
+        float win[9][12];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int yy = y + r - 4;
+            const bool row_in = yy >= 0 && yy < H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int xc = xa + 4 * c;
+                const bool in = row_in && xc >= 0 && xc < W;      // (W is a multiple of 8: a chunk is inside or outside as a whole)
+                const float4 v = *reinterpret_cast<const float4*>(sm + (in ? (int64_t)yy * W + xc : 0));
+                win[r][4 * c + 0] = in ? v.x : NEG_SENTINEL; win[r][4 * c + 1] = in ? v.y : NEG_SENTINEL;
+                win[r][4 * c + 2] = in ? v.z : NEG_SENTINEL; win[r][4 * c + 3] = in ? v.w : NEG_SENTINEL;
+            }
+        }
+        // window element (k, j) = win[k + 4][sh + j + 4], sh in 0..3: a 4-way select per element (registers cannot be indexed by a variable)
+        auto at = [&](int r, int e) -> float {                       // e = j + 4 in 0..8
+            const float a0 = win[r][e], a1 = win[r][e + 1], a2 = win[r][e + 2], a3 = win[r][e + 3];
+            return sh == 0 ? a0 : (sh == 1 ? a1 : (sh == 2 ? a2 : a3));
+        };
+        const float c0 = at(4, 4);
         uint32_t e_lo = 0, e_hi = 0, l_lo = 0, l_hi = 0;
 #pragma unroll
         for (int i = 0; i < 40; ++i) {
             const int k = (i < 36) ? (i / 9 - 4) : 0;
             const int j = (i < 36) ? (i - (k + 4) * 9 - 4) : (i - 40);
-            const bool in_e = (y + k >= 0) && (x + j >= 0) && (x + j < W);            // earlier: rows above / same row to the left (k <= 0)
-            const bool in_l = (y - k < H) && (x - j >= 0) && (x - j < W);             // later: the negated offset
-            const float ve = sm[in_e ? p + k * W + j : p], vl = sm[in_l ? p - k * W - j : p];
-            const uint32_t be = (in_e && ve > c0) ? 1u : 0u, bl = (in_l && vl > c0) ? 1u : 0u;
+            const uint32_t be = at(4 + k, 4 + j) > c0 ? 1u : 0u, bl = at(4 - k, 4 - j) > c0 ? 1u : 0u;
             if (i < 32) { e_lo |= be << i; l_lo |= bl << i; } else { e_hi |= be << (i - 32); l_hi |= bl << (i - 32); }
         }
+        out[ci] = p;
         mo[2 * (int64_t)ci] = ((uint64_t)e_hi << 32) | e_lo;
         mo[2 * (int64_t)ci + 1] = ((uint64_t)l_hi << 32) | l_lo;
     }
@@ -535,12 +585,13 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
     OMNI_REQUIRE(p.max_num >= 1 && p.max_num <= 1024, OMNI_ERR_CAPACITY, "max_num=%d outside [1,1024]", p.max_num);
     OMNI_REQUIRE(p.dist_thresh == 4, OMNI_ERR_INVALID, "NMS radius %d: the window masks are built for 4 (superpoint_tensorrt.cpp:183)", p.dist_thresh);
     if (sparse.cand_fused || sparse.cand_from_list) {
+        const int words = (p.width / 8) * (p.height / 8) * 2;
+        OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
         if (!sparse.cand_fused) {
-            OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
-            hipLaunchKernelGGL(sp_thresh_kernel, dim3(MASK_BLOCKS_PER_IMAGE, batch), dim3(256), 0, stream, semi, hw, p.thres, b.cand, b.counters);
+            hipLaunchKernelGGL(sp_thresh_kernel, dim3(cdiv(words, 256), batch), dim3(256), 0, stream, semi, p.width, p.height, p.thres, b.cand_bits);
             OMNI_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(sp_mask_kernel, dim3(MASK_BLOCKS_PER_IMAGE, batch), dim3(256), 0, stream, semi, p.width, p.height, b.cand, b.counters, b.cand_masks);
+        hipLaunchKernelGGL(sp_mask_kernel, dim3(cdiv(words, MK_WORDS), batch), dim3(256), 0, stream, semi, p.width, p.height, b.cand_bits, b.cand, b.cand_masks, b.counters);
     } else {
         OMNI_HIP_TRY(hipMemsetAsync(b.counters, 0, (size_t)batch * 4 * sizeof(int), stream));
         hipLaunchKernelGGL(sp_cand_kernel, dim3(cdiv(p.width, CT_W) * cdiv(p.height, CT_H), batch), dim3(256), 0, stream, semi, p.width, p.height,

@@ -322,7 +322,7 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     OMNI_HIP_TRY(hipMemsetAsync(s->pb.kps_xy, 0, B * M * 2 * 4, st));
     OMNI_HIP_TRY(hipMemsetAsync(s->pb.desc_out, 0, B * M * s->desc_dim * 4, st));
     OMNI_HIP_TRY(hipMemsetAsync(s->pb.scores, 0, B * M * 4, st));
-    s->pb.state = nullptr;
+    OMNI_HIP_TRY(hipMalloc((void**)&s->pb.cand_bits, B * (H / 8) * (W / 8) * 2 * 4));
     s->pb.pca_compT = s->pca_compT;
     s->pb.pca_mean = s->pca_mean;
     for (int i = 0; i <= OMNI_SP_NUM_STAGES; ++i) OMNI_HIP_TRY(hipEventCreate(&s->ev[i]));
@@ -441,7 +441,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     // the head thresholds its own output into the candidate lists when the post-processing follows (superpoint_tensorrt.cpp:167-173 inside the epilogue)
     DetCand dc;
     const bool cand_fused = run_post && s->fused_cand && s->conv_variant != 1;
-    if (cand_fused) { dc.thres = s->thres; dc.cand = s->pb.cand; dc.counters = s->pb.counters; dc.hw = H * W; }
+    if (cand_fused) { dc.thres = s->thres; dc.bits = s->pb.cand_bits; }
     if (s->conv_variant == 1) { if ((rc = detector_head(st, PH, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
     else if (P == OMNI_PREC_F16 && s->det16) {
         if ((rc = detector_head_mfma16(st, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount, dc))) return rc;
@@ -592,7 +592,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); if (s->bias_s[l]) (void)hipFree(s->bias_s[l]); }
     void* ptrs[] = {s->wPbA16, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
-                    s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->cx32, s->cy32, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
+                    s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->cx32, s->cy32, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_bits, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->zero_gray) (void)hipFree(s->zero_gray);
