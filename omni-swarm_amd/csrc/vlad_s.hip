@@ -43,7 +43,11 @@ struct SBlockCfg {
     static constexpr int XS = S1 * 32 + 16;
     static constexpr int TH = STRIDE == 1 ? 8 : 4, OPX = 8 * TH, NTN = OPX / 32;
     static constexpr int RWX = 7 * STRIDE + 3, RHY = (TH - 1) * STRIDE + 3, R = RWX * RHY, RT = (R + 31) / 32, RP = RT * 32;
-    static constexpr int THREADS = RT * 64;                                           // one wave per 32-pixel region tile
+    // one wave per 32-pixel region tile -- but never more than FOUR waves: at the ~210-250 registers these kernels need, a SIMD holds two waves, a CU
+    // eight; a five-wave workgroup (the stride-2 region: 17 x 9 = 153 pixels = 5 tiles) then fits ONCE per CU where a four-wave one fits twice
+    // (round 5: b1 / b3 / b6 / b13 ran at half the residency of the other blocks).  The fifth region tile is a second expand pass of wave 0, region
+    // pixels 128.. a second x -> LDS pass of the first threads.
+    static constexpr int NW = RT < 4 ? RT : 4, THREADS = NW * 64, XP = (R + THREADS / 2 - 1) / (THREADS / 2);
     static constexpr int CB = (S1 + S2) * 2048 + NT * 6144;                           // bytes of matrix fragments per chunk
     static constexpr int MQ = STRIDE == 1 ? (NT + 1) / 2 : 1;                         // projection m-tiles per wave
     // LDS: x rows | d_hi, d_lo | h rows | depthwise taps.  Only the R real region rows are kept (the MFMA tiles of the last wave read past the x
@@ -51,11 +55,16 @@ struct SBlockCfg {
     static constexpr size_t smem(int hid) { return (size_t)R * XS + 2 * (size_t)OPX * SB_DS + (size_t)R * SB_HS + (size_t)(hid / SB_CH) * SB_WD * 4; }
 };
 
+// waves per SIMD the register allocation aims at: 2 = up to 256 registers (what these kernels take when they may: 210-256, no spills); SB_WPE_SMALL (A/B
+// build switch for the cin <= 16 shapes) 3 = 168 registers, three workgroups per CU, at the price of 150-230 bytes of scratch per lane
+#ifndef SB_WPE_SMALL
+#define SB_WPE_SMALL 2
+#endif
 template <int STRIDE, int CIN, int NT>
-__global__ void __launch_bounds__((SBlockCfg<STRIDE, CIN, NT>::THREADS), (CIN > 32 ? 1 : 2))
+__global__ void __launch_bounds__((SBlockCfg<STRIDE, CIN, NT>::THREADS), (CIN > 32 ? 1 : (CIN <= 16 ? SB_WPE_SMALL : 2)))
 vlad_sblock_kernel(VladSBlockArgs a) {
     using C = SBlockCfg<STRIDE, CIN, NT>;
-    constexpr int S1 = C::S1, S2 = C::S2, XS = C::XS, TH = C::TH, OPX = C::OPX, RWX = C::RWX, R = C::R, CB = C::CB, MQ = C::MQ;
+    constexpr int S1 = C::S1, S2 = C::S2, XS = C::XS, TH = C::TH, OPX = C::OPX, RWX = C::RWX, R = C::R, CB = C::CB, MQ = C::MQ, NW = C::NW, RT = C::RT, XP = C::XP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n_chunks = a.hid / SB_CH;
     char* xin = smem;                                        // [R][XS]  halfs: x_hi | x_lo | 1 1 0...
@@ -90,7 +99,7 @@ vlad_sblock_kernel(VladSBlockArgs a) {
     const int pair = tid % 24, blk = tid / 24;               // depthwise work item (threads 0..191): channel pair x block of output pixels
     const int nt = STRIDE == 1 ? (wave & 1) : 0;             // projection tiles of this wave: pixel tile nt, m-tiles mt0 + MSTEP * q
     const int mt0 = STRIDE == 1 ? (wave >> 1) : wave;
-    constexpr int MSTEP = STRIDE == 1 ? 2 : 5;
+    constexpr int MSTEP = STRIDE == 1 ? 2 : NW;
     const bool pwave = mt0 < NT;
     sf4 pbias[MQ][4];
 #pragma unroll
@@ -109,19 +118,23 @@ vlad_sblock_kernel(VladSBlockArgs a) {
         toy = tty * TH; tox = (ttr - tty * tiles_x) * 8;
     };
     // input region of a tile: thread = (region pixel, half of its channels); fetched into registers one tile ahead
-    const int xr = tid >> 1, xhf = tid & 1, xry = xr / RWX, xrx = xr - xry * RWX;
-    sf4 xpre[CIN / 8];
-    bool xin_img = false;
+    const int xhf = tid & 1;
+    sf4 xpre[XP][CIN / 8];                                   // (XP = 1 unless the region has more pixels than half the threads: stride 2)
+    bool xin_img[XP];
     auto fetch_x = [&](int tile) {
         int tb, toy, tox;
         tile_origin(tile, tb, toy, tox);
-        const int gy = toy * STRIDE - 1 + xry, gx = tox * STRIDE - 1 + xrx;
-        xin_img = xr < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
-        const unsigned off = (unsigned)((tb * a.Hi + gy) * a.Wi + gx) * CIN + xhf * (CIN / 2);      // 32-bit element offset (checked by the launcher)
 #pragma unroll
-        for (int q = 0; q < CIN / 8; ++q) {
-            const sf4 z = {0.f, 0.f, 0.f, 0.f};
-            xpre[q] = xin_img ? *reinterpret_cast<const sf4*>(a.in + off + q * 4) : z;
+        for (int ps = 0; ps < XP; ++ps) {
+            const int xr = (tid >> 1) + ps * (C::THREADS / 2), xry = xr / RWX, xrx = xr - xry * RWX;
+            const int gy = toy * STRIDE - 1 + xry, gx = tox * STRIDE - 1 + xrx;
+            xin_img[ps] = xr < R && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
+            const unsigned off = (unsigned)((tb * a.Hi + gy) * a.Wi + gx) * CIN + xhf * (CIN / 2);      // 32-bit element offset (checked by the launcher)
+#pragma unroll
+            for (int q = 0; q < CIN / 8; ++q) {
+                const sf4 z = {0.f, 0.f, 0.f, 0.f};
+                xpre[ps][q] = xin_img[ps] ? *reinterpret_cast<const sf4*>(a.in + off + q * 4) : z;
+            }
         }
     };
     // this lane's output pixel of a tile, its residual (stride 1, cin == cout: the block input at the same pixel) and the final store.  The
@@ -168,7 +181,11 @@ vlad_sblock_kernel(VladSBlockArgs a) {
 
     // expand: this wave's 32 region pixels x the chunk's 48 channels (m-tile 0: channels 0-31, m-tile 1: 32-47 + 16 zero rows)
     auto expand = [&]() {
-        const char* xb = xin + (wave * 32 + n) * XS + kk * 16;
+#pragma unroll
+      for (int rt = 0; rt < (RT + NW - 1) / NW; ++rt) {
+        const int rw = wave + rt * NW;                       // this pass's region tile (wave-uniform)
+        if (rw >= RT) break;
+        const char* xb = xin + (rw * 32 + n) * XS + kk * 16;
         sf16 e0, e1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
@@ -184,8 +201,8 @@ vlad_sblock_kernel(VladSBlockArgs a) {
             e0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(we2[ks][0], xb8, e0, 0, 0, 0);
             e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(we2[ks][1], xb8, e1, 0, 0, 0);
         }
-        if (wave * 32 + n < R) {
-            char* hp = h + (wave * 32 + n) * SB_HS + kk * 16;    // channels 8 g + 4 kk + (0..3) of pixel n
+        if (rw * 32 + n < R) {
+            char* hp = h + (rw * 32 + n) * SB_HS + kk * 16;      // channels 8 g + 4 kk + (0..3) of pixel n
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 sf4 v;
@@ -201,6 +218,7 @@ vlad_sblock_kernel(VladSBlockArgs a) {
                 *reinterpret_cast<sf4*>(hp + 128 + g * 32) = v;
             }
         }
+      }
     };
 
     fetch_x(blockIdx.x);
@@ -208,19 +226,23 @@ vlad_sblock_kernel(VladSBlockArgs a) {
     for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
         const bool trw = a.trace && blockIdx.x == 0 && (tid & 63) == 0 && tile == (int)blockIdx.x + 2 * (int)gridDim.x;
         TR(8);
-        if (xr < R) {   // x_hi | x_lo, the two bias slots, zero pad -> LDS
-            char* row = xin + xr * XS;
 #pragma unroll
-            for (int q = 0; q < CIN / 8; ++q) {
-                const sf4 v = xpre[q];
-                const sh4 hi = __builtin_convertvector(v, sh4);
-                const sh4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, sf4), sh4);
-                *reinterpret_cast<sh4*>(row + (xhf * (CIN / 2) + q * 4) * 2) = hi;
-                *reinterpret_cast<sh4*>(row + CIN * 2 + (xhf * (CIN / 2) + q * 4) * 2) = lo;
+        for (int ps = 0; ps < XP; ++ps) {
+            const int xr = (tid >> 1) + ps * (C::THREADS / 2);
+            if (xr < R) {   // x_hi | x_lo, the two bias slots, zero pad -> LDS
+                char* row = xin + xr * XS;
+#pragma unroll
+                for (int q = 0; q < CIN / 8; ++q) {
+                    const sf4 v = xpre[ps][q];
+                    const sh4 hi = __builtin_convertvector(v, sh4);
+                    const sh4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, sf4), sh4);
+                    *reinterpret_cast<sh4*>(row + (xhf * (CIN / 2) + q * 4) * 2) = hi;
+                    *reinterpret_cast<sh4*>(row + CIN * 2 + (xhf * (CIN / 2) + q * 4) * 2) = lo;
+                }
+                sh8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (xhf == 0 && xin_img[ps]) { t[0] = (_Float16)1.f; t[1] = (_Float16)1.f; }
+                *reinterpret_cast<sh8*>(row + CIN * 4 + xhf * 16) = t;             // hf 0: the bias slots, hf 1: the 16 pad bytes behind them
             }
-            sh8 t = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (xhf == 0 && xin_img) { t[0] = (_Float16)1.f; t[1] = (_Float16)1.f; }
-            *reinterpret_cast<sh8*>(row + CIN * 4 + xhf * 16) = t;                 // hf 0: the bias slots, hf 1: the 16 pad bytes behind them
         }
         // global traffic of this iteration, oldest first: the previous tile's result, this tile's residual, the next tile's input
         store_out();
@@ -412,10 +434,18 @@ static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
     const int tiles = cdiv(a.Wo, 8) * cdiv(a.Ho, C::TH) * a.batch;
     OMNI_REQUIRE((int64_t)a.batch * a.Hi * a.Wi * a.cin < (1ll << 31) && (int64_t)a.batch * a.Ho * a.Wo * a.cout < (1ll << 31) && tiles < (1 << 20),
                  OMNI_ERR_CAPACITY, "vlad_sblock: tensor beyond 32-bit element offsets");
-    int per_cu = (int)((160 * 1024) / smem);
-    const int wave_cap = 32 / (C::THREADS / 64);                 // 8 waves per SIMD
-    if (per_cu > wave_cap) per_cu = wave_cap;
-    if (per_cu < 1) per_cu = 1;
+    // how many of these workgroups a CU really holds: the runtime knows (registers AND LDS AND wave slots).  Rounds 2-4 estimated it from the LDS alone
+    // (3 for b1 / b2 / b4 / b5) while the registers allow two waves per SIMD: a third of the persistent workgroups only started when the first ones had
+    // finished their share -- 1.5 rounds of work in the time of 2
+    static int per_cu_cached = 0;
+    static size_t per_cu_smem = 0;
+    if (!per_cu_cached || per_cu_smem != smem) {
+        int nb = 0;
+        OMNI_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kfn, C::THREADS, smem));
+        per_cu_cached = nb < 1 ? 1 : nb;
+        per_cu_smem = smem;
+    }
+    const int per_cu = per_cu_cached;
     // OMNI_VLAD_SB_PERSIST (A/B hook): 0 = one tile per workgroup, N >= 1 = N x (CUs x resident workgroups per CU) workgroups
     const int persist = a.persist;                               // (the handle's snapshot of the table)
     const int64_t cap = (int64_t)a.n_cu * per_cu * (persist > 0 ? persist : 1);
