@@ -1,6 +1,7 @@
 // config.hip -- the table behind config.h and its C entry points (include/omni_hip.h: omni_config_*)
 #include "config.h"
 
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <cstdlib>
@@ -13,10 +14,11 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
                                            "3 = ping-pong without the conv1a fusion -- 1-3 exist only in the test build of the library (lib_test/)"},
     {"OMNI_CONV_RS", 1, 0, 1, CFG_VARIANT, "cin=128 fp16 layers on the register-stationary kernel (0: generic kernel)"},
     {"OMNI_RS_TRN", -1, -1, 1, CFG_VARIANT, "register-stationary kernel: tile orientation, -1 = the one with fewer tiles, 0 = plain, 1 = transposed"},
-    {"OMNI_DET16", 1, 0, 1, CFG_VARIANT, "fp16 detector head on v_mfma_f32_32x32x16_f16 (0: the fp32-operand MFMA kernel)"},
+    {"OMNI_DET16", 1, 0, 1, CFG_VARIANT, "detector head of the fp16 and OMNI_PREC_SPLIT paths on v_mfma_f32_32x32x16_f16 with split (hi, lo) operands (0: the exact-f32 MFMA kernel)"},
     {"OMNI_SP_SPARSE_DESC", 1, 0, 1, CFG_VARIANT, "convDb + descriptor norm only at the cells around the key points (0: dense descriptor map)"},
     {"OMNI_SP_SPARSE_DA", 1, 0, 1, CFG_VARIANT, "convDa only at those cells too (fp16 and OMNI_PREC_SPLIT; 0: dense convDa)"},
     {"OMNI_SP_FUSED_CAND", 1, 0, 1, CFG_VARIANT, "getKeyPoints' threshold inside the detector head's epilogue + window masks from the candidate list (0: sp_cand_kernel re-reads the heat map)"},
+    {"OMNI_SP_SPLIT_DB", 1, 0, 1, CFG_VARIANT, "OMNI_PREC_SPLIT: convDb + descriptor norm at the key points' cells with split (hi, lo) operands on the fp16 matrix cores (0: exact-f32 MFMA convolution)"},
     {"OMNI_SP_MASK_SKIP", 1, 0, 1, CFG_VARIANT, "fp16: the tiles inside the constant region of the fisheye mask are left out of the tile walk (0: every tile)"},
     {"OMNI_SP_MASK_SKIP_SPLIT", 1, 0, 1, CFG_VARIANT, "the same for OMNI_PREC_SPLIT"},
     {"OMNI_SPLIT_FUSE1A", 1, 0, 1, CFG_VARIANT, "OMNI_PREC_SPLIT: conv1a built inside the conv1b kernel from the u8 image (0: separate exact-f32 conv1a pass)"},
@@ -89,8 +91,28 @@ int config_resolve(Config* out) {
     return OMNI_OK;
 }
 
+// the options read through config_process(): frozen for the process when the first of them is looked at (launch-site hooks, index thresholds)
+static bool is_process_wide(int i) {
+    switch (i) {
+        case CFG_CONV_RS: case CFG_CONV_XCD: case CFG_INDEX_CERT_FAIL: case CFG_INDEX_MIRROR: case CFG_INDEX_MIRROR_MIN_ROWS: case CFG_MQ_ROT:
+        case CFG_PP_DBG: case CFG_PP_TRACE: case CFG_RS_TRACE: case CFG_RS_TRN: case CFG_SCAN_ROWS_MIN: case CFG_SPLIT_DBG: case CFG_SPLIT_TRACE: case CFG_SPLIT_TRN:
+        case CFG_VLAD_BIG: case CFG_VLAD_SB_DBG: case CFG_VLAD_SB_LDSPAD: case CFG_VLAD_SB_TRACE:
+            return true;
+        default:
+            return false;
+    }
+}
+static std::atomic<bool> g_process_resolved{false};
+
+int config_option_now(CfgId i) {
+    int v; bool bad;
+    parse_one(kCfgOptions[i], &v, &bad);
+    return v;                                   // (an invalid value: the default)
+}
+
 const Config& config_process() {
     static const Config c = [] {
+        g_process_resolved.store(true);
         Config q;
         for (int i = 0; i < CFG_COUNT; ++i) {
             bool bad;
@@ -126,7 +148,11 @@ int omni_config_value(const char* env, int* value) {
     const int rc = omni::config_resolve(&c);
     if (rc) return rc;
     for (int i = 0; i < omni::CFG_COUNT; ++i)
-        if (!strcmp(omni::kCfgOptions[i].env, env)) { *value = c.v[i]; return OMNI_OK; }
+        if (!strcmp(omni::kCfgOptions[i].env, env)) {
+            // a process-wide option that is already frozen: what the kernels really use, whatever the environment says by now
+            *value = (omni::is_process_wide(i) && omni::g_process_resolved.load()) ? omni::config_process()[(omni::CfgId)i] : c.v[i];
+            return OMNI_OK;
+        }
     omni::set_error("omni_config_value: no option named %s", env);
     return OMNI_ERR_INVALID;
 }

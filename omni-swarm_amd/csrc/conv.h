@@ -118,7 +118,7 @@ struct DetCand { float thres = 0.f; uint32_t* bits = nullptr; };
 // Same on the matrix cores (v_mfma_f32_32x32x2_f32 for the 64 kept channels, VALU for the dustbin); weights packed on the host.
 void detector_pack_weights(const float* wT /*[256][65]*/, float* wA /*[16384]*/, float* wdust /*[256]*/);
 void detector_pack_weights16(const float* wT /*[256][65]*/, uint16_t* wA16 /*[32768]: split-fp16 A fragments*/);
-int detector_head_mfma16(hipStream_t stream, const void* in_f16, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
+int detector_head_mfma16(hipStream_t stream, int in_precision /* OMNI_PREC_F16: fp16 activations; else fp32 ones, split (hi, lo) on the fly */, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
                          const float* bias, float* semi, int n_cu, const DetCand& dc = DetCand{});
 int detector_head_mfma(hipStream_t stream, int precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc,
                        const float* wA, const float* wdust, const float* bias, float* semi, int n_cu, const DetCand& dc = DetCand{});
@@ -128,6 +128,10 @@ int l2norm_channels(hipStream_t stream, float* desc_nhwc, int64_t n_cells);
 // convDb + channel L2 norm fused (fp16 activations): in = NHWC fp16 with pixel stride in_cstride halfs, already offset to the 256 input
 // channels; wfrag from convdb_pack_weights; out = [n_pixels][256] f32, unit-norm per pixel
 void convdb_pack_weights(const float* w /*[256][256]*/, uint16_t* frag /*[65536]*/);
+// OMNI_PREC_SPLIT: the same pass over fp32 rows with split (hi, lo) operands on the fp16 matrix cores (fp32-class); in = [n_pixels][in_cstride] f32
+void convdb_pack_weights_split(const float* w /*[256][256]*/, uint16_t* frag_hi /*[65536]*/, uint16_t* frag_lo /*[65536]*/);
+int convdb_l2norm_split(hipStream_t stream, const omni_ctx* ctx, const float* in_f32, int in_cstride, const void* wfrag_hi, const void* wfrag_lo, const float* bias,
+                        float* out, int64_t n_pixels);
 int convdb_l2norm(hipStream_t stream, const omni_ctx* ctx, const void* in_f16, int in_cstride, const void* wfrag, const float* bias,
                   float* out, int64_t n_pixels);
 

@@ -1854,8 +1854,12 @@ int detector_head_mfma(hipStream_t st, int precision, const void* in, int in_str
 // cycles per 16 input channels instead of 16 MFMAs of 64 cycles.  B operand = 16 bytes of the cell's channels straight from HBM (no
 // conversion); the dustbin logit stays a VALU dot product over the same registers.  Epilogue (softmax over 65, depth-to-space) unchanged.
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(DETM_THREADS)
-detector_head_mfma16_kernel(const _Float16* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
+// T = float (OMNI_PREC_SPLIT: the heads layer's fp32 output): the activations are split as well, x = hi + lo in registers right behind the load, and the
+// product is the three terms of the split convolutions, w_lo x_hi + w_hi x_hi + w_hi x_lo (6 MFMAs of 32 cycles per 16 input channels where the exact-f32
+// kernel issues 16 of 64); the dustbin logit stays an fmaf chain over the fp32 values.
+template <typename T>
+__global__ void __launch_bounds__(DETM_THREADS, 2)      // two waves per SIMD: the launcher puts two workgroups on a CU (66 KB of LDS each); unbounded, hipcc took 290 registers = one
+detector_head_mfma16_kernel(const T* __restrict__ in, int in_stride, int in_off, int n_cells, int Hc, int Wc,
                             const uint4* __restrict__ wA16 /*[hl 2][m 2][s 16][lane 64] x 8 halfs*/, const float* __restrict__ wdust /*[256]*/,
                             const float* __restrict__ bias /*[65]*/, float* __restrict__ semi, DetCand dc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1873,31 +1877,41 @@ detector_head_mfma16_kernel(const _Float16* __restrict__ in, int in_stride, int 
     for (int f = blockIdx.x * 4 + wave; f < n_frag; f += gridDim.x * 4) {
         const int cell = f * 32 + n;
         const bool valid = cell < n_cells;
-        const _Float16* ip = in + (int64_t)(valid ? cell : n_cells - 1) * in_stride + in_off + hh * 8;     // k-step s: channels [16 s + 8 hh, + 8)
+        const T* ip = in + (int64_t)(valid ? cell : n_cells - 1) * in_stride + in_off + hh * 8;     // k-step s: channels [16 s + 8 hh, + 8)
         floatx16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
         float dust = 0.f;
-        half8_t xr[8], xn[8];
+        typedef T xvec_t __attribute__((ext_vector_type(8)));               // a lane's 8 channels of one k-step: 16 bytes of halfs or 32 bytes of floats
+        constexpr int KH = sizeof(T) == 2 ? 8 : 4, NCH = 16 / KH;     // k-steps per prefetched chunk: 64 registers of activations in flight either way
+        xvec_t xr[KH], xn[KH];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const half8_t*>(ip + i * 16);
+        for (int i = 0; i < KH; ++i) xr[i] = *reinterpret_cast<const xvec_t*>(ip + i * 16);
 #pragma unroll 1
-        for (int hf = 0; hf < 2; ++hf) {                      // two halves of 8 k-steps; the second half's loads fly during the first
-            if (hf == 0) {
+        for (int hf = 0; hf < NCH; ++hf) {                    // chunks of KH k-steps; the next chunk's loads fly during the current one
+            if (hf + 1 < NCH) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xn[i] = *reinterpret_cast<const half8_t*>(ip + (8 + i) * 16);
+                for (int i = 0; i < KH; ++i) xn[i] = *reinterpret_cast<const xvec_t*>(ip + ((hf + 1) * KH + i) * 16);
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int sidx = hf * 8 + t;
+            for (int t = 0; t < KH; ++t) {
+                const int sidx = hf * KH + t;
                 const half8_t a0h = __builtin_bit_cast(half8_t, wl[((0 * 2 + 0) * 16 + sidx) * 64 + lane]);
                 const half8_t a1h = __builtin_bit_cast(half8_t, wl[((0 * 2 + 1) * 16 + sidx) * 64 + lane]);
                 const half8_t a0l = __builtin_bit_cast(half8_t, wl[((1 * 2 + 0) * 16 + sidx) * 64 + lane]);
                 const half8_t a1l = __builtin_bit_cast(half8_t, wl[((1 * 2 + 1) * 16 + sidx) * 64 + lane]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, xr[t], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, xr[t], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, xr[t], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, xr[t], acc1, 0, 0, 0);
+                half8_t xh;
+                if constexpr (sizeof(T) == 2) xh = xr[t]; else xh = __builtin_convertvector(xr[t], half8_t);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, xh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, xh, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, xh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, xh, acc1, 0, 0, 0);
+                if constexpr (sizeof(T) == 4) {               // the activation's lo half: x - half(x), exactly representable differences rounded once
+                    typedef float f8_t __attribute__((ext_vector_type(8)));
+                    const half8_t xl = __builtin_convertvector(xr[t] - __builtin_convertvector(xh, f8_t), half8_t);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, xl, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, xl, acc1, 0, 0, 0);
+                }
                 const float4 d0 = *reinterpret_cast<const float4*>(wd + sidx * 16 + hh * 8), d1 = *reinterpret_cast<const float4*>(wd + sidx * 16 + hh * 8 + 4);
                 dust = fmaf((float)xr[t][0], d0.x, dust); dust = fmaf((float)xr[t][1], d0.y, dust);
                 dust = fmaf((float)xr[t][2], d0.z, dust); dust = fmaf((float)xr[t][3], d0.w, dust);
@@ -1905,7 +1919,7 @@ detector_head_mfma16_kernel(const _Float16* __restrict__ in, int in_stride, int 
                 dust = fmaf((float)xr[t][6], d1.z, dust); dust = fmaf((float)xr[t][7], d1.w, dust);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xr[i] = xn[i];
+            for (int i = 0; i < KH; ++i) xr[i] = xn[i];
         }
         dust = dust + __shfl_xor(dust, 32, 64) + dust_bias;
         float l0[16], l1[16], mx = dust;
@@ -1952,15 +1966,21 @@ void detector_pack_weights16(const float* wT /*[256][65]*/, uint16_t* wA16 /*2*2
                 }
 }
 
-int detector_head_mfma16(hipStream_t st, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
+int detector_head_mfma16(hipStream_t st, int in_precision, const void* in, int in_stride, int in_off, int batch, int Hc, int Wc, const void* wA16, const float* wdust,
                          const float* bias, float* semi, int n_cu, const DetCand& dc) {
     const int n_cells = batch * Hc * Wc;
     const size_t smem = (size_t)4096 * 16 + (256 + 80) * 4;
     int grid = cdiv(cdiv(n_cells, 32), 4);
     if (n_cu > 0 && grid > 2 * n_cu) grid = 2 * n_cu;         // 66 KB of LDS: two workgroups per CU
-    OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(detector_head_mfma16_kernel, dim3(grid), dim3(DETM_THREADS), smem, st, (const _Float16*)in, in_stride, in_off, n_cells, Hc, Wc,
-                       (const uint4*)wA16, wdust, bias, semi, dc);
+    if (in_precision == OMNI_PREC_F16) {
+        OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma16_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(detector_head_mfma16_kernel<_Float16>, dim3(grid), dim3(DETM_THREADS), smem, st, (const _Float16*)in, in_stride, in_off, n_cells, Hc, Wc,
+                           (const uint4*)wA16, wdust, bias, semi, dc);
+    } else {                                                  // fp32 activations, split on the fly (OMNI_PREC_SPLIT)
+        OMNI_HIP_TRY(hipFuncSetAttribute((const void*)detector_head_mfma16_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(detector_head_mfma16_kernel<float>, dim3(grid), dim3(DETM_THREADS), smem, st, (const float*)in, in_stride, in_off, n_cells, Hc, Wc,
+                           (const uint4*)wA16, wdust, bias, semi, dc);
+    }
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
@@ -2064,6 +2084,123 @@ int convdb_l2norm(hipStream_t st, const omni_ctx* ctx, const void* in_f16, int i
     const int64_t grid = tiles < cus ? tiles : cus;                     // one persistent workgroup per CU (152 VGPRs x 8 waves)
     hipLaunchKernelGGL(convdb_l2norm_kernel, dim3((unsigned)grid), dim3(64 * CDB_WAVES), 0, st, (const _Float16*)in_f16, in_cstride,
                        (const _Float16*)wfrag, bias, out, n_pixels);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// OMNI_PREC_SPLIT: convDb (1 x 1, 256 -> 256) + the per-row L2 norm over fp32 rows -- the compact [key point][corner] rows conv_split_c128_sparse leaves --
+// on the fp16 matrix cores with split operands, in ONE pass.  Structure of convdb_l2norm_kernel (8 waves x 32 output channels with register-resident A
+// fragments, 32-row tiles global -> registers two tiles ahead -> swizzled LDS, sum of squares across the waves through LDS); the weights are (hi, lo)
+// fragment pairs (128 registers), a row's fp32 values are split into a hi and a lo tile as they are parked in LDS, and a k-step is the three terms
+// w_lo x_hi + w_hi x_hi + w_hi x_lo.  Replaces an exact-f32 MFMA convolution (16 MFMAs of 64 cycles per 16 channels, 126 us per 51 200 rows) and a separate
+// normalisation pass; descriptors only (north_star: 1e-3): the key points do not see it.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * CDB_WAVES)
+convdb_l2norm_split_kernel(const float* __restrict__ in, int in_cstride, const _Float16* __restrict__ wfrag_hi, const _Float16* __restrict__ wfrag_lo,
+                           const float* __restrict__ bias, float* __restrict__ out, int64_t n_pixels) {
+    __shared__ __attribute__((aligned(16))) char tile[2][2][CDB_PX * 512];           // [buffer][hi | lo]
+    __shared__ float part[2][CDB_WAVES][CDB_PX];
+    __shared__ float sbias[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kg = lane >> 5;
+    half8_t wh[16], wl[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        wh[ks] = *reinterpret_cast<const half8_t*>(wfrag_hi + (((size_t)wave * 16 + ks) * 64 + lane) * 8);
+        wl[ks] = *reinterpret_cast<const half8_t*>(wfrag_lo + (((size_t)wave * 16 + ks) * 64 + lane) * 8);
+    }
+    if (tid < 256) sbias[tid] = bias[tid];
+    const int64_t n_tiles = (n_pixels + CDB_PX - 1) / CDB_PX;
+    const int64_t G = gridDim.x;
+    // staging: thread -> 4 of the tile's 2048 float4 (q = tid + 512 j: row q >> 6, float4 q & 63 = channels 4 (q & 63) ..), 1 KiB per row coalesced
+    const int f4 = tid & 63, chunk = f4 >> 1, hb = (f4 & 1) * 8;                       // its 8 bytes inside the 16-byte chunk of 8 halfs
+    auto load4 = [&](int64_t t, int j) -> float4 {
+        int64_t px = t * CDB_PX + (tid >> 6) + 8 * j;
+        px = px < n_pixels ? px : n_pixels - 1;                                        // ragged last tile: duplicates, never stored
+        return *reinterpret_cast<const float4*>(in + px * in_cstride + f4 * 4);
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t t = blockIdx.x;
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ra[j] = t < n_tiles ? load4(t, j) : zero4; rb[j] = t + G < n_tiles ? load4(t + G, j) : zero4; }
+    int buf = 0;
+    for (; t < n_tiles; t += G) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int spx = (tid >> 6) + 8 * j;
+            const int off = spx * 512 + ((chunk ^ (spx & 15)) << 4) + hb;
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+            const f4_t v = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+            const h4_t hi = __builtin_convertvector(v, h4_t);
+            const h4_t lo = __builtin_convertvector(v - __builtin_convertvector(hi, f4_t), h4_t);
+            *reinterpret_cast<h4_t*>(tile[buf][0] + off) = hi;
+            *reinterpret_cast<h4_t*>(tile[buf][1] + off) = lo;
+            ra[j] = rb[j];
+        }
+        if (t + 2 * G < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb[j] = load4(t + 2 * G, j);
+        }
+        __syncthreads();              // tile visible (the buffer's previous readers are two barriers behind)
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const char* bph = tile[buf][0] + n * 512;
+        const char* bpl = tile[buf][1] + n * 512;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int o = ((2 * ks + kg) ^ (n & 15)) << 4;
+            const half8_t xh = *reinterpret_cast<const half8_t*>(bph + o), xl = *reinterpret_cast<const half8_t*>(bpl + o);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl, acc, 0, 0, 0);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + sbias[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg];
+            acc[r] = v;
+            ss = fmaf(v, v, ss);
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        if (lane < 32) part[buf][wave][n] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < CDB_WAVES; ++w) tot += part[buf][w][n];
+        const float nrm = sqrtf(tot);
+        const int64_t px = t * CDB_PX + n;
+        if (px < n_pixels) {
+            float* op = out + px * 256 + 32 * wave + 4 * kg;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = acc[4 * g] / nrm; v.y = acc[4 * g + 1] / nrm; v.z = acc[4 * g + 2] / nrm; v.w = acc[4 * g + 3] / nrm;
+                *reinterpret_cast<float4*>(op + 8 * g) = v;
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// w (fp32) -> the two fragment arrays of convdb_l2norm_split: hi = half(w), lo = half(w - hi), each in convdb_pack_weights' order
+void convdb_pack_weights_split(const float* w /*[256][256]*/, uint16_t* frag_hi /*[65536]*/, uint16_t* frag_lo /*[65536]*/) {
+    std::vector<float> lo(65536);
+    for (int i = 0; i < 65536; ++i) lo[i] = w[i] - h2f(f2h_bits(w[i]));
+    convdb_pack_weights(w, frag_hi);
+    convdb_pack_weights(lo.data(), frag_lo);
+}
+
+int convdb_l2norm_split(hipStream_t st, const omni_ctx* ctx, const float* in_f32, int in_cstride, const void* wfrag_hi, const void* wfrag_lo, const float* bias,
+                        float* out, int64_t n_pixels) {
+    const int64_t tiles = cdiv64(n_pixels, CDB_PX);
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const int64_t grid = tiles < cus ? tiles : cus;
+    hipLaunchKernelGGL(convdb_l2norm_split_kernel, dim3((unsigned)grid), dim3(64 * CDB_WAVES), 0, st, in_f32, in_cstride, (const _Float16*)wfrag_hi,
+                       (const _Float16*)wfrag_lo, bias, out, n_pixels);
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }

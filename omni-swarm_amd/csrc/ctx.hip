@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
 namespace {
 struct HwQueues {
     HwQueues() {
-        const int n = omni::config_process()[omni::CFG_HW_QUEUES];
+        const int n = omni::config_option_now(omni::CFG_HW_QUEUES);      // this option only: the process-wide table stays unresolved until something uses it
         if (n > 0) { char v[16]; snprintf(v, sizeof(v), "%d", n); setenv("GPU_MAX_HW_QUEUES", v, 0); }
     }
 } g_hw_queues;

@@ -53,6 +53,8 @@ struct SpSparseDesc {
     // OMNI_PREC_SPLIT: convDa itself only at those cells (conv_split_c128_sparse) -- a4b_split: conv4b's split-64 frames; the rows land in cx directly
     // (cda_f32 is then not read); da_w / da_bias / da_g32_first as above, da_inv = the fused heads layer's split_inv
     const void* a4b_split = nullptr; float da_inv = 0.f;
+    // ... and convDb + the norm over those rows with split operands too (convdb_l2norm_split; null = the exact-f32 convolution + l2norm_channels)
+    const void* wdb_hi = nullptr; const void* wdb_lo = nullptr;
     // the detector head already thresholded the map (conv.h DetCand): SpPostBuffers::cand_bits is filled; sp_mask_kernel compacts it into the candidate
     // lists and makes the window masks of the candidates only -- sp_cand_kernel, which re-reads the whole heat map through LDS tiles, is not launched
     bool cand_fused = false;

@@ -626,12 +626,16 @@ int sp_postprocess(hipStream_t stream, const SpPostParams& p, const SpPostBuffer
                                b.kps_xy, b.n_kps, sparse.cx);
             OMNI_LAUNCH_CHECK();
         }
-        ConvArgs a;
-        a.in = sparse.cx; a.out = sparse.cy; a.w_packed = sparse.wdb_f32; a.bias = sparse.bias; a.batch = 1; a.H = 8; a.W = (int)(n_rows / 8); a.cin = 256;
-        a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false; a.out_f32 = true; a.in_cstride = 256; a.n_cu = sparse.n_cu; a.zero_page = sparse.zero_page;
-        int rc = conv_mfma(stream, OMNI_PREC_F32, a);
-        if (rc) return rc;
-        if ((rc = l2norm_channels(stream, sparse.cy, n_rows))) return rc;
+        int rc;
+        if (sparse.a4b_split && sparse.wdb_hi) {
+            if ((rc = convdb_l2norm_split(stream, sparse.ctx, sparse.cx, 256, sparse.wdb_hi, sparse.wdb_lo, sparse.bias, sparse.cy, n_rows))) return rc;
+        } else {
+            ConvArgs a;
+            a.in = sparse.cx; a.out = sparse.cy; a.w_packed = sparse.wdb_f32; a.bias = sparse.bias; a.batch = 1; a.H = 8; a.W = (int)(n_rows / 8); a.cin = 256;
+            a.cout = 256; a.ksize = 1; a.relu = false; a.pool = false; a.out_f32 = true; a.in_cstride = 256; a.n_cu = sparse.n_cu; a.zero_page = sparse.zero_page;
+            if ((rc = conv_mfma(stream, OMNI_PREC_F32, a))) return rc;
+            if ((rc = l2norm_channels(stream, sparse.cy, n_rows))) return rc;
+        }
         hipLaunchKernelGGL(sp_sample_compact_kernel, dim3(p.max_num, batch), dim3(256), 0, stream, sparse.cy, p.width, p.height, p.max_num, b.kps_xy, b.n_kps,
                            b.raw_desc);
         OMNI_LAUNCH_CHECK();

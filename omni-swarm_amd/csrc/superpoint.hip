@@ -56,6 +56,7 @@ struct omni_sp {
     bool dense_valid = false, dense_possible = false;   // `draw` holds / `heads` can still produce the dense map of the last forward pass
     int last_batch = 0;
     void* wDbFrag = nullptr;                    // convDb as register-resident fp16 A fragments (fused convDb + L2 norm, fp16 path)
+    void* wDbFragHi = nullptr; void* wDbFragLo = nullptr;      // OMNI_PREC_SPLIT: the same as (hi, lo) pairs (convdb_l2norm_split); OMNI_SP_SPLIT_DB=0: exact-f32 convDb
     float* bias_heads = nullptr;             // [512]
     float* lut = nullptr;
     uint16_t* w1a_frag = nullptr;            // conv1a split-fp16 A fragments (fused conv1a+conv1b, fp16 path)
@@ -213,6 +214,12 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         std::vector<uint16_t> db(65536);
         convdb_pack_weights(w->weight[LDB], db.data());
         if ((rc = dev_upload(&s->wDbFrag, db.data(), db.size() * 2, st))) return rc;
+    }
+    if (s->precision == OMNI_PREC_SPLIT && s->cfg[CFG_SP_SPLIT_DB] != 0) {
+        std::vector<uint16_t> hi(65536), lo(65536);
+        convdb_pack_weights_split(w->weight[LDB], hi.data(), lo.data());
+        if ((rc = dev_upload(&s->wDbFragHi, hi.data(), hi.size() * 2, st))) return rc;
+        if ((rc = dev_upload(&s->wDbFragLo, lo.data(), lo.size() * 2, st))) return rc;
     }
     if (s->precision == OMNI_PREC_SPLIT) {     // conv1a inside conv1b's kernel (conv1ab_split_fused): its weights x the activation scale, the u8 table
         std::vector<uint16_t> fr(2048);
@@ -443,8 +450,10 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const bool cand_fused = run_post && s->fused_cand && s->conv_variant != 1;
     if (cand_fused) { dc.thres = s->thres; dc.bits = s->pb.cand_bits; }
     if (s->conv_variant == 1) { if ((rc = detector_head(st, PH, s->heads, 512, 0, batch, s->Hc, s->Wc, s->wPbT, s->bias[LPB], s->semi))) return rc; }
-    else if (P == OMNI_PREC_F16 && s->det16) {
-        if ((rc = detector_head_mfma16(st, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi, s->ctx->prop.multiProcessorCount, dc))) return rc;
+    else if ((P == OMNI_PREC_F16 || P == OMNI_PREC_SPLIT) && s->det16) {
+        // fp16: exact operands, split weights; OMNI_PREC_SPLIT: the heads layer's fp32 output split on the fly as well (three terms: fp32-class logits)
+        if ((rc = detector_head_mfma16(st, P == OMNI_PREC_F16 ? OMNI_PREC_F16 : OMNI_PREC_F32, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA16, s->wPbDust, s->bias[LPB], s->semi,
+                                       s->ctx->prop.multiProcessorCount, dc))) return rc;
     } else if ((rc = detector_head_mfma(st, PH, cpa, cpa_stride, 0, batch, s->Hc, s->Wc, s->wPbA, s->wPbDust, s->bias[LPB], s->semi,
                                         s->ctx->prop.multiProcessorCount, dc))) return rc;
     if ((rc = mark())) return rc;
@@ -471,7 +480,8 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (run_post) {
         SpSparseDesc sd;
         if (sparse) { sd.ctx = s->ctx; sd.in_f16 = (const char*)s->heads + (size_t)256 * s->esz; sd.in_cstride = 512; sd.wfrag = s->wDbFrag; sd.bias = s->bias[LDB]; }
-        if (sparse_da32) { sd.ctx = s->ctx; sd.a4b_split = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_inv = s->winv[LPA]; }
+        if (sparse_da32) { sd.ctx = s->ctx; sd.a4b_split = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_inv = s->winv[LPA];
+                           sd.wdb_hi = s->wDbFragHi; sd.wdb_lo = s->wDbFragLo; }
         else if (sparse_da) { sd.a4b = s->a4b; sd.da_w = s->wpk[LPA]; sd.da_bias = s->bias_heads; sd.da_g32_first = 8; sd.da_compact = s->da_compact; }
         if (sparse32) {
             sd.cda_f32 = reinterpret_cast<const float*>(s->heads) + 256; sd.in_cstride = 512; sd.wdb_f32 = s->wpk[LDB]; sd.bias = s->bias[LDB];
@@ -591,7 +601,7 @@ void omni_sp_destroy(omni_sp* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); if (s->bias_s[l]) (void)hipFree(s->bias_s[l]); }
-    void* ptrs[] = {s->wPbA16, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
+    void* ptrs[] = {s->wPbA16, s->wDbFragHi, s->wDbFragLo, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
                     s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->cx32, s->cy32, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_bits, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);

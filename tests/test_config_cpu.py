@@ -15,7 +15,7 @@ VARIANT, TUNING, DEBUG, TEST, STRING = range(5)
 
 # every variant switch and the value that ships: anything else is an A/B or test configuration
 PRODUCTION = {
-    "OMNI_CONV_V1": 0, "OMNI_CONV_RS": 1, "OMNI_RS_TRN": -1, "OMNI_DET16": 1, "OMNI_SP_SPARSE_DESC": 1, "OMNI_SP_SPARSE_DA": 1, "OMNI_SP_FUSED_CAND": 1, "OMNI_SP_MASK_SKIP": 1,
+    "OMNI_CONV_V1": 0, "OMNI_CONV_RS": 1, "OMNI_RS_TRN": -1, "OMNI_DET16": 1, "OMNI_SP_SPARSE_DESC": 1, "OMNI_SP_SPARSE_DA": 1, "OMNI_SP_FUSED_CAND": 1, "OMNI_SP_SPLIT_DB": 1, "OMNI_SP_MASK_SKIP": 1,
     "OMNI_SP_MASK_SKIP_SPLIT": 1, "OMNI_SPLIT_FUSE1A": 1, "OMNI_SPLIT_TRN": -1, "OMNI_CONV_XCD": 1, "OMNI_VLAD_STEM_FUSE": 1, "OMNI_VLAD_UNFUSED": 0, "OMNI_VLAD_MFMA": 1,
     "OMNI_VLAD_SBLOCK": 1, "OMNI_VLAD_FC_MFMA": 1, "OMNI_VLAD_SB_PERSIST": 1, "OMNI_MQ_ROT": 1, "OMNI_INDEX_MIRROR": 1, "OMNI_GEOMETRY_ASYNC": 1, "OMNI_DETECTOR_ASYNC": 1, "OMNI_PIPELINE_ONE_STREAM": 0, "OMNI_PIPELINE_FIFO": -1,
 }
@@ -61,6 +61,18 @@ def test_values_come_from_the_environment_and_ranges_are_enforced(capi, monkeypa
     assert capi.config_value("OMNI_SPLIT_TRN") == -1
     with pytest.raises(capi.OmniError, match="no option"):
         capi.config_value("OMNI_NO_SUCH_SWITCH")
+
+
+def test_loading_the_library_freezes_no_process_wide_option(capi, monkeypatch):
+    """the library's load-time initializer used to resolve the whole process-wide table (every launch-site hook and index threshold frozen at
+    dlopen, before a caller could set anything).  It now reads OMNI_HW_QUEUES alone: a process-wide option set AFTER the library was loaded -- and before
+    anything used one -- is what omni_config_value reports and what the first use will freeze (no GPU here: nothing has used one)."""
+    capi.lib()
+    for name, v in (("OMNI_CONV_XCD", "0"), ("OMNI_INDEX_MIRROR", "0"), ("OMNI_INDEX_MIRROR_MIN_ROWS", "12345")):
+        monkeypatch.setenv(name, v)
+        assert capi.config_value(name) == int(v)
+        monkeypatch.delenv(name)
+        assert capi.config_value(name) == {o["env"]: o["default"] for o in capi.config_table()}[name]
 
 
 def test_nothing_reads_the_environment_outside_the_table(capi):

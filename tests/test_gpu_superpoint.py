@@ -167,14 +167,18 @@ def test_f16_sparse_descriptors_are_bit_identical_to_the_dense_map_path(omni, ct
             assert np.array_equal(res[flag][2][0][1], res[flag][0][nb - 1][1])          # batch 1 == batch n, sparse paths
 
 
-@pytest.mark.parametrize("prec", ["PREC_F32", "PREC_SPLIT"])
-def test_fp32_sparse_descriptor_head_is_bit_identical_to_the_dense_map_path(omni, ctx, monkeypatch, prec):
+@pytest.mark.parametrize("prec,split_db", [("PREC_F32", "1"), ("PREC_SPLIT", "0"), ("PREC_SPLIT", "1")])
+def test_fp32_sparse_descriptor_head_is_bit_identical_to_the_dense_map_path(omni, ctx, monkeypatch, prec, split_db):
     """OMNI_PREC_F32 / OMNI_PREC_SPLIT: convDb + L2 norm in exact f32 only at the cells around the key points (gather -> the dense path's own 1x1
     convolution kernel and per-cell norm on the compact rows -> sampling) against the dense map + sp_sample_kernel (OMNI_SP_SPARSE_DESC=0): same
     descriptors BIT FOR BIT -- with and without PCA, odd sizes, few / many / no key points, an odd number of rows (the compact buffer is padded to
-    a multiple of 8), several images per launch; omni_sp_get_dense after a sparse pass == the dense pass's map."""
+    a multiple of 8), several images per launch; omni_sp_get_dense after a sparse pass == the dense pass's map.
+    OMNI_PREC_SPLIT's default (OMNI_SP_SPLIT_DB=1, round 5) runs convDb + norm over those rows with split (hi, lo) operands on the fp16 matrix cores
+    (convdb_l2norm_split): fp32-class -- the same key points and scores, descriptors within 2e-6 of the exact-f32 path (measured 1.3e-7; bar 1e-3)."""
     weights = S.synth_weights(0)
     comp, mean = synth.pca()
+    monkeypatch.setenv("OMNI_SP_SPLIT_DB", split_db)
+    exact = not (prec == "PREC_SPLIT" and split_db == "1")
     for (h, w, nb, thr, maxn, pca) in ((480, 600, 2, 0.015, 200, True), (96, 128, 3, 0.015, 37, False), (104, 136, 1, 0.2, 200, True),
                                        (64, 96, 2, 0.001, 1000, True), (64, 96, 1, 0.999, 51, True)):
         imgs = np.stack([synth.image_u8(310 + i, h, w, n_shapes=60) for i in range(nb)])
@@ -190,7 +194,7 @@ def test_fp32_sparse_descriptor_head_is_bit_identical_to_the_dense_map_path(omni
         for b in range(nb):
             (k1, d1, s1), (k0, d0, s0) = res["1"][0][b], res["0"][0][b]
             assert (len(k1) > 0 or thr > 0.9) and np.array_equal(k1, k0) and np.array_equal(s1, s0)
-            assert np.array_equal(d1, d0), (h, w, b, np.abs(d1 - d0).max())
+            assert np.array_equal(d1, d0) if exact else (d1.shape == d0.shape and (d1.size == 0 or np.abs(d1 - d0).max() < 2e-6)), (h, w, b, np.abs(d1 - d0).max())
         assert np.array_equal(res["1"][1][0], res["0"][1][0]) and np.array_equal(res["1"][1][1], res["0"][1][1])
         assert np.array_equal(res["1"][2][0][1], res["1"][0][nb - 1][1])
 
