@@ -214,6 +214,7 @@ __device__ __forceinline__ int mask_bit_offset(int i, int W) {
 
 // ---- NMS2 (:237-310): the alive/dead recursion over the masks + top max_num ------------------------------------------
 #define NMS_RANK_CAP 1024          // keys ranked by counting (beyond that: bitonic fallback)
+#define NMS_RC 8                   // candidates per thread held in registers during the relaxation
 __global__ void __launch_bounds__(NMS_THREADS)
 sp_nms_kernel(const float* __restrict__ semi, int W, int H, int max_num, const int* __restrict__ cand, const uint64_t* __restrict__ masks,
               int* __restrict__ counters, uint64_t* __restrict__ surv_keys, float* __restrict__ kps_xy,
@@ -232,10 +233,25 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int max_num, const i
     uint64_t* sk = surv_keys + (int64_t)b * hw;
     const int n_cand = counters[b * 4 + 0];
 
-    for (int i = tid; i < state_words; i += NMS_THREADS) st[i] = 0u;
+    // a thread's first NMS_RC candidates (8192 per image) live in registers for the whole relaxation: their pixel index and earlier mask are loaded ONCE, all
+    // loads in flight together (round 5: every sweep re-read both from global memory, one dependent L2 round trip per candidate per sweep -- most of
+    // the kernel's 60 us); candidates beyond that (never at the reference's thresholds) keep the global path
+    int pc[NMS_RC];
+    uint64_t me[NMS_RC], ml[NMS_RC];                                  // pixel index, earlier mask, later mask
+#pragma unroll
+    for (int k = 0; k < NMS_RC; ++k) {
+        const int ci = tid + k * NMS_THREADS;
+        pc[k] = ci < n_cand ? cd[ci] : -1;
+        me[k] = ci < n_cand ? mk[2 * (int64_t)ci] : 0ull;
+        ml[k] = ci < n_cand ? mk[2 * (int64_t)ci + 1] : 0ull;
+    }
+    for (int i = tid; i < state_words; i += NMS_THREADS) st[i] = 0u;  // (the loads above fly meanwhile)
     if (tid < 4) sv[tid] = 0;
     __syncthreads();
-    for (int ci = tid; ci < n_cand; ci += NMS_THREADS) {              // grid(vv,uu) = 1 (:259); nothing earlier can kill it -> alive
+#pragma unroll
+    for (int k = 0; k < NMS_RC; ++k)
+        if (pc[k] >= 0) atomicOr(&st[pc[k] >> 4], (me[k] ? ST_UNKNOWN : ST_ALIVE) << ((pc[k] & 15) * 2));     // grid(vv,uu) = 1 (:259); nothing earlier can kill it -> alive
+    for (int ci = tid + NMS_RC * NMS_THREADS; ci < n_cand; ci += NMS_THREADS) {
         const int p = cd[ci];
         atomicOr(&st[p >> 4], (mk[2 * (int64_t)ci] ? ST_UNKNOWN : ST_ALIVE) << ((p & 15) * 2));
     }
@@ -245,7 +261,23 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int max_num, const i
     int iters = 0;
     for (;;) {
         int changed = 0;
-        for (int ci = tid; ci < n_cand; ci += NMS_THREADS) {
+#pragma unroll
+        for (int k = 0; k < NMS_RC; ++k) {
+            const int p = pc[k];
+            if (p < 0 || st_get(st, p) != ST_UNKNOWN) continue;
+            uint64_t m = me[k];
+            bool any_alive = false, any_unknown = false;
+            while (m) {
+                const int i = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const unsigned sq = st_get(st, p + mask_bit_offset(i, W));
+                any_alive |= (sq == ST_ALIVE);
+                any_unknown |= (sq == ST_UNKNOWN);
+            }
+            if (any_alive) { atomicOr(&st[p >> 4], 2u << ((p & 15) * 2)); changed = 1; }            // 01 -> 11 dead
+            else if (!any_unknown) { atomicXor(&st[p >> 4], 3u << ((p & 15) * 2)); changed = 1; }   // 01 -> 10 alive
+        }
+        for (int ci = tid + NMS_RC * NMS_THREADS; ci < n_cand; ci += NMS_THREADS) {
             const int p = cd[ci];
             if (st_get(st, p) != ST_UNKNOWN) continue;
             uint64_t m = mk[2 * (int64_t)ci];
@@ -266,7 +298,20 @@ sp_nms_kernel(const float* __restrict__ semi, int W, int H, int max_num, const i
     }
 
     // survive(): alive and not beaten by any alive neighbour (an earlier one cannot exist; a later one can)
-    for (int ci = tid; ci < n_cand; ci += NMS_THREADS) {
+#pragma unroll
+    for (int k = 0; k < NMS_RC; ++k) {
+        const int p = pc[k];
+        if (p < 0 || st_get(st, p) != ST_ALIVE) continue;
+        uint64_t m = ml[k];
+        bool beaten = false;
+        while (m) {
+            const int i = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            beaten |= (st_get(st, p - mask_bit_offset(i, W)) == ST_ALIVE);
+        }
+        if (!beaten) sk[atomicAdd(&sv[0], 1)] = omni_make_key(sm[p], (uint32_t)p);
+    }
+    for (int ci = tid + NMS_RC * NMS_THREADS; ci < n_cand; ci += NMS_THREADS) {
         const int p = cd[ci];
         if (st_get(st, p) != ST_ALIVE) continue;
         uint64_t m = mk[2 * (int64_t)ci + 1];

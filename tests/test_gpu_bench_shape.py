@@ -210,6 +210,8 @@ def test_cpp_host_loop_equals_python_host_loop(omni, ctx, tmp_path):
     hits_sh = ps.run(20, 0, [pins[0].ctypes.data, pins[1].ctypes.data], 0, pins[2].ctypes.data, True)
     hits_sh += ps.run(16, 20, [pins[0].ctypes.data, pins[1].ctypes.data], 0, None, True)
     assert hits_sh == hits_cpp and ps.db_rows == rows_cpp
+    ex = ps.exchange_us()                                       # device time of the two all-gathers of every exchange unit (HIP events inside the library)
+    assert ex.shape == (5, 2) and (ex > 0).all() and (ex < 1e5).all(), ex
     ps.close()
     # Python loop
     det = detector.LoopDetector(ctx, 1, inner_product_thres=0.3, init_mode_product_thres=0.2, match_index_dist=5, min_loop_num=30, min_direction_loop=3)
