@@ -35,6 +35,18 @@ def main(tag, images):
         # OMNI_PREC_SPLIT: conv1b = the FUSE1A instantiation <C128 = 0, POOL = 1, OUT_F32 = 0, TRN = 0, FUSE1A = 1> (conv1a is built inside it from the u8 image)
         "conv3x3_split_kernel<cin64,POOL,FUSE1A> (conv1b)": lambda n: "conv3x3_split_kernelILb0ELb1ELb0ELb0ELb1" in n,
         "conv3x3_split_c128_sparse_kernel (convDa at the key points)": lambda n: "conv3x3_split_c128_sparse_kernel" in n,
+        # OMNI_PREC_SPLIT, cin = 128 (template arguments <C128, POOL, OUT_F32, TRN, FUSE1A, FZMIX>): the layers VERDICT r4 asked a read traffic of <= 1.5 x the
+        # algorithmic input for (split-64 activations: 512 B per pixel at cin = 128)
+        "conv3x3_split_kernel<cin128,POOL> (conv3b)": lambda n: "conv3x3_split_kernelILb1ELb1ELb0ELb0ELb0" in n,
+        "conv3x3_split_kernel<cin128,TRN> (conv4a, conv4b)": lambda n: "conv3x3_split_kernelILb1ELb0ELb0ELb1ELb0" in n,
+        "conv3x3_split_kernel<cin128,OUT_F32,TRN> (convPa)": lambda n: "conv3x3_split_kernelILb1ELb0ELb1ELb1ELb0" in n,
+        "conv3x3_split_kernel<cin64,POOL> (conv2b)": lambda n: "conv3x3_split_kernelILb0ELb1ELb0ELb0ELb0" in n,
+    }
+    algorithmic_input = {   # bytes of the layer's input tensor per launch of `images` images (what a single pass over it reads)
+        "conv3x3_split_kernel<cin128,POOL> (conv3b)": 120 * 150 * 512 * images,
+        "conv3x3_split_kernel<cin128,TRN> (conv4a, conv4b)": 60 * 75 * 512 * images,
+        "conv3x3_split_kernel<cin128,OUT_F32,TRN> (convPa)": 60 * 75 * 512 * images,
+        "conv3x3_split_kernel<cin64,POOL> (conv2b)": 240 * 300 * 256 * images,
     }
     for key, m in kernels.items():
         rd = mean_by(f"gpurun_out/{tag}_pmc3", "FETCH_SIZE", m)
@@ -44,6 +56,9 @@ def main(tag, images):
             out[key] = {"read_bytes": round(r), "write_bytes": round(w), "bytes_per_launch": round(r + w), "dispatches": len(rd)}
             if "conv" in key:
                 out[key]["images_per_launch"] = images
+            if key in algorithmic_input:
+                out[key]["algorithmic_input_bytes"] = algorithmic_input[key]
+                out[key]["read_over_algorithmic_input"] = round(r / algorithmic_input[key], 3)
     # single-query scans: one entry per database size seen in the pass (launches clustered by FETCH_SIZE; rows = bytes / 16 384 rounded to 1 000)
     rd = sorted(mean_by(f"gpurun_out/{tag}_pmc3", "FETCH_SIZE", lambda n: "ip_scan_kernel<float, 1>" in n))
     clusters = []
