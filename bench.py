@@ -370,7 +370,7 @@ def main():
                                         "bytes_per_rank": {"new_rows": mb * 4 * 4096 * 4, "topk_lists": mb * world * K_SEARCH * 12}}
         if len(lat):
             out["keyframe_latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),
-                                          "micro_batches": int(len(lat)), "keyframes_in_flight": mb * pipelines,
+                                          "micro_batches": int(len(lat)), "keyframes_in_flight": mb * pl.units()[0],
                                           "definition": "start of a micro-batch's upload -> its key frames' detector (+ geometry) step done; the reference is "
                                                         "batch-1 and serial (tensorrt_generic.cpp:58-75)"}
         if geometry:
