@@ -7,6 +7,7 @@
 #include "fisheye_flatten.hpp"
 #include "keyframe_pipeline.hpp"
 #include "loop_net_wire.hpp"
+#include "swarm_loop_params.hpp"
 
 namespace {
 thread_local std::string g_err;
@@ -199,6 +200,89 @@ int omni_fisheye_maps(const double* mei, int img_width, double fov_deg, int cam_
         for (size_t v = 0; v < m.w.size(); ++v) { view_w[v] = m.w[v]; view_h[v] = m.h[v]; std::memcpy(maps[v], m.xy[v].data(), m.xy[v].size() * 4); }
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// The reference's launch files without ROS (host/swarm_loop_params.hpp): launch_xml = the text of a swarm_loop/launch/*.launch file, node_name = the node
+// whose private parameters are read (NULL: "swarm_loop"), args = "name:=value" overrides separated by newlines (NULL: none).  out receives one line per
+// parameter of SwarmLoop::Init (swarm_loop.cpp:215-270), "name=value", then "#mismatch name" for every parameter the file set with a type nh.param<T> refuses
+// (its default stays) and "#unknown name" for every name the node never reads.  Returns 0, 1 on error (omni_pipeline_last_error), 2 when out is too small.
+int omni_swarm_params_from_launch(const char* launch_xml, const char* node_name, const char* args, char* out, int cap) {
+    try {
+        std::map<std::string, std::string> av;
+        if (args) {
+            std::string a(args);
+            size_t i = 0;
+            while (i < a.size()) {
+                size_t j = a.find('\n', i);
+                if (j == std::string::npos) j = a.size();
+                const std::string item = a.substr(i, j - i);
+                const size_t k = item.find(":=");
+                if (k != std::string::npos) av[item.substr(0, k)] = item.substr(k + 2);
+                i = j + 1;
+            }
+        }
+        const omni::SwarmLoopParams p = omni::SwarmLoopParams::from_launch(launch_xml, node_name ? node_name : "swarm_loop", av);
+        std::string o;
+        for (const auto& f : omni::SwarmLoopParams::fields()) o += std::string(f.name) + "=" + p.get(f.name) + "\n";
+        for (const auto& m : p.type_mismatches) o += "#mismatch " + m + "\n";
+        for (const auto& m : p.unknown_parameters) o += "#unknown " + m + "\n";
+        if ((int)o.size() + 1 > cap) { g_err = "omni_swarm_params_from_launch: output buffer too small"; return 2; }
+        std::memcpy(out, o.c_str(), o.size() + 1);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+// A pipeline configured by one of the reference's launch files: image size, SuperPoint threshold / max_num, camera configuration, depth thresholds, PCA
+// files (when the launch file's paths exist as written; pca_comp_csv / pca_mean_csv override them), every detector and geometry threshold, self_id.  What a
+// launch file cannot know stays an argument: the weight files of THIS build (the launch files name TensorRT engines), precision, micro-batch, units in
+// flight, row storage, whether the geometry stage runs.  PINHOLE_DEPTH takes fx fy cx cy from intrinsics4 (NULL: 90 degree field of view, as omni_pipeline_create).
+omni_pipeline* omni_pipeline_create_from_launch(int device, const char* launch_xml, const char* node_name, const char* args, const char* sp_weights, const char* vlad_weights,
+                                                const char* pca_comp_csv, const char* pca_mean_csv, int precision, int microbatch, int pipelines, int storage, int geometry,
+                                                const double* intrinsics4) {
+    try {
+        std::map<std::string, std::string> av;
+        if (args) {
+            std::string a(args);
+            size_t i = 0;
+            while (i < a.size()) {
+                size_t j = a.find('\n', i);
+                if (j == std::string::npos) j = a.size();
+                const std::string item = a.substr(i, j - i);
+                const size_t k = item.find(":=");
+                if (k != std::string::npos) av[item.substr(0, k)] = item.substr(k + 2);
+                i = j + 1;
+            }
+        }
+        const omni::SwarmLoopParams p = omni::SwarmLoopParams::from_launch(launch_xml, node_name ? node_name : "swarm_loop", av);
+        if (p.camera_configuration != 1 && p.camera_configuration != 2)
+            throw std::runtime_error("camera_configuration " + std::to_string(p.camera_configuration) + ": STEREO_FISHEYE (1) and PINHOLE_DEPTH (2) are built");
+        omni::KeyframePipeline::Config c;
+        p.to_pipeline_config(c);
+        c.device = device; c.sp_weights = sp_weights; c.vlad_weights = vlad_weights; c.precision = precision; c.microbatch = microbatch; c.pipelines = pipelines;
+        c.storage = storage; c.geometry = geometry != 0;
+        if (pca_comp_csv) c.pca_comp = pca_comp_csv;
+        if (pca_mean_csv) c.pca_mean = pca_mean_csv;
+        if (intrinsics4) { c.fx = intrinsics4[0]; c.fy = intrinsics4[1]; c.cx = intrinsics4[2]; c.cy = intrinsics4[3]; }
+        else { c.cx = c.width / 2.0; c.cy = c.height / 2.0; c.fx = c.fy = c.width / 2.0; }
+        auto* pl = new omni::KeyframePipeline(c);
+        try { pl->apply_params(p); } catch (...) { delete pl; throw; }
+        return new omni_pipeline{pl};
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+// the table itself: one line per parameter, "name<TAB>I|B|D|S<TAB>default" (swarm_loop.cpp:215-270's order); 0, or 2 when out is too small
+int omni_swarm_params_table(char* out, int cap) {
+    const omni::SwarmLoopParams p;
+    std::string o;
+    for (const auto& f : omni::SwarmLoopParams::fields()) o += std::string(f.name) + "\t" + f.type + "\t" + p.get(f.name) + "\n";
+    if ((int)o.size() + 1 > cap) { g_err = "omni_swarm_params_table: output buffer too small"; return 2; }
+    std::memcpy(out, o.c_str(), o.size() + 1);
+    return 0;
+}
+// ... and onto a pipeline that exists: the thresholds of the detector and the geometry stage (the constructor arguments -- image size, SuperPoint threshold,
+// camera configuration -- are the caller's, from the same parameters)
+int omni_pipeline_apply_launch(omni_pipeline* h, const char* launch_xml, const char* node_name) {
+    try { h->p->apply_params(omni::SwarmLoopParams::from_launch(launch_xml, node_name ? node_name : "swarm_loop")); return 0; }
+    catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
 // omni::KeyframePipeline::host_times: the host thread's milliseconds per unit in {enqueue, wait for the GPU, build messages, detector step, geometry hand-over}

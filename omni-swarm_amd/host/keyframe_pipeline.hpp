@@ -281,6 +281,10 @@ public:
     }
 
     LoopDetectorCore& detector() { return det_; }
+    LoopGeometry& geometry() { return geo_; }
+    // the reference's launch parameters (host/swarm_loop_params.hpp) that reach the detector and the geometry stage AFTER construction (the constructor took
+    // what Config carries: SwarmLoopParams::to_pipeline_config)
+    template <class Params> void apply_params(const Params& p) { p.to_detector(det_); p.to_geometry(geo_); }
 
     // PINHOLE_DEPTH: the depth images (u16 millimetres, height x width, rows packed) of key frames msg_id = first_msg_id .. first_msg_id + n - 1,
     // image i at depth + i * width * height.  Borrowed: they must stay valid until the run() that consumes them returns.  A key frame without

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libomni_host.so")
 SYMBOLS = ["omni_pipeline_last_error", "omni_pipeline_create", "omni_pipeline_destroy", "omni_pipeline_preload", "omni_pipeline_db_rows",
            "omni_pipeline_run", "omni_pipeline_attach_shard", "omni_pipeline_prepare", "omni_pipeline_geometry_stats", "omni_pipeline_sync",
            "omni_pipeline_set_poses", "omni_pipeline_create_pinhole_depth", "omni_pipeline_set_depth", "omni_pipeline_push_keyframe", "omni_pipeline_flush", "omni_pipeline_host_times", "omni_pipeline_get_candidates", "omni_pipeline_get_edges", "omni_pipeline_get_latencies",
-           "omni_pipeline_poll", "omni_pipeline_set_latency", "omni_pipeline_units", "omni_pipeline_get_exchange_us"]
+           "omni_pipeline_poll", "omni_pipeline_set_latency", "omni_pipeline_units", "omni_pipeline_get_exchange_us", "omni_swarm_params_from_launch", "omni_swarm_params_table", "omni_pipeline_apply_launch", "omni_pipeline_create_from_launch"]
 _lib = None
 
 
@@ -43,6 +43,12 @@ def lib():
         L.omni_pipeline_set_latency.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.omni_pipeline_units.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.omni_pipeline_get_exchange_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
+        L.omni_swarm_params_from_launch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.omni_pipeline_apply_launch.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.omni_swarm_params_table.argtypes = [C.c_char_p, C.c_int]
+        L.omni_pipeline_create_from_launch.restype = C.c_void_p
+        L.omni_pipeline_create_from_launch.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                                      C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.omni_pipeline_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.omni_pipeline_geometry_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.omni_pipeline_destroy.argtypes = [C.c_void_p]
@@ -67,6 +73,33 @@ def _err(what):
     return capi.OmniError(f"{what}: {lib().omni_pipeline_last_error().decode()}")
 
 
+def swarm_params_from_launch(launch_xml: str, node_name: str = "swarm_loop", args: dict | None = None):
+    """The node's parameters as one of the reference's launch files sets them (host/swarm_loop_params.hpp; no ROS): -> (dict name -> value text,
+    names whose stored type nh.param<T> refuses (defaults kept), names the node never reads)."""
+    buf = C.create_string_buffer(1 << 16)
+    a = "\n".join(f"{k}:={v}" for k, v in (args or {}).items()).encode() or None
+    if lib().omni_swarm_params_from_launch(launch_xml.encode(), node_name.encode(), a, buf, len(buf)):
+        raise _err("omni_swarm_params_from_launch")
+    vals, mism, unk = {}, [], []
+    for line in buf.value.decode().splitlines():
+        if line.startswith("#mismatch "):
+            mism.append(line[10:])
+        elif line.startswith("#unknown "):
+            unk.append(line[9:])
+        else:
+            k, _, v = line.partition("=")
+            vals[k] = v
+    return vals, mism, unk
+
+
+def swarm_params_table():
+    """[(name, 'I' | 'B' | 'D' | 'S', default text)]: every parameter SwarmLoop::Init reads, in its order (host/swarm_loop_params.hpp)"""
+    buf = C.create_string_buffer(1 << 16)
+    if lib().omni_swarm_params_table(buf, len(buf)):
+        raise _err("omni_swarm_params_table")
+    return [tuple(l.split("\t")) if l.count("\t") == 2 else tuple(l.split("\t")) + ("",) for l in buf.value.decode().split("\n") if l]
+
+
 class KeyframePipeline:
     def __init__(self, device: int, sp_weights_path: str, pca_comp_csv: str, pca_mean_csv: str, vlad_weights_path: str, width=600, height=480,
                  thres=0.02, max_num=200, precision=capi.PREC_F16, microbatch=8, pipelines=0, storage=capi.STORE_F32, self_id=1,
@@ -87,6 +120,24 @@ class KeyframePipeline:
         self._depth = None
         if not self.h:
             raise _err("omni_pipeline_create")
+
+    @classmethod
+    def from_launch(cls, device: int, launch_xml: str, sp_weights_path: str, vlad_weights_path: str, pca_comp_csv: str | None = None, pca_mean_csv: str | None = None,
+                    precision=capi.PREC_F16, microbatch=8, pipelines=0, storage=capi.STORE_F32, geometry=False, node_name="swarm_loop", args: dict | None = None,
+                    intrinsics=None):
+        """A pipeline configured by one of the reference's launch files (omni_pipeline_create_from_launch): image size, thresholds, camera configuration and
+        self_id come from the file; weights, precision and batching are this build's."""
+        self = cls.__new__(cls)
+        a = "\n".join(f"{k}:={v}" for k, v in (args or {}).items()).encode() or None
+        k4 = (C.c_double * 4)(*intrinsics) if intrinsics is not None else None
+        self.microbatch = microbatch
+        self._depth = None
+        self.h = lib().omni_pipeline_create_from_launch(device, launch_xml.encode(), node_name.encode(), a, sp_weights_path.encode(), vlad_weights_path.encode(),
+                                                       pca_comp_csv.encode() if pca_comp_csv else None, pca_mean_csv.encode() if pca_mean_csv else None, precision,
+                                                       microbatch, pipelines, storage, int(geometry), k4)
+        if not self.h:
+            raise _err("omni_pipeline_create_from_launch")
+        return self
 
     def set_depth(self, first_msg_id: int, depth: np.ndarray):
         """depth [n][H][W] u16 millimetres of key frames first_msg_id .. first_msg_id + n - 1 (kept alive by this object)"""
@@ -213,6 +264,11 @@ class KeyframePipeline:
         out = np.zeros(max(n, 1), np.float64)
         lib().omni_pipeline_get_latencies(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), n, int(reset))
         return out[:n]
+
+    def apply_launch(self, launch_xml: str, node_name: str = "swarm_loop"):
+        """the detector's and the geometry stage's thresholds from one of the reference's launch files (omni_pipeline_apply_launch)"""
+        if lib().omni_pipeline_apply_launch(self.h, launch_xml.encode(), node_name.encode()):
+            raise _err("omni_pipeline_apply_launch")
 
     def exchange_us(self, reset: bool = True) -> np.ndarray:
         """sharded mode: [n][2] device microseconds of the two all-gathers (new rows, per-shard top-k lists) of every exchange unit since the last reset"""

@@ -94,3 +94,59 @@ def test_cpp_host_matches_oracle(tmp_path, omni, ctx, golden):
     assert np.array_equal(np.array(out["DETB"], np.int64).reshape(-1, 7), tr)      # on_images_recv_batch: same decisions
     # omni::LoopCamHIP (omni_cam): same key points / descriptors / global descriptor as the blocking calls, self-match diagonal
     assert out["CAM"][:2] == ["1", "1"] and int(out["CAM"][2]) == n, out["CAM"]
+
+
+PARAMS_PIN = os.path.join(ROOT, "oracle", "_ref", "params_pin")
+LAUNCH_DIR = os.path.join(ROOT, "oracle", "_ref", "launch")
+
+
+def _norm(t, v):
+    """one text per value whatever printed it (the pin prints %.17g doubles, Python's reader repr()s them)"""
+    return repr(float(v)) if t == "D" else v
+
+
+def test_launch_parameter_table_is_pinned_to_the_reference_text(omni):
+    """omni::SwarmLoopParams (host/swarm_loop_params.hpp): the 50 parameters of SwarmLoop::Init == the reference's own nh.param<T>(name, variable, default)
+    calls, compiled verbatim (swarm_loop.cpp:205-270 into oracle/_ref/params_pin): same names in the same order, same types, same defaults."""
+    from omni_swarm_amd import pipeline
+    assert os.path.exists(PARAMS_PIN), "make -C oracle ref"
+    ref = [tuple(l.split("\t")) for l in subprocess.run([PARAMS_PIN, "defaults"], capture_output=True, text=True, check=True).stdout.split("\n") if l]
+    ref = [r if len(r) == 3 else r + ("",) for r in ref]
+    mine = pipeline.swarm_params_table()
+    assert len(ref) == len(mine) == 50
+    assert [(n, t, _norm(t, d)) for n, t, d in ref] == [(n, t, _norm(t, d)) for n, t, d in mine]
+    # a launch file that sets nothing = the defaults
+    vals, mism, unk = pipeline.swarm_params_from_launch('<launch><node pkg="swarm_loop" type="swarm_loop_node" name="swarm_loop"/></launch>')
+    assert not mism and not unk and [(n, _norm(t, vals[n])) for n, t, _ in mine] == [(n, _norm(t, d)) for n, t, d in mine]
+
+
+@pytest.mark.parametrize("launch,args", [("realsense.launch", {}), ("realsense.launch", {"self_id": "7", "show": "true", "max_freq": "2.5", "match_index_dist": "3"}),
+                                         ("nodelet-sfisheye.launch", {}), ("node-sfisheye.launch", {"self_id": "2"}), ("pc-outdoor-fisheye.launch", {})])
+def test_reference_launch_files_configure_the_node_as_roslaunch_would(omni, launch, args):
+    """The reference's own launch files through omni::SwarmLoopParams::from_launch against the reference's own parameter block: an independent reader
+    (oracle/launch_ref.py: xml.etree + PyYAML, the YAML library roslaunch calls; roslaunch's convert_value for <param>) produces the typed content of the
+    parameter server, the verbatim block runs on it with roscpp's param<T> conversions, and every variable it sets equals the loader's field.  Includes the
+    quirk the files themselves hold: `loop_cov_pos: 1e-2` is a STRING in YAML 1.1, nh.param<double> refuses it, the node runs with the default 0.013."""
+    from omni_swarm_amd import pipeline
+    from oracle import launch_ref
+    path = os.path.join(LAUNCH_DIR, launch)
+    assert os.path.exists(PARAMS_PIN) and os.path.exists(path), "make -C oracle ref"
+    xml = open(path).read()
+    server = launch_ref.parameter_server(xml, "swarm_loop", args)
+    r = subprocess.run([PARAMS_PIN, "apply"], input="".join(f"{n}\t{t}\t{v}\n" for n, t, v in server), capture_output=True, text=True, check=True)
+    ref = dict(tuple(l.split("\t")) if l.count("\t") == 1 else (l.rstrip("\t"), "") for l in r.stdout.split("\n") if l)
+    vals, mism, unk = pipeline.swarm_params_from_launch(xml, "swarm_loop", args)
+    table = pipeline.swarm_params_table()
+    assert set(ref) == set(vals) == {n for n, _, _ in table}
+    for n, t, _ in table:
+        assert _norm(t, vals[n]) == _norm(t, ref[n]), (n, vals[n], ref[n])
+    names = {n for n, _, _ in table}
+    types = {n: t for n, t, _ in table}
+    ok = {"I": "ID", "D": "ID", "B": "B", "S": "S"}
+    assert sorted(unk) == sorted(n for n, _, _ in server if n not in names)
+    assert sorted(mism) == sorted(n for n, t, _ in server if n in names and t not in ok[types[n]])
+    if "sfisheye" in launch:
+        assert mism == ["loop_cov_pos"] and float(vals["loop_cov_pos"]) == 0.013          # the reference's own files: the YAML-1.1 string
+    if args.get("self_id"):
+        assert vals["self_id"] == args["self_id"]
+    assert "enable_pub_remote_img" in unk                                                  # set by every file, read by no code

@@ -335,6 +335,49 @@ def test_streaming_intake_latency_bound_poll_idle_dispatch_and_partial_units(omn
         ctx.host_free(p)
 
 
+def test_pipeline_configured_by_the_reference_launch_file(omni, ctx, tmp_path):
+    """omni_pipeline_create_from_launch: the reference's own nodelet-sfisheye.launch (400 x 208 flattened views, superpoint_thres 0.02, match_index_dist 5,
+    query_thres 0.3 ...; oracle/_ref/launch, copied by `make -C oracle ref`) configures the C++ pipeline -- same rows and candidates as the pipeline given the
+    same numbers by hand; a camera_configuration this build does not hold (STEREO_PINHOLE = 0) is refused with a message."""
+    import os
+    c = omni.capi
+    from omni_swarm_amd import pipeline, weights
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "launch", "nodelet-sfisheye.launch")
+    assert os.path.exists(path), "make -C oracle ref"
+    xml = open(path).read()
+    vals, _, _ = pipeline.swarm_params_from_launch(xml)
+    w, h = int(vals["width"]), int(vals["height"])
+    assert (w, h) == (400, 208) and vals["camera_configuration"] == "1"
+    sp_w, vw = S.synth_weights(0), V.synth_weights()
+    comp, mean = synth.pca()
+    files = weights.write_pipeline_files(str(tmp_path), sp_w, comp, mean, vw, V.layer_specs(), c.VLAD_KINDS)
+    rng = np.random.default_rng(8)
+    db = rng.standard_normal((80, 4096), dtype=np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    mb = 2
+    kfs = [[synth.image_u8(9100 + 8 * (m % 3) + i, h, w, n_shapes=80) for i in range(8)] for m in range(6)]           # key frames 3..5 revisit 0..2
+    pins = []
+    for u in range(3):
+        a = ctx.host_alloc((8 * mb, h, w), np.uint8)
+        a[:] = np.stack([kfs[2 * u + m][i] for m in range(mb) for i in range(4)] + [kfs[2 * u + m][4 + i] for m in range(mb) for i in range(4)])
+        pins.append(a)
+    a = pipeline.KeyframePipeline.from_launch(0, xml, files["sp"], files["vlad"], files["comp"], files["mean"], c.PREC_F16, mb, 2)
+    b = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], w, h, float(vals["superpoint_thres"]), int(vals["superpoint_max_num"]), c.PREC_F16,
+                                  mb, 2, c.STORE_F32, int(vals["self_id"]), float(vals["query_thres"]), float(vals["init_query_thres"]), int(vals["match_index_dist"]),
+                                  int(vals["min_loop_feature_num"]), int(vals["min_direction_loop"]))
+    hits = []
+    for pl in (a, b):
+        pl.preload(db)
+        hits.append(pl.run(6, 0, [p.ctypes.data for p in pins], 0, None, True))
+        assert pl.db_rows == 80 + 24
+    assert hits[0] == hits[1] and np.array_equal(a.candidates(), b.candidates())
+    a.close(); b.close()
+    with pytest.raises(c.OmniError, match="camera_configuration"):
+        pipeline.KeyframePipeline.from_launch(0, xml.replace("camera_configuration: 1", "camera_configuration: 0"), files["sp"], files["vlad"], files["comp"], files["mean"])
+    for p in pins:
+        ctx.host_free(p)
+
+
 def test_cam_enqueue_host_with_a_row_stride(omni, ctx):
     """omni_cam_enqueue_host from a host block whose rows are padded (stride > width: a cv::Mat ROI / aligned buffer): the 2-D upload packs
     the rows, results equal the packed upload."""
