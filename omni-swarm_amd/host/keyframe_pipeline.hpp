@@ -580,6 +580,14 @@ private:
         const int n = r.n_dirs, M = r.max_num, D = r.desc_dim, nd = cfg_.dirs();
         frames_.resize(lane.cur);
         const int G = r.global_dim;
+        // Without the geometry stage the detector's plan (which rows are appended, which searches run: LoopDetectorCore::begin_batch) reads counts and ids only:
+        // the messages are first built LIGHT (landmark_num, stamps), the detector step is enqueued, and the heavy part -- 75 KB of key points, descriptors and
+        // lifted points per image -- is copied into the frames the detector now holds while its searches run on the GPU.  With the geometry stage the landmarks
+        // can change landmark_num (generate_gray_depth_image_descriptor drops an image below ACCEPT_MIN_3D_PTS): everything is built first, as before.
+        const bool defer_heavy = !cfg_.geometry;
+        auto heavy = [&](ImageDescriptor& im, int i) {
+            fill_image_descriptor(im, r.kps_xy + (size_t)i * M * 2, r.n_kps[i], r.desc + (size_t)i * M * D, D, r.global_desc + (size_t)i * G, G, lift64_);
+        };
         for (int m = 0; m < lane.cur; ++m) {
             FisheyeFrameDescriptor& f = frames_[m];
             const bool streamed = !lane.meta.empty();
@@ -593,7 +601,7 @@ private:
                 const int i = nd * m + d;                                           // image i of the up cameras
                 ImageDescriptor& im = f.images[d];
                 // extractor_img_desc_deepnet (loop_cam.cpp:525-585) + the stamps of generate_stereo_image_descriptor (:362-374)
-                fill_image_descriptor(im, r.kps_xy + (size_t)i * M * 2, r.n_kps[i], r.desc + (size_t)i * M * D, D, r.global_desc + (size_t)i * G, G, lift64_);
+                if (defer_heavy) im.landmark_num = r.n_kps[i]; else heavy(im, i);
                 stamp_image_descriptor(im, stamp, cfg_.self_id, to_msg(view_extrinsic(d, true)), pose, kf_id);
                 if (cfg_.geometry && cfg_.mono()) {
                     // generate_gray_depth_image_descriptor's landmarks (loop_cam.cpp:260-304): read from the depth image under each key point
@@ -641,6 +649,13 @@ private:
         // the appends and the query gather read MobileNetVLAD's output buffer: the lane's next unit must not overwrite it before they have
         check(omni_ctx_order_after(lane.vlad_stream_ctx().get(), index_ctx_.get()), "omni_ctx_order_after");
         host_ms_[3] += since(t_a);
+        if (defer_heavy) {                                                      // the messages' contents, into the frames the detector holds, under its GPU work
+            t_a = std::chrono::steady_clock::now();
+            std::vector<FisheyeFrameDescriptor>& held = det_.held_frames();
+            for (int m = 0; m < lane.cur && m < (int)held.size(); ++m)
+                for (int d = 0; d < nd && d < (int)held[(size_t)m].images.size(); ++d) heavy(held[(size_t)m].images[(size_t)d], nd * m + d);
+            host_ms_[2] += since(t_a);
+        }
         if (!async_detector_) hits += collect_detector();                       // OMNI_DETECTOR_ASYNC=0: wait for it here, as before (A/B)
         return hits;
     }
