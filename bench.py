@@ -483,6 +483,19 @@ def main():
         t = torch.tensor([ok], device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         cpp_host = bool(t.item() > 0.5)
+        if cpp_host:
+            # ... and the communicator itself (ncclCommInitRank over every rank's GPU), once, on a throw-away shard: a node on which RCCL loads but
+            # cannot build its rings gives a line from the fallback path instead of no line
+            uid = shard_uid()
+            try:
+                probe = capi.Shard(ictx, capi.IndexFlatIP(ictx, 4096), rank, world, uid)
+                probe.close()
+            except Exception as e:                            # noqa: BLE001
+                print(f"[bench] rank {rank}: omni_shard_create failed ({e}); falling back to the torch.distributed exchange", file=sys.stderr)
+                ok = 0.0
+            t = torch.tensor([ok], device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            cpp_host = bool(t.item() > 0.5)
     if cpp_host:
         main_leg = cpp_leg(prec, capi.STORE_F32, 4 * args.db_keyframes, args.steps, args.warmup, args.min_time)
         hits = main_leg["loop_candidates_found"]
