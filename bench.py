@@ -611,6 +611,17 @@ def main():
                    traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", precision == "f16", n_img))}
 
     roofline = conv1b_roofline(prof, args.precision)
+    if args.precision != "f32" and rank == 0:
+        # what THIS board's fp16 matrix cores sustain (omni_ctx_mfma_ceiling: back-to-back MFMAs on every SIMD, ~0.1 s): `peak` is the guide's figure at the
+        # 2.4 GHz engine clock; saturated matrix cores run at the clock the power budget leaves (profiles/r05u_mfma_ceiling_probe.log: ~1.95 GHz, 2.0 PFLOP/s)
+        try:
+            cal = ictx.mfma_ceiling(100.0)
+            roofline["measured_ceiling"] = {"tflops": round(cal["tflops"], 1), "sclk_ghz": round(cal["sclk_ghz"], 3), "frac_of_peak": round(cal["tflops"] / PEAK_F16_TFLOPS, 4),
+                                            "frac_of_measured_ceiling": round(roofline["achieved"] / cal["tflops"], 4) if cal["tflops"] > 0 else None,
+                                            "definition": "v_mfma_f32_32x32x16_f16 back to back on every SIMD of this GPU for ~0.1 s, no memory traffic: TFLOP/s by HIP events, "
+                                                          "shader clock by s_memtime against s_memrealtime; extra information -- `frac` stays against `peak`"}
+        except Exception as e:                                    # noqa: BLE001
+            roofline["measured_ceiling"] = {"error": str(e)}
     roofline.update({
         "mask_skip": {"note": "stage times with the fisheye mask on, as the key-frame pipeline runs the network (loop_cam.cpp:536-539): the tiles whose whole "
                               "receptive field lies in the blanked rows hold one constant vector per layer, written once, and are left out of the tile walk "
@@ -630,6 +641,10 @@ def main():
         roofline_parity.update({"stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof_s},
                                 "superpoint_ms_per_keyframe": round(sum(p["ms"] for p in prof_s) / MB, 3),
                                 "tiles_left_out_by_stage": {p["stage"]: round(p["tiles_left_out"], 4) for p in prof_s if p["tiles_left_out"] > 0}})
+        mc = roofline.get("measured_ceiling") or {}
+        if mc.get("tflops"):
+            roofline_parity["measured_ceiling"] = {"tflops": mc["tflops"], "sclk_ghz": mc["sclk_ghz"], "frac_of_measured_ceiling": round(roofline_parity["achieved"] / mc["tflops"], 4),
+                                                   "definition": "see roofline.measured_ceiling"}
     ictx.free(pool_dev)
 
     # ---- p50 loop-match latency on big DBs (node total rows, sharded when N > 1): 100k rows and 100k key frames = 400k rows ----------

@@ -96,6 +96,9 @@ void      omni_ctx_destroy(omni_ctx* ctx);
 int       omni_ctx_sync(omni_ctx* ctx);
 void*     omni_ctx_stream(omni_ctx* ctx);                 /* hipStream_t, for callers that enqueue their own work */
 int       omni_ctx_device_info(omni_ctx* ctx, char* name, int name_len, int* n_cu, int* clock_mhz, size_t* hbm_bytes);
+/* Calibration (measurement support, no counterpart in the reference): v_mfma_f32_32x32x16_f16 back to back on every SIMD for about `ms` milliseconds;
+ * returns what the board sustained (TFLOP/s) and the shader clock it held meanwhile -- bench.py quotes it next to the data-sheet peak. */
+int       omni_ctx_mfma_ceiling(omni_ctx* ctx, float ms, float* tflops, float* sclk_ghz);
 
 void* omni_dev_alloc(omni_ctx* ctx, size_t bytes);        /* HBM; NULL on failure */
 int   omni_dev_free(omni_ctx* ctx, void* p);

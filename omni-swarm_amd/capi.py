@@ -27,7 +27,7 @@ VLAD_KINDS = {"conv3x3": 0, "pw_relu6": 1, "dw3x3_relu6": 2, "pw_linear": 3, "pw
 # every symbol include/omni_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "omni_abi_version", "omni_last_error", "omni_ctx_create", "omni_ctx_create_priority", "omni_ctx_order_after", "omni_memcpy_d2h_async", "omni_ctx_destroy", "omni_ctx_sync", "omni_ctx_stream",
-    "omni_ctx_device_info", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
+    "omni_ctx_device_info", "omni_ctx_mfma_ceiling", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_image_size", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
     "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_sp_stage_tiles_left_out", "omni_sp_mask_skip_plan", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block",
@@ -99,6 +99,7 @@ def lib():
     sig("omni_ctx_sync", C.c_int, [_vp])
     sig("omni_ctx_stream", _vp, [_vp])
     sig("omni_ctx_device_info", C.c_int, [_vp, C.c_char_p, C.c_int, _ip, _ip, C.POINTER(C.c_size_t)])
+    sig("omni_ctx_mfma_ceiling", C.c_int, [_vp, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)])
     sig("omni_dev_alloc", _vp, [_vp, C.c_size_t])
     sig("omni_dev_free", C.c_int, [_vp, _vp])
     sig("omni_host_alloc", _vp, [C.c_size_t])
@@ -241,6 +242,12 @@ class Context:
         ncu, mhz, mem = C.c_int(), C.c_int(), C.c_size_t()
         _check(lib().omni_ctx_device_info(self.h, name, 256, C.byref(ncu), C.byref(mhz), C.byref(mem)))
         return {"name": name.value.decode(), "n_cu": ncu.value, "clock_mhz": mhz.value, "hbm_bytes": mem.value}
+
+    def mfma_ceiling(self, ms: float = 100.0):
+        """what the fp16 matrix cores of this board sustain (calibration: back-to-back MFMAs on every SIMD for ~ms milliseconds)"""
+        tf, ghz = C.c_float(), C.c_float()
+        _check(lib().omni_ctx_mfma_ceiling(self.h, C.c_float(ms), C.byref(tf), C.byref(ghz)))
+        return {"tflops": tf.value, "sclk_ghz": ghz.value}
 
     def alloc(self, nbytes: int) -> int:
         p = lib().omni_dev_alloc(self.h, nbytes)

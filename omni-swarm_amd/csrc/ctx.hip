@@ -98,6 +98,73 @@ int omni_ctx_device_info(omni_ctx* c, char* name, int name_len, int* n_cu, int* 
     return OMNI_OK;
 }
 
+// ---- calibration (measurement support, like omni_sp_profile): what the fp16 matrix cores of THIS board sustain -------------------------------------
+// Every SIMD of the device issues v_mfma_f32_32x32x16_f16 back to back on registers (one wave per SIMD, four independent accumulators, no memory
+// traffic).  The guide's dense peak is 4096 FLOP per clock and CU at the 2.4 GHz engine clock; with the matrix cores saturated the board's power budget
+// decides the clock (tools/probes/mfma_peak_probe.hip, profiles/r05u_*: 1.95 GHz, 2.0 PFLOP/s).  bench.py quotes this next to `roofline.peak`.
+namespace omni {
+typedef _Float16 cal_half8 __attribute__((ext_vector_type(8)));
+typedef float cal_f16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) mfma_ceiling_kernel(int iters, float* sink, unsigned long long* ticks) {
+    cal_half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (float)(threadIdx.x + i)); b[i] = (_Float16)(0.002f * (float)((int)threadIdx.x - i)); }
+    cal_f16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();       // constant 100 MHz
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();           // shader clock
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    if (s == 12345.678f) sink[0] = s;                                      // keeps the loop alive
+    if (threadIdx.x == 0 && blockIdx.x == 0) { ticks[0] = t1 - t0; ticks[1] = r1 - r0; }
+}
+}  // namespace omni
+
+int omni_ctx_mfma_ceiling(omni_ctx* c, float ms, float* tflops, float* sclk_ghz) {
+    OMNI_REQUIRE(c && ms > 0.f && ms <= 2000.f, OMNI_ERR_INVALID, "omni_ctx_mfma_ceiling: null ctx or a duration outside (0, 2000] ms");
+    (void)hipSetDevice(c->device);
+    const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    float* sink = nullptr;
+    unsigned long long* ticks = nullptr;
+    OMNI_HIP_TRY(hipMalloc((void**)&sink, 4));
+    if (hipMalloc((void**)&ticks, 16) != hipSuccess) { (void)hipFree(sink); OMNI_REQUIRE(false, OMNI_ERR_HIP, "omni_ctx_mfma_ceiling: hipMalloc"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = OMNI_OK;
+    float best = 0.f, ghz = 0.f;
+    do {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { omni::set_error("omni_ctx_mfma_ceiling: hipEventCreate"); rc = OMNI_ERR_HIP; break; }
+        // four MFMAs per iteration at ~17 ns each; a quarter of the time as warm-up (clocks settle), then the measured launch
+        const int iters = (int)(ms * 1e6f / (4.f * 17.f)) + 1;
+        for (int pass = 0; pass < 2 && rc == OMNI_OK; ++pass) {
+            const int it = pass == 0 ? iters / 4 + 1 : iters;
+            if (hipEventRecord(e0, c->stream) != hipSuccess) { rc = OMNI_ERR_HIP; break; }
+            hipLaunchKernelGGL(omni::mfma_ceiling_kernel, dim3(cus), dim3(256), 0, c->stream, it, sink, ticks);
+            if (hipGetLastError() != hipSuccess || hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = OMNI_ERR_HIP; break; }
+            float t = 0.f;
+            unsigned long long h[2] = {0, 0};
+            if (hipEventElapsedTime(&t, e0, e1) != hipSuccess || hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = OMNI_ERR_HIP; break; }
+            if (pass == 1 && t > 0.f) {
+                best = (float)((double)cus * 4.0 * it * 4.0 * 32.0 * 32.0 * 16.0 * 2.0 / (t * 1e-3) / 1e12);
+                ghz = h[1] ? (float)((double)h[0] / ((double)h[1] * 10.0)) : 0.f;
+            }
+        }
+        if (rc != OMNI_OK) omni::set_error("omni_ctx_mfma_ceiling: the calibration launch failed");
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink); (void)hipFree(ticks);
+    if (rc != OMNI_OK) return rc;
+    if (tflops) *tflops = best;
+    if (sclk_ghz) *sclk_ghz = ghz;
+    return OMNI_OK;
+}
+
 void* omni_dev_alloc(omni_ctx* c, size_t bytes) {
     if (!c) { omni::set_error("null ctx"); return nullptr; }
     (void)hipSetDevice(c->device);

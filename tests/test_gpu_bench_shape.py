@@ -403,3 +403,16 @@ def test_cam_enqueue_host_with_a_row_stride(omni, ctx):
         assert np.array_equal(a["image_desc"], b["image_desc"]) and np.array_equal(a["ids_up"], b["ids_up"])
     ctx.host_free(packed); ctx.host_free(padded)
     cam.close()
+
+
+def test_mfma_ceiling_calibration_is_sane(omni, ctx):
+    """omni_ctx_mfma_ceiling (what bench.py quotes next to the data-sheet peak): back-to-back fp16 MFMAs on every SIMD cannot beat 4096 FLOP per clock and CU
+    at the clock they ran at, and on an MI355X they sustain well over a PFLOP/s."""
+    cal = ctx.mfma_ceiling(30.0)
+    info = ctx.device_info()
+    assert 0.3 < cal["sclk_ghz"] < 2.6, cal
+    bound = info["n_cu"] * 4096 * cal["sclk_ghz"] * 1e9 / 1e12
+    assert 0.5 * bound < cal["tflops"] <= 1.02 * bound, (cal, bound)
+    with pytest.raises(omni.capi.OmniError):
+        ctx.mfma_ceiling(0.0)
+
