@@ -820,6 +820,10 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
     float4* const xch_mine = reinterpret_cast<float4*>(smem_raw + 2 * SPL_BUF_BYTES) + ((co * 2 + part) * 4) * 64 + lane;
     const uint32_t xch_theirs = lds0 + 2 * SPL_BUF_BYTES + (((co * 2 + (part ^ 1)) * 4) * 64 + lane) * 16;
 
+    auto read_partner = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e.p[i]) : "v"(xch_theirs), "i"(i * 1024) : "memory");
+    };
     const bool tr = trace != nullptr && blockIdx.x == 0 && (tid == 0 || tid == 192);
     int tk = -2;                                   // the trace skips the first two tiles
     auto stamp = [&](int i) {
@@ -848,12 +852,23 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
         half8_t fb[SPL_NB];
+        // cin = 128: the partner's partial sums of the PREVIOUS tile (written before the barrier that ended it), in front of this tile's fragment reads and
+        // consumed in the slices (steps >= 8: the ring's waits cover them; LDS returns in order).  Read HERE, in the block that consumes them -- not behind the
+        // barrier at the end of the previous iteration: registers written by an asm read must not cross the loop's back edge before their data has landed (a
+        // copy there is legal for hipcc and wrong for the kernel; profiles/r05q_*).  The first tile reads what nobody wrote: its epilogue stores nothing.
+        if constexpr (C128) read_partner();
         spl_prime(row_base, n_eff, hh, fb);
         stamp(1);
         __builtin_amdgcn_sched_barrier(0);
         spl_steps<0, Epi::NPK * spl_parts_per_pair<OUT_F32>(), FUSE1A ? 0 : PPW, C128, std::conditional_t<FUSE1A, SplFuseSched, SplPlainSched>>(
             row_base, n_eff, hh, wreg, acc, fb,
-            [&](auto SC) { spl_epi_part<decltype(SC)::value, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part); },
+            [&](auto SC) {
+                // the first part sits behind step 8's ring wait: the partner's sums have landed (LDS returns in order) -- and hipcc must not use them any
+                // earlier: to the compiler the asm reads above DEFINED e.p, nothing stops it from adding e.v + e.p at the top of the block.  An empty asm
+                // that redefines them here (no instruction) pins every use behind this point of the stream
+                if constexpr (C128 && decltype(SC)::value == 0) asm volatile("" : "+v"(e.p[0]), "+v"(e.p[1]), "+v"(e.p[2]), "+v"(e.p[3]));
+                spl_epi_part<decltype(SC)::value, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part);
+            },
             [&](auto JC) { dma_piece(org_n, cur ^ 1, JC); }, fz_step);
         stamp(2);
 #ifdef SPL_STEP_TRACE
@@ -918,15 +933,13 @@ conv3x3_split_kernel(const char* __restrict__ in, void* __restrict__ out, const 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // next tile landed (and the previous tile's stores, issued early in the stream, retired)
         stamp(4);
         __syncthreads();
-        if constexpr (C128) {
-            // the partner's partial sums: in front of the next tile's fragment reads, consumed in the slices (steps >= 8: the ring's waits cover them)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e.p[i]) : "v"(xch_theirs), "i"(i * 1024) : "memory");
-        }
         stamp(5);
         ++tk;
     }
-    if constexpr (C128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (C128) {
+        read_partner();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e.p[0]), "+v"(e.p[1]), "+v"(e.p[2]), "+v"(e.p[3]) :: "memory");
+    }
     spl_epi_all<0, C128, POOL, OUT_F32>(e, bs, inv, relu, hh, part);       // the last tile's
 }
 
