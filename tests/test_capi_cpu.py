@@ -106,3 +106,27 @@ def test_vlad_split_fp16_weight_blob_layout_and_exactness(omni):
                 if rows:
                     assert np.abs(hi[:rows] + lo[:rows] - ref).max() <= 2.0 ** -21 * np.abs(ref).max()
                 assert not hi[rows:].any() and not lo[rows:].any()
+
+def test_header_is_plain_c_and_links_from_a_c_program(omni, tmp_path):
+    """The boundary is a C ABI: include/omni_hip.h compiles as C99 (-pedantic: no C++ in it), and a C program built with gcc alone links against
+    libomni_hip.so and reads its ABI version -- what a cgo / JNI / ctypes binding relies on (no GPU needed: no compute call)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "omni_hip.h"\n'
+                   'int main(void) {\n'
+                   '    int v = 0;\n'
+                   '    if (omni_abi_version() != OMNI_ABI_VERSION) return 1;\n'
+                   '    if (omni_config_value("OMNI_SP_SPARSE_DA", &v) != OMNI_OK || v != 1) return 2;\n'
+                   '    if (omni_ctx_mfma_ceiling(NULL, 1.0f, NULL, NULL) == OMNI_OK) return 3;      /* argument errors are codes, not aborts */\n'
+                   '    printf("abi %d: %s\\n", omni_abi_version(), omni_last_error());\n'
+                   '    return 0;\n}\n')
+    libdir = os.path.join(ROOT, "omni-swarm_amd", "lib")
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lomni_hip",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    for k in [k for k in env if k.startswith("OMNI_")]:
+        env.pop(k)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("abi 2:"), (r.returncode, r.stdout, r.stderr)
