@@ -8,6 +8,7 @@
 #include "keyframe_pipeline.hpp"
 #include "loop_net_wire.hpp"
 #include "swarm_loop_params.hpp"
+#include "omni_host.h"      // include/: the declarations of everything below (a mismatch is a compile error)
 
 namespace {
 thread_local std::string g_err;

@@ -130,3 +130,23 @@ def test_header_is_plain_c_and_links_from_a_c_program(omni, tmp_path):
         env.pop(k)
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("abi 2:"), (r.returncode, r.stdout, r.stderr)
+
+def test_host_library_exports_what_its_c_header_declares(tmp_path):
+    """include/omni_host.h declares the C entry points of libomni_host.so (the C++ key-frame loop behind plain C): valid C99, every declaration exported,
+    nothing exported that is not declared (host_capi.cpp includes the header, so a signature mismatch is a compile error), and the Python bindings
+    (pipeline.py, flatten.py) use exactly this set."""
+    import re
+    import subprocess
+    hdr_path = os.path.join(ROOT, "include", "omni_host.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr_path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = re.sub(r"/\*.*?\*/", "", open(hdr_path).read(), flags=re.S)                       # declarations only
+    declared = set(re.findall(r"\b(omni_[a-z0-9_]+)\s*\(", text))
+    lib = os.path.join(ROOT, "omni-swarm_amd", "lib", "libomni_host.so")
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if l.split() and l.split()[-1].startswith("omni_") and " T " in l}
+    assert declared == exported, (sorted(declared - exported), sorted(exported - declared))
+    src = open(os.path.join(ROOT, "omni-swarm_amd", "pipeline.py")).read()
+    bound = set(re.findall(r'"(omni_[a-z0-9_]+)"', re.search(r"SYMBOLS\s*=\s*\[(.*?)\]", src, re.S).group(1))) | {"omni_fisheye_maps"}      # (flatten.py binds the last one)
+    assert bound == declared, (sorted(bound ^ declared))
+    assert len(declared) == 28
