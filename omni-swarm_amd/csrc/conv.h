@@ -73,6 +73,14 @@ int split_to_nchw_f32(hipStream_t stream, const void* in_split, float* out, int 
 // matrix cores with split operands); a = the conv1b layer (a.in unused); w1a_frag from conv1a_split_pack_fused, lut_hl from conv1a_make_split_lut
 void conv1a_split_pack_fused(const float* w /*[64][9]*/, const float* bias /*[64]*/, uint16_t* frag /*[2048]*/);
 int conv1ab_split_fused(hipStream_t stream, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const void* w1a_frag, const uint32_t* lut_hl);
+// OMNI_PREC_SPLIT, Winograd F(2x2,3x3) form of the cin = 64 layers (conv_wino.hip): a.in = "raw-32" frames (the zero frame below, 64 fp32 channels per pixel,
+// values x conv_split_act_scale()); a.w_packed / a.split_inv from conv_pack_weights_wino (cin * cout * 16 * 2 halfs); a.bias = act scale x bias;
+// a.out = raw-32 frames (next layer: Winograd) or, out_split, split-64 frames (next layer: a direct kernel)
+float conv_pack_weights_wino(const float* w_oihw, int cin, int cout, uint16_t* out);
+int conv_wino(hipStream_t stream, const ConvArgs& a, bool out_split);
+int conv1ab_wino_fused(hipStream_t stream, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const void* w1a_frag, const uint32_t* lut_hl, bool out_split);
+int split_to_raw32(hipStream_t stream, const void* in_split, void* out_raw, int batch, int C, int H, int W);      // split-64 frames -> raw-32 frames (out of place)
+int raw32_to_nchw_f32(hipStream_t stream, const void* in_raw, float* out, int batch, int C, int H, int W);        // test hook
 // A split-64 H x W map lives in a zero frame of split_frame_h(H) rows x split_frame_w(W) pixels, pixel (y, x) at row y + 1, column x + 1:
 // one pixel of zero padding all round plus the overhang of the last 32-pixel tile in either direction.  The frame must be zeroed once
 // (the kernels only ever write the map).

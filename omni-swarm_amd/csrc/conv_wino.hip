@@ -1,0 +1,557 @@
+// OMNI_PREC_SPLIT, Winograd form: the cin = 64 3x3 convolutions of the SuperPoint graph (conv1b, conv2a, conv2b: swarm_loop/superpoint.ipynb:144-147,
+// 65 % of the network's FLOPs) as F(2x2, 3x3) -- 16 products per 2 x 2 outputs and input channel instead of 36 -- still at fp32-class accuracy on the
+// fp16 matrix cores:
+//     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        d = 4 x 4 input patch, g = 3 x 3 filter, B^T, G, A^T = the F(2x2,3x3) matrices (entries 0, +-1, +-1/2)
+//   * U = G g G^T is computed on the host in double, scaled by a power of two and split into (hi, lo) halfs (conv_pack_weights_wino);
+//   * V = B^T d B is computed IN fp32 on the VALU (every entry a sum of four inputs at most), THEN split: hi = half(V), lo = half(V - hi);
+//   * a product is the three v_mfma_f32_32x32x16_f16 terms Uh.Vh + Ul.Vh + Uh.Vl of conv_split.hip (fp32 accumulation; the dropped Ul.Vl is 2^-22 relative);
+//   * A^T M A, bias, ReLU (and the 2 x 2 max-pool: exactly one Winograd tile) in fp32.
+// Measured on the CPU against the torch oracle (tools/round6/wino_numerics.py): 1.2-1.7e-6 per layer, the same as the direct split kernels (gate: 2e-5 of
+// the layer's magnitude, tests/test_gpu_superpoint.py).
+//
+// Activation layout ("raw-32" frames): the zero frame of conv.h (split_frame_h x split_frame_w pixels, pixel (y, x) at row y + 1, column x + 1), per pixel
+// 64 fp32 channels = 256 bytes -- the same bytes per pixel as split-64, the values likewise x conv_split_act_scale().  A Winograd layer reads raw-32 (its
+// transforms need the fp32 value: a split-64 input would cost two more VALU operations per input) and writes raw-32 (next layer Winograd) or split-64
+// (next layer direct).  |activation| must stay below 16 000 / scale = 500 (a transformed entry sums four: fp16's range); the epilogues clamp there.
+//
+// Kernel: 4 waves, ONE per SIMD with the whole register file (512).  Wave i owns the four Winograd positions (i, j = 0..3) -- row i of the transformed
+// patch -- for all 64 output channels: its U fragments (4 j x 4 k-groups x 2 channel fragments x (hi, lo) = 64 fragments) stay in 256 registers, its
+// 4 x 2 accumulators in 128.  Tile = 4 output rows x 32 columns = 2 x 16 Winograd tiles; lane (n, hh) = (tile n = 16 trow + tcol, input channels
+// 8 hh .. 8 hh + 7 of a 16-channel k-group).  A lane TRANSFORMS ITS OWN B OPERANDS: it reads the two halo rows its position row needs (B^T has two non-zero
+// entries per row) x 4 columns x 8 channels from the raw-32 halo in LDS (6 x 34 pixels, filled by LDS-DMA, 16-byte chunks XOR-swizzled with the pixel
+// column so that the 16 lanes of a ds_read_b128 phase hit 16 different bank groups), combines them vertically (1 FMA per value) and horizontally (1 add),
+// splits (1.5 instructions per value) and feeds 6 MFMAs per position: V never touches LDS.  The output transform along j is lane-local; along i the four
+// waves meet through 48 KB of LDS: every wave finishes a quarter of the output channels.
+#include "config.h"
+#include "conv.h"
+#include <type_traits>
+
+namespace omni {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v_t __attribute__((ext_vector_type(2)));
+typedef float float2v_t __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float wn_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t wn_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t wn_u2 __attribute__((ext_vector_type(2)));
+
+#define WN_ITW 34
+#define WN_HPIX (6 * WN_ITW)                          // 204 halo pixels
+#define WN_HALO_BYTES (WN_HPIX * 256)                 // 52 224
+#define WN_XCH_OFF (2 * WN_HALO_BYTES)                // 104 448
+#define WN_XCH_BYTES (4 * 3 * 4 * 1024)               // [source wave][destination among the other three][slot = 2 b + q][lane] x 16 B
+#define WN_BIAS_OFF (WN_XCH_OFF + WN_XCH_BYTES)       // 153 600: the 64 biases of the workgroup's output channels
+#define WN_LUT_OFF (WN_BIAS_OFF + 256)                // FUSE1A: the u8 -> (xh | xl << 16) table, 1 KiB
+#define WN_W1A_OFF (WN_LUT_OFF + 1024)                // FUSE1A: conv1a's four A fragments, 4 KiB
+#define WN_ZERO_OFF (WN_W1A_OFF + 4096)               // 4 KiB of zeros: the exchange slot a wave reads in place of its own terms
+#define WN_SMEM (WN_ZERO_OFF + 4096)                  // 163 072 of 163 840
+#define WN_ACT_SCALE 32.0f                            // = SPL_ACT_SCALE (conv_split.hip): raw-32 and split-64 frames hold activations x 32
+#define WN_ACT_CLAMP 16000.0f                         // |stored activation|: four of them must sum inside fp16's range
+
+static inline uint16_t wn_f2h_bits(float v) { const __half h = __float2half_rn(v); uint16_t u; memcpy(&u, &h, 2); return u; }
+static inline float wn_h2f(uint16_t u) { __half h; memcpy(&h, &u, 2); return __half2float(h); }
+
+// OIHW fp32 (3x3, cin = 64) -> the transformed, split A fragments [cg = cout / 64][i][hl][j][kg][m][lane][8 halfs] of U(i, j) = (G g G^T)(i, j) * 2^k:
+//   cout = 64 cg + (32 m + (lane & 31) + 16 i) mod 64, cin = 16 kg + 8 (lane >> 5) + e (the operand order of v_mfma_f32_32x32x16_f16); k: max |U| 2^k in [256, 512).
+// Returns 2^-k.  out: cin * cout * 16 * 2 halfs.
+float conv_pack_weights_wino(const float* w, int cin, int cout, uint16_t* out) {
+    static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    std::vector<float> U((size_t)16 * cout * cin);
+    double mx = 0;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = w + ((size_t)co * cin + ci) * 9;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    double s = 0;
+                    for (int k = 0; k < 3; ++k)
+                        for (int l = 0; l < 3; ++l) s += G[i][k] * (double)g[k * 3 + l] * G[j][l];
+                    U[((size_t)(i * 4 + j) * cout + co) * cin + ci] = (float)s;
+                    if (fabs(s) > mx) mx = fabs(s);
+                }
+        }
+    int ex = 0;
+    if (mx > 0) (void)frexp(mx, &ex);
+    const int k = 9 - ex;
+    size_t o = 0;
+    for (int cg = 0; cg < cout / 64; ++cg)
+        for (int i = 0; i < 4; ++i)
+            for (int hl = 0; hl < 2; ++hl)
+                for (int j = 0; j < 4; ++j)
+                    for (int kg = 0; kg < cin / 16; ++kg)
+                        for (int m = 0; m < 2; ++m)
+                            for (int l = 0; l < 64; ++l)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int co = cg * 64 + ((m * 32 + (l & 31) + 16 * i) & 63), ci = kg * 16 + (l >> 5) * 8 + e;      // (rotated by wave: see the exchange)
+                                    const float v = ldexpf(U[((size_t)(i * 4 + j) * cout + co) * cin + ci], k);
+                                    const uint16_t hi = wn_f2h_bits(v);
+                                    out[o++] = hl ? wn_f2h_bits(v - wn_h2f(hi)) : hi;
+                                }
+    return ldexpf(1.f, -k);
+}
+
+// the tiles of an image that run (ConvArgs::skip_*), as SplSkip of conv_split.hip: the 4 x 32 tile grid is the direct kernel's
+struct WnSkip { int act, n_above, n_upto, y0, y1, x0, w, bw; uint32_t magic_tx, magic_bw; int xcd; };
+struct WnTileIx { int b, r, ty, tx; };
+struct WnFuse {
+    const uint8_t* gray = nullptr; int gstride = 0, mask_r0 = 0, mask_r1 = 0;
+    const _Float16* w1a_frag = nullptr;   // conv1a_split_pack_fused: [2 k-halves][2 m][64 lanes][8 halfs], weights and bias x the activation scale
+    const uint32_t* lut_hl = nullptr;     // conv1a_make_split_lut
+};
+
+template <int J, int N, typename F>
+__device__ __forceinline__ void wn_for_each(F&& f) {
+    if constexpr (J < N) { f(std::integral_constant<int, J>{}); wn_for_each<J + 1, N>(f); }
+}
+__device__ __forceinline__ wn_f4 wn_lds_ld(const char* smem, uint32_t off) { return *reinterpret_cast<const wn_f4*>(smem + off); }
+__device__ __forceinline__ void wn_lds_st(char* smem, uint32_t off, wn_f4 v) { *reinterpret_cast<wn_f4*>(smem + off) = v; }
+
+// hi = half(v), lo = half(v - hi) of eight values: four v_cvt_pk_f16_f32 and eight v_fma_mix{lo,hi}_f16 (x - float(hi) is exact in f32: one rounding)
+__device__ __forceinline__ void wn_split8(const wn_f4& a, const wn_f4& b, half8_t& hi, half8_t& lo) {
+    uint32_t dh[4], dl[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = p < 2 ? a[2 * p] : b[2 * p - 4], x1 = p < 2 ? a[2 * p + 1] : b[2 * p - 3];
+        float2v_t fv; fv[0] = x0; fv[1] = x1;
+        dh[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(fv, half2v_t));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dl[p]) : "v"(dh[p]), "v"(x0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(dl[p]) : "v"(dh[p]), "v"(x1));
+    }
+    hi = __builtin_bit_cast(half8_t, wn_u4{dh[0], dh[1], dh[2], dh[3]});
+    lo = __builtin_bit_cast(half8_t, wn_u4{dl[0], dl[1], dl[2], dl[3]});
+}
+
+// POOL: 2 x 2 max-pool behind the ReLU (one Winograd tile = one pooled pixel).  OUT_SPLIT: the output frame is split-64 (next layer: a direct kernel of
+// conv_split.hip), else raw-32.  FUSE1A (conv1b): the halo is built from the u8 image -- conv1a (1 -> 64 channels, 3x3, + ReLU) on the matrix cores with
+// split operands, the scheme and the packed constants of conv_split.hip's FUSE1A -- instead of being DMA'd from a conv1a tensor.
+template <bool POOL, bool OUT_SPLIT, bool FUSE1A>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _Float16* __restrict__ wp, const float* __restrict__ bias,
+                    float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, WnSkip sk, WnFuse fz) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = i, the row of the transformed patch this wave owns
+    const int n = lane & 31, hh = lane >> 5, trow = n >> 4, tcol = n & 15;
+    const int bid = xcd_block_id(sk.xcd);
+    const int cg = bid % n_cg, wg = bid / n_cg, nwg = gridDim.x / n_cg;
+    const int tiles_per_img = sk.act;
+    const int total = batch * tiles_per_img;
+    // row i of B^T: W = d[ra] + beta d[rb]
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float beta = wave == 1 ? 1.f : -1.f;
+
+    half8_t wreg[64];                                                    // [hl][j][kg][m]
+    {
+        const _Float16* wbase = wp + ((size_t)(cg * 4 + wave) * 64) * 512 + lane * 8;
+#pragma unroll
+        for (int s = 0; s < 64; ++s) wreg[s] = *reinterpret_cast<const half8_t*>(wbase + s * 512);
+    }
+    if (tid < 64) reinterpret_cast<float*>(smem + WN_BIAS_OFF)[tid] = bias[cg * 64 + tid];
+    reinterpret_cast<uint4*>(smem + WN_ZERO_OFF)[tid] = make_uint4(0, 0, 0, 0);
+    if constexpr (FUSE1A) {
+        reinterpret_cast<uint32_t*>(smem + WN_LUT_OFF)[tid] = fz.lut_hl[tid];
+        reinterpret_cast<uint4*>(smem + WN_W1A_OFF)[tid] = reinterpret_cast<const uint4*>(fz.w1a_frag)[tid];
+    }
+
+    // ---- the tile walk (conv_split.hip's) ----------------------------------------------------------------------------------------------------
+    const int step_b = nwg / tiles_per_img, step_r = nwg - step_b * tiles_per_img;
+    auto decode = [&](WnTileIx& q) {
+        int r = q.r, ty, tx;
+        if (r < sk.n_above || r >= sk.n_upto) {
+            int base = 0;
+            if (r >= sk.n_upto) { r -= sk.n_upto; base = sk.y1; }
+            const int ry = sk.magic_tx ? (int)__umulhi((uint32_t)r, sk.magic_tx) : r;
+            tx = r - ry * tiles_x; ty = ry + base;
+        } else {
+            r -= sk.n_above;
+            const int qy = sk.magic_bw ? (int)__umulhi((uint32_t)r, sk.magic_bw) : r;
+            const int c = r - qy * sk.bw;
+            ty = sk.y0 + qy; tx = c < sk.x0 ? c : c + sk.w;
+        }
+        q.ty = ty; q.tx = tx;
+    };
+    auto advance = [&](WnTileIx& q) {
+        q.r += step_r;
+        if (q.r >= tiles_per_img) { q.r -= tiles_per_img; ++q.b; }
+        q.b += step_b;
+        decode(q);
+    };
+
+    // ---- the halo in LDS: pixel (R, X) at (R * 34 + X) * 256, its 16-byte chunk c (channels 4 c .. 4 c + 3) in slot c ^ ((X >> 1) & 15) -----------
+    const int Wf = split_frame_w(W), Hf = split_frame_h(H);
+    const uint32_t in_img_bytes = (uint32_t)Hf * Wf * 256u;
+    // DMA piece p (1 KiB) = halo pixels [4 p, 4 p + 4): lane -> (pixel 4 p + lane / 16, slot lane % 16)
+    constexpr int NPIECES = 51, PPW = 13;
+    uint32_t goff[PPW];
+    if constexpr (!FUSE1A) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            int piece = wave * PPW + j;
+            piece = piece < NPIECES ? piece : NPIECES - 1;
+            const int hp = piece * 4 + (lane >> 4), slot = lane & 15;
+            const int R = hp / WN_ITW, X = hp - R * WN_ITW;
+            goff[j] = (uint32_t)(R * Wf + X) * 256u + (uint32_t)((slot ^ ((X >> 1) & 15)) << 4);
+        }
+    }
+    struct Org { __amdgpu_buffer_rsrc_t r; uint32_t soff; };
+    auto origin = [&](int qb, int qty, int qtx) -> Org {
+        Org o;
+        o.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in) + (int64_t)qb * in_img_bytes - 4096, 0, in_img_bytes + 8192, 0x00020000);
+        o.soff = (uint32_t)(qty * 4 * Wf + qtx * 32) * 256u + 4096u;      // halo origin (4 ty - 1, 32 tx - 1) = frame pixel (4 ty, 32 tx)
+        return o;
+    };
+    auto dma_piece = [&](const Org& o, int which, auto JC) {
+        constexpr int j = decltype(JC)::value, g = j / 4;
+        [[maybe_unused]] constexpr int k = j % 4;
+        int first = wave * PPW + 4 * g;
+        first = first < NPIECES ? first : NPIECES - 1;
+#if __HIP_DEVICE_COMPILE__
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(o.r, (__attribute__((address_space(3))) void*)(smem + which * WN_HALO_BYTES + first * 1024), 16,
+                                                 goff[j], o.soff - k * 1024, k * 1024, 0);
+#else
+        (void)o; (void)which; (void)first;
+#endif
+    };
+    auto dma_tile = [&](int qb, int qty, int qtx, int which) {
+        const Org o = origin(qb, qty, qtx);
+        wn_for_each<0, PPW>([&](auto JC) { dma_piece(o, which, JC); });
+    };
+
+    // FUSE1A: wave w builds halo pixels [64 w, 64 w + 64) (two 32-pixel fragments) of tile (b, ty, tx) into halo buffer `which`
+    auto build_tile = [&](int qb, int qty, int qtx, int which) {
+        const int ty0 = qty * 4, tx0 = qtx * 32;
+        const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + WN_LUT_OFF);
+        const uint8_t* const gimg = fz.gray + (int64_t)qb * H * fz.gstride;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int vp = 64 * wave + 32 * f + n;
+            const int R = vp / WN_ITW, X = vp - R * WN_ITW;
+            const int py = ty0 - 1 + R, px = tx0 - 1 + X;                           // the image pixel under this halo pixel
+            const bool valid = (vp < WN_HPIX) & ((unsigned)py < (unsigned)H) & ((unsigned)px < (unsigned)W);
+            uint32_t T[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int t0 = k, t1 = k < 4 ? 5 + k : 8;                           // lanes 0-31: taps 0-4, lanes 32-63: taps 5-8 (the fifth slot idles)
+                const int dy = hh ? t1 / 3 : t0 / 3, dx = hh ? t1 % 3 : t0 % 3;
+                const int y = py - 1 + dy, x = px - 1 + dx;
+                const bool ok = valid & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W) & ((unsigned)(y - fz.mask_r0) >= (unsigned)(fz.mask_r1 - fz.mask_r0));
+                uint32_t byte = 0;
+                if (ok) byte = gimg[(uint32_t)(y * fz.gstride + x)];
+                T[k] = lut[byte];                                                  // (0 -> 0: a tap outside the image or under the mask contributes nothing)
+            }
+            const uint32_t h01 = __builtin_amdgcn_perm(T[1], T[0], 0x05040100u), h23 = __builtin_amdgcn_perm(T[3], T[2], 0x05040100u);
+            const uint32_t x3 = hh ? (valid ? 0x3C003C00u : 0u) : T[4];             // lanes 32-63: the bias slots (1.0, 1.0); a pixel outside the image is conv1b's zero padding
+            const half8_t B0 = __builtin_bit_cast(half8_t, wn_u4{T[0], T[1], T[2], T[3]});
+            const half8_t B1 = __builtin_bit_cast(half8_t, wn_u4{T[4], h01, h23, x3});
+            const uint32_t dst = (uint32_t)(which * WN_HALO_BYTES + vp * 256);
+            const int swz = (X >> 1) & 15;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                floatx16 a;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = 0.f;
+                const half8_t wa0 = *reinterpret_cast<const half8_t*>(smem + WN_W1A_OFF + m * 1024 + lane * 16);
+                const half8_t wa1 = *reinterpret_cast<const half8_t*>(smem + WN_W1A_OFF + (2 + m) * 1024 + lane * 16);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, B0, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, B1, a, 0, 0, 0);
+                if (vp < WN_HPIX) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        wn_f4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(a[4 * g + e], 0.f, WN_ACT_CLAMP);
+                        const int c = m * 8 + g * 2 + hh;                           // channels 32 m + 8 g + 4 hh + (0..3)
+                        wn_lds_st(smem, dst + (uint32_t)((c ^ swz) << 4), v);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto fill_tile = [&](const WnTileIx& q, int which) {
+        if constexpr (FUSE1A) build_tile(q.b, q.ty, q.tx, which); else dma_tile(q.b, q.ty, q.tx, which);
+    };
+
+    // this lane's read addresses inside a halo buffer: [column pair p][16-byte half q of its 8 channels], rows ra and rb; the k-group toggles bits 6-7
+    uint32_t adA[2][2], adB[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t lo8 = (uint32_t)(((hh * 2 + q) ^ ((tcol + p) & 15)) << 4);
+            adA[p][q] = (uint32_t)(((2 * trow + ra) * WN_ITW + 2 * tcol + 2 * p) * 256) + lo8;
+            adB[p][q] = (uint32_t)(((2 * trow + rb) * WN_ITW + 2 * tcol + 2 * p) * 256) + lo8;
+        }
+
+    // output addressing
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const int Wof = split_frame_w(Wo);
+    const int64_t opix = (int64_t)cout * 4;                                        // raw-32 and split-64: 4 bytes per channel
+    const int64_t out_img_bytes = (int64_t)split_frame_h(Ho) * Wof * opix;
+    // the channels this wave finishes: 16 wave + 8 q + 4 hh + (0..3) of the workgroup's 64
+
+    // the exchange: where this wave writes the quarter of wave (wave + k) & 3 and where it reads source s's terms for its own quarter (s = itself: zeros)
+    uint32_t xw[3], xr[4];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const int d = (wave + k) & 3; xw[k - 1] = (uint32_t)(WN_XCH_OFF + (3 * wave + (d < wave ? d : d - 1)) * 4096); }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xr[s] = s == wave ? (uint32_t)WN_ZERO_OFF : (uint32_t)(WN_XCH_OFF + (3 * s + (wave < s ? wave : wave - 1)) * 4096);
+    const float c0 = wave == 3 ? 0.f : 1.f, c1 = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);        // column `wave` of A^T
+    int t = wg;
+    WnTileIx cur_ix, nxt_ix;
+    cur_ix.b = t / tiles_per_img;
+    cur_ix.r = t - cur_ix.b * tiles_per_img;
+    decode(cur_ix);
+    nxt_ix = cur_ix;
+    advance(nxt_ix);
+    __syncthreads();                                                               // bias (and FUSE1A's table and fragments) in LDS
+    if (t < total) fill_tile(cur_ix, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (; t < total; t += nwg, cur ^= 1) {
+        const bool has_next = t + nwg < total;
+        if (has_next) fill_tile(nxt_ix, cur ^ 1);
+        const char* halo = smem + cur * WN_HALO_BYTES;
+        floatx16 acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][m][q] = 0.f;
+        // The stream: per k-group four steps (j = 0..3) of 6 MFMAs; a step's column reads are issued one step ahead (columns 0 and 2 feed j = 0, column 1
+        // joins for j = 1, 2, column 3 for j = 3), so that at most 8 reads (32 registers) are in flight next to three live column sums
+        wn_f4 ra_[4][2], rb_[4][2];                                                // landing registers of column cc: [cc][q], rows ra and rb
+        wn_f4 Wc[4][2];
+        auto issue = [&](int kg, int cc) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ra_[cc][q] = wn_lds_ld(halo, (adA[cc >> 1][q] ^ (uint32_t)(kg << 6)) + (cc & 1) * 256);
+                rb_[cc][q] = wn_lds_ld(halo, (adB[cc >> 1][q] ^ (uint32_t)(kg << 6)) + (cc & 1) * 256);
+            }
+        };
+        auto vsum = [&](int cc) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Wc[cc][q][e] = fmaf(beta, rb_[cc][q][e], ra_[cc][q][e]);
+        };
+        auto mma = [&](int kg, int j, const wn_f4& v0, const wn_f4& v1) {
+            half8_t vh, vl;
+            wn_split8(v0, v1, vh, vl);
+            const int s = (j * 4 + kg) * 2;
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vh, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vh, acc[j][1], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s], vh, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s + 1], vh, acc[j][1], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vl, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vl, acc[j][1], 0, 0, 0);
+        };
+        issue(0, 0); issue(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            issue(kg, 1);
+            vsum(0); vsum(2);
+            mma(kg, 0, Wc[0][0] - Wc[2][0], Wc[0][1] - Wc[2][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(kg, 3);
+            vsum(1);
+            mma(kg, 1, Wc[1][0] + Wc[2][0], Wc[1][1] + Wc[2][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg < 3) issue(kg + 1, 0);
+            mma(kg, 2, Wc[2][0] - Wc[1][0], Wc[2][1] - Wc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg < 3) issue(kg + 1, 2);
+            vsum(3);
+            mma(kg, 3, Wc[1][0] - Wc[3][0], Wc[1][1] - Wc[3][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- output transform along j (lane-local): T'(b) = sum_j A^T(b, j) M(i, j): T'(0) = (M0 + M1) + M2, T'(1) = (M1 - M2) - M3, one register group
+        // (four channels of the lane's tile) at a time, straight into the exchange (or, the wave's own groups, into 16 registers) ---------------------------
+        auto tprime = [&](int m, int g, int b) -> wn_f4 {
+            wn_f4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = 4 * g + e;
+                r[e] = b == 0 ? (acc[0][m][q] + acc[1][m][q]) + acc[2][m][q] : (acc[1][m][q] - acc[2][m][q]) - acc[3][m][q];
+            }
+            return r;
+        };
+        // ---- ... along i through LDS.  The packed weights ROTATE the output channels per wave (conv_pack_weights_wino): in wave i, register group g of channel
+        // fragment m holds channels 16 ((i + k) & 3) + 8 (g & 1) + 4 hh + (0..3), k = 2 m + g / 2 -- its OWN quarter (k = 0) always in fragment 0, groups 0-1,
+        // whatever i is: the code below is the same for the four waves (a switch over the wave with the accumulators live sent 100 registers to scratch).
+        // Region (source s, destination d) = 3 s + (d < s ? d : d - 1), slot 2 b + q (q = g & 1).
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    wn_lds_st(smem, xw[k - 1] + (uint32_t)((2 * b + q) * 1024) + lane * 16, tprime(k >> 1, 2 * (k & 1) + q, b));
+        wn_f4 own[2][2];                                                           // [b][q]
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) own[b][q] = tprime(0, q, b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        // y(a, b) = sum_s A^T(a, s) T'_s(b) = (T0 + T1) + T2 and (T1 - T2) - T3 over the OTHER three waves' terms (the wave's own slot reads zeros), its own
+        // term added last with its coefficient: a channel is always finished by the same wave, in the same order
+        {
+            // bias, ReLU, (pool), store: tile (trow, tcol) of the 2 x 16 = output pixels (ty0 + 2 trow + a, tx0 + 2 tcol + b)
+            const int ty0 = cur_ix.ty * 4, tx0 = cur_ix.tx * 32;
+            const int oy = ty0 + 2 * trow, ox = tx0 + 2 * tcol;
+            char* const oimg = out + (int64_t)cur_ix.b * out_img_bytes;
+            const float lo_lim = relu ? 0.f : -WN_ACT_CLAMP;
+            auto store = [&](int y, int x, int q, const wn_f4& raw) {             // output pixel (y, x) of the (pooled) map, quad q
+                wn_f4 v;
+                const float4 bb = *reinterpret_cast<const float4*>(smem + WN_BIAS_OFF + (16 * wave + 8 * q + 4 * hh) * 4);
+                v[0] = __builtin_amdgcn_fmed3f(fmaf(raw[0], inv, bb.x), lo_lim, WN_ACT_CLAMP);
+                v[1] = __builtin_amdgcn_fmed3f(fmaf(raw[1], inv, bb.y), lo_lim, WN_ACT_CLAMP);
+                v[2] = __builtin_amdgcn_fmed3f(fmaf(raw[2], inv, bb.z), lo_lim, WN_ACT_CLAMP);
+                v[3] = __builtin_amdgcn_fmed3f(fmaf(raw[3], inv, bb.w), lo_lim, WN_ACT_CLAMP);
+                char* const pp = oimg + ((int64_t)(y + 1) * Wof + (x + 1)) * opix;
+                const int ch = 16 * wave + 8 * q + 4 * hh;                         // channel inside the workgroup's 64-channel block cg
+                if constexpr (OUT_SPLIT) {
+                    float2v_t f0, f1; f0[0] = v[0]; f0[1] = v[1]; f1[0] = v[2]; f1[1] = v[3];
+                    const uint32_t h0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f0, half2v_t));
+                    const uint32_t h1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f1, half2v_t));
+                    uint32_t l0, l1;
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "v"(v[0]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(h0), "v"(v[1]));
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h1), "v"(v[2]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "v"(v[3]));
+                    *reinterpret_cast<wn_u2*>(pp + cg * 256 + ch * 2) = wn_u2{h0, h1};
+                    *reinterpret_cast<wn_u2*>(pp + cg * 256 + 128 + ch * 2) = wn_u2{l0, l1};
+                } else {
+                    *reinterpret_cast<wn_f4*>(pp + (cg * 64 + ch) * 4) = v;
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                wn_f4 pmax;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    wn_f4 ts[4], y0, y1;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) ts[s] = wn_lds_ld(smem, xr[s] + (uint32_t)((2 * b + q) * 1024) + lane * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y0[e] = fmaf(own[b][q][e], c0, (ts[0][e] + ts[1][e]) + ts[2][e]);
+                        y1[e] = fmaf(own[b][q][e], c1, (ts[1][e] - ts[2][e]) - ts[3][e]);
+                    }
+                    if constexpr (POOL) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pmax[e] = b == 0 ? fmaxf(y0[e], y1[e]) : fmaxf(pmax[e], fmaxf(y0[e], y1[e]));
+                    } else {
+                        if (oy < H && ox + b < W) store(oy, ox + b, q, y0);
+                        if (oy + 1 < H && ox + b < W) store(oy + 1, ox + b, q, y1);
+                    }
+                }
+                if constexpr (POOL) { if (oy < H && ox < W) store(oy >> 1, ox >> 1, q, pmax); }
+            }
+        }
+        cur_ix = nxt_ix;
+        advance(nxt_ix);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // the next tile's halo landed; the exchange has been read
+        __syncthreads();
+    }
+}
+
+template <bool POOL, bool OUT_SPLIT, bool FUSE1A>
+static int launch_wino(hipStream_t st, const ConvArgs& a, const WnFuse& fz) {
+    auto kfn = conv3x3_wino_kernel<POOL, OUT_SPLIT, FUSE1A>;
+    static DynSmemState smem_state;
+    OMNI_HIP_TRY(ensure_dyn_smem(smem_state, (const void*)kfn, WN_SMEM));
+    const int tiles_x = cdiv(a.W, 32), tiles_y = cdiv(a.H, 4), n_cg = a.cout / 64;
+    const bool skip = a.skip_ty1 > a.skip_ty0 && a.skip_tx1 > a.skip_tx0;
+    OMNI_REQUIRE(!skip || (a.skip_ty0 >= 0 && a.skip_ty1 <= tiles_y && a.skip_tx0 >= 0 && a.skip_tx1 <= tiles_x), OMNI_ERR_INVALID, "conv_wino: skip rectangle outside the tile grid");
+    WnSkip sk;
+    sk.y0 = skip ? a.skip_ty0 : 0; sk.y1 = skip ? a.skip_ty1 : 0; sk.x0 = skip ? a.skip_tx0 : 0; sk.w = skip ? a.skip_tx1 - a.skip_tx0 : 0;
+    sk.bw = tiles_x - sk.w;
+    sk.act = tiles_x * tiles_y - (sk.y1 - sk.y0) * sk.w;
+    sk.n_above = skip ? sk.y0 * tiles_x : sk.act;
+    sk.n_upto = sk.n_above + (sk.y1 - sk.y0) * sk.bw;
+    OMNI_REQUIRE(sk.act > 0, OMNI_ERR_INVALID, "conv_wino: the skip rectangle covers the whole image");
+    auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
+    sk.magic_tx = magic(tiles_x); sk.magic_bw = magic(sk.bw);
+    sk.xcd = config_process()[CFG_CONV_XCD];
+    const int total = a.batch * sk.act;
+    int per_cg = a.n_cu / n_cg;
+    if (per_cg < 1) per_cg = 1;
+    if (per_cg > total) per_cg = total;
+    hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), WN_SMEM, st, reinterpret_cast<const char*>(a.in), reinterpret_cast<char*>(a.out),
+                       reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.split_inv, a.H, a.W, a.cout, n_cg, tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, sk, fz);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+static int wino_check(const ConvArgs& a) {
+    OMNI_REQUIRE(a.ksize == 3 && a.cin == 64 && a.cout % 64 == 0, OMNI_ERR_INVALID, "conv_wino: cin=%d cout=%d ksize=%d", a.cin, a.cout, a.ksize);
+    OMNI_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, OMNI_ERR_INVALID, "conv_wino: F(2x2,3x3) tiles need even H, W (%d x %d)", a.H, a.W);
+    OMNI_REQUIRE(a.n_cu > 0 && a.split_inv > 0.f, OMNI_ERR_INVALID, "conv_wino: n_cu / split_inv not set");
+    OMNI_REQUIRE((int64_t)split_frame_h(a.H) * split_frame_w(a.W) * 256 < (1ll << 32) - 16384, OMNI_ERR_INVALID, "conv_wino: image too large for 32-bit pixel offsets");
+    return OMNI_OK;
+}
+
+// a.in: raw-32 frames; a.w_packed / a.split_inv from conv_pack_weights_wino; a.bias = act scale x bias; a.out: raw-32 or (out_split) split-64 frames
+int conv_wino(hipStream_t st, const ConvArgs& a, bool out_split) {
+    int rc;
+    if ((rc = wino_check(a))) return rc;
+    const WnFuse fz;
+    if (a.pool) return out_split ? launch_wino<true, true, false>(st, a, fz) : launch_wino<true, false, false>(st, a, fz);
+    return out_split ? launch_wino<false, true, false>(st, a, fz) : launch_wino<false, false, false>(st, a, fz);
+}
+
+// conv1a + conv1b + ReLU + 2x2 max-pool in one launch: a = the conv1b layer (a.in unused), the constants of conv1ab_split_fused
+int conv1ab_wino_fused(hipStream_t st, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const void* w1a_frag, const uint32_t* lut_hl, bool out_split) {
+    int rc;
+    if ((rc = wino_check(a))) return rc;
+    OMNI_REQUIRE(a.pool && a.cout == 64, OMNI_ERR_INVALID, "conv1ab_wino_fused: conv1b is 64 -> 64 channels, pooled");
+    WnFuse fz;
+    fz.gray = gray; fz.gstride = gstride;
+    if (fisheye_mask) omni_fisheye_mask_rows(a.H, 1, &fz.mask_r0, &fz.mask_r1);
+    fz.w1a_frag = reinterpret_cast<const _Float16*>(w1a_frag); fz.lut_hl = lut_hl;
+    return out_split ? launch_wino<true, true, true>(st, a, fz) : launch_wino<true, false, true>(st, a, fz);
+}
+
+// ---- format converters (test hooks and the mixed configurations of OMNI_SPLIT_WINO) -----------------------------------------------------------------
+// split-64 frame -> raw-32 frame (same geometry, out of place): value = float(hi) + float(lo)
+__global__ void split_to_raw32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int64_t n_blocks64) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (pixel block of 64 channels, channel)
+    if (i >= n_blocks64 * 64) return;
+    const int64_t blk = i >> 6;
+    const int c = (int)(i & 63);
+    const __half hi = __ushort_as_half(in[blk * 128 + c]), lo = __ushort_as_half(in[blk * 128 + 64 + c]);
+    out[i] = __half2float(hi) + __half2float(lo);
+}
+int split_to_raw32(hipStream_t st, const void* in_split, void* out_raw, int batch, int C, int H, int W) {
+    const int64_t nb = (int64_t)batch * split_frame_h(H) * split_frame_w(W) * (C / 64);
+    hipLaunchKernelGGL(split_to_raw32_kernel, dim3((unsigned)cdiv64(nb * 64, 256)), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(in_split),
+                       reinterpret_cast<float*>(out_raw), nb);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+// raw-32 frames -> NCHW fp32, true values (test hook: omni_sp_debug_layer)
+__global__ void raw32_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int batch, int C, int H, int W, int Hf, int Wf, float inv_scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)batch * C * H * W;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % C), b = (int)(i / ((int64_t)W * H * C));
+    out[i] = in[(((int64_t)b * Hf + y + 1) * Wf + x + 1) * C + c] * inv_scale;
+}
+int raw32_to_nchw_f32(hipStream_t st, const void* in_raw, float* out, int batch, int C, int H, int W) {
+    const int64_t total = (int64_t)batch * C * H * W;
+    hipLaunchKernelGGL(raw32_to_nchw_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(in_raw), out, batch, C, H, W,
+                       split_frame_h(H), split_frame_w(W), 1.f / WN_ACT_SCALE);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
+}  // namespace omni

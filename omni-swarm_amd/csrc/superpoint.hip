@@ -63,6 +63,14 @@ struct omni_sp {
     uint32_t* lut_hl = nullptr;              // u8 -> (half hi, half lo) table
     bool fuse1a = false;
     bool split_fuse1a = false;               // OMNI_PREC_SPLIT: conv1a is built inside conv1b's kernel (OMNI_SPLIT_FUSE1A=0: the separate conv1a_split pass)
+    // OMNI_PREC_SPLIT, Winograd F(2x2,3x3) kernels (conv_wino.hip) for the cin = 64 layers: bit 0 = conv1b (needs the conv1a fusion), 1 = conv2a, 2 = conv2b
+    // (OMNI_SPLIT_WINO).  Between two Winograd layers the activation frame is raw-32 instead of split-64 (same geometry, same bytes): raw_1b / raw_2a say
+    // what the LAST pass left in a1b / a2a; a_tmp: the converted input of a Winograd layer behind a direct one (mixed configurations only)
+    int wino = 0;
+    void* wpk_w[OMNI_SP_NUM_LAYERS] = {};
+    float winv_w[OMNI_SP_NUM_LAYERS] = {};
+    bool raw_1b = false, raw_2a = false;
+    void* a_tmp = nullptr;
     bool mask_skip_cal_fused = false;        // ... and which of the two the mask's constant region was calibrated with
     float* pca_compT = nullptr;
     float* pca_mean = nullptr;
@@ -265,6 +273,17 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
         if ((rc = pack_upload(LPA, wh.data(), 128, 512, 3))) return rc;
     }
     if (s->precision == OMNI_PREC_SPLIT) {
+        s->wino = s->cfg[CFG_SPLIT_WINO];
+        if (s->H % 4 != 0 || s->W % 4 != 0) s->wino &= 1;                         // conv2a / conv2b: even H / 2, W / 2 (F(2x2,3x3) tiles)
+        if (s->H % 2 != 0 || s->W % 2 != 0 || !s->split_fuse1a) s->wino &= ~1;
+        for (int l : {L1B, L2A, L2B}) {
+            if (!(s->wino & (l == L1B ? 1 : l == L2A ? 2 : 4))) continue;
+            std::vector<uint16_t> p((size_t)64 * 64 * 16 * 2);
+            s->winv_w[l] = conv_pack_weights_wino(w->weight[l], 64, 64, p.data());
+            if ((rc = dev_upload(&s->wpk_w[l], p.data(), p.size() * 2, st))) return rc;
+        }
+    }
+    if (s->precision == OMNI_PREC_SPLIT) {
         const float S = conv_split_act_scale();
         for (int l : {L1B, L2A, L2B, L3A, L3B, L4A, L4B}) {
             std::vector<float> b(kLayers[l].cout);
@@ -387,9 +406,12 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (use_skip && s->mask_skip_ready && s->mask_skip_cal_fused != fuse1a) s->mask_skip_ready = false;      // (conv1a's own rectangle is only filled by an unfused calibration)
     if (use_skip && !s->mask_skip_ready && (rc = sp_calibrate_mask_skip(s, stride))) return rc;
     auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
+    // OMNI_PREC_SPLIT: which of the cin = 64 layers run as Winograd kernels in THIS pass, and the frame format between them
+    const bool w1b = P == OMNI_PREC_SPLIT && (s->wino & 1) && fuse1a, w2a = P == OMNI_PREC_SPLIT && (s->wino & 2) != 0, w2b = P == OMNI_PREC_SPLIT && (s->wino & 4) != 0;
     auto skip_of = [&](int l, ConvArgs& a) {
         const int i = l == L1B ? 1 : l == L2A ? 2 : l == L2B ? 3 : l == L3A ? 4 : l == L3B ? 5 : -1;
-        if (use_skip && i >= 0) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
+        // (an unpooled Winograd layer's constant region is constant per position in the 2 x 2 tile, not per pixel: conv2a recomputes it)
+        if (use_skip && i >= 0 && !(l == L2A && w2a)) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
     };
     auto conv = [&](int l, const void* in, void* out, const float* bias, int h, int w, int cin, int cout, int ks, bool relu,
                     bool pool, bool out_f32) -> int {
@@ -416,15 +438,35 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
         a.in = nullptr; a.out = s->a1b; a.w_packed = s->wpk[L1B]; a.bias = s->bias[L1B]; a.batch = batch; a.H = H; a.W = W; a.cin = 64;
         a.cout = 64; a.ksize = 3; a.relu = true; a.pool = true; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount; a.zero_page = s->ctx->zero_page;
         skip_of(L1B, a);
-        if (P == OMNI_PREC_SPLIT) {
+        if (P == OMNI_PREC_SPLIT && w1b) {
+            a.w_packed = s->wpk_w[L1B]; a.split_inv = s->winv_w[L1B]; a.bias = s->bias_s[L1B];
+            if ((rc = conv1ab_wino_fused(st, a, gray_dev, stride, fisheye_mask, s->w1a_frag, s->lut_hl, /*out_split=*/!w2a))) return rc;
+        } else if (P == OMNI_PREC_SPLIT) {
             a.split_inv = s->winv[L1B]; a.bias = s->bias_s[L1B];
             if ((rc = conv1ab_split_fused(st, a, gray_dev, stride, fisheye_mask, s->w1a_frag, s->lut_hl))) return rc;
         } else if ((rc = conv1ab_fused(st, a, gray_dev, stride, fisheye_mask, reinterpret_cast<const _Float16*>(s->w1a_frag), s->bias[L1A], s->lut_hl))) return rc;
     } else if ((rc = conv(L1B, s->a1a, s->a1b, s->bias[L1B], H, W, 64, 64, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;
-    if ((rc = conv(L2A, s->a1b, s->a2a, s->bias[L2A], H / 2, W / 2, 64, 64, 3, true, false, false))) return rc;
+    // a Winograd layer: raw-32 input (converted into a_tmp when the layer before it wrote split-64: mixed configurations), raw-32 or split-64 output
+    auto wino_layer = [&](int l, const void* in, bool in_raw, void* out, int h, int w, bool pool, bool out_split) -> int {
+        if (!in_raw) {
+            if (!s->a_tmp) OMNI_HIP_TRY(hipMalloc(&s->a_tmp, (size_t)s->max_batch * split_frame_bytes(H / 2, W / 2, 64)));
+            if ((rc = split_to_raw32(st, in, s->a_tmp, batch, 64, h, w))) return rc;
+            in = s->a_tmp;
+        }
+        ConvArgs a;
+        a.in = in; a.out = out; a.w_packed = s->wpk_w[l]; a.bias = s->bias_s[l]; a.batch = batch; a.H = h; a.W = w; a.cin = 64; a.cout = 64; a.ksize = 3;
+        a.relu = true; a.pool = pool; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount; a.split_inv = s->winv_w[l];
+        skip_of(l, a);
+        return conv_wino(st, a, out_split);
+    };
+    const bool raw_1b = w1b && w2a, raw_2a = w2a && w2b;
+    if (P == OMNI_PREC_SPLIT) { s->raw_1b = raw_1b; s->raw_2a = raw_2a; }
+    if (w2a) { if ((rc = wino_layer(L2A, s->a1b, raw_1b, s->a2a, H / 2, W / 2, false, !w2b))) return rc; }
+    else if ((rc = conv(L2A, s->a1b, s->a2a, s->bias[L2A], H / 2, W / 2, 64, 64, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
-    if ((rc = conv(L2B, s->a2a, s->a2b, s->bias[L2B], H / 2, W / 2, 64, 64, 3, true, true, false))) return rc;
+    if (w2b) { if ((rc = wino_layer(L2B, s->a2a, raw_2a, s->a2b, H / 2, W / 2, true, true))) return rc; }
+    else if ((rc = conv(L2B, s->a2a, s->a2b, s->bias[L2B], H / 2, W / 2, 64, 64, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;
     if ((rc = conv(L3A, s->a2b, s->a3a, s->bias[L3A], H / 4, W / 4, 64, 128, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
@@ -600,7 +642,8 @@ void omni_sp_destroy(omni_sp* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); if (s->bias_s[l]) (void)hipFree(s->bias_s[l]); }
+    if (s->a_tmp) (void)hipFree(s->a_tmp);
+    for (int l = 0; l < OMNI_SP_NUM_LAYERS; ++l) { if (s->wpk_w[l]) (void)hipFree(s->wpk_w[l]); if (s->wpk[l]) (void)hipFree(s->wpk[l]); if (s->bias[l]) (void)hipFree(s->bias[l]); if (s->bias_s[l]) (void)hipFree(s->bias_s[l]); }
     void* ptrs[] = {s->wPbA16, s->wDbFragHi, s->wDbFragLo, s->w1a, s->w1a_frag, s->lut_hl, s->wPbT, s->wPbA, s->wPbDust, s->wDbFrag, s->bias_heads, s->lut, s->pca_compT, s->pca_mean, s->a1a, s->a1b, s->a2a, s->a2b, s->a3a, s->a3b,
                     s->a4a, s->a4b, s->heads, s->headsP, s->da_compact, s->cx32, s->cy32, s->draw, s->semi, s->gray_stage, s->pb.cand, s->pb.cand_bits, s->pb.cand_masks, s->pb.counters, s->pb.surv_keys,
                     s->pb.raw_desc, s->pb.norm_partial, s->pb.kps_xy, s->pb.scores, s->pb.n_kps, s->pb.desc_out};
@@ -733,7 +776,9 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
         const size_t n = (size_t)batch * e.c * h * w;
         int rc;
         if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
-        if (e.prec == OMNI_PREC_SPLIT) { if ((rc = omni::split_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h, w))) return rc; }
+        if (e.prec == OMNI_PREC_SPLIT && ((e.p == s->a1b && s->raw_1b) || (e.p == s->a2a && s->raw_2a))) {      // a raw-32 frame between two Winograd layers
+            if ((rc = omni::raw32_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h, w))) return rc;
+        } else if (e.prec == OMNI_PREC_SPLIT) { if ((rc = omni::split_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h, w))) return rc; }
         else if ((rc = omni::nhwc_any_to_nchw_f32(s->ctx->stream, e.prec, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc;
         OMNI_HIP_TRY(hipMemcpyAsync(out_nchw_host, s->dense_tmp.p, n * 4, hipMemcpyDeviceToHost, s->ctx->stream));
         OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
