@@ -128,7 +128,8 @@ __device__ __forceinline__ void wn_split8(const wn_f4& a, const wn_f4& b, half8_
 template <bool POOL, bool OUT_SPLIT, bool FUSE1A>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _Float16* __restrict__ wp, const float* __restrict__ bias,
-                    float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, WnSkip sk, WnFuse fz) {
+                    float inv, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, WnSkip sk, WnFuse fz,
+                    unsigned long long* trace /* OMNI_WINO_TRACE=1: s_memtime stamps of workgroup 0, waves 0 and 3 (debug), else nullptr */) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = i, the row of the transformed patch this wave owns
@@ -146,7 +147,13 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
     {
         const _Float16* wbase = wp + ((size_t)(cg * 4 + wave) * 64) * 512 + lane * 8;
 #pragma unroll
-        for (int s = 0; s < 64; ++s) wreg[s] = *reinterpret_cast<const half8_t*>(wbase + s * 512);
+        for (int s = 0; s < 64; ++s) {
+            wreg[s] = *reinterpret_cast<const half8_t*>(wbase + s * 512);
+            // ... in the ACCUMULATOR half of the register file, where the MFMAs read them in place: the 256 architectural registers are the accumulators' (128:
+            // the output transform reads them with plain VALU instructions) and the transforms' (left to itself hipcc puts the accumulators there, parks the weights
+            // in what is left of it and copies four registers in front of every MFMA)
+            asm volatile("" : "+a"(wreg[s]));
+        }
     }
     if (tid < 64) reinterpret_cast<float*>(smem + WN_BIAS_OFF)[tid] = bias[cg * 64 + tid];
     reinterpret_cast<uint4*>(smem + WN_ZERO_OFF)[tid] = make_uint4(0, 0, 0, 0);
@@ -311,10 +318,21 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
+    const bool tr = trace != nullptr && blockIdx.x == 0 && (tid == 0 || tid == 192);
+    int tk = -2;                                   // the trace skips the first two tiles
+    auto stamp = [&](int i) {
+        if (tr && tk >= 0 && tk < 4) {
+            const unsigned long long v = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            trace[(tid ? 32 : 0) + tk * 8 + i] = v;
+        }
+    };
     int cur = 0;
     for (; t < total; t += nwg, cur ^= 1) {
+        stamp(0);
         const bool has_next = t + nwg < total;
         if (has_next) fill_tile(nxt_ix, cur ^ 1);
+        stamp(1);
         const char* halo = smem + cur * WN_HALO_BYTES;
         floatx16 acc[4][2];
 #pragma unroll
@@ -372,6 +390,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        stamp(2);
         // ---- output transform along j (lane-local): T'(b) = sum_j A^T(b, j) M(i, j): T'(0) = (M0 + M1) + M2, T'(1) = (M1 - M2) - M3, one register group
         // (four channels of the lane's tile) at a time, straight into the exchange (or, the wave's own groups, into 16 registers) ---------------------------
         auto tprime = [&](int m, int g, int b) -> wn_f4 {
@@ -399,8 +418,10 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q) own[b][q] = tprime(0, q, b);
+        stamp(3);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        stamp(4);
         // y(a, b) = sum_s A^T(a, s) T'_s(b) = (T0 + T1) + T2 and (T1 - T2) - T3 over the OTHER three waves' terms (the wave's own slot reads zeros), its own
         // term added last with its coefficient: a channel is always finished by the same wave, in the same order
         {
@@ -459,8 +480,11 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         }
         cur_ix = nxt_ix;
         advance(nxt_ix);
+        stamp(5);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // the next tile's halo landed; the exchange has been read
         __syncthreads();
+        stamp(6);
+        ++tk;
     }
 }
 
@@ -486,9 +510,29 @@ static int launch_wino(hipStream_t st, const ConvArgs& a, const WnFuse& fz) {
     int per_cg = a.n_cu / n_cg;
     if (per_cg < 1) per_cg = 1;
     if (per_cg > total) per_cg = total;
+    static const bool want_trace = config_process()[CFG_WINO_TRACE] != 0;
+    static unsigned long long* trace_dev = nullptr;
+    if (want_trace) {
+        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
+        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * 8, st));
+    }
     hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), WN_SMEM, st, reinterpret_cast<const char*>(a.in), reinterpret_cast<char*>(a.out),
-                       reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.split_inv, a.H, a.W, a.cout, n_cg, tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, sk, fz);
+                       reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.split_inv, a.H, a.W, a.cout, n_cg, tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, sk, fz,
+                       want_trace ? trace_dev : nullptr);
     OMNI_LAUNCH_CHECK();
+    if (want_trace) {
+        unsigned long long h[64];
+        OMNI_HIP_TRY(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, st));
+        OMNI_HIP_TRY(hipStreamSynchronize(st));
+        static int launches = 0;                   // per instantiation: launches 3 and 4 (the first ones run on cold TLBs and caches)
+        if (total >= 8 * per_cg && ++launches >= 3 && launches <= 4)
+            for (int w = 0; w < 2; ++w)
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long* q = h + w * 32 + k * 8;
+                    fprintf(stderr, "wino trace pool=%d split=%d fuse1a=%d H=%d W=%d wave %d tile %d: fill %llu stream %llu j-transform+write %llu barrier %llu finish %llu wait+barrier %llu | total %llu\n",
+                            (int)POOL, (int)OUT_SPLIT, (int)FUSE1A, a.H, a.W, w * 3, k + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[6] - q[0]);
+                }
+    }
     return OMNI_OK;
 }
 
