@@ -44,8 +44,9 @@ typedef uint32_t wn_u2 __attribute__((ext_vector_type(2)));
 #define WN_BIAS_OFF (WN_XCH_OFF + WN_XCH_BYTES)       // 153 600: the 64 biases of the workgroup's output channels
 #define WN_LUT_OFF (WN_BIAS_OFF + 256)                // FUSE1A: the u8 -> (xh | xl << 16) table, 1 KiB
 #define WN_W1A_OFF (WN_LUT_OFF + 1024)                // FUSE1A: conv1a's four A fragments, 4 KiB
-#define WN_ZERO_OFF (WN_W1A_OFF + 4096)               // 4 KiB of zeros: the exchange slot a wave reads in place of its own terms
-#define WN_SMEM (WN_ZERO_OFF + 4096)                  // 163 072 of 163 840
+#define WN_ZERO_OFF (WN_W1A_OFF + 4096)               // 1 KiB of zeros: what a wave reads in place of its own terms of the exchange; FUSE1A: the taps of a halo pixel outside the image
+#define WN_PATCH_OFF (WN_ZERO_OFF + 1024)             // FUSE1A: 4 waves x 256 B, the wave's 5-row x 40-byte patch of the u8 image
+#define WN_SMEM (WN_PATCH_OFF + 1024)                 // 161 024 of 163 840
 #define WN_ACT_SCALE 32.0f                            // = SPL_ACT_SCALE (conv_split.hip): raw-32 and split-64 frames hold activations x 32
 #define WN_ACT_CLAMP 16000.0f                         // |stored activation|: four of them must sum inside fp16's range
 
@@ -156,7 +157,8 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         }
     }
     if (tid < 64) reinterpret_cast<float*>(smem + WN_BIAS_OFF)[tid] = bias[cg * 64 + tid];
-    reinterpret_cast<uint4*>(smem + WN_ZERO_OFF)[tid] = make_uint4(0, 0, 0, 0);
+    if (tid < 64) reinterpret_cast<uint4*>(smem + WN_ZERO_OFF)[tid] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint32_t*>(smem + WN_PATCH_OFF)[tid] = 0u;
     if constexpr (FUSE1A) {
         reinterpret_cast<uint32_t*>(smem + WN_LUT_OFF)[tid] = fz.lut_hl[tid];
         reinterpret_cast<uint4*>(smem + WN_W1A_OFF)[tid] = reinterpret_cast<const uint4*>(fz.w1a_frag)[tid];
@@ -226,34 +228,60 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         wn_for_each<0, PPW>([&](auto JC) { dma_piece(o, which, JC); });
     };
 
-    // FUSE1A: wave w builds halo pixels [64 w, 64 w + 64) (two 32-pixel fragments) of tile (b, ty, tx) into halo buffer `which`
-    auto build_tile = [&](int qb, int qty, int qtx, int which) {
-        const int ty0 = qty * 4, tx0 = qtx * 32;
+    // FUSE1A: wave w builds halo pixels [64 w, 64 w + 64) (two 32-pixel fragments; pixels >= 204 are nobody's) of a tile into halo buffer `which`: conv1a on
+    // the matrix cores with split operands, conv_split.hip's scheme and packed constants.  Those pixels lie in at most 3 halo rows = a 5-row x 40-byte patch
+    // of the image: ONE buffer_load_dword per lane, issued a whole tile ahead (patch_issue: the stream of tile t loads the patch of tile t + 2), parked --
+    // rows / columns outside the image and the fisheye mask's rows zeroed -- in a wave-private LDS slot (patch_park), from which a lane reads the bytes under
+    // ITS taps (lanes 0-31: taps 0-4, lanes 32-63: taps 5-8 and the bias slots) and then their table entries (xh | xl << 16), which ARE the MFMA's operand dwords.
+    [[maybe_unused]] const int fz_r0 = (64 * wave) / WN_ITW;                        // first halo row the wave's pixels touch
+    [[maybe_unused]] const int fz_pj = lane / 10 + fz_r0 - 2, fz_pd = 4 * (lane % 10) - 4;       // the lane's patch dword: image row 4 ty + fz_pj, columns 32 tx + fz_pd ..
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(fz.gray), 0, 0x7fffffff, 0x00020000);
+    uint32_t pv = 0;                                                               // the patch dword in flight
+    auto patch_issue = [&](int qb, int qty, int qtx) {
+        int yy = qty * 4 + fz_pj, xx = qtx * 32 + fz_pd;
+        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+        xx = xx < 0 ? 0 : (xx > fz.gstride - 4 ? fz.gstride - 4 : xx);            // (clamped to valid addresses here, zeroed when parked)
+        pv = __builtin_amdgcn_raw_buffer_load_b32(fz_rsrc, (qb * H + yy) * fz.gstride + xx, 0, 0);
+    };
+    auto patch_park = [&](int qty, int qtx) {
+        const int y = qty * 4 + fz_pj, x = qtx * 32 + fz_pd;
+        const bool ok = ((unsigned)y < (unsigned)H) & ((unsigned)(y - fz.mask_r0) >= (unsigned)(fz.mask_r1 - fz.mask_r0)) & (x >= 0) & (x < W);
+        const int left = W - x;                                                    // bytes of the dword inside the row (W need not be a multiple of 4)
+        const uint32_t keep = left >= 4 ? 0xffffffffu : (1u << (8 * (left & 3))) - 1u;
+        reinterpret_cast<uint32_t*>(smem + WN_PATCH_OFF + wave * 256)[lane] = ok ? (pv & keep) : 0u;
+    };
+    auto build_tile = [&](int qty, int qtx, int which) {
         const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + WN_LUT_OFF);
-        const uint8_t* const gimg = fz.gray + (int64_t)qb * H * fz.gstride;
+        const int ty0 = qty * 4, tx0 = qtx * 32;
+        uint32_t U[2][5];
+        bool valid[2];
+        int vp[2], X[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const int vp = 64 * wave + 32 * f + n;
-            const int R = vp / WN_ITW, X = vp - R * WN_ITW;
-            const int py = ty0 - 1 + R, px = tx0 - 1 + X;                           // the image pixel under this halo pixel
-            const bool valid = (vp < WN_HPIX) & ((unsigned)py < (unsigned)H) & ((unsigned)px < (unsigned)W);
-            uint32_t T[5];
+            vp[f] = 64 * wave + 32 * f + n;
+            const int R = vp[f] / WN_ITW;
+            X[f] = vp[f] - R * WN_ITW;
+            const int gy = ty0 - 1 + R, gx = tx0 - 1 + X[f];                        // the image pixel under this halo pixel
+            valid[f] = (vp[f] < WN_HPIX) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            // the byte under tap (0, 0): patch row R - fz_r0, patch column X + 2 (patch column 0 = image column 32 tx - 4); a pixel outside the image is conv1b's
+            // zero padding: its taps read zeros, its bias slots are zero
+            const uint32_t pb = valid[f] ? (uint32_t)(WN_PATCH_OFF + wave * 256 + (R - fz_r0) * 40 + X[f] + 2) : (uint32_t)WN_ZERO_OFF;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const int t0 = k, t1 = k < 4 ? 5 + k : 8;                           // lanes 0-31: taps 0-4, lanes 32-63: taps 5-8 (the fifth slot idles)
-                const int dy = hh ? t1 / 3 : t0 / 3, dx = hh ? t1 % 3 : t0 % 3;
-                const int y = py - 1 + dy, x = px - 1 + dx;
-                const bool ok = valid & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W) & ((unsigned)(y - fz.mask_r0) >= (unsigned)(fz.mask_r1 - fz.mask_r0));
-                uint32_t byte = 0;
-                if (ok) byte = gimg[(uint32_t)(y * fz.gstride + x)];
-                T[k] = lut[byte];                                                  // (0 -> 0: a tap outside the image or under the mask contributes nothing)
+                const int t1 = k < 4 ? 5 + k : 8;
+                const int c0 = (k / 3) * 40 + k % 3, c1 = (t1 / 3) * 40 + t1 % 3;
+                U[f][k] = *reinterpret_cast<const uint8_t*>(smem + pb + (hh ? c1 : c0));
             }
-            const uint32_t h01 = __builtin_amdgcn_perm(T[1], T[0], 0x05040100u), h23 = __builtin_amdgcn_perm(T[3], T[2], 0x05040100u);
-            const uint32_t x3 = hh ? (valid ? 0x3C003C00u : 0u) : T[4];             // lanes 32-63: the bias slots (1.0, 1.0); a pixel outside the image is conv1b's zero padding
-            const half8_t B0 = __builtin_bit_cast(half8_t, wn_u4{T[0], T[1], T[2], T[3]});
-            const half8_t B1 = __builtin_bit_cast(half8_t, wn_u4{T[4], h01, h23, x3});
-            const uint32_t dst = (uint32_t)(which * WN_HALO_BYTES + vp * 256);
-            const int swz = (X >> 1) & 15;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) U[f][k] = lut[U[f][k]];
+            const uint32_t h01 = __builtin_amdgcn_perm(U[f][1], U[f][0], 0x05040100u), h23 = __builtin_amdgcn_perm(U[f][3], U[f][2], 0x05040100u);
+            const uint32_t x3 = hh ? (valid[f] ? 0x3C003C00u : 0u) : U[f][4];       // lanes 32-63: the bias slots (1.0, 1.0)
+            const half8_t B0 = __builtin_bit_cast(half8_t, wn_u4{U[f][0], U[f][1], U[f][2], U[f][3]});
+            const half8_t B1 = __builtin_bit_cast(half8_t, wn_u4{U[f][4], h01, h23, x3});
+            // chunk c = 8 m + 2 g + hh of the pixel goes to slot c ^ swizzle: (base | ((swizzle ^ hh) << 4)) ^ ((8 m + 2 g) << 4), one v_xor per store -- and NOT sixteen
+            // loop-invariant addresses hoisted out of the tile loop into registers the stream has no room for (the empty asm pins the base inside the loop)
+            uint32_t dstb = (uint32_t)(which * WN_HALO_BYTES + vp[f] * 256) + (uint32_t)(((((X[f] >> 1) & 15) ^ hh)) << 4);
+            asm volatile("" : "+v"(dstb));
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 floatx16 a;
@@ -263,34 +291,27 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
                 const half8_t wa1 = *reinterpret_cast<const half8_t*>(smem + WN_W1A_OFF + (2 + m) * 1024 + lane * 16);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, B0, a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, B1, a, 0, 0, 0);
-                if (vp < WN_HPIX) {
+                if (vp[f] < WN_HPIX) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         wn_f4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(a[4 * g + e], 0.f, WN_ACT_CLAMP);
-                        const int c = m * 8 + g * 2 + hh;                           // channels 32 m + 8 g + 4 hh + (0..3)
-                        wn_lds_st(smem, dst + (uint32_t)((c ^ swz) << 4), v);
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(a[4 * g + e], 0.f);
+                        wn_lds_st(smem, dstb ^ (uint32_t)((m * 8 + g * 2) << 4), v);    // channels 32 m + 8 g + 4 hh + (0..3)
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    auto fill_tile = [&](const WnTileIx& q, int which) {
-        if constexpr (FUSE1A) build_tile(q.b, q.ty, q.tx, which); else dma_tile(q.b, q.ty, q.tx, which);
-    };
 
     // this lane's read addresses inside a halo buffer: [column pair p][16-byte half q of its 8 channels], rows ra and rb; the k-group toggles bits 6-7
-    uint32_t adA[2][2], adB[2][2];
+    uint32_t adA[2][2];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t lo8 = (uint32_t)(((hh * 2 + q) ^ ((tcol + p) & 15)) << 4);
-            adA[p][q] = (uint32_t)(((2 * trow + ra) * WN_ITW + 2 * tcol + 2 * p) * 256) + lo8;
-            adB[p][q] = (uint32_t)(((2 * trow + rb) * WN_ITW + 2 * tcol + 2 * p) * 256) + lo8;
-        }
+        for (int q = 0; q < 2; ++q)
+            adA[p][q] = (uint32_t)(((2 * trow + ra) * WN_ITW + 2 * tcol + 2 * p) * 256) + (uint32_t)(((hh * 2 + q) ^ ((tcol + p) & 15)) << 4);
+    const int dAB = (rb - ra) * WN_ITW * 256;                                      // row rb's address = row ra's + this (wave-uniform)
 
     // output addressing
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
@@ -300,11 +321,13 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
     // the channels this wave finishes: 16 wave + 8 q + 4 hh + (0..3) of the workgroup's 64
 
     // the exchange: where this wave writes the quarter of wave (wave + k) & 3 and where it reads source s's terms for its own quarter (s = itself: zeros)
-    uint32_t xw[3], xr[4];
+    uint32_t xw[3], xr[4][4];                                                      // xr[s][slot] (the wave's own s: the 1 KiB of zeros, whatever the slot)
 #pragma unroll
     for (int k = 1; k < 4; ++k) { const int d = (wave + k) & 3; xw[k - 1] = (uint32_t)(WN_XCH_OFF + (3 * wave + (d < wave ? d : d - 1)) * 4096); }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) xr[s] = s == wave ? (uint32_t)WN_ZERO_OFF : (uint32_t)(WN_XCH_OFF + (3 * s + (wave < s ? wave : wave - 1)) * 4096);
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) xr[s][sl] = s == wave ? (uint32_t)WN_ZERO_OFF : (uint32_t)(WN_XCH_OFF + (3 * s + (wave < s ? wave : wave - 1)) * 4096 + sl * 1024);
     const float c0 = wave == 3 ? 0.f : 1.f, c1 = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);        // column `wave` of A^T
     int t = wg;
     WnTileIx cur_ix, nxt_ix;
@@ -314,8 +337,18 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
     nxt_ix = cur_ix;
     advance(nxt_ix);
     __syncthreads();                                                               // bias (and FUSE1A's table and fragments) in LDS
-    if (t < total) fill_tile(cur_ix, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (t < total) {                                                               // the workgroup's first tile: nothing to hide behind
+        if constexpr (FUSE1A) {
+            patch_issue(cur_ix.b, cur_ix.ty, cur_ix.tx);
+            patch_park(cur_ix.ty, cur_ix.tx);
+            build_tile(cur_ix.ty, cur_ix.tx, 0);
+            const bool n1 = t + nwg < total;                                       // the patch of the tile the first stream builds
+            patch_issue(n1 ? nxt_ix.b : cur_ix.b, n1 ? nxt_ix.ty : cur_ix.ty, n1 ? nxt_ix.tx : cur_ix.tx);
+        } else {
+            dma_tile(cur_ix.b, cur_ix.ty, cur_ix.tx, 0);
+        }
+    }
+    if constexpr (FUSE1A) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
     const bool tr = trace != nullptr && blockIdx.x == 0 && (tid == 0 || tid == 192);
@@ -327,84 +360,237 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             trace[(tid ? 32 : 0) + tk * 8 + i] = v;
         }
     };
+    // ---- the pending finish of a tile: its own T' terms and where its outputs go ----------------------------------------------------------------
+    wn_f4 own[2][2];                                                               // [b][q]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) own[b][q] = wn_f4{0.f, 0.f, 0.f, 0.f};
+    int pend = 0, p_b = 0, p_ty = 0, p_tx = 0;
+    // y(a, b) = sum_s A^T(a, s) T'_s(b) = (T0 + T1) + T2 and (T1 - T2) - T3 over the OTHER three waves' terms (the wave's own slot reads zeros), its own term
+    // added last with its coefficient: a channel is always finished by the same wave, in the same order.  Then bias, ReLU, (pool), store: tile (trow, tcol)
+    // of the 2 x 16 = output pixels (4 ty + 2 trow + a, 32 tx + 2 tcol + b)
+    auto finish = [&]() {
+        const int oy = p_ty * 4 + 2 * trow, ox = p_tx * 32 + 2 * tcol;
+        // the output image as a raw buffer: a lane with nothing to store carries an offset outside it (the store is dropped: no branch in the stream)
+        const __amdgpu_buffer_rsrc_t oimg = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)p_b * out_img_bytes, 0, (int)out_img_bytes, 0x00020000);
+        const float lo_lim = relu ? 0.f : -WN_ACT_CLAMP;
+        const int ch0 = 16 * wave + 4 * hh;                                        // + 8 q: the channel inside the workgroup's 64-channel block cg
+        const uint32_t chan_off = OUT_SPLIT ? (uint32_t)(cg * 256 + ch0 * 2) : (uint32_t)((cg * 64 + ch0) * 4);
+        auto pix_off = [&](int y, int x, bool ok) -> uint32_t {                   // output pixel (y, x) of the (pooled) map
+            return ok ? (uint32_t)((y + 1) * Wof + (x + 1)) * (uint32_t)opix + chan_off : 0x80000000u;
+        };
+        auto store = [&](uint32_t off, int q, const wn_f4& raw) {
+            wn_f4 v;
+            const float4 bb = *reinterpret_cast<const float4*>(smem + WN_BIAS_OFF + (16 * wave + 8 * q + 4 * hh) * 4);
+            v[0] = __builtin_amdgcn_fmed3f(fmaf(raw[0], inv, bb.x), lo_lim, WN_ACT_CLAMP);
+            v[1] = __builtin_amdgcn_fmed3f(fmaf(raw[1], inv, bb.y), lo_lim, WN_ACT_CLAMP);
+            v[2] = __builtin_amdgcn_fmed3f(fmaf(raw[2], inv, bb.z), lo_lim, WN_ACT_CLAMP);
+            v[3] = __builtin_amdgcn_fmed3f(fmaf(raw[3], inv, bb.w), lo_lim, WN_ACT_CLAMP);
+            if constexpr (OUT_SPLIT) {
+                float2v_t f0, f1; f0[0] = v[0]; f0[1] = v[1]; f1[0] = v[2]; f1[1] = v[3];
+                const uint32_t h0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f0, half2v_t));
+                const uint32_t h1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f1, half2v_t));
+                uint32_t l0, l1;
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "v"(v[0]));
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h1), "v"(v[2]));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(h0), "v"(v[1]));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "v"(v[3]));
+                __builtin_amdgcn_raw_buffer_store_b64(wn_u2{h0, h1}, oimg, off + q * 16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(wn_u2{l0, l1}, oimg, off + q * 16 + 128, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, v), oimg, off + q * 32, 0, 0);
+            }
+        };
+        uint32_t off[POOL ? 1 : 4];
+        if constexpr (POOL) off[0] = pix_off(oy >> 1, ox >> 1, (oy < H) & (ox < W));
+        else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) off[2 * a + b] = pix_off(oy + a, ox + b, (oy + a < H) & (ox + b < W));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wn_f4 pmax;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                wn_f4 ts[4], y0, y1;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) ts[s] = wn_lds_ld(smem, xr[s][2 * b + q] + lane * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y0[e] = fmaf(own[b][q][e], c0, (ts[0][e] + ts[1][e]) + ts[2][e]);
+                    y1[e] = fmaf(own[b][q][e], c1, (ts[1][e] - ts[2][e]) - ts[3][e]);
+                }
+                if constexpr (POOL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pmax[e] = b == 0 ? fmaxf(y0[e], y1[e]) : fmaxf(pmax[e], fmaxf(y0[e], y1[e]));
+                } else {
+                    store(off[b], q, y0);
+                    store(off[2 + b], q, y1);
+                }
+            }
+            if constexpr (POOL) store(off[0], q, pmax);
+        }
+    };
+
+    // ---- the stream: 16 steps x = 4 kg + j of 6 MFMAs (three terms x two channel fragments), software-pipelined by hand: region r issues the MFMAs of step r
+    // and, between them, the transform of step r + 1 (column sums, the position's difference, the (hi, lo) split) and the LDS reads of step r + 2 -- plus, in
+    // the regions that can afford the registers (accumulators j = 2, 3 are first written in regions 2, 3), the previous tile's finish (region 0) and the next
+    // tile's halo (DMA pieces one per region; FUSE1A: byte loads in region 0, the two fragments in regions 1 and 2).  One wave per SIMD and in-order issue:
+    // whatever is not placed between two MFMAs idles the matrix cores.
     int cur = 0;
+    uint32_t ax[2][2][2];                                                          // [row a / b][column pair][q]: this tile's, this k-group's read addresses
+    wn_f4 rA[4][2], rB[4][2];                                                      // landing registers of column cc, rows ra and rb
+    wn_f4 Wc[4][2];                                                                // the column sums
+    half8_t vh[2], vl[2];                                                          // the B operands of step x in buffer x & 1
+    auto loads = [&](auto XC) {
+        constexpr int x = decltype(XC)::value, kg = x >> 2, j = x & 3;
+        if constexpr (x < 16 && j != 2) {
+            if constexpr (j == 0 && kg > 0) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { ax[0][p][q] ^= (uint32_t)(((kg - 1) ^ kg) << 6); ax[1][p][q] ^= (uint32_t)(((kg - 1) ^ kg) << 6); }
+            }
+            auto col = [&](int cc) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    rA[cc][q] = wn_lds_ld(smem, ax[0][cc >> 1][q] + (cc & 1) * 256);
+                    rB[cc][q] = wn_lds_ld(smem, ax[1][cc >> 1][q] + (cc & 1) * 256);
+                }
+            };
+            if constexpr (j == 0) { col(0); col(2); } else if constexpr (j == 1) col(1); else col(3);
+        }
+    };
+    auto vsum = [&](int cc) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Wc[cc][q][e] = fmaf(beta, rB[cc][q][e], rA[cc][q][e]);
+    };
+    wn_f4 Vt[2];
+    uint32_t dh[4], dl[4];
+    // the transform of step x in five parts (one per gap between two MFMAs of the region before)
+    auto tpart = [&](auto XC, auto GC) {
+        constexpr int x = decltype(XC)::value, j = x & 3, G = decltype(GC)::value;
+        if constexpr (x < 16) {
+            if constexpr (G == 0) { if constexpr (j == 0) vsum(0); else if constexpr (j == 1) vsum(1); else if constexpr (j == 3) vsum(3); }
+            else if constexpr (G == 1) { if constexpr (j == 0) vsum(2); }
+            else if constexpr (G == 2) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) Vt[q] = j == 0 ? Wc[0][q] - Wc[2][q] : j == 1 ? Wc[1][q] + Wc[2][q] : j == 2 ? Wc[2][q] - Wc[1][q] : Wc[1][q] - Wc[3][q];
+            } else if constexpr (G == 3) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float2v_t fv; fv[0] = Vt[p >> 1][2 * (p & 1)]; fv[1] = Vt[p >> 1][2 * (p & 1) + 1];
+                    dh[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(fv, half2v_t));
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dl[p]) : "v"(dh[p]), "v"(Vt[p >> 1][2 * (p & 1)]));
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(dl[p]) : "v"(dh[p]), "v"(Vt[p >> 1][2 * (p & 1) + 1]));
+                vh[x & 1] = __builtin_bit_cast(half8_t, wn_u4{dh[0], dh[1], dh[2], dh[3]});
+                vl[x & 1] = __builtin_bit_cast(half8_t, wn_u4{dl[0], dl[1], dl[2], dl[3]});
+            }
+        }
+    };
+    WnTileIx fill_ix = cur_ix;                                                     // the tile whose halo this stream fills (the next one; the last stream: its own again)
     for (; t < total; t += nwg, cur ^= 1) {
         stamp(0);
         const bool has_next = t + nwg < total;
-        if (has_next) fill_tile(nxt_ix, cur ^ 1);
-        stamp(1);
-        const char* halo = smem + cur * WN_HALO_BYTES;
-        floatx16 acc[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[j][m][q] = 0.f;
-        // The stream: per k-group four steps (j = 0..3) of 6 MFMAs; a step's column reads are issued one step ahead (columns 0 and 2 feed j = 0, column 1
-        // joins for j = 1, 2, column 3 for j = 3), so that at most 8 reads (32 registers) are in flight next to three live column sums
-        wn_f4 ra_[4][2], rb_[4][2];                                                // landing registers of column cc: [cc][q], rows ra and rb
-        wn_f4 Wc[4][2];
-        auto issue = [&](int kg, int cc) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                ra_[cc][q] = wn_lds_ld(halo, (adA[cc >> 1][q] ^ (uint32_t)(kg << 6)) + (cc & 1) * 256);
-                rb_[cc][q] = wn_lds_ld(halo, (adB[cc >> 1][q] ^ (uint32_t)(kg << 6)) + (cc & 1) * 256);
-            }
-        };
-        auto vsum = [&](int cc) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Wc[cc][q][e] = fmaf(beta, rb_[cc][q][e], ra_[cc][q][e]);
-        };
-        auto mma = [&](int kg, int j, const wn_f4& v0, const wn_f4& v1) {
-            half8_t vh, vl;
-            wn_split8(v0, v1, vh, vl);
-            const int s = (j * 4 + kg) * 2;
-            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vh, acc[j][0], 0, 0, 0);
-            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vh, acc[j][1], 0, 0, 0);
-            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s], vh, acc[j][0], 0, 0, 0);
-            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s + 1], vh, acc[j][1], 0, 0, 0);
-            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vl, acc[j][0], 0, 0, 0);
-            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vl, acc[j][1], 0, 0, 0);
-        };
-        issue(0, 0); issue(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            issue(kg, 1);
-            vsum(0); vsum(2);
-            mma(kg, 0, Wc[0][0] - Wc[2][0], Wc[0][1] - Wc[2][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(kg, 3);
-            vsum(1);
-            mma(kg, 1, Wc[1][0] + Wc[2][0], Wc[1][1] + Wc[2][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kg < 3) issue(kg + 1, 0);
-            mma(kg, 2, Wc[2][0] - Wc[1][0], Wc[2][1] - Wc[1][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kg < 3) issue(kg + 1, 2);
-            vsum(3);
-            mma(kg, 3, Wc[1][0] - Wc[3][0], Wc[1][1] - Wc[3][1]);
-            __builtin_amdgcn_sched_barrier(0);
+        fill_ix.b = has_next ? nxt_ix.b : cur_ix.b; fill_ix.ty = has_next ? nxt_ix.ty : cur_ix.ty; fill_ix.tx = has_next ? nxt_ix.tx : cur_ix.tx;
+        [[maybe_unused]] const Org org_n = origin(fill_ix.b, fill_ix.ty, fill_ix.tx);
+        [[maybe_unused]] WnTileIx nn_ix = nxt_ix;                                  // FUSE1A: the tile after next, whose patch this stream loads
+        if constexpr (FUSE1A) {
+            advance(nn_ix);
+            if (!(t + 2 * nwg < total)) nn_ix = fill_ix;                           // (none: any valid patch, nobody parks it)
         }
-
+        // the stream's head: this tile's addresses (k-group 0), the reads of steps 0 and 1, the transform of step 0
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { ax[0][p][q] = adA[p][q] + (uint32_t)(cur * WN_HALO_BYTES); ax[1][p][q] = ax[0][p][q] + (uint32_t)dAB; }
+        loads(std::integral_constant<int, 0>{});
+        loads(std::integral_constant<int, 1>{});
+        wn_for_each<0, 5>([&](auto GC) { tpart(std::integral_constant<int, 0>{}, GC); });
+        stamp(1);
+        floatx16 acc[4][2];
+#ifdef WN_STEP_TRACE
+        unsigned long long ts[17];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        wn_for_each<0, 16>([&](auto RC) {
+            constexpr int r = decltype(RC)::value, kg = r >> 2, j = r & 3, s = (j * 4 + kg) * 2;
+            constexpr auto X1 = std::integral_constant<int, r + 1>{};
+            floatx16 zero;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) zero[q] = 0.f;
+#ifdef WN_STEP_TRACE      // separate build (tools/round6/steptrace.sh): s_memtime at the top of every region (the values are read after the stream)
+            asm volatile("s_memtime %0" : "=s"(ts[r]));
+#endif
+            if constexpr (r == 3) __builtin_amdgcn_s_barrier();                    // every wave has read the previous tile's exchange (region 0): it may be rewritten
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vh[r & 1], kg == 0 ? zero : acc[j][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FUSE1A && r == 0) { patch_park(fill_ix.ty, fill_ix.tx); patch_issue(nn_ix.b, nn_ix.ty, nn_ix.tx); build_tile(fill_ix.ty, fill_ix.tx, cur ^ 1); }
+            if constexpr (r == (FUSE1A ? 1 : 0)) { if (pend) finish(); }
+            tpart(X1, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vh[r & 1], kg == 0 ? zero : acc[j][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            tpart(X1, std::integral_constant<int, 1>{});
+            loads(std::integral_constant<int, r + 2>{});                           // (into the registers the column sums have just freed; read a region later)
+            if constexpr (r == 14) {                                               // the output transform along j starts while the last accumulators fill: M0 + M1
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[0][m] = acc[0][m] + acc[1][m];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s], vh[r & 1], acc[j][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            tpart(X1, std::integral_constant<int, 2>{});
+            if constexpr (!FUSE1A && 2 * r < PPW) dma_piece(org_n, cur ^ 1, std::integral_constant<int, 2 * r>{});
+            if constexpr (r == 15) {                                               // T'(0) = (M0 + M1) + M2
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[0][m] = acc[0][m] + acc[2][m];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s + 1], vh[r & 1], acc[j][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            tpart(X1, std::integral_constant<int, 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vl[r & 1], acc[j][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            tpart(X1, std::integral_constant<int, 4>{});
+            if constexpr (!FUSE1A && 2 * r + 1 < PPW) dma_piece(org_n, cur ^ 1, std::integral_constant<int, 2 * r + 1>{});
+            if constexpr (r == 15) {                                               // M1 - M2 (T'(1) = (M1 - M2) - M3 behind the last MFMA)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[1][m] = acc[1][m] - acc[2][m];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vl[r & 1], acc[j][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef WN_STEP_TRACE
+        asm volatile("s_memtime %0" : "=s"(ts[16]));
+        if (tr && tk >= 0 && tk < 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 17; ++k) trace[64 + (tid ? 68 : 0) + tk * 17 + k] = ts[k];
+        }
+#endif
         stamp(2);
         // ---- output transform along j (lane-local): T'(b) = sum_j A^T(b, j) M(i, j): T'(0) = (M0 + M1) + M2, T'(1) = (M1 - M2) - M3, one register group
         // (four channels of the lane's tile) at a time, straight into the exchange (or, the wave's own groups, into 16 registers) ---------------------------
-        auto tprime = [&](int m, int g, int b) -> wn_f4 {
-            wn_f4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int q = 4 * g + e;
-                r[e] = b == 0 ? (acc[0][m][q] + acc[1][m][q]) + acc[2][m][q] : (acc[1][m][q] - acc[2][m][q]) - acc[3][m][q];
-            }
-            return r;
+        for (int m = 0; m < 2; ++m) acc[1][m] = acc[1][m] - acc[3][m];
+        auto tprime = [&](int m, int g, int b) -> wn_f4 {
+            return wn_f4{acc[b][m][4 * g], acc[b][m][4 * g + 1], acc[b][m][4 * g + 2], acc[b][m][4 * g + 3]};
         };
         // ---- ... along i through LDS.  The packed weights ROTATE the output channels per wave (conv_pack_weights_wino): in wave i, register group g of channel
         // fragment m holds channels 16 ((i + k) & 3) + 8 (g & 1) + 4 hh + (0..3), k = 2 m + g / 2 -- its OWN quarter (k = 0) always in fragment 0, groups 0-1,
-        // whatever i is: the code below is the same for the four waves (a switch over the wave with the accumulators live sent 100 registers to scratch).
+        // whatever i is: the code is the same for the four waves (a switch over the wave with the accumulators live sent 100 registers to scratch).
         // Region (source s, destination d) = 3 s + (d < s ? d : d - 1), slot 2 b + q (q = g & 1).
 #pragma unroll
         for (int k = 1; k < 4; ++k)
@@ -413,79 +599,21 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     wn_lds_st(smem, xw[k - 1] + (uint32_t)((2 * b + q) * 1024) + lane * 16, tprime(k >> 1, 2 * (k & 1) + q, b));
-        wn_f4 own[2][2];                                                           // [b][q]
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q) own[b][q] = tprime(0, q, b);
-        stamp(3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        stamp(4);
-        // y(a, b) = sum_s A^T(a, s) T'_s(b) = (T0 + T1) + T2 and (T1 - T2) - T3 over the OTHER three waves' terms (the wave's own slot reads zeros), its own
-        // term added last with its coefficient: a channel is always finished by the same wave, in the same order
-        {
-            // bias, ReLU, (pool), store: tile (trow, tcol) of the 2 x 16 = output pixels (ty0 + 2 trow + a, tx0 + 2 tcol + b)
-            const int ty0 = cur_ix.ty * 4, tx0 = cur_ix.tx * 32;
-            const int oy = ty0 + 2 * trow, ox = tx0 + 2 * tcol;
-            char* const oimg = out + (int64_t)cur_ix.b * out_img_bytes;
-            const float lo_lim = relu ? 0.f : -WN_ACT_CLAMP;
-            auto store = [&](int y, int x, int q, const wn_f4& raw) {             // output pixel (y, x) of the (pooled) map, quad q
-                wn_f4 v;
-                const float4 bb = *reinterpret_cast<const float4*>(smem + WN_BIAS_OFF + (16 * wave + 8 * q + 4 * hh) * 4);
-                v[0] = __builtin_amdgcn_fmed3f(fmaf(raw[0], inv, bb.x), lo_lim, WN_ACT_CLAMP);
-                v[1] = __builtin_amdgcn_fmed3f(fmaf(raw[1], inv, bb.y), lo_lim, WN_ACT_CLAMP);
-                v[2] = __builtin_amdgcn_fmed3f(fmaf(raw[2], inv, bb.z), lo_lim, WN_ACT_CLAMP);
-                v[3] = __builtin_amdgcn_fmed3f(fmaf(raw[3], inv, bb.w), lo_lim, WN_ACT_CLAMP);
-                char* const pp = oimg + ((int64_t)(y + 1) * Wof + (x + 1)) * opix;
-                const int ch = 16 * wave + 8 * q + 4 * hh;                         // channel inside the workgroup's 64-channel block cg
-                if constexpr (OUT_SPLIT) {
-                    float2v_t f0, f1; f0[0] = v[0]; f0[1] = v[1]; f1[0] = v[2]; f1[1] = v[3];
-                    const uint32_t h0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f0, half2v_t));
-                    const uint32_t h1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f1, half2v_t));
-                    uint32_t l0, l1;
-                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "v"(v[0]));
-                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(h0), "v"(v[1]));
-                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h1), "v"(v[2]));
-                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "v"(v[3]));
-                    *reinterpret_cast<wn_u2*>(pp + cg * 256 + ch * 2) = wn_u2{h0, h1};
-                    *reinterpret_cast<wn_u2*>(pp + cg * 256 + 128 + ch * 2) = wn_u2{l0, l1};
-                } else {
-                    *reinterpret_cast<wn_f4*>(pp + (cg * 64 + ch) * 4) = v;
-                }
-            };
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                wn_f4 pmax;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    wn_f4 ts[4], y0, y1;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) ts[s] = wn_lds_ld(smem, xr[s] + (uint32_t)((2 * b + q) * 1024) + lane * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        y0[e] = fmaf(own[b][q][e], c0, (ts[0][e] + ts[1][e]) + ts[2][e]);
-                        y1[e] = fmaf(own[b][q][e], c1, (ts[1][e] - ts[2][e]) - ts[3][e]);
-                    }
-                    if constexpr (POOL) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pmax[e] = b == 0 ? fmaxf(y0[e], y1[e]) : fmaxf(pmax[e], fmaxf(y0[e], y1[e]));
-                    } else {
-                        if (oy < H && ox + b < W) store(oy, ox + b, q, y0);
-                        if (oy + 1 < H && ox + b < W) store(oy + 1, ox + b, q, y1);
-                    }
-                }
-                if constexpr (POOL) { if (oy < H && ox < W) store(oy >> 1, ox >> 1, q, pmax); }
-            }
-        }
+        pend = 1; p_b = cur_ix.b; p_ty = cur_ix.ty; p_tx = cur_ix.tx;
         cur_ix = nxt_ix;
         advance(nxt_ix);
-        stamp(5);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // the next tile's halo landed; the exchange has been read
+        stamp(3);
+        // the next tile's halo landed, the exchange is written (FUSE1A: the patch load in flight is NOT waited for -- and hipcc must not do it either)
+        if constexpr (FUSE1A) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        stamp(6);
+        stamp(4);
         ++tk;
     }
+    if (pend) finish();                                                            // the last tile's
 }
 
 template <bool POOL, bool OUT_SPLIT, bool FUSE1A>
@@ -513,15 +641,15 @@ static int launch_wino(hipStream_t st, const ConvArgs& a, const WnFuse& fz) {
     static const bool want_trace = config_process()[CFG_WINO_TRACE] != 0;
     static unsigned long long* trace_dev = nullptr;
     if (want_trace) {
-        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 64 * 8));
-        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * 8, st));
+        if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 256 * 8));
+        OMNI_HIP_TRY(hipMemsetAsync(trace_dev, 0, 256 * 8, st));
     }
     hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), WN_SMEM, st, reinterpret_cast<const char*>(a.in), reinterpret_cast<char*>(a.out),
                        reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.split_inv, a.H, a.W, a.cout, n_cg, tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, sk, fz,
                        want_trace ? trace_dev : nullptr);
     OMNI_LAUNCH_CHECK();
     if (want_trace) {
-        unsigned long long h[64];
+        unsigned long long h[256];
         OMNI_HIP_TRY(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, st));
         OMNI_HIP_TRY(hipStreamSynchronize(st));
         static int launches = 0;                   // per instantiation: launches 3 and 4 (the first ones run on cold TLBs and caches)
@@ -529,8 +657,16 @@ static int launch_wino(hipStream_t st, const ConvArgs& a, const WnFuse& fz) {
             for (int w = 0; w < 2; ++w)
                 for (int k = 0; k < 4; ++k) {
                     const unsigned long long* q = h + w * 32 + k * 8;
-                    fprintf(stderr, "wino trace pool=%d split=%d fuse1a=%d H=%d W=%d wave %d tile %d: fill %llu stream %llu j-transform+write %llu barrier %llu finish %llu wait+barrier %llu | total %llu\n",
-                            (int)POOL, (int)OUT_SPLIT, (int)FUSE1A, a.H, a.W, w * 3, k + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[6] - q[0]);
+#ifdef WN_STEP_TRACE
+                    {
+                        const unsigned long long* u = h + 64 + w * 68 + k * 17;
+                        fprintf(stderr, "wino step trace pool=%d split=%d fuse1a=%d wave %d tile %d:", (int)POOL, (int)OUT_SPLIT, (int)FUSE1A, w * 3, k + 2);
+                        for (int r = 0; r < 16; ++r) fprintf(stderr, " %llu", u[r + 1] - u[r]);
+                        fprintf(stderr, "\n");
+                    }
+#endif
+                    fprintf(stderr, "wino trace pool=%d split=%d fuse1a=%d H=%d W=%d wave %d tile %d: head %llu stream %llu j-transform+write %llu wait+barrier %llu | total %llu\n",
+                            (int)POOL, (int)OUT_SPLIT, (int)FUSE1A, a.H, a.W, w * 3, k + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[4] - q[0]);
                 }
     }
     return OMNI_OK;
