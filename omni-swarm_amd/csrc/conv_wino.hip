@@ -101,12 +101,16 @@ struct WnFuse {
     const uint32_t* lut_hl = nullptr;     // conv1a_make_split_lut
 };
 
+__device__ __forceinline__ float wn_max(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }      // no canonicalisation of the operands
 template <int J, int N, typename F>
 __device__ __forceinline__ void wn_for_each(F&& f) {
     if constexpr (J < N) { f(std::integral_constant<int, J>{}); wn_for_each<J + 1, N>(f); }
 }
-__device__ __forceinline__ wn_f4 wn_lds_ld(const char* smem, uint32_t off) { return *reinterpret_cast<const wn_f4*>(smem + off); }
-__device__ __forceinline__ void wn_lds_st(char* smem, uint32_t off, wn_f4 v) { *reinterpret_cast<wn_f4*>(smem + off) = v; }
+// LDS accesses by 32-bit LDS address: the workgroup's dynamic LDS starts at address 0 (no static LDS in this kernel; checked once by the launcher's
+// first block through `lds_base_is_zero`), so an offset IS the address and the instruction's immediate offset field takes the constant part
+typedef __attribute__((address_space(3))) wn_f4 wn_lds_f4;
+__device__ __forceinline__ wn_f4 wn_lds_ld(const char*, uint32_t off) { return *reinterpret_cast<const wn_lds_f4*>((uintptr_t)off); }
+__device__ __forceinline__ void wn_lds_st(char*, uint32_t off, wn_f4 v) { *reinterpret_cast<wn_lds_f4*>((uintptr_t)off) = v; }
 
 // hi = half(v), lo = half(v - hi) of eight values: four v_cvt_pk_f16_f32 and eight v_fma_mix{lo,hi}_f16 (x - float(hi) is exact in f32: one rounding)
 __device__ __forceinline__ void wn_split8(const wn_f4& a, const wn_f4& b, half8_t& hi, half8_t& lo) {
@@ -133,6 +137,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
                     unsigned long long* trace /* OMNI_WINO_TRACE=1: s_memtime stamps of workgroup 0, waves 0 and 3 (debug), else nullptr */) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();      // (wn_lds_ld / wn_lds_st address LDS from 0)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = i, the row of the transformed patch this wave owns
     const int n = lane & 31, hh = lane >> 5, trow = n >> 4, tcol = n & 15;
     const int bid = xcd_block_id(sk.xcd);
@@ -296,7 +301,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
                     for (int g = 0; g < 4; ++g) {
                         wn_f4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(a[4 * g + e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(a[4 * g + e], 0.f, WN_ACT_CLAMP);      // (fmaxf: a canonicalising v_max in front of the v_max)
                         wn_lds_st(smem, dstb ^ (uint32_t)((m * 8 + g * 2) << 4), v);    // channels 32 m + 8 g + 4 hh + (0..3)
                     }
                 }
@@ -370,7 +375,14 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
     // y(a, b) = sum_s A^T(a, s) T'_s(b) = (T0 + T1) + T2 and (T1 - T2) - T3 over the OTHER three waves' terms (the wave's own slot reads zeros), its own term
     // added last with its coefficient: a channel is always finished by the same wave, in the same order.  Then bias, ReLU, (pool), store: tile (trow, tcol)
     // of the 2 x 16 = output pixels (4 ty + 2 trow + a, 32 tx + 2 tcol + b)
-    auto finish = [&]() {
+    wn_f4 xt[2][4];                                                                // [b][s]: the four waves' terms of one quad of the pending tile (the wave's own slot: zeros)
+    auto xch_issue = [&](int q) {                                                  // quad 0: at the head of the next tile's stream; quad 1: behind quad 0's finish
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xt[b][s] = wn_lds_ld(smem, xr[s][2 * b + q] + lane * 16);
+    };
+    auto finish = [&](int q) {
         const int oy = p_ty * 4 + 2 * trow, ox = p_tx * 32 + 2 * tcol;
         // the output image as a raw buffer: a lane with nothing to store carries an offset outside it (the store is dropped: no branch in the stream)
         const __amdgpu_buffer_rsrc_t oimg = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)p_b * out_img_bytes, 0, (int)out_img_bytes, 0x00020000);
@@ -378,7 +390,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         const int ch0 = 16 * wave + 4 * hh;                                        // + 8 q: the channel inside the workgroup's 64-channel block cg
         const uint32_t chan_off = OUT_SPLIT ? (uint32_t)(cg * 256 + ch0 * 2) : (uint32_t)((cg * 64 + ch0) * 4);
         auto pix_off = [&](int y, int x, bool ok) -> uint32_t {                   // output pixel (y, x) of the (pooled) map
-            return ok ? (uint32_t)((y + 1) * Wof + (x + 1)) * (uint32_t)opix + chan_off : 0x80000000u;
+            return (ok & (pend != 0)) ? (uint32_t)((y + 1) * Wof + (x + 1)) * (uint32_t)opix + chan_off : 0x80000000u;
         };
         auto store = [&](uint32_t off, int q, const wn_f4& raw) {
             wn_f4 v;
@@ -410,22 +422,19 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
 #pragma unroll
                 for (int b = 0; b < 2; ++b) off[2 * a + b] = pix_off(oy + a, ox + b, (oy + a < H) & (ox + b < W));
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        {
             wn_f4 pmax;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                wn_f4 ts[4], y0, y1;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) ts[s] = wn_lds_ld(smem, xr[s][2 * b + q] + lane * 16);
+                wn_f4 y0, y1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    y0[e] = fmaf(own[b][q][e], c0, (ts[0][e] + ts[1][e]) + ts[2][e]);
-                    y1[e] = fmaf(own[b][q][e], c1, (ts[1][e] - ts[2][e]) - ts[3][e]);
+                    y0[e] = fmaf(own[b][q][e], c0, (xt[b][0][e] + xt[b][1][e]) + xt[b][2][e]);
+                    y1[e] = fmaf(own[b][q][e], c1, (xt[b][1][e] - xt[b][2][e]) - xt[b][3][e]);
                 }
                 if constexpr (POOL) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pmax[e] = b == 0 ? fmaxf(y0[e], y1[e]) : fmaxf(pmax[e], fmaxf(y0[e], y1[e]));
+                    for (int e = 0; e < 4; ++e) pmax[e] = b == 0 ? wn_max(y0[e], y1[e]) : wn_max(pmax[e], wn_max(y0[e], y1[e]));
                 } else {
                     store(off[b], q, y0);
                     store(off[2 + b], q, y1);
@@ -497,6 +506,16 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             }
         }
     };
+    // the exchange writes of T'(b) for the quarter of wave (wave + k) & 3: register groups 2 (k & 1) + q of channel fragment k >> 1 (see the rotation below)
+    auto xwrite = [&](floatx16 (&acc)[4][2], auto BC, auto KC) {
+        constexpr int b = decltype(BC)::value, k = decltype(KC)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            constexpr int m = k >> 1;
+            const int g = 2 * (k & 1) + q;
+            wn_lds_st(smem, xw[k - 1] + (uint32_t)((2 * b + q) * 1024) + lane * 16, wn_f4{acc[b][m][4 * g], acc[b][m][4 * g + 1], acc[b][m][4 * g + 2], acc[b][m][4 * g + 3]});
+        }
+    };
     WnTileIx fill_ix = cur_ix;                                                     // the tile whose halo this stream fills (the next one; the last stream: its own again)
     for (; t < total; t += nwg, cur ^= 1) {
         stamp(0);
@@ -515,6 +534,8 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             for (int q = 0; q < 2; ++q) { ax[0][p][q] = adA[p][q] + (uint32_t)(cur * WN_HALO_BYTES); ax[1][p][q] = ax[0][p][q] + (uint32_t)dAB; }
         loads(std::integral_constant<int, 0>{});
         loads(std::integral_constant<int, 1>{});
+        xch_issue(0);
+        if constexpr (FUSE1A) { patch_park(fill_ix.ty, fill_ix.tx); patch_issue(nn_ix.b, nn_ix.ty, nn_ix.tx); }
         wn_for_each<0, 5>([&](auto GC) { tpart(std::integral_constant<int, 0>{}, GC); });
         stamp(1);
         floatx16 acc[4][2];
@@ -531,11 +552,11 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
 #ifdef WN_STEP_TRACE      // separate build (tools/round6/steptrace.sh): s_memtime at the top of every region (the values are read after the stream)
             asm volatile("s_memtime %0" : "=s"(ts[r]));
 #endif
-            if constexpr (r == 3) __builtin_amdgcn_s_barrier();                    // every wave has read the previous tile's exchange (region 0): it may be rewritten
+            if constexpr (r == 2) __builtin_amdgcn_s_barrier();                    // every wave has read the previous tile's exchange (at its head): it may be rewritten
             acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vh[r & 1], kg == 0 ? zero : acc[j][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FUSE1A && r == 0) { patch_park(fill_ix.ty, fill_ix.tx); patch_issue(nn_ix.b, nn_ix.ty, nn_ix.tx); build_tile(fill_ix.ty, fill_ix.tx, cur ^ 1); }
-            if constexpr (r == (FUSE1A ? 1 : 0)) { if (pend) finish(); }
+            if constexpr (r == 0) { finish(0); xch_issue(1); }
+            if constexpr (FUSE1A && r == 1) build_tile(fill_ix.ty, fill_ix.tx, cur ^ 1);
             tpart(X1, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
             acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vh[r & 1], kg == 0 ? zero : acc[j][1], 0, 0, 0);
@@ -550,7 +571,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s], vh[r & 1], acc[j][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             tpart(X1, std::integral_constant<int, 2>{});
-            if constexpr (!FUSE1A && 2 * r < PPW) dma_piece(org_n, cur ^ 1, std::integral_constant<int, 2 * r>{});
+            if constexpr (!FUSE1A && r >= 1 && 2 * (r - 1) < PPW) dma_piece(org_n, cur ^ 1, std::integral_constant<int, 2 * (r - 1)>{});
             if constexpr (r == 15) {                                               // T'(0) = (M0 + M1) + M2
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acc[0][m] = acc[0][m] + acc[2][m];
@@ -559,14 +580,17 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[32 + s + 1], vh[r & 1], acc[j][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             tpart(X1, std::integral_constant<int, 3>{});
+            if constexpr (r == 15) xwrite(acc, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // T'(0) of the quarters of waves + 1 ..
             __builtin_amdgcn_sched_barrier(0);
             acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vl[r & 1], acc[j][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             tpart(X1, std::integral_constant<int, 4>{});
-            if constexpr (!FUSE1A && 2 * r + 1 < PPW) dma_piece(org_n, cur ^ 1, std::integral_constant<int, 2 * r + 1>{});
+            if constexpr (r == 0) finish(1);
+            if constexpr (!FUSE1A && r >= 1 && 2 * (r - 1) + 1 < PPW) dma_piece(org_n, cur ^ 1, std::integral_constant<int, 2 * (r - 1) + 1>{});
             if constexpr (r == 15) {                                               // M1 - M2 (T'(1) = (M1 - M2) - M3 behind the last MFMA)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acc[1][m] = acc[1][m] - acc[2][m];
+                xwrite(acc, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});                           // .. + 2
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vl[r & 1], acc[j][1], 0, 0, 0);
@@ -585,24 +609,18 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         // (four channels of the lane's tile) at a time, straight into the exchange (or, the wave's own groups, into 16 registers) ---------------------------
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[1][m] = acc[1][m] - acc[3][m];
-        auto tprime = [&](int m, int g, int b) -> wn_f4 {
-            return wn_f4{acc[b][m][4 * g], acc[b][m][4 * g + 1], acc[b][m][4 * g + 2], acc[b][m][4 * g + 3]};
-        };
+        xwrite(acc, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+        xwrite(acc, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        xwrite(acc, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+        xwrite(acc, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
         // ---- ... along i through LDS.  The packed weights ROTATE the output channels per wave (conv_pack_weights_wino): in wave i, register group g of channel
         // fragment m holds channels 16 ((i + k) & 3) + 8 (g & 1) + 4 hh + (0..3), k = 2 m + g / 2 -- its OWN quarter (k = 0) always in fragment 0, groups 0-1,
         // whatever i is: the code is the same for the four waves (a switch over the wave with the accumulators live sent 100 registers to scratch).
         // Region (source s, destination d) = 3 s + (d < s ? d : d - 1), slot 2 b + q (q = g & 1).
 #pragma unroll
-        for (int k = 1; k < 4; ++k)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    wn_lds_st(smem, xw[k - 1] + (uint32_t)((2 * b + q) * 1024) + lane * 16, tprime(k >> 1, 2 * (k & 1) + q, b));
-#pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) own[b][q] = tprime(0, q, b);
+            for (int q = 0; q < 2; ++q) own[b][q] = wn_f4{acc[b][0][4 * q], acc[b][0][4 * q + 1], acc[b][0][4 * q + 2], acc[b][0][4 * q + 3]};
         pend = 1; p_b = cur_ix.b; p_ty = cur_ix.ty; p_tx = cur_ix.tx;
         cur_ix = nxt_ix;
         advance(nxt_ix);
@@ -613,7 +631,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         stamp(4);
         ++tk;
     }
-    if (pend) finish();                                                            // the last tile's
+    xch_issue(0); finish(0); xch_issue(1); finish(1);                              // the last tile's (nothing pending: every store is dropped)
 }
 
 template <bool POOL, bool OUT_SPLIT, bool FUSE1A>
