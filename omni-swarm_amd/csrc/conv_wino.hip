@@ -255,56 +255,71 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         const uint32_t keep = left >= 4 ? 0xffffffffu : (1u << (8 * (left & 3))) - 1u;
         reinterpret_cast<uint32_t*>(smem + WN_PATCH_OFF + wave * 256)[lane] = ok ? (pv & keep) : 0u;
     };
+    // (all four (fragment, channel fragment) chains side by side: bytes -> table entries -> two dependent MFMAs -> ReLU -> four 16-byte LDS stores are
+    // dependent LDS / matrix-core round trips; run at the HEAD of a tile's stream, where the accumulators are dead and the registers are there)
     auto build_tile = [&](int qty, int qtx, int which) {
         const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + WN_LUT_OFF);
         const int ty0 = qty * 4, tx0 = qtx * 32;
-        uint32_t U[2][5];
-        bool valid[2];
-        int vp[2], X[2];
+        uint32_t U[2][5], dstb[2];
+        bool valid[2], inside[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            vp[f] = 64 * wave + 32 * f + n;
-            const int R = vp[f] / WN_ITW;
-            X[f] = vp[f] - R * WN_ITW;
-            const int gy = ty0 - 1 + R, gx = tx0 - 1 + X[f];                        // the image pixel under this halo pixel
-            valid[f] = (vp[f] < WN_HPIX) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            // MFMA column n <-> pixel 2 (n & 15) + (n >> 4) of the fragment: the eight lanes of a ds_write_b128 phase then store pixels two columns apart, whose
+            // swizzles (X >> 1) differ (pixels n, n + 1 share one: a two-way bank conflict on every store)
+            const int vp = 64 * wave + 32 * f + 2 * (n & 15) + (n >> 4);
+            const int R = vp / WN_ITW, X = vp - R * WN_ITW;
+            const int gy = ty0 - 1 + R, gx = tx0 - 1 + X;                           // the image pixel under this halo pixel
+            inside[f] = vp < WN_HPIX;
+            valid[f] = inside[f] & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
             // the byte under tap (0, 0): patch row R - fz_r0, patch column X + 2 (patch column 0 = image column 32 tx - 4); a pixel outside the image is conv1b's
             // zero padding: its taps read zeros, its bias slots are zero
-            const uint32_t pb = valid[f] ? (uint32_t)(WN_PATCH_OFF + wave * 256 + (R - fz_r0) * 40 + X[f] + 2) : (uint32_t)WN_ZERO_OFF;
+            const uint32_t pb = valid[f] ? (uint32_t)(WN_PATCH_OFF + wave * 256 + (R - fz_r0) * 40 + X + 2) : (uint32_t)WN_ZERO_OFF;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int t1 = k < 4 ? 5 + k : 8;
                 const int c0 = (k / 3) * 40 + k % 3, c1 = (t1 / 3) * 40 + t1 % 3;
                 U[f][k] = *reinterpret_cast<const uint8_t*>(smem + pb + (hh ? c1 : c0));
             }
+            // chunk c = 8 m + 2 g + hh of the pixel goes to slot c ^ swizzle: (base | ((swizzle ^ hh) << 4)) ^ ((8 m + 2 g) << 4), one v_xor per store -- and NOT sixteen
+            // loop-invariant addresses hoisted out of the tile loop into registers the stream has no room for (the empty asm pins the base inside the loop)
+            dstb[f] = (uint32_t)(which * WN_HALO_BYTES + vp * 256) + (uint32_t)(((((X >> 1) & 15) ^ hh)) << 4);
+            asm volatile("" : "+v"(dstb[f]));
+        }
+        half8_t wa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const half8_t*>(smem + WN_W1A_OFF + i * 1024 + lane * 16);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int k = 0; k < 5; ++k) U[f][k] = lut[U[f][k]];
+        floatx16 a[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
             const uint32_t h01 = __builtin_amdgcn_perm(U[f][1], U[f][0], 0x05040100u), h23 = __builtin_amdgcn_perm(U[f][3], U[f][2], 0x05040100u);
             const uint32_t x3 = hh ? (valid[f] ? 0x3C003C00u : 0u) : U[f][4];       // lanes 32-63: the bias slots (1.0, 1.0)
             const half8_t B0 = __builtin_bit_cast(half8_t, wn_u4{U[f][0], U[f][1], U[f][2], U[f][3]});
             const half8_t B1 = __builtin_bit_cast(half8_t, wn_u4{U[f][4], h01, h23, x3});
-            // chunk c = 8 m + 2 g + hh of the pixel goes to slot c ^ swizzle: (base | ((swizzle ^ hh) << 4)) ^ ((8 m + 2 g) << 4), one v_xor per store -- and NOT sixteen
-            // loop-invariant addresses hoisted out of the tile loop into registers the stream has no room for (the empty asm pins the base inside the loop)
-            uint32_t dstb = (uint32_t)(which * WN_HALO_BYTES + vp[f] * 256) + (uint32_t)(((((X[f] >> 1) & 15) ^ hh)) << 4);
-            asm volatile("" : "+v"(dstb));
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                floatx16 a;
+                floatx16 z;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = 0.f;
-                const half8_t wa0 = *reinterpret_cast<const half8_t*>(smem + WN_W1A_OFF + m * 1024 + lane * 16);
-                const half8_t wa1 = *reinterpret_cast<const half8_t*>(smem + WN_W1A_OFF + (2 + m) * 1024 + lane * 16);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, B0, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, B1, a, 0, 0, 0);
-                if (vp[f] < WN_HPIX) {
+                for (int q = 0; q < 16; ++q) z[q] = 0.f;
+                a[f][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[m], B0, z, 0, 0, 0);
+                a[f][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[2 + m], B1, a[f][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (inside[f]) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         wn_f4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(a[4 * g + e], 0.f, WN_ACT_CLAMP);      // (fmaxf: a canonicalising v_max in front of the v_max)
-                        wn_lds_st(smem, dstb ^ (uint32_t)((m * 8 + g * 2) << 4), v);    // channels 32 m + 8 g + 4 hh + (0..3)
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(a[f][m][4 * g + e], 0.f, WN_ACT_CLAMP);      // (fmaxf: a canonicalising v_max in front of the v_max)
+                        wn_lds_st(smem, dstb[f] ^ (uint32_t)((m * 8 + g * 2) << 4), v);    // channels 32 m + 8 g + 4 hh + (0..3)
                     }
-                }
             }
         }
     };
@@ -489,7 +504,10 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             else if constexpr (G == 1) { if constexpr (j == 0) vsum(2); }
             else if constexpr (G == 2) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) Vt[q] = j == 0 ? Wc[0][q] - Wc[2][q] : j == 1 ? Wc[1][q] + Wc[2][q] : j == 2 ? Wc[2][q] - Wc[1][q] : Wc[1][q] - Wc[3][q];
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        Vt[q][e] = j == 0 ? Wc[0][q][e] - Wc[2][q][e] : j == 1 ? Wc[1][q][e] + Wc[2][q][e] : j == 2 ? Wc[2][q][e] - Wc[1][q][e] : Wc[1][q][e] - Wc[3][q][e];
             } else if constexpr (G == 3) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -535,7 +553,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         loads(std::integral_constant<int, 0>{});
         loads(std::integral_constant<int, 1>{});
         xch_issue(0);
-        if constexpr (FUSE1A) { patch_park(fill_ix.ty, fill_ix.tx); patch_issue(nn_ix.b, nn_ix.ty, nn_ix.tx); }
+        if constexpr (FUSE1A) { patch_park(fill_ix.ty, fill_ix.tx); patch_issue(nn_ix.b, nn_ix.ty, nn_ix.tx); build_tile(fill_ix.ty, fill_ix.tx, cur ^ 1); }
         wn_for_each<0, 5>([&](auto GC) { tpart(std::integral_constant<int, 0>{}, GC); });
         stamp(1);
         floatx16 acc[4][2];
@@ -556,7 +574,6 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vh[r & 1], kg == 0 ? zero : acc[j][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (r == 0) { finish(0); xch_issue(1); }
-            if constexpr (FUSE1A && r == 1) build_tile(fill_ix.ty, fill_ix.tx, cur ^ 1);
             tpart(X1, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
             acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vh[r & 1], kg == 0 ? zero : acc[j][1], 0, 0, 0);
