@@ -131,3 +131,44 @@ def test_threshold_inside_the_detector_head_equals_the_separate_candidate_kernel
         xy, conf, _, _ = P.get_keypoints(semi, thr, max_num)
         assert np.array_equal(ka.astype(np.int32), xy) and np.array_equal(sa, conf)
         fused.close(); plain.close()
+
+
+def test_near_ties_at_the_top_k_cut(omni, ctx):
+    """The cut at rank max_num (superpoint_tensorrt.cpp:173-189: sort by confidence, keep max_num) is a discontinuity: confidences one fp32 ulp apart -- and exactly
+    equal -- placed ACROSS the cut must be ordered by the product exactly as by the oracle (confidence descending, ties in row-major order), whatever the value
+    differences are; what the north-star gate "same key points up to confidence ties below the fp32 noise" leaves open is the NET's noise, not the sort's."""
+    w, h, max_num, thr = 160, 96, 24, 0.1
+    sp, comp, mean = _sp(omni, ctx, w, h, thr, max_num=max_num)
+    rng = np.random.default_rng(11)
+    desc = rng.standard_normal((256, h // 8, w // 8)).astype(np.float32)
+    desc /= np.linalg.norm(desc, axis=0, keepdims=True)
+    # isolated peaks on a 12-pixel lattice (NMS2's radius is 4: none suppresses another), 20 clear winners, then a cluster of 12 around the cut
+    sites = [(6 + 12 * (i // 12), 6 + 12 * (i % 12)) for i in range(60)]
+    rng.shuffle(sites)
+    base = np.float32(0.5)
+    up = lambda v, k: np.nextafter(v, np.float32(1.0), dtype=np.float32) if k == 0 else up(np.nextafter(v, np.float32(1.0), dtype=np.float32), k - 1)
+    for variant in range(4):
+        semi = np.zeros((h, w), np.float32)
+        for i, (y, x) in enumerate(sites[:20]):
+            semi[y, x] = 0.9 - 0.01 * i
+        cluster = sites[20:32]
+        if variant == 0:      # all twelve exactly equal: row-major order decides who makes the cut
+            vals = [base] * 12
+        elif variant == 1:    # one ulp apart, in shuffled positions
+            vals = [up(base, k) for k in range(12)]
+        elif variant == 2:    # pairs of equal values one ulp apart from the next pair
+            vals = [up(base, k // 2) for k in range(12)]
+        else:                 # one ulp apart, descending against the row-major order of the sites
+            order = np.argsort([y * w + x for (y, x) in cluster])
+            vals = [None] * 12
+            for rank, idx in enumerate(order):
+                vals[idx] = up(base, rank)
+        for (y, x), v in zip(cluster, vals):
+            semi[y, x] = v
+        for (y, x) in sites[32:]:
+            semi[y, x] = 0.2 + 0.001 * rng.random()
+        n = _compare(sp, semi, desc, w, h, thr, max_num, comp, mean)
+        assert n == max_num
+        xy, conf, _, _ = P.get_keypoints(semi, thr, max_num)
+        assert conf[19] > base and conf[20] <= up(base, 12) and conf[-1] >= base       # the cut runs through the cluster
+    sp.close()

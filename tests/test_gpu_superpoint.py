@@ -77,6 +77,33 @@ def test_f32_layers_and_dense_outputs(omni, ctx, shape, prec, monkeypatch):
     assert np.abs(desc - desc_r).max() < 2e-5, np.abs(desc - desc_r).max()
 
 
+@pytest.mark.parametrize("mask", [0, 1, 2, 4, 6])
+def test_split_winograd_layer_subsets_meet_the_same_gates(omni, ctx, monkeypatch, mask):
+    """OMNI_PREC_SPLIT runs conv1b / conv2a / conv2b as Winograd F(2x2,3x3) kernels with split operands (csrc/conv_wino.hip; OMNI_SPLIT_WINO bit 0 / 1 / 2, default
+    all three: what test_f32_layers_and_dense_outputs[PREC_SPLIT] gates).  Every subset -- a Winograd layer behind a direct one reads a converted raw-32 frame, one
+    in front of a direct one writes split-64 -- meets the same per-layer bar (2e-5 of the layer's magnitude) and the same dense-output bars, at a shape whose tiles
+    overhang the image on both sides and at the full frame; 0 = the direct kernels of conv_split.hip."""
+    weights = S.synth_weights(0)
+    comp, mean = synth.pca()
+    monkeypatch.setenv("OMNI_SPLIT_WINO", str(mask))
+    for (h, w) in ((72, 104), (480, 600)):
+        imgs = np.stack([synth.image_u8(400 + i, h, w, n_shapes=60 if h < 100 else 200) for i in range(2)])
+        sp = omni.capi.SuperPoint(ctx, weights, comp, mean, w, h, 0.015, 200, omni.capi.PREC_SPLIT, 2)
+        res = sp.inference(imgs, fisheye_mask=(h == 480))
+        semi_r, desc_r, layers_r = _oracle_layers(weights, S.preprocess_u8(imgs, fisheye_mask=(h == 480)))
+        for n in LAYERS[1:] + ["heads"]:
+            got, ref = sp.debug_layer(n, 2), layers_r[n]
+            assert np.isfinite(got).all(), n
+            err = np.abs(got - ref).max()
+            assert err < 2e-5 * max(1.0, np.abs(ref).max()), (mask, n, err)
+        semi, desc = sp.get_dense(2)
+        assert np.abs(semi - semi_r).max() < CONF_TOL and np.abs(desc - desc_r).max() < 2e-5
+        for b in range(2):
+            xy, conf, _, _ = P.get_keypoints(semi_r[b], 0.015, 200)
+            assert_same_keypoints(res[b][0], res[b][2], xy, conf)
+        sp.close()
+
+
 def test_f32_end_to_end_matches_golden_full_frames(omni, ctx, golden):
     g = golden("sp_full.npz")
     weights = S.synth_weights(0)
