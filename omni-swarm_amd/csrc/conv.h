@@ -80,6 +80,10 @@ float conv_pack_weights_wino(const float* w_oihw, int cin, int cout, uint16_t* o
 int conv_wino(hipStream_t stream, const ConvArgs& a, bool out_split);
 int conv1ab_wino_fused(hipStream_t stream, const ConvArgs& a, const uint8_t* gray, int gstride, int fisheye_mask, const void* w1a_frag, const uint32_t* lut_hl, bool out_split);
 int split_to_raw32(hipStream_t stream, const void* in_split, void* out_raw, int batch, int C, int H, int W);      // split-64 frames -> raw-32 frames (out of place)
+// the mask's constant region behind an unpooled Winograd layer: one vector per position in the 2 x 2 tile (vec: 4 x pix_bytes; y, x even)
+int conv_read_pixels2x2_bytes(hipStream_t stream, const void* map, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y, int x, void* vec);
+int conv_fill_rect2x2_bytes(hipStream_t stream, void* map, int batch, int64_t img_bytes, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y0, int y1, int x0, int x1,
+                            const void* vec);
 int raw32_to_nchw_f32(hipStream_t stream, const void* in_raw, float* out, int batch, int C, int H, int W);        // test hook
 // A split-64 H x W map lives in a zero frame of split_frame_h(H) rows x split_frame_w(W) pixels, pixel (y, x) at row y + 1, column x + 1:
 // one pixel of zero padding all round plus the overhang of the last 32-pixel tile in either direction.  The frame must be zeroed once

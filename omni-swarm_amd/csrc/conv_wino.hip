@@ -753,6 +753,47 @@ int split_to_raw32(hipStream_t st, const void* in_split, void* out_raw, int batc
     OMNI_LAUNCH_CHECK();
     return OMNI_OK;
 }
+// The constant region of the fisheye mask behind an UNPOOLED Winograd layer is constant per position inside the 2 x 2 output tile, not per pixel (the four
+// outputs of a tile go through different rows of A^T): the four vectors of the tile at even (y, x) -> vec[2 py + px][pix_bytes], and the rectangle filled with
+// them by the parity of the absolute coordinates (conv_read_pixel_bytes / conv_fill_rect_bytes of conv.hip for one vector)
+__global__ void read_pixels2x2_kernel(const uint4* __restrict__ map, int64_t chunk0, int64_t row_chunks, int chunks, uint4* __restrict__ vec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * chunks) return;
+    const int k = i / chunks, c = i - k * chunks;
+    vec[i] = map[chunk0 + (k >> 1) * row_chunks + (int64_t)(k & 1) * chunks + c];
+}
+int conv_read_pixels2x2_bytes(hipStream_t st, const void* map, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y, int x, void* vec) {
+    OMNI_REQUIRE(pix_bytes % 16 == 0 && row_bytes % 16 == 0 && org_bytes % 16 == 0 && y >= 0 && x >= 0 && y % 2 == 0 && x % 2 == 0, OMNI_ERR_INVALID, "conv_read_pixels2x2_bytes: bad pixel");
+    const int chunks = pix_bytes / 16;
+    hipLaunchKernelGGL(read_pixels2x2_kernel, dim3(cdiv(4 * chunks, 64)), dim3(64), 0, st, (const uint4*)map, (org_bytes + y * row_bytes + (int64_t)x * pix_bytes) / 16, row_bytes / 16, chunks,
+                       (uint4*)vec);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+__global__ void fill_rect2x2_kernel(char* __restrict__ map, int64_t img_bytes, int64_t row_bytes, int64_t org_bytes, int chunks, int y0, int x0, int rh, int rw,
+                                    const uint4* __restrict__ vec, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // ((b * rh + y) * rw + x) * chunks + c
+    if (i >= total) return;
+    const int c = (int)(i % chunks);
+    const int64_t px = i / chunks;
+    const int x = x0 + (int)(px % rw);
+    const int64_t by = px / rw;
+    const int y = y0 + (int)(by % rh);
+    const int64_t b = by / rh;
+    *reinterpret_cast<uint4*>(map + b * img_bytes + org_bytes + y * row_bytes + ((int64_t)x * chunks + c) * 16) = vec[((y & 1) * 2 + (x & 1)) * chunks + c];
+}
+int conv_fill_rect2x2_bytes(hipStream_t st, void* map, int batch, int64_t img_bytes, int64_t row_bytes, int64_t org_bytes, int pix_bytes, int y0, int y1, int x0, int x1,
+                            const void* vec) {
+    OMNI_REQUIRE(pix_bytes % 16 == 0 && img_bytes % 16 == 0 && row_bytes % 16 == 0 && org_bytes % 16 == 0 && y0 >= 0 && x0 >= 0, OMNI_ERR_INVALID, "conv_fill_rect2x2_bytes: bad layout");
+    if (y1 <= y0 || x1 <= x0 || batch <= 0) return OMNI_OK;
+    const int chunks = pix_bytes / 16;
+    const int64_t total = (int64_t)batch * (y1 - y0) * (x1 - x0) * chunks;
+    hipLaunchKernelGGL(fill_rect2x2_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (char*)map, img_bytes, row_bytes, org_bytes, chunks, y0, x0, y1 - y0, x1 - x0,
+                       (const uint4*)vec, total);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+
 // raw-32 frames -> NCHW fp32, true values (test hook: omni_sp_debug_layer)
 __global__ void raw32_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int batch, int C, int H, int W, int Hf, int Wf, float inv_scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

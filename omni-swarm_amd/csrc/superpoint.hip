@@ -175,7 +175,7 @@ static int sp_plan_mask_skip(omni_sp* s) {
             k.pix_bytes = k.oc * 2; k.row_bytes = (int64_t)k.ow * k.pix_bytes; k.img_bytes = k.row_bytes * k.oh; k.org_bytes = 0;
         }
         if (k.ty1 > k.ty0) {
-            OMNI_HIP_TRY(hipMalloc(&k.vec, (size_t)k.pix_bytes));
+            OMNI_HIP_TRY(hipMalloc(&k.vec, (size_t)k.pix_bytes * 4));                // (x 4: conv2a as a Winograd layer keeps one vector per position in the 2 x 2 tile)
             s->mask_skip = true;
         }
     }
@@ -377,6 +377,11 @@ static int sp_calibrate_mask_skip(omni_sp* s, int stride) {
     s->mask_skip_cal_fused = s->fuse1a;
     for (const omni_sp::MaskSkip& k : s->mskip) {
         if (k.ty1 <= k.ty0 || (k.map == &s->a1a && s->fuse1a)) continue;
+        if (k.map == &s->a2a && s->precision == OMNI_PREC_SPLIT && (s->wino & 2)) {     // an unpooled Winograd layer: constant per position in the 2 x 2 output tile
+            if ((rc = conv_read_pixels2x2_bytes(st, *k.map, k.row_bytes, k.org_bytes, k.pix_bytes, ((k.oy0 + k.oy1) / 2) & ~1, ((k.ox0 + k.ox1) / 2) & ~1, k.vec))) return rc;
+            if ((rc = conv_fill_rect2x2_bytes(st, *k.map, s->max_batch, k.img_bytes, k.row_bytes, k.org_bytes, k.pix_bytes, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
+            continue;
+        }
         if ((rc = conv_read_pixel_bytes(st, *k.map, k.row_bytes, k.org_bytes, k.pix_bytes, (k.oy0 + k.oy1) / 2, (k.ox0 + k.ox1) / 2, k.vec))) return rc;
         if ((rc = conv_fill_rect_bytes(st, *k.map, s->max_batch, k.img_bytes, k.row_bytes, k.org_bytes, k.pix_bytes, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
     }
@@ -410,8 +415,7 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     const bool w1b = P == OMNI_PREC_SPLIT && (s->wino & 1) && fuse1a, w2a = P == OMNI_PREC_SPLIT && (s->wino & 2) != 0, w2b = P == OMNI_PREC_SPLIT && (s->wino & 4) != 0;
     auto skip_of = [&](int l, ConvArgs& a) {
         const int i = l == L1B ? 1 : l == L2A ? 2 : l == L2B ? 3 : l == L3A ? 4 : l == L3B ? 5 : -1;
-        // (an unpooled Winograd layer's constant region is constant per position in the 2 x 2 tile, not per pixel: conv2a recomputes it)
-        if (use_skip && i >= 0 && !(l == L2A && w2a)) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
+        if (use_skip && i >= 0) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
     };
     auto conv = [&](int l, const void* in, void* out, const float* bias, int h, int w, int cin, int cout, int ks, bool relu,
                     bool pool, bool out_f32) -> int {
