@@ -534,7 +534,17 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             wn_lds_st(smem, xw[k - 1] + (uint32_t)((2 * b + q) * 1024) + lane * 16, wn_f4{acc[b][m][4 * g], acc[b][m][4 * g + 1], acc[b][m][4 * g + 2], acc[b][m][4 * g + 3]});
         }
     };
+    // a tile's addresses (k-group 0) and the reads of its steps 0 and 1 from halo buffer `which` (valid once the barrier behind its fill has been passed)
+    auto head_loads = [&](int which) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { ax[0][p][q] = adA[p][q] + (uint32_t)(which * WN_HALO_BYTES); ax[1][p][q] = ax[0][p][q] + (uint32_t)dAB; }
+        loads(std::integral_constant<int, 0>{});
+        loads(std::integral_constant<int, 1>{});
+    };
     WnTileIx fill_ix = cur_ix;                                                     // the tile whose halo this stream fills (the next one; the last stream: its own again)
+    head_loads(0);
     for (; t < total; t += nwg, cur ^= 1) {
         stamp(0);
         const bool has_next = t + nwg < total;
@@ -545,13 +555,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             advance(nn_ix);
             if (!(t + 2 * nwg < total)) nn_ix = fill_ix;                           // (none: any valid patch, nobody parks it)
         }
-        // the stream's head: this tile's addresses (k-group 0), the reads of steps 0 and 1, the transform of step 0
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { ax[0][p][q] = adA[p][q] + (uint32_t)(cur * WN_HALO_BYTES); ax[1][p][q] = ax[0][p][q] + (uint32_t)dAB; }
-        loads(std::integral_constant<int, 0>{});
-        loads(std::integral_constant<int, 1>{});
+        // the stream's head: the reads of steps 0 and 1 were issued inside the previous tile's last region (head_loads), the exchange's are issued here
         xch_issue(0);
         if constexpr (FUSE1A) { patch_park(fill_ix.ty, fill_ix.tx); patch_issue(nn_ix.b, nn_ix.ty, nn_ix.tx); build_tile(fill_ix.ty, fill_ix.tx, cur ^ 1); }
         wn_for_each<0, 5>([&](auto GC) { tpart(std::integral_constant<int, 0>{}, GC); });
@@ -570,11 +574,17 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
 #ifdef WN_STEP_TRACE      // separate build (tools/round6/steptrace.sh): s_memtime at the top of every region (the values are read after the stream)
             asm volatile("s_memtime %0" : "=s"(ts[r]));
 #endif
-            if constexpr (r == 2) __builtin_amdgcn_s_barrier();                    // every wave has read the previous tile's exchange (at its head): it may be rewritten
+            if constexpr (r == 15) {
+                // the barrier in front of the last region: every wave's share of the next tile's halo has landed (DMA issued by region 7; FUSE1A: built at the head)
+                // -- its first reads go out under this region's MFMAs --, and every wave has read the previous tile's exchange (regions 0): it is rewritten below
+                if constexpr (FUSE1A) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vh[r & 1], kg == 0 ? zero : acc[j][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (r == 0) { finish(0); xch_issue(1); }
             tpart(X1, std::integral_constant<int, 0>{});
+            if constexpr (r == 15) head_loads(cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s + 1], vh[r & 1], kg == 0 ? zero : acc[j][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -642,9 +652,9 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         cur_ix = nxt_ix;
         advance(nxt_ix);
         stamp(3);
-        // the next tile's halo landed, the exchange is written (FUSE1A: the patch load in flight is NOT waited for -- and hipcc must not do it either)
-        if constexpr (FUSE1A) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        // the exchange is written (FUSE1A: the patch load in flight is NOT waited for -- and hipcc must not do it either)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         stamp(4);
         ++tk;
     }
