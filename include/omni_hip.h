@@ -356,6 +356,10 @@ int       omni_cam_enqueue_dev(omni_cam* cam, const uint8_t* gray_dev, int strid
  * owned by the handle, then the work of omni_cam_enqueue_dev.  gray_host should be pinned (omni_host_alloc) and must stay untouched
  * until omni_cam_wait returns. */
 int       omni_cam_enqueue_host(omni_cam* cam, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask);
+/* the same from segments of (pinned) host memory, rows packed: the up cameras' images = the concatenation of n_up parts of up_images[i] images each, the down
+ * cameras' likewise (n_down = 0 for a mono handle); the totals must be the unit's active size (omni_cam_set_active).  One asynchronous copy per part. */
+int       omni_cam_enqueue_host_parts(omni_cam* cam, const uint8_t* const* up, const int* up_images, int n_up, const uint8_t* const* down, const int* down_images,
+                                      int n_down, int width, int height, int fisheye_mask);
 int       omni_cam_wait(omni_cam* cam, omni_cam_result* out);
 /* A unit smaller than the handle was created for (a partly filled micro-batch of key frames that must not wait any longer): the next enqueues read
  * cams * n_dirs images -- the up cameras' first, the down cameras' right behind them -- and every array of omni_cam_result has that leading dimension.

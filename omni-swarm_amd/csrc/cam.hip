@@ -139,6 +139,36 @@ int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int
     return cam_enqueue_locked(c, c->d_gray, width, fisheye_mask);
 }
 
+// The same from SEGMENTS of host memory: the up cameras' n images are the concatenation of n_up parts (up[i]: up_images[i] images, rows packed), the down
+// cameras' likewise (n_down = 0 for a mono handle).  What a key-frame loop needs to cut a run of key frames into units of ITS choice out of blocks laid out
+// for another unit size (KeyframePipeline::run): every part is one asynchronous 1-D copy; MobileNetVLAD starts behind the up cameras' parts.
+int omni_cam_enqueue_host_parts(omni_cam* c, const uint8_t* const* up, const int* up_images, int n_up, const uint8_t* const* down, const int* down_images, int n_down,
+                                int width, int height, int fisheye_mask) {
+    OMNI_REQUIRE(c && up && up_images && n_up > 0 && (n_down == 0 || (down && down_images)), OMNI_ERR_INVALID, "null argument");
+    OMNI_REQUIRE(width == c->W && height == c->H, OMNI_ERR_INVALID, "omni_cam_enqueue_host_parts: images are %dx%d but the networks were created for %dx%d", width, height, c->W, c->H);
+    int nu = 0, nd = 0;
+    for (int i = 0; i < n_up; ++i) { OMNI_REQUIRE(up[i] && up_images[i] > 0, OMNI_ERR_INVALID, "omni_cam_enqueue_host_parts: empty part"); nu += up_images[i]; }
+    for (int i = 0; i < n_down; ++i) { OMNI_REQUIRE(down[i] && down_images[i] > 0, OMNI_ERR_INVALID, "omni_cam_enqueue_host_parts: empty part"); nd += down_images[i]; }
+    OMNI_REQUIRE(nu == c->n && nd == (c->cams - 1) * c->n, OMNI_ERR_INVALID, "omni_cam_enqueue_host_parts: %d + %d images for a unit of %d x %d", nu, nd, c->cams, c->n);
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->c1->device);
+    const size_t img = (size_t)width * height, need = (size_t)c->cams * c->n * img;
+    if (c->d_gray_bytes < need) {
+        (void)hipStreamSynchronize(c->c1->stream);
+        (void)hipStreamSynchronize(c->c2->stream);
+        if (c->d_gray) (void)hipFree(c->d_gray);
+        c->d_gray = nullptr; c->d_gray_bytes = 0;
+        OMNI_HIP_TRY(hipMalloc((void**)&c->d_gray, need));
+        c->d_gray_bytes = need;
+    }
+    size_t at = 0;
+    for (int i = 0; i < n_up; ++i) { OMNI_HIP_TRY(hipMemcpyAsync(c->d_gray + at, up[i], up_images[i] * img, hipMemcpyHostToDevice, c->c1->stream)); at += up_images[i] * img; }
+    OMNI_HIP_TRY(hipEventRecord(c->e_up, c->c1->stream));
+    OMNI_HIP_TRY(hipStreamWaitEvent(c->c2->stream, c->e_up, 0));
+    for (int i = 0; i < n_down; ++i) { OMNI_HIP_TRY(hipMemcpyAsync(c->d_gray + at, down[i], down_images[i] * img, hipMemcpyHostToDevice, c->c1->stream)); at += down_images[i] * img; }
+    return cam_enqueue_locked(c, c->d_gray, width, fisheye_mask);
+}
+
 static int cam_enqueue_locked(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask) {
     const int n = c->n, M = c->M, D = c->D, ni = c->cams * c->n;
     int rc;

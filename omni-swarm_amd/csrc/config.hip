@@ -64,6 +64,8 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
                                                    "enqueued before it; 0: the units' kernels take turns; -1: by measurement -- 1 for the fp32-class precisions, whose time is all "
                                                    "CU-filling convolutions (+2-4 %), and for an fp16 run() of fewer than 8 units (it drains: +7-11 %), 0 for fp16 otherwise, whose small-grid "
                                                    "tails the next units' kernels fill (-5 % when chained)"},
+    {"OMNI_PIPELINE_UNIT_PLAN", 1, 0, 2, CFG_VARIANT, "KeyframePipeline::run on host blocks, a run that is not a whole number of micro-batches: 1 = units of equal size (20 key frames = "
+                                                       "7 + 7 + 6), 2 = the same behind half a unit, 0 = the blocks' own cut (8 + 8 + 4)"},
     // ---- runtime ---------------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_HW_QUEUES", 8, 0, 64, CFG_TUNING, "hardware queues asked of the HIP runtime when the library is loaded (GPU_MAX_HW_QUEUES, unless already set): the pipeline's five "
                                             "streams must not share one; 0 = the runtime's default of 4"},

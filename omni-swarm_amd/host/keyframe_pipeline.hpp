@@ -320,30 +320,64 @@ public:
     // (omni_cam_enqueue_host); otherwise the pool entries are device pointers.  Returns the number of loop candidates found.
     int run(int n_keyframes, int64_t first_msg_id, const uint8_t* const* pool, int n_pool, int first_slot, const uint8_t* tail, bool from_host) {
         if (open_ || !stream_pending_.empty()) throw std::runtime_error("run: key frames pushed through push_keyframe are still open -- flush() first");
-        const int MB = cfg_.microbatch;
+        const int MB = cfg_.microbatch, nd = cfg_.dirs();
         const int full = n_keyframes / MB, rem = n_keyframes % MB;
-        Lane* tail_lane = rem ? prepare(n_keyframes) : nullptr;
+        // The units of this call.  Host blocks can be cut anywhere (a unit's upload is a list of segments: omni_cam_enqueue_host_parts), so a run that is not a
+        // whole number of micro-batches is cut into units of (nearly) EQUAL size -- 20 key frames = 7 + 7 + 6, not 8 + 8 + 4: a unit far below the size the
+        // kernels' grids were sized for runs the same launches at a fraction of the work, and at the reference's key-frame rates (swarm_loop.cpp:140-170: 0.3-1 Hz
+        // per drone) every run() is a short one.  Device-resident blocks and the sharded database keep the blocks' own cut (a unit there is one exchange step).
+        std::vector<int> sizes;
+        const bool recut = from_host && !shard_ && unit_plan_ != 0 && rem != 0 && full >= 1;
+        if (recut) sizes = plan_units(n_keyframes, MB, unit_plan_);
+        else { sizes.assign(full, MB); if (rem) sizes.push_back(rem); }
+        Lane* tail_lane = (!recut && rem) ? prepare(n_keyframes) : nullptr;
         std::deque<std::pair<Lane*, int64_t>> pending;
         int hits = 0;
         // units oldest first (omni_cam_order_after)?  OMNI_PIPELINE_FIFO >= 0 decides; the default (-1) does by what this call is given: the fp32-class
         // modes always (CU-filling convolutions end to end: +2-4 %); fp16 when the run drains before the pipeline is in steady state (fewer than 8
         // units: the first unit then finishes early and the host's work on it overlaps the rest, +7-11 % at 20 key frames,
         // profiles/r04ab_short_regions.log), not in a run that keeps the pipeline full (the units' kernels taking turns fill each other's tails: +5 %)
-        const int n_units = full + (rem ? 1 : 0);
+        const int n_units = (int)sizes.size();
         const int fifo = fifo_cfg_ >= 0 ? fifo_cfg_ : ((cfg_.precision != OMNI_PREC_F16 || n_units < 8) ? 1 : 0);
         last_fifo_ = fifo;
+        const size_t img = (size_t)cfg_.width * cfg_.height;
+        // key frame f of the call: its block (pool entry or the tail), the block's frame count, its index inside
+        auto block_of = [&](int f, const uint8_t*& base, int& cnt, int& idx) {
+            const int e = f / MB;
+            if (e < full) { base = pool[(first_slot + e) % n_pool]; cnt = MB; idx = f - e * MB; }
+            else { base = tail; cnt = rem; idx = f - full * MB; }
+        };
+        std::vector<const uint8_t*> up, down;
+        std::vector<int> upn, downn;
+        int f0 = 0;
         for (int s = 0; s < n_units; ++s) {
-            Lane* lane = s < full ? lanes_[s % lanes_.size()].get() : tail_lane;
-            const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
+            const int m = sizes[s];
+            Lane* lane = (recut || s < full) ? lanes_[s % lanes_.size()].get() : tail_lane;
             if (pend_lane_ == lane) check(omni_shard_rows_consumed(shard_), "omni_shard_rows_consumed");      // its row buffer is the exchange's input
             lane->t_enqueue = std::chrono::steady_clock::now();
             lane->meta.clear();
-            if (lane->cur != lane->mb) { lane->cam.set_active(cfg_.dirs() * lane->mb); lane->cur = lane->mb; }     // (the streaming intake may have left a partial unit's size)
+            const int want = recut ? m : lane->mb;
+            if (lane->cur != want) { lane->cam.set_active(nd * want); lane->cur = want; }     // (the streaming intake or a recut run may have left another size)
             chain(lane, fifo);
-            if (from_host) lane->cam.enqueue_host(src, cfg_.width, !cfg_.mono());       // loop_cam.cpp:536: only STEREO_FISHEYE blanks rows
-            else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
+            if (recut) {
+                up.clear(); down.clear(); upn.clear(); downn.clear();
+                for (int f = f0; f < f0 + m;) {                                  // maximal runs of frames inside one block
+                    const uint8_t* base; int cnt, idx;
+                    block_of(f, base, cnt, idx);
+                    const int take = std::min(cnt - idx, f0 + m - f);
+                    up.push_back(base + (size_t)idx * nd * img); upn.push_back(take * nd);
+                    if (!cfg_.mono()) { down.push_back(base + ((size_t)cnt + idx) * nd * img); downn.push_back(take * nd); }
+                    f += take;
+                }
+                lane->cam.enqueue_host_parts(up, upn, down, downn, !cfg_.mono());
+            } else {
+                const uint8_t* src = s < full ? pool[(first_slot + s) % n_pool] : tail;
+                if (from_host) lane->cam.enqueue_host(src, cfg_.width, !cfg_.mono());       // loop_cam.cpp:536: only STEREO_FISHEYE blanks rows
+                else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
+            }
             host_ms_[0] += since(lane->t_enqueue);
-            pending.emplace_back(lane, first_msg_id + (int64_t)s * MB);
+            pending.emplace_back(lane, first_msg_id + f0);
+            f0 += m;
             if (pending.size() >= lanes_.size()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
         }
         while (!pending.empty()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
@@ -351,6 +385,17 @@ public:
         hits += collect_detector();
         drain_geometry();
         return hits;
+    }
+    // the sizes of the units a run of n key frames is cut into (each <= MB, sum = n); plan 1: ceil(n / MB) units of equal size (+- 1, the larger ones first);
+    // plan 2: the same with half a unit in front, so that the first kernels start behind half an upload
+    static std::vector<int> plan_units(int n, int MB, int plan) {
+        std::vector<int> out;
+        if (n <= 0) return out;
+        int head = 0;
+        if (plan == 2 && n > MB) { head = std::max(1, MB / 2); out.push_back(head); n -= head; }
+        const int k = (n + MB - 1) / MB;
+        for (int i = 0; i < k; ++i) out.push_back(n / k + (i < n % k ? 1 : 0));
+        return out;
     }
 
     // latency of every micro-batch processed so far: from the start of its upload to the end of its detector / geometry step (milliseconds;
@@ -697,6 +742,7 @@ private:
     int host_units_ = 0;
     // units in flight run oldest first (omni_cam_order_after): the unit about to be enqueued starts behind the convolution stack of the one enqueued last
     Lane* last_enqueued_ = nullptr;
+    int unit_plan_ = cfg_int("OMNI_PIPELINE_UNIT_PLAN");    // how run() cuts a run that is not a whole number of micro-batches (plan_units; 0: the blocks' own cut)
     int fifo_cfg_ = cfg_int("OMNI_PIPELINE_FIFO");          // >= 0: as asked; -1: run() and the streaming intake decide (see run())
     int last_fifo_ = 0;                                      // what the last run() used (reported by the bench line)
     void chain(Lane* lane, int fifo_streams) {

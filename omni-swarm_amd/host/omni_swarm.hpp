@@ -286,6 +286,12 @@ public:
     void enqueue_host(const uint8_t* gray_host, int stride, bool fisheye_mask = true) {
         check(omni_cam_enqueue_host(h_, gray_host, stride, w_, h_img_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_host");
     }
+    // the unit's images as segments of packed host memory (omni_cam_enqueue_host_parts): up cameras' parts, then the down cameras' (none for a mono rig)
+    void enqueue_host_parts(const std::vector<const uint8_t*>& up, const std::vector<int>& up_images, const std::vector<const uint8_t*>& down, const std::vector<int>& down_images,
+                            bool fisheye_mask = true) {
+        check(omni_cam_enqueue_host_parts(h_, up.data(), up_images.data(), (int)up.size(), down.empty() ? nullptr : down.data(), down.empty() ? nullptr : down_images.data(),
+                                          (int)down.size(), w_, h_img_, fisheye_mask ? 1 : 0), "omni_cam_enqueue_host_parts");
+    }
     void enqueue_dev(const uint8_t* gray_dev, int stride, bool fisheye_mask = true) {      // images already in HBM
         check(omni_cam_enqueue_dev(h_, gray_dev, stride, fisheye_mask ? 1 : 0), "omni_cam_enqueue_dev");
     }

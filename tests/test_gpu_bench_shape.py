@@ -416,3 +416,38 @@ def test_mfma_ceiling_calibration_is_sane(omni, ctx):
     with pytest.raises(omni.capi.OmniError):
         ctx.mfma_ceiling(0.0)
 
+
+
+@pytest.mark.parametrize("plan", [1, 2])
+def test_run_recuts_a_partial_run_into_equal_units_with_the_same_decisions(omni, ctx, tmp_path, monkeypatch, plan):
+    """KeyframePipeline::run cuts a run that is not a whole number of micro-batches into units of equal size (20 key frames: 7 + 7 + 6, OMNI_PIPELINE_UNIT_PLAN=1, the
+    default; 2: 4 + 6 + 5 + 5) out of host blocks laid out for 8 + 8 + 4 -- units that straddle two blocks go up as segments (omni_cam_enqueue_host_parts).  Same
+    rows, same candidates in the same order (key frame by key frame: query id, matched id, direction pair) as the blocks' own cut (plan 0)."""
+    c = omni.capi
+    from omni_swarm_amd import pipeline, weights
+    sp_w, vw = S.synth_weights(0), V.synth_weights()
+    comp, mean = synth.pca()
+    files = weights.write_pipeline_files(str(tmp_path), sp_w, comp, mean, vw, V.layer_specs(), c.VLAD_KINDS)
+    rng = np.random.default_rng(3)
+    db = rng.standard_normal((400, 4096), dtype=np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    blocks = [_microbatch(7000), _microbatch(7000 + 64)]
+    tails = {4: _microbatch(7000, mb=4), 3: _microbatch(7000 + 16, mb=3)}
+    pins = {}
+    for k, b in list(enumerate(blocks)) + [(f"t{m}", t) for m, t in tails.items()]:
+        pins[k] = ctx.host_alloc(b.shape, np.uint8)
+        pins[k][:] = b
+    out = {}
+    for pl_id in (0, plan):
+        monkeypatch.setenv("OMNI_PIPELINE_UNIT_PLAN", str(pl_id))
+        pl = pipeline.KeyframePipeline(0, files["sp"], files["comp"], files["mean"], files["vlad"], W, H, THR, MAXN, c.PREC_F16, MB, 2, c.STORE_F32, 1, 0.3, 0.2, 5, 30, 3)
+        pl.preload(db)
+        hits = pl.run(20, 0, [pins[0].ctypes.data, pins[1].ctypes.data], 0, pins["t4"].ctypes.data, True)
+        hits += pl.run(19, 20, [pins[0].ctypes.data, pins[1].ctypes.data], 0, pins["t3"].ctypes.data, True)       # 19 = 7 + 6 + 6: units straddling both blocks and the tail
+        hits += pl.run(16, 39, [pins[0].ctypes.data, pins[1].ctypes.data], 0, None, True)                          # whole micro-batches: never recut
+        out[pl_id] = (hits, pl.db_rows, pl.candidates().copy())
+        pl.close()
+    assert out[0][0] == out[plan][0] and out[0][1] == out[plan][1] == 400 + 55 * 4 and out[0][0] >= 20
+    assert np.array_equal(out[0][2], out[plan][2])
+    for p in pins.values():
+        ctx.host_free(p)
