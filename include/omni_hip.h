@@ -70,6 +70,10 @@ typedef struct omni_flatten omni_flatten;
 
 int         omni_abi_version(void);
 const char* omni_last_error(void);
+/* roctx ranges (OMNI_ROCTX=1; no-ops otherwise): the library brackets its own stages with them and the host loop its own through these two -- what the reference's
+ * per-stage timers print (swarm_loop/src/superpoint_tensorrt.cpp:130-162, loop_cam.cpp:205-207) as a `rocprofv3 --marker-trace` timeline */
+void        omni_trace_push(const char* name);
+void        omni_trace_pop(void);
 
 /* ---- configuration: EVERY switch of the library is an entry of one table (csrc/config.h): environment variable, default, valid range, class
  * (0 = variant: another kernel for the same results -- A/B measurements, bit-identity tests; 1 = tuning threshold; 2 = debug / timing ablation;
@@ -169,6 +173,10 @@ int omni_sp_debug_layer(omni_sp* sp, const char* name, int batch, float* out_nch
  * stage_ms [OMNI_SP_NUM_STAGES] MEDIAN ms per call over the repetitions; names via omni_sp_stage_name(). */
 #define OMNI_SP_NUM_STAGES 16
 int         omni_sp_profile(omni_sp* sp, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms);
+/* enable_perf of the reference's runners (superpoint_tensorrt.cpp:130-162): with perf on every pass records its stage events; omni_sp_last_stage_ms waits for the
+ * handle's stream and returns the LAST pass's device time per stage in milliseconds (stage_ms[OMNI_SP_NUM_STAGES], names: omni_sp_stage_name) */
+int         omni_sp_set_perf(omni_sp* sp, int on);
+int         omni_sp_last_stage_ms(omni_sp* sp, float* stage_ms);
 const char* omni_sp_stage_name(int stage);
 double      omni_sp_stage_flops(const omni_sp* sp, int stage);   /* algorithmic FLOP per image for that stage */
 /* share of the stage's output tiles a fisheye-masked pass leaves out of the kernel's tile walk (the constant region of the mask, loop_cam.cpp:536-539:

@@ -197,6 +197,7 @@ extern "C" {
 int omni_bf_match_batched_dev(omni_ctx* ctx, int n_pairs, int max_n, int dim, int mode, const float* q_dev, int64_t q_stride,
                               const int* nq_dev, const float* t_dev, int64_t t_stride, const int* nt_dev, int* q_idx_dev,
                               int* t_idx_dev, float* dist_dev, int* n_matches_dev) {
+    omni::TraceRange trace_range("BF match (batched)");
     OMNI_REQUIRE(ctx && q_dev && t_dev && nq_dev && nt_dev && q_idx_dev && t_idx_dev && dist_dev && n_matches_dev,
                  OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(n_pairs >= 1, OMNI_ERR_INVALID, "n_pairs=%d", n_pairs);

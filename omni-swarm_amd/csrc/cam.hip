@@ -98,6 +98,7 @@ void omni_cam_destroy(omni_cam* c) {
 static int cam_enqueue_locked(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask);
 
 int omni_cam_enqueue_dev(omni_cam* c, const uint8_t* gray_dev, int stride, int fisheye_mask) {
+    omni::TraceRange trace_range("omni_cam_enqueue_dev");
     OMNI_REQUIRE(c && gray_dev, OMNI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->c1->device);
@@ -105,6 +106,7 @@ int omni_cam_enqueue_dev(omni_cam* c, const uint8_t* gray_dev, int stride, int f
 }
 
 int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int width, int height, int fisheye_mask) {
+    omni::TraceRange trace_range("omni_cam_enqueue_host (upload + unit)");
     OMNI_REQUIRE(c && gray_host, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(width > 0 && height > 0 && stride >= width, OMNI_ERR_INVALID, "bad image geometry %dx%d stride %d", width, height, stride);
     // the networks read cams * n images of THEIR size from the staging buffer: any other size would run them past its end
@@ -144,6 +146,7 @@ int omni_cam_enqueue_host(omni_cam* c, const uint8_t* gray_host, int stride, int
 // for another unit size (KeyframePipeline::run): every part is one asynchronous 1-D copy; MobileNetVLAD starts behind the up cameras' parts.
 int omni_cam_enqueue_host_parts(omni_cam* c, const uint8_t* const* up, const int* up_images, int n_up, const uint8_t* const* down, const int* down_images, int n_down,
                                 int width, int height, int fisheye_mask) {
+    omni::TraceRange trace_range("omni_cam_enqueue_host_parts (upload + unit)");
     OMNI_REQUIRE(c && up && up_images && n_up > 0 && (n_down == 0 || (down && down_images)), OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(width == c->W && height == c->H, OMNI_ERR_INVALID, "omni_cam_enqueue_host_parts: images are %dx%d but the networks were created for %dx%d", width, height, c->W, c->H);
     int nu = 0, nd = 0;
@@ -238,6 +241,7 @@ int omni_cam_ready(omni_cam* c, int* ready) {
 }
 
 int omni_cam_wait(omni_cam* c, omni_cam_result* out) {
+    omni::TraceRange trace_range("omni_cam_wait");
     OMNI_REQUIRE(c && out, OMNI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     OMNI_REQUIRE(c->pending, OMNI_ERR_INVALID, "omni_cam_wait without a pending omni_cam_enqueue_dev");

@@ -38,6 +38,12 @@ void set_error(const char* fmt, ...);
         }                                                                                    \
     } while (0)
 
+// roctx ranges around the stages of the hot path (ctx.hip; OMNI_ROCTX=1: librocprofiler-sdk-roctx / libroctx64 resolved by dlopen, like RCCL): what the
+// reference's per-stage timers print (superpoint_tensorrt.cpp:130-162, loop_cam.cpp:205-207) becomes a `rocprofv3 --marker-trace` timeline.  No-ops when off.
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange { explicit TraceRange(const char* name) { trace_push(name); } ~TraceRange() { trace_pop(); } TraceRange(const TraceRange&) = delete; };
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what was set per (kernel instantiation, device)

@@ -34,6 +34,8 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_SPLIT_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the split-precision kernel"},
     {"OMNI_SPLIT_DBG", 0, 0, 3, CFG_DEBUG, "split-precision kernel timing ablations: 1 = no stores, 2 = every DMA reads tile 0 (WRONG results)"},
     {"OMNI_WINO_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the Winograd split kernel"},
+    {"OMNI_ROCTX", 0, 0, 1, CFG_DEBUG, "roctx ranges around upload / SuperPoint / MobileNetVLAD / post-processing / BF match / index add + search / exchange and the host loop's "
+                                      "stages (rocprofv3 --marker-trace; the library is resolved by dlopen)"},
     // ---- MobileNetVLAD ------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_VLAD_BIG", 0, 0, 128, CFG_TUNING, "64 / 128: the 64- / 128-pixel tiles of the unfused block kernel (measured slower at 600x480)"},
     {"OMNI_VLAD_STEM_FUSE", 1, 0, 1, CFG_VARIANT, "stem + block 0 in one kernel (0: two kernels)"},
@@ -100,7 +102,7 @@ int config_resolve(Config* out) {
 static bool is_process_wide(int i) {
     switch (i) {
         case CFG_CONV_RS: case CFG_CONV_XCD: case CFG_INDEX_CERT_FAIL: case CFG_INDEX_MIRROR: case CFG_INDEX_MIRROR_MIN_ROWS: case CFG_MQ_ROT:
-        case CFG_PP_DBG: case CFG_PP_TRACE: case CFG_RS_TRACE: case CFG_RS_TRN: case CFG_SCAN_ROWS_MIN: case CFG_SPLIT_DBG: case CFG_SPLIT_TRACE: case CFG_SPLIT_TRN: case CFG_WINO_TRACE:
+        case CFG_PP_DBG: case CFG_PP_TRACE: case CFG_RS_TRACE: case CFG_RS_TRN: case CFG_SCAN_ROWS_MIN: case CFG_SPLIT_DBG: case CFG_SPLIT_TRACE: case CFG_SPLIT_TRN: case CFG_WINO_TRACE: case CFG_ROCTX:
         case CFG_VLAD_BIG: case CFG_VLAD_SB_DBG: case CFG_VLAD_SB_LDSPAD: case CFG_VLAD_SB_TRACE:
             return true;
         default:

@@ -5,6 +5,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <dlfcn.h>
 
 namespace omni {
 static thread_local char g_err[512] = "";
@@ -30,9 +31,33 @@ struct HwQueues {
 } g_hw_queues;
 }  // namespace
 
+namespace omni {
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        if (!config_process()[CFG_ROCTX]) return;
+        void* so = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) { so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
+        if (!so) { fprintf(stderr, "libomni_hip: OMNI_ROCTX=1 but no roctx library could be loaded (%s): no ranges\n", dlerror()); return; }
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(so, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(so, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void trace_push(const char* name) { Roctx& r = roctx(); if (r.push) (void)r.push(name); }
+void trace_pop() { Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
+}  // namespace omni
+
 static omni_ctx* ctx_create(int device_id, bool high_priority);
 
 extern "C" {
+
+void omni_trace_push(const char* name) { if (name) omni::trace_push(name); }
+void omni_trace_pop(void) { omni::trace_pop(); }
 
 int omni_abi_version(void) { return OMNI_ABI_VERSION; }
 const char* omni_last_error(void) { return omni::g_err; }

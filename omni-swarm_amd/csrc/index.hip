@@ -928,6 +928,7 @@ int omni_index_set_shard(omni_index* ix, int rank, int world) {
 }
 
 int omni_index_add_dev(omni_index* ix, int64_t n, const float* x_dev) {
+    omni::TraceRange trace_range("index add");
     OMNI_REQUIRE(ix && x_dev && n >= 0, OMNI_ERR_INVALID, "bad argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     (void)hipSetDevice(ix->ctx->device);
@@ -936,6 +937,7 @@ int omni_index_add_dev(omni_index* ix, int64_t n, const float* x_dev) {
 }
 
 int omni_index_add(omni_index* ix, int64_t n, const float* x_host) {
+    omni::TraceRange trace_range("index add (host rows)");
     OMNI_REQUIRE(ix && x_host && n >= 0, OMNI_ERR_INVALID, "bad argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     (void)hipSetDevice(ix->ctx->device);
@@ -964,6 +966,7 @@ int omni_index_add(omni_index* ix, int64_t n, const float* x_host) {
 }
 
 int omni_index_search_dev(omni_index* ix, int nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev) {
+    omni::TraceRange trace_range("index search");
     OMNI_REQUIRE(ix && q_dev && D_dev && I_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(nq >= 1 && nq <= 4096, OMNI_ERR_CAPACITY, "nq=%d outside [1,4096]", nq);
     OMNI_REQUIRE(k >= 1 && k <= TOPK_MAX_K, OMNI_ERR_CAPACITY, "k=%d outside [1,%d]", k, TOPK_MAX_K);
@@ -973,6 +976,7 @@ int omni_index_search_dev(omni_index* ix, int nq, const float* q_dev, int k, flo
 }
 
 int omni_index_search_prefix_dev(omni_index* ix, int nq, const float* q_dev, int k, int64_t n_limit, float* D_dev, int64_t* I_dev) {
+    omni::TraceRange trace_range("index search (prefix)");
     OMNI_REQUIRE(ix && q_dev && D_dev && I_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(nq >= 1 && nq <= 4096, OMNI_ERR_CAPACITY, "nq=%d outside [1,4096]", nq);
     OMNI_REQUIRE(k >= 1 && k <= TOPK_MAX_K, OMNI_ERR_CAPACITY, "k=%d outside [1,%d]", k, TOPK_MAX_K);
@@ -984,6 +988,7 @@ int omni_index_search_prefix_dev(omni_index* ix, int nq, const float* q_dev, int
 
 int omni_index_search_batch_prefix_dev(omni_index* ix, int nq, const float* rows_dev, const int64_t* row_idx, int k,
                                        const int64_t* n_limits, float* D_dev, int64_t* I_dev) {
+    omni::TraceRange trace_range("index search (batch, prefix)");
     OMNI_REQUIRE(ix && rows_dev && n_limits && D_dev && I_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(nq >= 1 && nq <= MQ_NQ, OMNI_ERR_CAPACITY, "nq=%d outside [1,%d]", nq, MQ_NQ);
     OMNI_REQUIRE(k >= 1 && k <= TOPK_MAX_K, OMNI_ERR_CAPACITY, "k=%d outside [1,%d]", k, TOPK_MAX_K);
@@ -1009,6 +1014,7 @@ int omni_index_search_batch_prefix_dev(omni_index* ix, int nq, const float* rows
 }
 
 int omni_index_search(omni_index* ix, int nq, const float* q_host, int k, float* D, int64_t* I) {
+    omni::TraceRange trace_range("index search (host queries)");
     OMNI_REQUIRE(ix && q_host && D && I, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(nq >= 1 && nq <= 4096, OMNI_ERR_CAPACITY, "nq=%d outside [1,4096]", nq);
     OMNI_REQUIRE(k >= 1 && k <= TOPK_MAX_K, OMNI_ERR_CAPACITY, "k=%d outside [1,%d]", k, TOPK_MAX_K);

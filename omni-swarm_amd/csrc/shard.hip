@@ -206,6 +206,7 @@ static int merge_mine(const omni_shard* s, const char* h, int per_shard, int k, 
 // enqueuing the next micro-batch's CNN work while the collectives, the scan and the copy run.  omni_shard_rows_consumed() / omni_shard_step_wait()
 // are the two points where the host (or, through an event, another stream) meets it again.
 int omni_shard_step_enqueue(omni_shard* s, int F, int m, const float* rows_dev, int query_row, int k) {
+    omni::TraceRange trace_range("exchange step enqueue (all-gather rows, scan, all-gather top-k)");
     OMNI_REQUIRE(s && rows_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(F >= 1 && m >= 1 && query_row >= 0 && query_row < m && k >= 1, OMNI_ERR_INVALID, "bad F/m/query_row/k");
     OMNI_REQUIRE((int64_t)F * s->world <= 4096, OMNI_ERR_CAPACITY, "F * world = %d queries per exchange is too many", F * s->world);
@@ -280,6 +281,7 @@ int omni_shard_rows_consumed(omni_shard* s) {
 // second half: waits for the exchange in flight (an event, not the stream: later work on the stream is not waited for), merges the lists of
 // THIS rank's F queries (D_host, I_host: [F][k]) and moves the global row count
 int omni_shard_step_wait(omni_shard* s, float* D_host, int64_t* I_host) {
+    omni::TraceRange trace_range("exchange step wait + merge");
     OMNI_REQUIRE(s && D_host && I_host, OMNI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OMNI_REQUIRE(s->pending, OMNI_ERR_INVALID, "no exchange in flight");

@@ -84,6 +84,7 @@ struct omni_sp {
     omni::DevBuf dense_tmp;
     hipEvent_t ev[OMNI_SP_NUM_STAGES + 1] = {};
     hipEvent_t ev_convs = nullptr;           // recorded behind the last CU-filling kernel of a pass (the detector head): what omni_cam_order_after waits for
+    bool perf = false, perf_valid = false;    // omni_sp_set_perf: every pass records its stage events (omni_sp_last_stage_ms)
     int conv_variant = 0;                    // OMNI_CONV_V1=1: generic conv kernel everywhere, 2: v2 persistent kernel (A/B and debugging)
     // The constant region of the fisheye mask (fp16 path; OMNI_SP_MASK_SKIP=0 switches it off).  LoopCam blanks rows [3H/4, 3H/4 + H/4) of every image before the
     // network sees it (loop_cam.cpp:536-539): a few pixels inside that band -- one per 3x3 convolution, doubling with every pool -- every
@@ -670,12 +671,14 @@ int omni_sp_image_size(const omni_sp* s, int* width, int* height) {
 }
 
 int omni_sp_enqueue_dev(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {
+    omni::TraceRange trace_range("SuperPoint enqueue (convolutions + heads + post-processing)");
     OMNI_REQUIRE(s && gray_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
     OMNI_REQUIRE(stride >= s->W, OMNI_ERR_INVALID, "stride=%d < width=%d", stride, s->W);
     std::lock_guard<std::mutex> lk(s->mu);
     (void)hipSetDevice(s->ctx->device);
-    return omni::sp_forward(s, gray_dev, stride, batch, fisheye_mask, false, true);
+    s->perf_valid = s->perf;
+    return omni::sp_forward(s, gray_dev, stride, batch, fisheye_mask, s->perf, true);
 }
 
 int omni_sp_fetch(omni_sp* s, int batch, float* kps_xy, int* n_kps, float* desc, float* scores) {
@@ -688,6 +691,7 @@ int omni_sp_fetch(omni_sp* s, int batch, float* kps_xy, int* n_kps, float* desc,
 
 int omni_sp_infer(omni_sp* s, const uint8_t* gray_host, int stride, int batch, int fisheye_mask, float* kps_xy, int* n_kps,
                   float* desc, float* scores) {
+    omni::TraceRange trace_range("SuperPoint inference (upload, network, post-processing, download)");
     OMNI_REQUIRE(s && gray_host && kps_xy && n_kps && desc, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(batch >= 1 && batch <= s->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, s->max_batch);
     OMNI_REQUIRE(stride >= s->W, OMNI_ERR_INVALID, "stride=%d < width=%d", stride, s->W);
@@ -695,7 +699,8 @@ int omni_sp_infer(omni_sp* s, const uint8_t* gray_host, int stride, int batch, i
     (void)hipSetDevice(s->ctx->device);
     int rc;
     if ((rc = omni::upload_gray(s, gray_host, stride, batch))) return rc;
-    if ((rc = omni::sp_forward(s, s->gray_stage, s->W, batch, fisheye_mask, false, true))) return rc;
+    s->perf_valid = s->perf;
+    if ((rc = omni::sp_forward(s, s->gray_stage, s->W, batch, fisheye_mask, s->perf, true))) return rc;
     return omni::sp_fetch_locked(s, batch, kps_xy, n_kps, desc, scores);
 }
 
@@ -828,6 +833,26 @@ double omni_sp_stage_tiles_left_out(const omni_sp* s, int stage) {
     if (!s || !s->mask_skip) return 0.0;
     const int i = stage == ST_CONV1A ? 0 : stage == ST_CONV1B ? 1 : stage == ST_CONV2A ? 2 : stage == ST_CONV2B ? 3 : stage == ST_CONV3A ? 4 : stage == ST_CONV3B ? 5 : -1;
     return i < 0 ? 0.0 : s->mskip[i].frac;
+}
+
+// enable_perf of the reference's runners (superpoint_tensorrt.cpp:130-162 prints the engine time and the post-processing time of every call): with perf on, every
+// pass records an event in front of each stage (a dozen hipEventRecord: microseconds of host time) and omni_sp_last_stage_ms returns the LAST pass's stage times
+int omni_sp_set_perf(omni_sp* s, int on) {
+    OMNI_REQUIRE(s, OMNI_ERR_INVALID, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->perf = on != 0;
+    if (!s->perf) s->perf_valid = false;
+    return OMNI_OK;
+}
+int omni_sp_last_stage_ms(omni_sp* s, float* stage_ms) {
+    OMNI_REQUIRE(s && stage_ms, OMNI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OMNI_REQUIRE(s->perf_valid, OMNI_ERR_INVALID, "omni_sp_last_stage_ms: no pass was run with omni_sp_set_perf on");
+    (void)hipSetDevice(s->ctx->device);
+    OMNI_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    for (int i = 0; i < OMNI_SP_NUM_STAGES; ++i) stage_ms[i] = 0.f;
+    for (int i = 0; i < ST_COUNT; ++i) OMNI_HIP_TRY(hipEventElapsedTime(&stage_ms[i], s->ev[i], s->ev[i + 1]));
+    return OMNI_OK;
 }
 
 int omni_sp_profile(omni_sp* s, const uint8_t* gray_dev, int stride, int batch, int reps, float* stage_ms) {

@@ -1489,6 +1489,7 @@ int omni_vlad_set_precision(omni_vlad* v, int precision) {
 }
 
 int omni_vlad_enqueue_dev(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {
+    omni::TraceRange trace_range("MobileNetVLAD enqueue");
     OMNI_REQUIRE(v && gray_dev, OMNI_ERR_INVALID, "null argument");
     OMNI_REQUIRE(batch >= 1 && batch <= v->max_batch, OMNI_ERR_CAPACITY, "batch=%d outside [1,%d]", batch, v->max_batch);
     OMNI_REQUIRE(stride >= v->W, OMNI_ERR_INVALID, "stride=%d < width=%d", stride, v->W);

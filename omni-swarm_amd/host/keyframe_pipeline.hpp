@@ -355,6 +355,7 @@ public:
             Lane* lane = (recut || s < full) ? lanes_[s % lanes_.size()].get() : tail_lane;
             if (pend_lane_ == lane) check(omni_shard_rows_consumed(shard_), "omni_shard_rows_consumed");      // its row buffer is the exchange's input
             lane->t_enqueue = std::chrono::steady_clock::now();
+            omni_trace_push("host: unit enqueue (upload + launches)");
             lane->meta.clear();
             const int want = recut ? m : lane->mb;
             if (lane->cur != want) { lane->cam.set_active(nd * want); lane->cur = want; }     // (the streaming intake or a recut run may have left another size)
@@ -376,6 +377,7 @@ public:
                 else lane->cam.enqueue_dev(src, cfg_.width, !cfg_.mono());
             }
             host_ms_[0] += since(lane->t_enqueue);
+            omni_trace_pop();
             pending.emplace_back(lane, first_msg_id + f0);
             f0 += m;
             if (pending.size() >= lanes_.size()) { hits += finish_timed(*pending.front().first, pending.front().second); pending.pop_front(); }
@@ -588,6 +590,8 @@ private:
     int collect_detector() {
         if (!det_pending_.active) return 0;
         auto t_a = std::chrono::steady_clock::now();
+        omni_trace_push("host: detector collect (result lists, rules) + geometry hand-over");
+        struct Pop { ~Pop() { omni_trace_pop(); } } pop_at_exit;
         int hits = 0, fi = 0;
         det_pending_.active = false;                     // first: if end_images_batch() throws (its rollback has dropped the batch), the next unit starts clean
         for (auto& c : det_.end_images_batch()) {
@@ -610,9 +614,12 @@ private:
     // buffer in HBM ([4*mb][4096], key-frame major) -- wait() has synchronised with the MobileNetVLAD stream
     int finish(Lane& lane, int64_t first_id) {
         auto t_a = std::chrono::steady_clock::now();
+        omni_trace_push("host: wait for the unit's GPU work");
         const omni_cam_result r = lane.cam.wait();
+        omni_trace_pop();
         host_ms_[1] += since(t_a); ++host_units_;
         t_a = std::chrono::steady_clock::now();
+        struct Range { explicit Range(const char* n) { omni_trace_push(n); } ~Range() { omni_trace_pop(); } } range_rest("host: messages + detector step of the unit");
         if (shard_) {
             // the exchange of THIS micro-batch is enqueued (two collectives, the scan, the copy of the lists: no host wait) and its results are
             // collected when the NEXT micro-batch gets here (or at the end of run()): meanwhile the host enqueues the next CNN unit

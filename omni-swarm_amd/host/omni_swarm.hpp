@@ -14,6 +14,7 @@
 // omni_last_error() from constructors and return empty results + set last_status from inference calls.
 #pragma once
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -141,6 +142,7 @@ public:
         h_ = omni_sp_create(ctx.get(), &sw, comp.empty() ? nullptr : comp.data(), mean.empty() ? nullptr : mean.data(), rows, width, height,
                             thres, max_num, precision, max_batch);
         if (!h_) throw std::runtime_error(std::string("omni_sp_create: ") + omni_last_error());
+        if (enable_perf_) (void)omni_sp_set_perf(h_, 1);
         dim_ = omni_sp_desc_dim(h_);
     }
     ~SuperPointHIP() { omni_sp_destroy(h_); }
@@ -151,6 +153,7 @@ public:
     // (superpoint_tensorrt.cpp:117-162): keypoints/local_descriptors are cleared first (:120-121); descriptors are n x dim.
     void inference(const uint8_t* gray, int stride, std::vector<omni::Point2f>& keypoints, std::vector<float>& local_descriptors,
                    bool fisheye_mask = false) {
+        const auto t_call = std::chrono::steady_clock::now();
         keypoints.clear();
         local_descriptors.clear();
         kps_.resize((size_t)max_num_ * 2);
@@ -161,7 +164,22 @@ public:
         keypoints.reserve(n);
         for (int i = 0; i < n; ++i) keypoints.push_back({kps_[2 * i], kps_[2 * i + 1]});
         local_descriptors.assign(desc_.begin(), desc_.begin() + (size_t)n * dim_);
-        if (enable_perf_) std::printf(" SuperPointHIP features %d desc size %zu\n", n, local_descriptors.size());
+        if (enable_perf_) {
+            // the reference's line (superpoint_tensorrt.cpp:130-162): engine time, from_blob (nothing to wrap here), getKeyPoints + computeDescriptors (one GPU stage
+            // here: nms + top-k + describe), the whole call on the host's clock -- then the stages one by one, which the reference cannot see inside its engine
+            float st[OMNI_SP_NUM_STAGES] = {};
+            if (omni_sp_last_stage_ms(h_, st) == OMNI_OK) {
+                float net = 0.f;
+                for (int i = 0; i + 1 < OMNI_SP_NUM_STAGES && omni_sp_stage_name(i + 1)[0]; ++i) net += st[i];          // every stage but the last named one
+                int last = 0;
+                while (last + 1 < OMNI_SP_NUM_STAGES && omni_sp_stage_name(last + 1)[0]) ++last;
+                std::printf("Inference Time %.3f from_blob 0 getKeyPoints+computeDescriptors %.3f inference all %.3f features %d desc size %zu\n", net, st[last],
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n, local_descriptors.size());
+                std::printf("  stages (ms):");
+                for (int i = 0; i <= last; ++i) std::printf(" %s %.3f", omni_sp_stage_name(i), st[i]);
+                std::printf("\n");
+            }
+        }
     }
 #ifdef OMNI_WITH_OPENCV
     void inference(const cv::Mat& input, std::vector<cv::Point2f>& keypoints, std::vector<float>& local_descriptors) {

@@ -131,6 +131,14 @@ int main(int argc, char** argv) {
         for (int i = 0; diag && i < r.n_matches[0]; ++i) diag = r.match_up[i] == i && r.match_down[i] == i && r.match_dist[i] == 0.f;
         std::printf("\nCAM %d %d %d", same, diag, r.n_matches[0]);
     }
+    {   // enable_perf = true (superpoint_tensorrt.h:20-28): the reference's timing line of every call (superpoint_tensorrt.cpp:130-162), then the stages
+        Swarm::SuperPointHIP sp_perf(ctx, argv[1], argv[2], argv[3], W, H, 0.015f, 200, true, OMNI_PREC_F32);
+        std::vector<omni::Point2f> k2;
+        std::vector<float> d2;
+        std::printf("\n");
+        sp_perf.inference(img.data(), W, k2, d2);
+        std::printf("PERF_SAME %d", (int)(k2.size() == features.size() && d2 == feature_descriptor));
+    }
     std::printf("\nOK\n");
     return 0;
 }

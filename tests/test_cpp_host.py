@@ -78,6 +78,13 @@ def test_cpp_host_matches_oracle(tmp_path, omni, ctx, golden):
     d64, _ = P.compute_descriptors(desc[0], xy, W, H, comp, mean)
     n, dim = int(out["SP_N"][0]), int(out["SP_N"][1])
     assert n == len(xy) and dim == 64
+    # enable_perf: the reference's line (superpoint_tensorrt.cpp:130-162: "Inference Time .. from_blob .. getKeyPoints+computeDescriptors .. inference all .. features .. desc size ..")
+    perf = out["Inference"]
+    assert perf[0] == "Time" and perf[2] == "from_blob" and perf[4] == "getKeyPoints+computeDescriptors" and perf[6:8] == ["inference", "all"] and perf[9] == "features"
+    assert float(perf[1]) > 0 and float(perf[5]) > 0 and float(perf[8]) >= float(perf[1]) and int(perf[10]) == n and int(perf[13]) == n * dim
+    stages = [ln for ln in r.stdout.split("\n") if ln.startswith("  stages (ms):")]
+    assert len(stages) == 1 and "conv1b+pool" in stages[0] and "nms+topk+describe" in stages[0]
+    assert out["PERF_SAME"] == ["1"]
     assert np.array_equal(np.array(out["SP_KPS"], int).reshape(-1, 2), xy)
     assert np.abs(np.array(out["SP_DESC"], np.float32).reshape(n, 64) - d64).max() < 1e-4
     y = V.forward(vw, img)[0]
