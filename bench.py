@@ -367,6 +367,8 @@ def main():
             p50 = lambda a: float(np.median(a)) if len(a) else 0.0
             out["all_gather_us_p50"] = {"new_rows": [round(v, 1) for v in gather_all(p50(ex[:, 0]))], "topk_lists": [round(v, 1) for v in gather_all(p50(ex[:, 1]))],
                                         "exchange_units": int(len(ex)),
+                                        "definition": "device time between the events that bracket each ncclAllGather on the shard's stream: the collective INCLUDING the wait for "
+                                                      "the slowest rank to arrive (per rank; the minimum over the ranks is the closest to pure transfer time)",
                                         "bytes_per_rank": {"new_rows": mb * 4 * 4096 * 4, "topk_lists": mb * world * K_SEARCH * 12}}
         if len(lat):
             out["keyframe_latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 3), "p99": round(float(np.percentile(lat, 99)), 3),

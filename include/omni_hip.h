@@ -84,6 +84,8 @@ int omni_config_describe(int i, const char** env, int* def, int* lo, int* hi, in
 /* what a handle created NOW would see for option `env` (defaults overridden by the current environment); OMNI_ERR_INVALID on an unknown name or
  * on any option holding a value outside its range */
 int omni_config_value(const char* env, int* value);
+/* 1: the option is read process-wide (frozen at first use: launch-site hooks, index thresholds), 0: snapshot per handle at creation */
+int         omni_config_is_process_wide(int i);
 
 /* ---- context: one per GPU/stream; owns a HIP stream, scratch and timers -------------------------------------
  * replaces TensorRTInferenceGeneric's cudaStreamCreate / cudaMalloc plumbing (tensorrt_generic.cpp:14-36,99-120) */

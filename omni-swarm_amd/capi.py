@@ -35,7 +35,7 @@ SYMBOLS = [
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
-    "omni_trace_push", "omni_trace_pop", "omni_sp_set_perf", "omni_sp_last_stage_ms", "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_config_count", "omni_config_describe", "omni_config_value", "omni_cam_create", "omni_cam_create_mono", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_enqueue_host_parts", "omni_cam_wait", "omni_cam_order_after", "omni_cam_set_active", "omni_cam_ready",
+    "omni_trace_push", "omni_trace_pop", "omni_sp_set_perf", "omni_sp_last_stage_ms", "omni_bf_match", "omni_bf_match_multi", "omni_bf_match_batched_dev", "omni_config_count", "omni_config_describe", "omni_config_value", "omni_config_is_process_wide", "omni_cam_create", "omni_cam_create_mono", "omni_cam_destroy", "omni_cam_enqueue_dev", "omni_cam_enqueue_host", "omni_cam_enqueue_host_parts", "omni_cam_wait", "omni_cam_order_after", "omni_cam_set_active", "omni_cam_ready",
     "omni_shard_unique_id", "omni_shard_library_path", "omni_shard_create", "omni_shard_destroy", "omni_shard_ntotal", "omni_shard_preload_local", "omni_shard_step_batch_dev", "omni_shard_step_enqueue", "omni_shard_rows_consumed", "omni_shard_step_wait", "omni_shard_last_exchange_us",
     "omni_shard_search", "omni_flatten_create", "omni_flatten_destroy", "omni_flatten_out_bytes", "omni_flatten_enqueue_dev",
 ]
@@ -160,6 +160,7 @@ def lib():
     sig("omni_cam_destroy", None, [_vp])
     sig("omni_cam_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int])
     sig("omni_trace_push", None, [C.c_char_p])
+    sig("omni_config_is_process_wide", C.c_int, [C.c_int])
     sig("omni_sp_set_perf", C.c_int, [_vp, C.c_int])
     sig("omni_sp_last_stage_ms", C.c_int, [_vp, _vp])
     sig("omni_trace_pop", None, [])

@@ -98,7 +98,9 @@ int config_resolve(Config* out) {
     return OMNI_OK;
 }
 
-// the options read through config_process(): frozen for the process when the first of them is looked at (launch-site hooks, index thresholds)
+// the options read through config_process(): frozen for the process when the first of them is looked at (launch-site hooks, index thresholds).  ONE list, used by
+// omni_config_value (what it reports once frozen) and exported (omni_config_is_process_wide): tests/test_config_cpu.py scans the sources for
+// config_process()[...] call sites and asserts that they are exactly this list, so it cannot drift from them unnoticed.
 static bool is_process_wide(int i) {
     switch (i) {
         case CFG_CONV_RS: case CFG_CONV_XCD: case CFG_INDEX_CERT_FAIL: case CFG_INDEX_MIRROR: case CFG_INDEX_MIRROR_MIN_ROWS: case CFG_MQ_ROT:
@@ -148,6 +150,8 @@ int omni_config_describe(int i, const char** env, int* def, int* lo, int* hi, in
     if (doc) *doc = o.doc;
     return OMNI_OK;
 }
+
+int omni_config_is_process_wide(int i) { return (i >= 0 && i < omni::CFG_COUNT && omni::is_process_wide(i)) ? 1 : 0; }
 
 int omni_config_value(const char* env, int* value) {
     OMNI_REQUIRE(env && value, OMNI_ERR_INVALID, "null argument");

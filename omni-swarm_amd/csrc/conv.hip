@@ -2062,14 +2062,17 @@ convdb_l2norm_kernel(const _Float16* __restrict__ in, int in_cstride, const _Flo
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < CDB_WAVES; ++w) tot += part[buf][w][n];
+        // (rows of key-point slots that do not exist hold zeros or stale data and are never read back -- sp_sample_compact_kernel stops at n_kps -- but a zero
+        // norm must not turn them into NaN / Inf either: such a row is written as zeros)
         const float nrm = sqrtf(tot);
+        const float den = nrm > 0.f ? nrm : __builtin_inff();
         const int64_t px = t * CDB_PX + n;
         if (px < n_pixels) {
             float* op = out + px * 256 + 32 * wave + 4 * kg;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 v;
-                v.x = acc[4 * g] / nrm; v.y = acc[4 * g + 1] / nrm; v.z = acc[4 * g + 2] / nrm; v.w = acc[4 * g + 3] / nrm;
+                v.x = acc[4 * g] / den; v.y = acc[4 * g + 1] / den; v.z = acc[4 * g + 2] / den; v.w = acc[4 * g + 3] / den;
                 *reinterpret_cast<float4*>(op + 8 * g) = v;
             }
         }

@@ -155,7 +155,7 @@ omni_shard* omni_shard_create(omni_ctx* ctx, omni_index* local, int dim, int ran
     for (hipEvent_t& e : s->t)
         if (hipEventCreate(&e) != hipSuccess) { omni::set_error("hipEventCreate failed"); omni_shard_destroy(s); return nullptr; }
     ncclResult_t r = rccl().CommInitRank(&s->comm, world, id, rank);
-    if (r != ncclSuccess) { omni::set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r)); delete s; return nullptr; }
+    if (r != ncclSuccess) { omni::set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r)); s->comm = nullptr; omni_shard_destroy(s); return nullptr; }
     return s;
 }
 

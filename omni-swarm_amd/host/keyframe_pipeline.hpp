@@ -433,6 +433,8 @@ public:
         for (int i = 0; i < cams * nd; ++i) if (!k.images[i]) throw std::invalid_argument("push_keyframe: a null image pointer");
         const size_t img = (size_t)cfg_.width * cfg_.height;
         int hits = carried_hits_; carried_hits_ = 0;
+        // whatever throws below: the candidates counted so far are not lost -- they go back into carried_hits_ and the next call returns them
+        struct Carry { int& hits; int& carried; bool ok = false; ~Carry() { if (!ok) carried += hits; } } carry{hits, carried_hits_};
         hits += reap_ready();                                   // units the GPU has finished meanwhile (non-blocking): "idle" below is then the truth
         if (!open_) {
             // round robin over the lanes: with fewer than `pipelines` units in flight the next lane is free (a poll() may have sent a partial unit without
@@ -465,6 +467,7 @@ public:
             dispatch_open();
             while (stream_pending_.size() >= lanes_.size()) { Lane* l = stream_pending_.front(); stream_pending_.pop_front(); hits += finish_timed(*l, 0); }
         }
+        carry.ok = true;
         return hits;
     }
     // The latency bound of the streaming intake, to be called from a timer (or after every push): never waits for a CNN unit.  (1) a partly filled

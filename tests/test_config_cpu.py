@@ -97,3 +97,17 @@ def test_reference_conv_variants_are_only_in_the_test_build():
     generic16 = "conv_mfma_kernelIDF16_Li3E"
     assert v2 not in nm(shipped) and generic16 not in nm(shipped)
     assert v2 in nm(test) and generic16 in nm(test)
+
+
+def test_process_wide_options_are_exactly_the_ones_read_through_config_process(capi):
+    """config.hip keeps ONE list of the options frozen process-wide (what omni_config_value reports once frozen): it must be exactly the set the sources read
+    through config_process()[...] -- an option read there but classed per-handle would report a value the kernels do not use."""
+    used = set()
+    for path in glob.glob(os.path.join(ROOT, "omni-swarm_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "omni-swarm_amd", "csrc", "*.h")):
+        used |= set(re.findall(r"config_process\(\)\[(?:omni::)?(CFG_[A-Z0-9_]+)\]", open(path).read()))
+    table = capi.config_table()
+    ids = re.search(r"enum CfgId \{(.*?)CFG_COUNT", open(os.path.join(ROOT, "omni-swarm_amd", "csrc", "config.h")).read(), re.S).group(1)
+    names = [n for n in re.findall(r"CFG_[A-Z0-9_]+", re.sub(r"//.*", "", ids))]
+    assert len(names) == len(table)
+    listed = {names[i] for i in range(len(names)) if capi.lib().omni_config_is_process_wide(i)}
+    assert listed == used, (sorted(listed - used), sorted(used - listed))
