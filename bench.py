@@ -591,14 +591,20 @@ def main():
         out of the tile walk) x 3 MFMA terms per product in OMNI_PREC_SPLIT; the layer's algorithmic FLOP / time is kept as frac_algorithmic."""
         c1b = next(p for p in stages if p["stage"].startswith("conv1b"))
         alg = c1b["flops_per_image"] * n_img
-        terms = 3 if precision == "split" else 1          # OMNI_PREC_SPLIT executes three fp16 MFMA terms per algorithmic product
+        split = precision == "split"
+        wino = split and (capi.config_value("OMNI_SPLIT_WINO") & 1) != 0      # conv1b as the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip): 16 products per 2 x 2 outputs, not 36
+        # OMNI_PREC_SPLIT executes three fp16 MFMA terms per product; the Winograd form has 16 / 36 of the direct form's products: 4/3 of the algorithmic FLOP
+        terms = (3.0 * 16.0 / 36.0 if wino else 3.0) if split else 1.0
         executed = terms * alg * (1.0 - c1b["tiles_left_out"])
         t = c1b["ms"] * 1e-3
         pk = PEAK_F32_TFLOPS if precision == "f32" else PEAK_F16_TFLOPS
-        split = precision == "split"
-        trace = rocprof_trace("conv3x3_split_kernelILb0ELb1ELb0ELb0ELb1" if split else "conv3x3_c64_pp_kernelILb1ELi0ELb1")
+        trace = rocprof_trace(("conv3x3_wino_kernelILb1ELb0ELb1" if wino else "conv3x3_split_kernelILb0ELb1ELb0ELb0ELb1") if split else "conv3x3_c64_pp_kernelILb1ELi0ELb1")
         return {"bound": "mfma",
-                "kernel": ("conv3x3_split_kernel<cin 64, POOL, FUSE1A> = conv1a (built tile by tile from the u8 image, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 with split "
+                "kernel": ("conv3x3_wino_kernel<POOL, FUSE1A> = conv1a (built tile by tile from the u8 image, on the matrix cores) + conv1b 3x3 64->64 as Winograd F(2x2,3x3) + ReLU + maxpool2 "
+                           "with split (hi, lo) fp16 operands: 16 x 3 MFMA terms per 2 x 2 outputs and input channel (the direct form: 36 x 3) -- `frac` counts the MFMA FLOP the "
+                           "kernel executes (4/3 of the layer's algorithmic FLOP), `frac_algorithmic` the layer's own FLOP: the fraction that says how fast the LAYER runs; "
+                           "FLOP counted for conv1b only" if wino else
+                           "conv3x3_split_kernel<cin 64, POOL, FUSE1A> = conv1a (built tile by tile from the u8 image, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 with split "
                            "(hi, lo) fp16 operands: three MFMA terms per product; FLOP counted for conv1b only" if split else
                            "conv3x3_c64_pp_kernel<POOL, FUSE1A> = conv1a (u8 -> 64 ch, on the matrix cores) + conv1b 3x3 64->64 + ReLU + maxpool2 in one launch; "
                            "FLOP counted for conv1b only"),
@@ -609,7 +615,7 @@ def main():
                 "rocprof_trace": trace,
                 "rocprof_trace_note": "median launch duration of the same kernel under rocprofv3 --kernel-trace (committed summary); frac recomputed from it = "
                                       + (str(round(executed / (trace["median_us"] * 1e-6) / 1e12 / pk, 4)) if trace else "n/a: no trace committed yet"),
-                **(traffic_fields("conv3x3_split_kernel<cin64,POOL,FUSE1A> (conv1b)", True, n_img) if split else
+                **(traffic_fields("conv3x3_wino_kernel<POOL,FUSE1A> (conv1b)" if wino else "conv3x3_split_kernel<cin64,POOL,FUSE1A> (conv1b)", True, n_img) if split else
                    traffic_fields("conv3x3_c64_pp_kernel<POOL,FUSE1A>", precision == "f16", n_img))}
 
     roofline = conv1b_roofline(prof, args.precision)

@@ -612,6 +612,7 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
             acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], vl[r & 1], acc[j][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             tpart(X1, std::integral_constant<int, 4>{});
+            if constexpr (r == 15) xwrite(acc, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});                             // .. + 3
             if constexpr (r == 0) finish(1);
             if constexpr (!FUSE1A && r >= 1 && 2 * (r - 1) + 1 < PPW) dma_piece(org_n, cur ^ 1, std::integral_constant<int, 2 * (r - 1) + 1>{});
             if constexpr (r == 15) {                                               // M1 - M2 (T'(1) = (M1 - M2) - M3 behind the last MFMA)
@@ -636,7 +637,6 @@ conv3x3_wino_kernel(const char* __restrict__ in, char* __restrict__ out, const _
         // (four channels of the lane's tile) at a time, straight into the exchange (or, the wave's own groups, into 16 registers) ---------------------------
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[1][m] = acc[1][m] - acc[3][m];
-        xwrite(acc, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
         xwrite(acc, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         xwrite(acc, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
         xwrite(acc, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
