@@ -41,12 +41,19 @@ def main(tag, images):
         "conv3x3_split_kernel<cin128,TRN> (conv4a, conv4b)": lambda n: "conv3x3_split_kernelILb1ELb0ELb0ELb1ELb0" in n,
         "conv3x3_split_kernel<cin128,OUT_F32,TRN> (convPa)": lambda n: "conv3x3_split_kernelILb1ELb0ELb1ELb1ELb0" in n,
         "conv3x3_split_kernel<cin64,POOL> (conv2b)": lambda n: "conv3x3_split_kernelILb0ELb1ELb0ELb0ELb0" in n,
+        # OMNI_PREC_SPLIT, Winograd F(2x2,3x3) kernels of conv_wino.hip (template arguments <POOL, OUT_SPLIT, FUSE1A>)
+        "conv3x3_wino_kernel<POOL,FUSE1A> (conv1b)": lambda n: "conv3x3_wino_kernelILb1ELb0ELb1" in n,
+        "conv3x3_wino_kernel (conv2a)": lambda n: "conv3x3_wino_kernelILb0ELb0ELb0" in n,
+        "conv3x3_wino_kernel<POOL,OUT_SPLIT> (conv2b)": lambda n: "conv3x3_wino_kernelILb1ELb1ELb0" in n,
     }
     algorithmic_input = {   # bytes of the layer's input tensor per launch of `images` images (what a single pass over it reads)
         "conv3x3_split_kernel<cin128,POOL> (conv3b)": 120 * 150 * 512 * images,
         "conv3x3_split_kernel<cin128,TRN> (conv4a, conv4b)": 60 * 75 * 512 * images,
         "conv3x3_split_kernel<cin128,OUT_F32,TRN> (convPa)": 60 * 75 * 512 * images,
         "conv3x3_split_kernel<cin64,POOL> (conv2b)": 240 * 300 * 256 * images,
+        "conv3x3_wino_kernel<POOL,FUSE1A> (conv1b)": 480 * 600 * images,                   # the u8 image: conv1a is built inside the kernel
+        "conv3x3_wino_kernel (conv2a)": 240 * 300 * 256 * images,                          # raw-32 frames: 256 B per pixel
+        "conv3x3_wino_kernel<POOL,OUT_SPLIT> (conv2b)": 240 * 300 * 256 * images,
     }
     for key, m in kernels.items():
         rd = mean_by(f"gpurun_out/{tag}_pmc3", "FETCH_SIZE", m)
