@@ -1,7 +1,7 @@
 """CPU checks around the constant region of the fisheye mask (csrc/superpoint.hip sp_plan_mask_skip, csrc/conv.hip tile_origin; the GPU side is
 tests/test_gpu_mask_skip.py): the integer arithmetic of the tile walk -- the decode of a tile number into (image, tile row, tile column) over the
 tiles that run, by multiply-high divisions -- enumerates every tile outside the rectangle exactly once, for every rectangle of several grids; the
-plan bench.py mirrors for its FLOP accounting gives the rectangles worked out by hand for 600 x 480."""
+plan bench.py mirrors for its FLOP accounting gives the rectangles worked out by hand for 600 x 480 (docs/history/rounds_2_to_5.md, round 3)."""
 import importlib.util
 import os
 
