@@ -12,7 +12,8 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     // ---- SuperPoint ---------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_CONV_V1", 0, 0, 3, CFG_VARIANT, "fp16 3x3 layers: 0 = production (conv1a fused into the ping-pong conv1b, register-stationary cin=128); 1 = generic kernel, 2 = persistent LDS-DMA kernel, "
                                            "3 = ping-pong without the conv1a fusion -- 1-3 exist only in the test build of the library (lib_test/)"},
-    {"OMNI_CONV_RS", 1, 0, 1, CFG_VARIANT, "cin=128 fp16 layers on the register-stationary kernel (0: generic kernel)"},
+    {"OMNI_CONV_RS", 2, 0, 2, CFG_VARIANT, "cin=128 fp16 layers: 2 = the register-stationary kernel with its epilogue and DMA inside the MFMA stream (3 / 4-row tiles), 1 = the 6-row-tile "
+                                          "register-stationary kernel of rounds 1-5, 0 = generic kernel"},
     {"OMNI_RS_TRN", -1, -1, 1, CFG_VARIANT, "register-stationary kernel: tile orientation, -1 = the one with fewer tiles, 0 = plain, 1 = transposed"},
     {"OMNI_DET16", 1, 0, 1, CFG_VARIANT, "detector head of the fp16 and OMNI_PREC_SPLIT paths on v_mfma_f32_32x32x16_f16 with split (hi, lo) operands (0: the exact-f32 MFMA kernel)"},
     {"OMNI_SP_SPARSE_DESC", 1, 0, 1, CFG_VARIANT, "convDb + descriptor norm only at the cells around the key points (0: dense descriptor map)"},

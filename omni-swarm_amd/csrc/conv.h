@@ -17,6 +17,7 @@ namespace omni {
 #define CONV_TW 32         // output tile cols  (2 fragments x 16)
 #define RS_TH 6            // the register-stationary cin = 128 kernel's output tile (plain orientation): 6 rows x 32 columns
 #define RS_TW 32
+int conv_rs_pool_tile_rows();   // rows of the pooled cin = 128 fp16 layer's tile grid (ConvArgs::skip_* of conv3b): 4 (OMNI_CONV_RS=2) or RS_TH
 struct RsSkip { int act, n_above, n_upto, y0, y1, x0, w, bw, xcd /* OMNI_CONV_XCD: xcd_block_id() */; };      // conv3x3_c128_rs_kernel: the tiles of an image that run (ConvArgs::skip_*)
 #define CONV_COUT_TILE 64  // output channels per workgroup (2 fragments x 32)
 #define CONV_CIN_CHUNK 64  // input channels staged per pass

@@ -1,6 +1,7 @@
 // SuperPoint convolution kernels for gfx950 (see conv.h for the design summary and reference map).
 #include "config.h"
 #include "conv.h"
+#include <type_traits>
 
 namespace omni {
 
@@ -1007,6 +1008,10 @@ static int launch_conv_pp(hipStream_t st, const ConvArgs& a, int n_cu) {
 //     each feeds up to three MFMAs (the three ky that map the row onto an output row): 432 MFMAs per tile per wave,
 //     0.44 LDS reads per MFMA.
 // ---------------------------------------------------------------------------------------------------------------
+template <int J, int N, typename F>
+__device__ __forceinline__ void spl2_for_each(F&& f) {
+    if constexpr (J < N) { f(std::integral_constant<int, J>{}); spl2_for_each<J + 1, N>(f); }
+}
 #define CSP_KP 8                                  // key points per tile of the sparse descriptor kernels (32 corner cells)
 bool conv_rs_transposed(int H, int W);
 // (RS_TH x RS_TW = 6 x 32: conv.h)
@@ -1251,6 +1256,279 @@ static int launch_conv_rs(hipStream_t st, const ConvArgs& a, int n_cu) {
     }
     return OMNI_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// v5 (round 6): the register-stationary kernel with NOTHING outside its MFMA stream -- the scheme conv_split.hip's cin = 128 kernel has used
+// since round 3.  The v4 kernel above spends 19.9 k cycles per 6 x 32 tile for 13.8 k of MFMA: the 17-instruction DMA burst in front of the
+// stream (1.5 k), the epilogue behind it (3.1 k: 96 accumulator values per wave -> bias, ReLU, halfs, swaps, stores) and the closing wait.
+// One wave per SIMD: whatever is not issued between two MFMAs idles the matrix cores.  Here
+//   * the tile is 3 rows (POOL: 4) x 32 pixels, so that the 48 (POOL: 64 -> 32 after the vertical maximum) raw values of the PREVIOUS tile fit
+//     next to this tile's accumulators and the 288 weight registers: its epilogue runs inside this tile's stream, one PART (four values of a
+//     row: bias, ReLU, halfs; every second part the v_permlane32_swap and the 16-byte store) per "dense" step (a halo row that feeds three
+//     MFMAs), pinned one MFMA / five VALU by sched_group_barrier;
+//   * the next tile's LDS-DMA goes out one piece per two-MFMA step;
+//   * stores are raw-buffer stores whose offset is out of range for lanes with nothing to store (no exec branch in the stream); issued in the
+//     first half of the stream, they have retired when the tile's closing s_waitcnt vmcnt(0) comes.
+// Same weights, same LDS image, same order of summation per output pixel (tap column outer, tap row, 16-channel group inner) as v4: bit-identical
+// results (tests/test_gpu_superpoint.py::test_f16_persistent_kernels_are_bit_identical_to_generic_kernel).  OMNI_CONV_RS=1 keeps v4.
+// ---------------------------------------------------------------------------------------------------------------
+#define RS2_RING 3
+template <int TH> struct Rs2Cfg {
+    static constexpr int ITH = TH + 2, PIX = ITH * RS_ITW, NPIECES = (PIX * 16 + 63) / 64, PPW = (NPIECES + 3) / 4, BUF = NPIECES * 1024, NL = 3 * ITH * 8;
+    static constexpr size_t smem() { return 2 * (size_t)BUF + 512; }
+};
+template <int L, int ITH>
+__device__ __forceinline__ void rs2_read(uint32_t row_base /* lds + (n * 256) */, int n, int hh, half8_t& dst) {
+    constexpr int kx = L / (ITH * 8), r = (L / 8) % ITH, kg = L % 8;
+    constexpr int pc = r * RS_ITW + kx;
+    const uint32_t addr = (row_base + pc * 256 + ((((pc + n) & 15) ^ hh) << 4)) ^ (kg << 5);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int TH> constexpr int rs2_nmfma(int L) { const int r = (L / 8) % (TH + 2); int c = 0; for (int ky = 0; ky < 3; ++ky) if (r - ky >= 0 && r - ky < TH) ++c; return c; }
+template <int TH> constexpr int rs2_count_before(int L, int want) { int c = 0; for (int l = 0; l < L; ++l) c += rs2_nmfma<TH>(l) == want ? 1 : 0; return c; }
+template <int L, int TH, int NPARTS, int NDMA, typename Epi, typename Dma>
+__device__ __forceinline__ void rs2_steps(uint32_t row_base, int n, int hh, const half8_t (&wreg)[72], floatx16 (&acc)[TH], half8_t (&fb)[RS2_RING], Epi&& epi, Dma&& dma) {
+    constexpr int ITH = TH + 2, NL = 3 * ITH * 8;
+    if constexpr (L < NL) {
+        constexpr int kx = L / (ITH * 8), r = (L / 8) % ITH, kg = L % 8;
+        constexpr int D = RS2_RING - 1;                                               // fragments read ahead
+        if constexpr (L + D < NL) rs2_read<L + D, ITH>(row_base, n, hh, fb[(L + D) % RS2_RING]);
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fb[L % RS2_RING]) : "i"((L + D < NL) ? D : (NL - 1 - L)));
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int nm = rs2_nmfma<TH>(L);
+        if constexpr (r >= 0 && r < TH) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(0 * 3 + kx) * 8 + kg], fb[L % RS2_RING], acc[r], 0, 0, 0);
+        if constexpr (r - 1 >= 0 && r - 1 < TH) acc[r - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(1 * 3 + kx) * 8 + kg], fb[L % RS2_RING], acc[r - 1], 0, 0, 0);
+        if constexpr (r - 2 >= 0 && r - 2 < TH) acc[r - 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[(2 * 3 + kx) * 8 + kg], fb[L % RS2_RING], acc[r - 2], 0, 0, 0);
+        if constexpr (nm == 3) {
+            constexpr int d = rs2_count_before<TH>(L, 3);
+            if constexpr (d < NPARTS) {
+                epi(std::integral_constant<int, d>{});
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+        } else if constexpr (nm == 2) {
+            constexpr int d = rs2_count_before<TH>(L, 2);
+            if constexpr (d < NDMA) dma(std::integral_constant<int, d>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rs2_steps<L + 1, TH, NPARTS, NDMA>(row_base, n, hh, wreg, acc, fb, epi, dma);
+    }
+}
+
+template <bool POOL, bool TRN = false>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_c128_rs2_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, const _Float16* __restrict__ wp,
+                        const float* __restrict__ bias, int H, int W, int cout, int n_cg, int tiles_x, int tiles_y, int batch, int relu, RsSkip sk) {
+    constexpr int TH = POOL ? 4 : 3;
+    using C = Rs2Cfg<TH>;
+    constexpr int ITH = C::ITH, PPW = C::PPW, NPIECES = C::NPIECES;
+    static_assert(!TRN || !POOL, "transposed tiles: no pooling");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hh = lane >> 5;
+    const int bid = xcd_block_id(sk.xcd);
+    const int cg = bid % n_cg, wg = bid / n_cg, nwg = gridDim.x / n_cg;
+    const int tiles_per_img = sk.act;
+    const int total = batch * tiles_per_img;
+    const int g32 = cg * 4 + wave;
+
+    half8_t wreg[72];
+    {
+        const _Float16* wbase = wp + (int64_t)(g32 >> 1) * 2 * 9 * 4096 + (g32 & 1) * 512 + lane * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 72; ++s2) {
+            const int tk = s2 >> 3, ch = (s2 >> 2) & 1, kg4 = s2 & 3;
+            const int tap = TRN ? (tk % 3) * 3 + tk / 3 : tk;
+            wreg[s2] = *reinterpret_cast<const half8_t*>(wbase + ((ch * 9 + tap) * 4 + kg4) * 1024);
+        }
+    }
+    float* const bias_lds = reinterpret_cast<float*>(smem_raw + 2 * C::BUF);
+    if (tid < 128) bias_lds[tid] = bias[cg * 128 + tid];
+
+    auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
+        b = t / tiles_per_img;
+        int r = t - b * tiles_per_img, ry, rx;
+        if (r < sk.n_above || r >= sk.n_upto) {
+            int base = 0;
+            if (r >= sk.n_upto) { r -= sk.n_upto; base = sk.y1; }
+            ry = r / tiles_x; rx = r - ry * tiles_x; ry += base;
+        } else {
+            r -= sk.n_above;
+            const int q = r / sk.bw, c = r - q * sk.bw;
+            ry = sk.y0 + q; rx = c < sk.x0 ? c : c + sk.w;
+        }
+        ty0 = ry * (TRN ? RS_TW : TH); tx0 = rx * (TRN ? TH : RS_TW);
+    };
+    uint32_t goff[PPW];                       // byte offset of this lane's chunk of piece j relative to the halo origin
+    uint32_t hx[(PPW + 4) / 5];               // ... and the halo column (image x) of its pixel, 6 bits per piece
+#pragma unroll
+    for (int i = 0; i < (PPW + 4) / 5; ++i) hx[i] = 0;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        int piece = wave * PPW + j;
+        piece = piece < NPIECES ? piece : NPIECES - 1;         // (the last wave repeats its last piece)
+        const int idx = piece * 64 + lane;
+        const int pix = idx >> 4, phys = idx & 15;
+        const int iv = pix / RS_ITW, iu = pix - iv * RS_ITW;
+        const int iy = TRN ? iu : iv, ix = TRN ? iv : iu;
+        goff[j] = (uint32_t)((iy * W + ix) * 256 + ((phys ^ (pix & 15)) << 4));
+        hx[j / 5] |= (uint32_t)(ix & 63) << (6 * (j % 5));
+    }
+    const uint32_t in_img_bytes = (uint32_t)H * W * 256u;
+    struct Src { __amdgpu_buffer_rsrc_t r; uint32_t sorg; int x0; };
+    auto source = [&](int t) -> Src {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        Src s;
+        s.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in) + (int64_t)b * H * W * 128, 0, in_img_bytes, 0x00020000);
+        s.x0 = tx0 - 1;
+        s.sorg = (uint32_t)(((ty0 - 1) * W + s.x0) * 256);
+        return s;
+    };
+    auto dma_piece = [&](const Src& s, int which, auto JC) {
+        constexpr int j = decltype(JC)::value;
+        int piece = wave * PPW + j;
+        piece = piece < NPIECES ? piece : NPIECES - 1;
+        const uint32_t x = (uint32_t)(s.x0 + (int)((hx[j / 5] >> (6 * (j % 5))) & 63u));
+        const uint32_t voff = x < (uint32_t)W ? goff[j] + s.sorg : 0x80000000u;
+#if __HIP_DEVICE_COMPILE__
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(s.r, (__attribute__((address_space(3))) void*)(smem_raw + which * C::BUF + piece * 1024), 16, voff, 0, 0, 0);
+#else
+        (void)s; (void)which; (void)piece; (void)voff;
+#endif
+    };
+    int t = wg;
+    if (t < total) {
+        const Src s0 = source(t);
+        spl2_for_each<0, PPW>([&](auto JC) { dma_piece(s0, 0, JC); });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float4 bs[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const float4*>(bias_lds + wave * 32 + 8 * g + 4 * hh);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bs[g].x), "+v"(bs[g].y), "+v"(bs[g].z), "+v"(bs[g].w));
+
+    // ---- the pending epilogue: the previous tile's raw values (POOL: the vertical maxima of its row pairs), its image and the lane's offsets ------
+    constexpr int NPF = POOL ? TH / 2 : TH;                    // pending fragment rows
+    constexpr int NPARTS = NPF * 4;
+    float pv[NPF][16];
+    uint32_t poff[NPF];
+#pragma unroll
+    for (int f = 0; f < NPF; ++f) {
+        poff[f] = 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[f][i] = 0.f;
+    }
+    const uint32_t out_img_bytes = (uint32_t)((int64_t)(POOL ? (H >> 1) * (W >> 1) : H * W) * cout * 2);
+    __amdgpu_buffer_rsrc_t oimg = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_img_bytes, 0x00020000);
+    uint32_t dq[2] = {0u, 0u};                                 // the first group's two packed dwords of the pair being built
+    // part P = (fragment row P / 4, register group g = P % 4): four values -> bias, ReLU, two packed dwords; g odd: swap with the group before it
+    // across the half-waves (the lower one then owns channels [16 gp, +8), the upper one [16 gp + 8, +8)) and one 16-byte store
+    auto epi_part = [&](auto PC) {
+        constexpr int P = decltype(PC)::value, f = P / 4, g = P % 4;
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = pv[f][4 * g + e];
+            if constexpr (POOL) v = vmax_med3(v, dpp_swap_pairs(v));
+            x[e] = v;
+        }
+        const uint32_t d0 = pack_relu_f16<false>(x[0] + bs[g].x, x[1] + bs[g].y, 1), d1 = pack_relu_f16<false>(x[2] + bs[g].z, x[3] + bs[g].w, 1);      // (ReLU: the launcher insists)
+        if constexpr ((g & 1) == 0) { dq[0] = d0; dq[1] = d1; }
+        else {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(dq[0], d0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(dq[1], d1, false, false);
+            typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+            const u4_t dd = {r0[0], r1[0], r0[1], r1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(dd, oimg, poff[f] + (uint32_t)((16 * (g >> 1) + 8 * hh) * 2), 0, 0);
+        }
+    };
+
+    int cur = 0;
+    for (; t < total; t += nwg, cur ^= 1) {
+        const int tn = t + nwg;
+        const Src sn = source(tn < total ? tn : t);               // (the last tile loads itself again: no branch in the stream; nobody reads that buffer)
+        const uint32_t row_base = lds0 + cur * C::BUF + n * 256;
+        floatx16 acc[TH];
+#pragma unroll
+        for (int f = 0; f < TH; ++f)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+        half8_t fb[RS2_RING];
+        rs2_read<0, ITH>(row_base, n, hh, fb[0]);
+        rs2_read<1, ITH>(row_base, n, hh, fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        rs2_steps<0, TH, NPARTS, PPW>(row_base, n, hh, wreg, acc, fb, epi_part, [&](auto JC) { dma_piece(sn, cur ^ 1, JC); });
+
+        // this tile's raw values and addresses become the pending epilogue
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        oimg = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)b * (out_img_bytes / 2), 0, out_img_bytes, 0x00020000);
+        const int ox = tx0 + n;
+        if constexpr (POOL) {
+#pragma unroll
+            for (int f2 = 0; f2 < TH / 2; ++f2) {
+                const int oy = ty0 + 2 * f2;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pv[f2][i] = vmax_med3(acc[2 * f2][i], acc[2 * f2 + 1][i]);
+                poff[f2] = ((oy < H) && (ox < W) && !(n & 1)) ? (uint32_t)((((oy >> 1) * (W >> 1) + (ox >> 1)) * cout + g32 * 32) * 2) : 0x80000000u;
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < TH; ++f) {
+                const int oy = TRN ? ty0 + n : ty0 + f, oxx = TRN ? tx0 + f : ox;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pv[f][i] = acc[f][i];
+                poff[f] = ((oy < H) && (oxx < W)) ? (uint32_t)(((oy * W + oxx) * cout + g32 * 32) * 2) : 0x80000000u;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile landed (and the previous tile's stores, issued early in the stream, retired)
+        __syncthreads();
+    }
+    spl2_for_each<0, NPARTS>(epi_part);                           // the last tile's
+}
+
+template <bool POOL, bool TRN = false>
+static int launch_conv_rs2(hipStream_t st, const ConvArgs& a, int n_cu) {
+    constexpr int TH = POOL ? 4 : 3;
+    if constexpr (!POOL && !TRN) {
+        static const int force = config_process()[CFG_RS_TRN];
+        const int plain = cdiv(a.W, RS_TW) * cdiv(a.H, TH), trn = cdiv(a.W, TH) * cdiv(a.H, RS_TW);
+        if (force == 1 || (force < 0 && trn < plain)) return launch_conv_rs2<false, true>(st, a, n_cu);
+    }
+    OMNI_REQUIRE(a.relu, OMNI_ERR_INVALID, "conv_rs2: instantiated with the ReLU in its epilogue (every cin = 128 layer of the graph has one)");
+    auto kfn = conv3x3_c128_rs2_kernel<POOL, TRN>;
+    static DynSmemState smem_state;
+    OMNI_HIP_TRY(ensure_dyn_smem(smem_state, (const void*)kfn, Rs2Cfg<TH>::smem()));
+    const int tiles_x = cdiv(a.W, TRN ? TH : RS_TW), tiles_y = cdiv(a.H, TRN ? RS_TW : TH), n_cg = a.cout / 128;
+    const bool skip = !TRN && a.skip_ty1 > a.skip_ty0 && a.skip_tx1 > a.skip_tx0;
+    OMNI_REQUIRE(!skip || (a.skip_ty0 >= 0 && a.skip_ty1 <= tiles_y && a.skip_tx0 >= 0 && a.skip_tx1 <= tiles_x), OMNI_ERR_INVALID, "conv_rs2: skip rectangle outside the tile grid");
+    OMNI_REQUIRE((int64_t)a.H * a.W * 256 < (1ll << 31) && (int64_t)a.H * a.W * a.cout * 2 < (1ll << 31), OMNI_ERR_INVALID, "conv_rs2: image too large for 32-bit offsets");
+    RsSkip sk;
+    sk.y0 = skip ? a.skip_ty0 : 0; sk.y1 = skip ? a.skip_ty1 : 0; sk.x0 = skip ? a.skip_tx0 : 0; sk.w = skip ? a.skip_tx1 - a.skip_tx0 : 0;
+    sk.bw = tiles_x - sk.w;
+    sk.act = tiles_x * tiles_y - (sk.y1 - sk.y0) * sk.w;
+    sk.n_above = skip ? sk.y0 * tiles_x : sk.act;
+    sk.n_upto = sk.n_above + (sk.y1 - sk.y0) * sk.bw;
+    OMNI_REQUIRE(sk.act > 0 && sk.bw > 0, OMNI_ERR_INVALID, "conv_rs2: the skip rectangle covers whole tile rows");
+    sk.xcd = config_process()[CFG_CONV_XCD];
+    const int total = a.batch * sk.act;
+    int per_cg = n_cu / n_cg;
+    if (per_cg < 1) per_cg = 1;
+    if (per_cg > total) per_cg = total;
+    hipLaunchKernelGGL(kfn, dim3(per_cg * n_cg), dim3(256), Rs2Cfg<TH>::smem(), st, reinterpret_cast<const _Float16*>(a.in), reinterpret_cast<_Float16*>(a.out),
+                       reinterpret_cast<const _Float16*>(a.w_packed), a.bias, a.H, a.W, a.cout, n_cg, tiles_x, tiles_y, a.batch, a.relu ? 1 : 0, sk);
+    OMNI_LAUNCH_CHECK();
+    return OMNI_OK;
+}
+// rows of the pooled cin = 128 fp16 layer's tile (the grid ConvArgs::skip_* is given in)
+int conv_rs_pool_tile_rows() { return RS_TH; }                  // (the pooled layer runs on v4 in every configuration)
 
 // the tile orientation launch_conv_rs picks for a non-pooled H x W layer (it fixes the order the taps are summed in)
 bool conv_rs_transposed(int H, int W) {
@@ -1506,7 +1784,13 @@ int conv_mfma(hipStream_t st, int precision, const ConvArgs& a) {
     static const bool no_rs = config_process()[CFG_CONV_RS] == 0;     // A/B hook
     if (precision == OMNI_PREC_F16 && a.ksize == 3 && a.cin == 128 && a.cout % 128 == 0 && !a.out_f32 && (a.in_cstride == 0 || a.in_cstride == 128) &&
         a.n_cu > 0 && a.zero_page && a.variant == 0 && !no_rs && (!a.pool || a.H % 2 == 0))
+    {
+        static const int rs_ver = config_process()[CFG_CONV_RS];
+        // v5 for the unpooled layers (conv4a, conv4b, convPa|convDa); the pooled conv3b stays on v4: its v5 form (4-row tiles) measured the same time and sits at
+        // the register limit (13 registers of scratch)
+        if (rs_ver >= 2 && a.relu && !a.pool) return launch_conv_rs2<false>(st, a, a.n_cu);
         return a.pool ? launch_conv_rs<true>(st, a, a.n_cu) : launch_conv_rs<false>(st, a, a.n_cu);
+    }
     if (precision == OMNI_PREC_F16) {
 #ifdef OMNI_TEST_VARIANTS              // the generic kernel on the fp16 3x3 layers (OMNI_CONV_V1=1): the other bit-identity reference of the test build
         if (a.ksize == 3) return a.pool ? launch_conv<_Float16, 3, true>(st, a) : launch_conv<_Float16, 3, false>(st, a);

@@ -142,7 +142,7 @@ static void sp_mask_skip_rects(int H, int W, bool split, omni_sp::MaskSkip (&ks)
     static_assert(CONV_TW == 32, "tile width");
     const int TW = 32;
     for (int i = 0; i < 5; ++i) {                          // conv1b, conv2a, conv2b, conv3a, conv3b (cin = 128: the split kernel's 2 x 32 tiles, the fp16 register-stationary kernel's 6 x 32)
-        const int TH = split ? (i == 4 ? 2 : 4) : (i == 4 ? RS_TH : CONV_TH);  // the kernels' output tiles (conv_split.hip: 4 x 32 / 2 x 32, conv.hip: CONV_TH x CONV_TW / RS_TH x RS_TW)
+        const int TH = split ? (i == 4 ? 2 : 4) : (i == 4 ? conv_rs_pool_tile_rows() : CONV_TH);  // the kernels' output tiles (conv_split.hip: 4 x 32 / 2 x 32, conv.hip: CONV_TH x CONV_TW / RS_TH x RS_TW)
         a += 1; b -= 1; c += 1; d -= 1;                    // a 3x3 convolution (zero padding is NOT the constant): one pixel in from every side
         omni_sp::MaskSkip& k = ks[1 + i];
         if (b < a || d < c) break;                         // nothing constant from here on
