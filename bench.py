@@ -637,7 +637,7 @@ def main():
                       "tiles_left_out": {p["stage"]: round(p["tiles_left_out"], 4) for p in prof if p["tiles_left_out"] > 0}},
         "conv_stack_tflops": round(mfma_terms_of(args.precision) * sp_flop_executed(args.precision, MAXN, True, left_out_flop) * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
         "conv_stack_note": "MFMA FLOP executed by the stages named conv* (fp16 path: without convDa / convDb, which run only at the cells around the key points "
-                           "inside the post-processing stage; split: x 3 terms) / their time",
+                           "inside the post-processing stage; split: x 3 terms of the direct form for every layer -- the layers OMNI_SPLIT_WINO runs as Winograd kernels execute 4/3 -- so this is a rate of useful work) / their time",
         "stages_ms_per_keyframe": {p["stage"]: round(p["ms"] / MB, 4) for p in prof}, "superpoint_ms_per_keyframe": round(sp_ms, 3)})
     # the same kernel figure for the precision that meets north_star's tolerance (value_parity's conv1b), in the default run
     roofline_parity = None
