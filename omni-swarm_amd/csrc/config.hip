@@ -23,8 +23,8 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_SP_MASK_SKIP", 1, 0, 1, CFG_VARIANT, "fp16: the tiles inside the constant region of the fisheye mask are left out of the tile walk (0: every tile)"},
     {"OMNI_SP_MASK_SKIP_SPLIT", 1, 0, 1, CFG_VARIANT, "the same for OMNI_PREC_SPLIT"},
     {"OMNI_SPLIT_FUSE1A", 1, 0, 1, CFG_VARIANT, "OMNI_PREC_SPLIT: conv1a built inside the conv1b kernel from the u8 image (0: separate exact-f32 conv1a pass)"},
-    {"OMNI_SPLIT_WINO", 7, 0, 7, CFG_VARIANT, "OMNI_PREC_SPLIT: the cin = 64 layers as Winograd F(2x2,3x3) kernels with split operands (conv_wino.hip), bit 0 = conv1b (with the conv1a "
-                                              "fusion), 1 = conv2a, 2 = conv2b; 0: the direct kernels of conv_split.hip"},
+    {"OMNI_SPLIT_WINO", 7, 0, 15, CFG_VARIANT, "OMNI_PREC_SPLIT: the cin = 64 layers as Winograd F(2x2,3x3) kernels with split operands (conv_wino.hip), bit 0 = conv1b (with the conv1a "
+                                                "fusion), 1 = conv2a, 2 = conv2b, 3 = conv3a (off by default: same time as the direct kernel, profiles/r06g); 0: the direct kernels of conv_split.hip"},
     {"OMNI_SPLIT_TRN", -1, -1, 1, CFG_VARIANT, "OMNI_PREC_SPLIT cin=128 kernel: tile orientation, as OMNI_RS_TRN"},
     {"OMNI_CONV_XCD", 1, 0, 1, CFG_VARIANT, "persistent convolution kernels derive (cout group, tile walk) from an XCD-aware block id: the cout groups of a pixel tile and its neighbours "
                                            "share one L2 (0: plain blockIdx; process-wide, same results either way)"},

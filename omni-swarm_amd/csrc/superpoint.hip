@@ -63,13 +63,13 @@ struct omni_sp {
     uint32_t* lut_hl = nullptr;              // u8 -> (half hi, half lo) table
     bool fuse1a = false;
     bool split_fuse1a = false;               // OMNI_PREC_SPLIT: conv1a is built inside conv1b's kernel (OMNI_SPLIT_FUSE1A=0: the separate conv1a_split pass)
-    // OMNI_PREC_SPLIT, Winograd F(2x2,3x3) kernels (conv_wino.hip) for the cin = 64 layers: bit 0 = conv1b (needs the conv1a fusion), 1 = conv2a, 2 = conv2b
+    // OMNI_PREC_SPLIT, Winograd F(2x2,3x3) kernels (conv_wino.hip) for the cin = 64 layers: bit 0 = conv1b (needs the conv1a fusion), 1 = conv2a, 2 = conv2b, 3 = conv3a (64 -> 128: two output-channel groups)
     // (OMNI_SPLIT_WINO).  Between two Winograd layers the activation frame is raw-32 instead of split-64 (same geometry, same bytes): raw_1b / raw_2a say
     // what the LAST pass left in a1b / a2a; a_tmp: the converted input of a Winograd layer behind a direct one (mixed configurations only)
     int wino = 0;
     void* wpk_w[OMNI_SP_NUM_LAYERS] = {};
     float winv_w[OMNI_SP_NUM_LAYERS] = {};
-    bool raw_1b = false, raw_2a = false;
+    bool raw_1b = false, raw_2a = false, raw_2b = false;
     void* a_tmp = nullptr;
     bool mask_skip_cal_fused = false;        // ... and which of the two the mask's constant region was calibrated with
     float* pca_compT = nullptr;
@@ -275,12 +275,14 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     }
     if (s->precision == OMNI_PREC_SPLIT) {
         s->wino = s->cfg[CFG_SPLIT_WINO];
-        if (s->H % 4 != 0 || s->W % 4 != 0) s->wino &= 1;                         // conv2a / conv2b: even H / 2, W / 2 (F(2x2,3x3) tiles)
+        if (s->H % 8 != 0 || s->W % 8 != 0) s->wino &= 7;                         // conv3a: even H / 4, W / 4 (F(2x2,3x3) tiles)
+        if (s->H % 4 != 0 || s->W % 4 != 0) s->wino &= 1;                         // conv2a / conv2b: even H / 2, W / 2
         if (s->H % 2 != 0 || s->W % 2 != 0 || !s->split_fuse1a) s->wino &= ~1;
-        for (int l : {L1B, L2A, L2B}) {
-            if (!(s->wino & (l == L1B ? 1 : l == L2A ? 2 : 4))) continue;
-            std::vector<uint16_t> p((size_t)64 * 64 * 16 * 2);
-            s->winv_w[l] = conv_pack_weights_wino(w->weight[l], 64, 64, p.data());
+        for (int l : {L1B, L2A, L2B, L3A}) {
+            if (!(s->wino & (l == L1B ? 1 : l == L2A ? 2 : l == L2B ? 4 : 8))) continue;
+            const int co = kLayers[l].cout;
+            std::vector<uint16_t> p((size_t)64 * co * 16 * 2);
+            s->winv_w[l] = conv_pack_weights_wino(w->weight[l], 64, co, p.data());
             if ((rc = dev_upload(&s->wpk_w[l], p.data(), p.size() * 2, st))) return rc;
         }
     }
@@ -378,7 +380,7 @@ static int sp_calibrate_mask_skip(omni_sp* s, int stride) {
     s->mask_skip_cal_fused = s->fuse1a;
     for (const omni_sp::MaskSkip& k : s->mskip) {
         if (k.ty1 <= k.ty0 || (k.map == &s->a1a && s->fuse1a)) continue;
-        if (k.map == &s->a2a && s->precision == OMNI_PREC_SPLIT && (s->wino & 2)) {     // an unpooled Winograd layer: constant per position in the 2 x 2 output tile
+        if (s->precision == OMNI_PREC_SPLIT && ((k.map == &s->a2a && (s->wino & 2)) || (k.map == &s->a3a && (s->wino & 8)))) {     // an unpooled Winograd layer: constant per position in the 2 x 2 output tile
             if ((rc = conv_read_pixels2x2_bytes(st, *k.map, k.row_bytes, k.org_bytes, k.pix_bytes, ((k.oy0 + k.oy1) / 2) & ~1, ((k.ox0 + k.ox1) / 2) & ~1, k.vec))) return rc;
             if ((rc = conv_fill_rect2x2_bytes(st, *k.map, s->max_batch, k.img_bytes, k.row_bytes, k.org_bytes, k.pix_bytes, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
             continue;
@@ -413,7 +415,8 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
     if (use_skip && !s->mask_skip_ready && (rc = sp_calibrate_mask_skip(s, stride))) return rc;
     auto mark = [&]() -> int { if (with_events) OMNI_HIP_TRY(hipEventRecord(s->ev[stage], st)); ++stage; return OMNI_OK; };
     // OMNI_PREC_SPLIT: which of the cin = 64 layers run as Winograd kernels in THIS pass, and the frame format between them
-    const bool w1b = P == OMNI_PREC_SPLIT && (s->wino & 1) && fuse1a, w2a = P == OMNI_PREC_SPLIT && (s->wino & 2) != 0, w2b = P == OMNI_PREC_SPLIT && (s->wino & 4) != 0;
+    const bool w1b = P == OMNI_PREC_SPLIT && (s->wino & 1) && fuse1a, w2a = P == OMNI_PREC_SPLIT && (s->wino & 2) != 0, w2b = P == OMNI_PREC_SPLIT && (s->wino & 4) != 0,
+               w3a = P == OMNI_PREC_SPLIT && (s->wino & 8) != 0;
     auto skip_of = [&](int l, ConvArgs& a) {
         const int i = l == L1B ? 1 : l == L2A ? 2 : l == L2B ? 3 : l == L3A ? 4 : l == L3B ? 5 : -1;
         if (use_skip && i >= 0) { a.skip_ty0 = s->mskip[i].ty0; a.skip_ty1 = s->mskip[i].ty1; a.skip_tx0 = s->mskip[i].tx0; a.skip_tx1 = s->mskip[i].tx1; }
@@ -460,20 +463,21 @@ static int sp_forward(omni_sp* s, const uint8_t* gray_dev, int stride, int batch
             in = s->a_tmp;
         }
         ConvArgs a;
-        a.in = in; a.out = out; a.w_packed = s->wpk_w[l]; a.bias = s->bias_s[l]; a.batch = batch; a.H = h; a.W = w; a.cin = 64; a.cout = 64; a.ksize = 3;
+        a.in = in; a.out = out; a.w_packed = s->wpk_w[l]; a.bias = s->bias_s[l]; a.batch = batch; a.H = h; a.W = w; a.cin = 64; a.cout = kLayers[l].cout; a.ksize = 3;
         a.relu = true; a.pool = pool; a.out_f32 = false; a.n_cu = s->ctx->prop.multiProcessorCount; a.split_inv = s->winv_w[l];
         skip_of(l, a);
         return conv_wino(st, a, out_split);
     };
-    const bool raw_1b = w1b && w2a, raw_2a = w2a && w2b;
-    if (P == OMNI_PREC_SPLIT) { s->raw_1b = raw_1b; s->raw_2a = raw_2a; }
+    const bool raw_1b = w1b && w2a, raw_2a = w2a && w2b, raw_2b = w2b && w3a;
+    if (P == OMNI_PREC_SPLIT) { s->raw_1b = raw_1b; s->raw_2a = raw_2a; s->raw_2b = raw_2b; }
     if (w2a) { if ((rc = wino_layer(L2A, s->a1b, raw_1b, s->a2a, H / 2, W / 2, false, !w2b))) return rc; }
     else if ((rc = conv(L2A, s->a1b, s->a2a, s->bias[L2A], H / 2, W / 2, 64, 64, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
-    if (w2b) { if ((rc = wino_layer(L2B, s->a2a, raw_2a, s->a2b, H / 2, W / 2, true, true))) return rc; }
+    if (w2b) { if ((rc = wino_layer(L2B, s->a2a, raw_2a, s->a2b, H / 2, W / 2, true, !w3a))) return rc; }
     else if ((rc = conv(L2B, s->a2a, s->a2b, s->bias[L2B], H / 2, W / 2, 64, 64, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;
-    if ((rc = conv(L3A, s->a2b, s->a3a, s->bias[L3A], H / 4, W / 4, 64, 128, 3, true, false, false))) return rc;
+    if (w3a) { if ((rc = wino_layer(L3A, s->a2b, raw_2b, s->a3a, H / 4, W / 4, false, true))) return rc; }
+    else if ((rc = conv(L3A, s->a2b, s->a3a, s->bias[L3A], H / 4, W / 4, 64, 128, 3, true, false, false))) return rc;
     if ((rc = mark())) return rc;
     if ((rc = conv(L3B, s->a3a, s->a3b, s->bias[L3B], H / 4, W / 4, 128, 128, 3, true, true, false))) return rc;
     if ((rc = mark())) return rc;
@@ -785,7 +789,7 @@ int omni_sp_debug_layer(omni_sp* s, const char* name, int batch, float* out_nchw
         const size_t n = (size_t)batch * e.c * h * w;
         int rc;
         if ((rc = s->dense_tmp.ensure(n * 4))) return rc;
-        if (e.prec == OMNI_PREC_SPLIT && ((e.p == s->a1b && s->raw_1b) || (e.p == s->a2a && s->raw_2a))) {      // a raw-32 frame between two Winograd layers
+        if (e.prec == OMNI_PREC_SPLIT && ((e.p == s->a1b && s->raw_1b) || (e.p == s->a2a && s->raw_2a) || (e.p == s->a2b && s->raw_2b))) {      // a raw-32 frame between two Winograd layers
             if ((rc = omni::raw32_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h, w))) return rc;
         } else if (e.prec == OMNI_PREC_SPLIT) { if ((rc = omni::split_to_nchw_f32(s->ctx->stream, e.p, s->dense_tmp.as<float>(), batch, e.c, h, w))) return rc; }
         else if ((rc = omni::nhwc_any_to_nchw_f32(s->ctx->stream, e.prec, e.p, s->dense_tmp.as<float>(), batch, e.c, h * w))) return rc;

@@ -77,10 +77,10 @@ def test_f32_layers_and_dense_outputs(omni, ctx, shape, prec, monkeypatch):
     assert np.abs(desc - desc_r).max() < 2e-5, np.abs(desc - desc_r).max()
 
 
-@pytest.mark.parametrize("mask", [0, 1, 2, 4, 6])
+@pytest.mark.parametrize("mask", [0, 1, 2, 4, 6, 8, 12])
 def test_split_winograd_layer_subsets_meet_the_same_gates(omni, ctx, monkeypatch, mask):
-    """OMNI_PREC_SPLIT runs conv1b / conv2a / conv2b as Winograd F(2x2,3x3) kernels with split operands (csrc/conv_wino.hip; OMNI_SPLIT_WINO bit 0 / 1 / 2, default
-    all three: what test_f32_layers_and_dense_outputs[PREC_SPLIT] gates).  Every subset -- a Winograd layer behind a direct one reads a converted raw-32 frame, one
+    """OMNI_PREC_SPLIT runs conv1b / conv2a / conv2b / conv3a as Winograd F(2x2,3x3) kernels with split operands (csrc/conv_wino.hip; OMNI_SPLIT_WINO bit 0 / 1 / 2 / 3, default
+    the first three -- conv3a with its two output-channel groups runs at the direct kernel's time --: what test_f32_layers_and_dense_outputs[PREC_SPLIT] gates).  Every subset -- a Winograd layer behind a direct one reads a converted raw-32 frame, one
     in front of a direct one writes split-64 -- meets the same per-layer bar (2e-5 of the layer's magnitude) and the same dense-output bars, at a shape whose tiles
     overhang the image on both sides and at the full frame; 0 = the direct kernels of conv_split.hip."""
     weights = S.synth_weights(0)

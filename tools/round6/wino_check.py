@@ -30,7 +30,7 @@ def main():
             ref[n] = (F.max_pool2d(a, 2, 2) if n in ("conv1b", "conv2b", "conv3b") else a).numpy()
         ref["heads"] = np.concatenate([inter["convPa"], inter["convDa"]], 1)
         base = None
-        for mask in (0, 4, 2, 6, 1, 7):
+        for mask in (0, 8, 12, 4, 2, 6, 1, 7, 15):
             try:
                 res, layers, semi, desc = run(mask, h, w, imgs, weights, comp, mean)
             except Exception as e:
