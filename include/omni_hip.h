@@ -227,6 +227,9 @@ int omni_vlad_infer(omni_vlad* v, const uint8_t* gray_host, int stride, int batc
 int omni_vlad_enqueue_dev(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask);
 int omni_vlad_fetch(omni_vlad* v, int batch, float* out);
 int omni_vlad_dev_output(omni_vlad* v, const float** out_dev);
+/* The layers (0 = stem + block 0, k = block k) whose tiles inside the constant region of the fisheye mask a masked pass leaves out (loop_cam.cpp:536-539
+ * blanks the rows before netvlad_net.inference, :556-558): returns their number, frac[k] = the share of layer k's tiles left out (up to max_layers). */
+int omni_vlad_mask_skip_layers(const omni_vlad* v, double* frac, int max_layers);
 
 /* ---- global-descriptor index: faiss::IndexFlatIP(d) --------------------------------------------------------- */
 omni_index* omni_index_create(omni_ctx* ctx, int dim, int storage, int64_t initial_capacity_rows);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_image_size", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
     "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_sp_stage_tiles_left_out", "omni_sp_mask_skip_plan", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block",
-    "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_index_create",
+    "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_vlad_mask_skip_layers", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
     "omni_index_save", "omni_index_load",
@@ -132,6 +132,7 @@ def lib():
     sig("omni_vlad_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int])
     sig("omni_vlad_fetch", C.c_int, [_vp, C.c_int, _fp])
     sig("omni_vlad_dev_output", C.c_int, [_vp, C.POINTER(_vp)])
+    sig("omni_vlad_mask_skip_layers", C.c_int, [_vp, C.POINTER(C.c_double), C.c_int])
     sig("omni_index_create", _vp, [_vp, C.c_int, C.c_int, C.c_int64])
     sig("omni_index_destroy", None, [_vp])
     sig("omni_index_add", C.c_int, [_vp, C.c_int64, _fp])
@@ -460,6 +461,12 @@ class MobileNetVLAD:
         p = _vp()
         _check(lib().omni_vlad_dev_output(self.h, C.byref(p)))
         return p.value
+
+    def mask_skip_layers(self) -> list:
+        """Share of the tiles of the stem (+ block 0) and of blocks 1, 2, ... that a fisheye-masked pass leaves out (the mask's constant region)."""
+        f = (C.c_double * 32)()
+        n = lib().omni_vlad_mask_skip_layers(self.h, f, 32)
+        return [f[i] for i in range(min(n, 32))]
 
 
 def vlad_pack_block(cin, hid, cout, stride, we, be, wd, bd, wp):

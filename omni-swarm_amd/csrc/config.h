@@ -18,7 +18,7 @@ enum CfgId {
     CFG_SPLIT_TRN, CFG_CONV_XCD, CFG_SP_PROFILE_MASK, CFG_PP_TRACE, CFG_PP_DBG, CFG_RS_TRACE, CFG_SPLIT_TRACE, CFG_SPLIT_DBG, CFG_WINO_TRACE, CFG_ROCTX,
     // MobileNetVLAD
     CFG_VLAD_BIG, CFG_VLAD_STEM_FUSE, CFG_VLAD_UNFUSED, CFG_VLAD_MFMA, CFG_VLAD_SBLOCK, CFG_VLAD_MBLOCK_PX, CFG_VLAD_MFMA_PX, CFG_VLAD_FC_MFMA, CFG_VLAD_MBLOCK_CPW,
-    CFG_VLAD_SB_LDSPAD, CFG_VLAD_SB_PERSIST, CFG_VLAD_SB_TRACE, CFG_VLAD_SB_DBG,
+    CFG_VLAD_SB_LDSPAD, CFG_VLAD_SB_PERSIST, CFG_VLAD_SB_TRACE, CFG_VLAD_SB_DBG, CFG_VLAD_MASK_SKIP,
     // index
     CFG_SCAN_ROWS_MIN, CFG_MQ_ROT, CFG_MQ_MIN, CFG_INDEX_MIRROR, CFG_INDEX_MIRROR_MIN_ROWS, CFG_INDEX_CERT_FAIL,
     // host loop (libomni_host.so reads them through omni_config_value)

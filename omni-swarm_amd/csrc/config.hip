@@ -51,6 +51,8 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_VLAD_SB_PERSIST", 1, 0, 16, CFG_VARIANT, "split block kernel: 0 = one tile per workgroup, N >= 1 = N x (CUs x resident workgroups) persistent workgroups"},
     {"OMNI_VLAD_SB_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the split block kernel"},
     {"OMNI_VLAD_SB_DBG", 0, 0, 255, CFG_DEBUG, "split block kernel timing ablations (WRONG results)"},
+    {"OMNI_VLAD_MASK_SKIP", 1, 0, 1, CFG_VARIANT, "fisheye-masked passes leave the tiles of the first blocks that lie in the constant region of the mask out of the tile walk "
+                                                  "(bit-identical; 0: the dense pass)"},
     // ---- index -----------------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_SCAN_ROWS_MIN", 4, 1, 1 << 20, CFG_TUNING, "fp32 scan: from this many queries on, the rows-stationary kernel"},
     {"OMNI_MQ_ROT", 1, 0, 1, CFG_VARIANT, "matrix-core multi-query scan: rotated query fragments"},

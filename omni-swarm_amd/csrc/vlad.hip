@@ -12,6 +12,7 @@
 #include "config.h"
 #include "common.h"
 #include "vlad_h.h"
+#include "conv.h"          // conv_read_pixel_bytes / conv_fill_rect_bytes (the constant region of the fisheye mask)
 
 struct VladLayerDev { int kind, cin, cout, stride, hin, win, hout, wout; float* w; float* b; };
 
@@ -47,6 +48,22 @@ struct omni_vlad {
     float *assign = nullptr, *vlad = nullptr, *out = nullptr;
     uint8_t* gray_stage = nullptr;
     omni::HostBuf hstage;
+    // The constant region of the fisheye mask (round 6; the SuperPoint side: superpoint.hip, omni_sp::MaskSkip).  LoopCam blanks the bottom quarter of the
+    // frame BEFORE both networks run (loop_cam.cpp:536-539, 556-558): inside the band, one 3x3 tap in from its borders per convolution, the output of the
+    // stem and of every block is one constant vector.  A planned layer writes into a buffer of its own (mskip[k].buf: the rotating buffers are shared between
+    // layers) whose rectangle is filled once, from a dense pass over a blank masked frame (vlad_calibrate_mask_skip), and the tiles inside the rectangle are
+    // left out of the tile walk: bit-identical to the dense pass (tests/test_gpu_vlad_detector.py).  mskip[0] = stem + block 0, mskip[k] = block k.
+    struct MaskSkip {
+        int ty0 = 0, ty1 = 0, tx0 = 0, tx1 = 0;       // tile rectangle in the layer's output tile grid
+        int oy0 = 0, oy1 = 0, ox0 = 0, ox1 = 0;       // the same in output pixels
+        int oh = 0, ow = 0, oc = 0;
+        float* buf = nullptr;                         // [max_batch][oh][ow][oc]
+        void* vec = nullptr;                          // [oc] the constant
+        double frac = 0.0;                            // the rectangle's share of the layer's tiles
+    };
+    std::vector<MaskSkip> mskip;
+    bool mask_skip_ready = false;
+    uint8_t* zero_gray = nullptr;
     std::mutex mu;
 };
 
@@ -1055,7 +1072,11 @@ __global__ void __launch_bounds__(256)
 vlad_stem_b0_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, int mask0, int mask1, int Ho, int Wo,
                     const float* __restrict__ ws /*[16][9]*/, const float* __restrict__ bs, const float* __restrict__ wd_t /*[9][16]*/,
                     const float* __restrict__ bd, const float* __restrict__ wp_t /*[16][8]*/, const float* __restrict__ bp,
-                    float* __restrict__ out /*[B][Ho][Wo][8]*/) {
+                    float* __restrict__ out /*[B][Ho][Wo][8]*/, int sk_y0, int sk_y1, int sk_x0, int sk_x1) {
+    {   // tiles inside the constant region of the fisheye mask hold their values already (omni_vlad::MaskSkip)
+        const int tx_n = (Wo + SB_TW - 1) / SB_TW, tyy = (int)blockIdx.x / tx_n, txx = (int)blockIdx.x - tyy * tx_n;
+        if (tyy >= sk_y0 && tyy < sk_y1 && txx >= sk_x0 && txx < sk_x1) return;
+    }
     constexpr int RW = SB_TW + 2, RH = SB_TH + 2, R = RW * RH;           // 18 x 10 stem pixels
     constexpr int PW = 2 * RW + 1, PH = 2 * RH + 1;                       // 37 x 21 input pixels
     __shared__ float patch[PH * PW];
@@ -1142,9 +1163,12 @@ vlad_stem_b0_kernel(const uint8_t* __restrict__ gray, int stride, int H, int W, 
 }
 
 // stem + one fused kernel per inverted-residual block (v->blocks, built at create time)
-static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, int* cur_out) {
+// skip_mode: 0 = the rotating buffers, every tile; 1 = the planned layers write into their own buffers, every tile (the calibration pass); 2 = ... and leave
+// the tiles of their constant rectangles out.  *out_ptr = the backbone's output.
+static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask, int skip_mode, const float** out_ptr) {
     hipStream_t st = v->ctx->stream;
     const int H = v->H, W = v->W;
+    const float* in_over = nullptr;          // the previous layer wrote into a buffer of its own: this layer's input (instead of buf[cur])
     int m0, m1;
     omni_fisheye_mask_rows(H, fisheye_mask, &m0, &m1);
     const VladLayerDev& S = v->layers[0];
@@ -1156,9 +1180,11 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
         B0->stride == 1) {
         // stem + block 0 in one kernel: the 16-channel stem map never reaches HBM
         hipLaunchKernelGGL(vlad_stem_b0_kernel, dim3(cdiv(B0->wout, SB_TW) * cdiv(B0->hout, SB_TH), batch), dim3(256), 0, st, gray_dev, stride, H,
-                           W, m0, m1, S.hout, S.wout, S.w, S.b, B0->wd_t, B0->bd, B0->wp_t, B0->bp, v->buf[1]);
+                           W, m0, m1, S.hout, S.wout, S.w, S.b, B0->wd_t, B0->bd, B0->wp_t, B0->bp, skip_mode ? v->mskip[0].buf : v->buf[1],
+                           skip_mode == 2 ? v->mskip[0].ty0 : 0, skip_mode == 2 ? v->mskip[0].ty1 : 0, v->mskip.empty() ? 0 : v->mskip[0].tx0, v->mskip.empty() ? 0 : v->mskip[0].tx1);
         OMNI_LAUNCH_CHECK();
         cur = 1; first = 1;
+        if (skip_mode) in_over = v->mskip[0].buf;
     } else {
         hipLaunchKernelGGL(vlad_stem4_kernel, dim3(cdiv(S.hout * S.wout * (S.cout / 4), 256), batch), dim3(256), 0, st, gray_dev, stride, H, W, m0,
                            m1, S.hout, S.wout, S.cout, S.stride, S.w, S.b, v->buf[0]);
@@ -1167,9 +1193,11 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
     for (size_t bi = first; bi < v->blocks.size(); ++bi) {
         const VladFusedBlock& B = v->blocks[bi];
         const int64_t Pin = (int64_t)batch * B.hin * B.win, Pout = (int64_t)batch * B.hout * B.wout;
+        const float* const in = in_over ? in_over : v->buf[cur];
+        in_over = nullptr;
         if (v->prec == OMNI_PREC_F16 && B.hblob) {
             VladHBlockArgs ha;
-            ha.in = v->buf[cur]; ha.out = v->buf[(cur + 1) % 3]; ha.blob = B.hblob; ha.bp = B.bp;
+            ha.in = in; ha.out = v->buf[(cur + 1) % 3]; ha.blob = B.hblob; ha.bp = B.bp;
             ha.Hi = B.hin; ha.Wi = B.win; ha.Ho = B.hout; ha.Wo = B.wout; ha.cin = B.cin; ha.hid = B.hid; ha.cout = B.cout; ha.res = B.res; ha.batch = batch;
             if ((rc = launch_vlad_hblock(st, ha, B.stride))) return rc;
             cur = (cur + 1) % 3;
@@ -1177,17 +1205,20 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
         }
         if (v->sblock && B.sblob) {
             VladSBlockArgs sa;
-            sa.in = v->buf[cur]; sa.out = v->buf[(cur + 1) % 3]; sa.blob = B.sblob; sa.bp = B.bp;
+            const bool own = skip_mode && bi < v->mskip.size();          // a planned layer: its own output buffer (the ring is not advanced)
+            sa.in = in; sa.out = own ? v->mskip[bi].buf : v->buf[(cur + 1) % 3]; sa.blob = B.sblob; sa.bp = B.bp;
+            if (own && skip_mode == 2) { sa.sk_y0 = v->mskip[bi].ty0; sa.sk_y1 = v->mskip[bi].ty1; sa.sk_x0 = v->mskip[bi].tx0; sa.sk_w = v->mskip[bi].tx1 - v->mskip[bi].tx0; }
             sa.Hi = B.hin; sa.Wi = B.win; sa.Ho = B.hout; sa.Wo = B.wout; sa.cin = B.cin; sa.hid = B.hid; sa.cout = B.cout; sa.res = B.res; sa.batch = batch;
             sa.n_cu = v->ctx->prop.multiProcessorCount > 0 ? v->ctx->prop.multiProcessorCount : 256; sa.trace = nullptr; sa.dbg = 0;
             sa.persist = v->cfg[omni::CFG_VLAD_SB_PERSIST];
             if ((rc = launch_vlad_sblock(st, sa, B.stride))) return rc;
-            cur = (cur + 1) % 3;
+            if (own) in_over = v->mskip[bi].buf;
+            else cur = (cur + 1) % 3;
             continue;
         }
         if (B.mblob && B.hin * B.win <= v->mblock_max_px) {                  // per-image size: batch-independent numerics
             VladMBlockArgs m;
-            m.in = v->buf[cur]; m.out = v->buf[(cur + 1) % 3]; m.blob = B.mblob; m.bp = B.bp;
+            m.in = in; m.out = v->buf[(cur + 1) % 3]; m.blob = B.mblob; m.bp = B.bp;
             m.Hi = B.hin; m.Wi = B.win; m.Ho = B.hout; m.Wo = B.wout; m.cin = B.cin; m.hid = B.hid; m.cout = B.cout; m.cop = B.cop;
             m.stride = B.stride; m.res = B.res; m.batch = batch;
             const int n_chunks = (B.hid + 31) / 32, tiles = cdiv(B.wout, 8) * cdiv(B.hout, 8) * batch;
@@ -1202,46 +1233,113 @@ static int vlad_backbone_fused(omni_vlad* v, const uint8_t* gray_dev, int stride
             // low-resolution block: expand / project as f32-MFMA pointwise GEMMs, depthwise in between (three launches; the fused
             // VALU kernel has too few workgroups at these sizes and is latency-bound)
             const int e = (cur + 1) % 3, d = (cur + 2) % 3;
-            if ((rc = vlad_pw_mfma(st, v->buf[cur], Pin, B.cin, B.hid, B.we_t, B.be, nullptr, 1, v->buf[e]))) return rc;
+            if ((rc = vlad_pw_mfma(st, in, Pin, B.cin, B.hid, B.we_t, B.be, nullptr, 1, v->buf[e]))) return rc;
             const int64_t total = Pout * (B.hid / 4);
             hipLaunchKernelGGL(vlad_dw_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, v->buf[e], B.hin, B.win, B.hid, B.hout, B.wout,
                                B.stride, B.wd_t, B.bd, v->buf[d], total);
             OMNI_LAUNCH_CHECK();
-            if ((rc = vlad_pw_mfma(st, v->buf[d], Pout, B.hid, B.cout, B.wp_t, B.bp, B.res ? v->buf[cur] : nullptr, 0, v->buf[e]))) return rc;
+            if ((rc = vlad_pw_mfma(st, v->buf[d], Pout, B.hid, B.cout, B.wp_t, B.bp, B.res ? in : nullptr, 0, v->buf[e]))) return rc;
             cur = e;
             continue;
         }
         VladBlockArgs a;
-        a.in = v->buf[cur]; a.out = v->buf[(cur + 1) % 3];
+        a.in = in; a.out = v->buf[(cur + 1) % 3];
         a.blob = B.blob; a.bp = B.bp;
         a.Hi = B.hin; a.Wi = B.win; a.Ho = B.hout; a.Wo = B.wout; a.hid = B.hid; a.cout = B.cout; a.stride = B.stride;
         a.expand = B.expand; a.res = B.res; a.batch = batch;
         if ((rc = vlad_block(st, B.cin, a))) return rc;
         cur = (cur + 1) % 3;
     }
-    *cur_out = cur;
+    *out_ptr = in_over ? in_over : v->buf[cur];
     return OMNI_OK;
+}
+
+// One dense pass over a blank masked frame with the planned layers writing into their own buffers; each layer's constant is read from the middle of its
+// rectangle and written into that rectangle of every image slot.  Passes without the mask use the rotating buffers: the rectangles stay valid.
+static int vlad_calibrate_mask_skip(omni_vlad* v) {
+    hipStream_t st = v->ctx->stream;
+    if (!v->zero_gray) {
+        OMNI_HIP_TRY(hipMalloc((void**)&v->zero_gray, (size_t)v->W * v->H));
+        OMNI_HIP_TRY(hipMemsetAsync(v->zero_gray, 0, (size_t)v->W * v->H, st));
+    }
+    const float* unused;
+    int rc;
+    if ((rc = vlad_backbone_fused(v, v->zero_gray, v->W, 1, 1, 1, &unused))) return rc;
+    for (const omni_vlad::MaskSkip& k : v->mskip) {
+        const int pix = k.oc * 4;
+        const int64_t row = (int64_t)k.ow * pix, img = row * k.oh;
+        if ((rc = conv_read_pixel_bytes(st, k.buf, row, 0, pix, (k.oy0 + k.oy1) / 2, (k.ox0 + k.ox1) / 2, k.vec))) return rc;
+        if ((rc = conv_fill_rect_bytes(st, k.buf, v->max_batch, img, row, 0, pix, k.oy0, k.oy1, k.ox0, k.ox1, k.vec))) return rc;
+    }
+    v->mask_skip_ready = true;
+    return OMNI_OK;
+}
+
+// Where the stem's / the blocks' outputs are constant under the fisheye mask, and the tile rectangles inside (omni_vlad::MaskSkip): integer arithmetic on
+// (H, W), the layers' strides and the kernels' tile shapes (vlad_stem_b0_kernel: SB_TH x SB_TW; vlad_sblock_kernel: 8 x 8 at stride 1, 4 rows x 8 at stride 2).
+// A 3x3 convolution with padding 1 at stride s reads input rows s r - 1 .. s r + 1: the zero padding is not the constant.
+static void vlad_plan_mask_skip(omni_vlad* v) {
+    v->mskip.clear();
+    if (!v->fused || !v->sblock || !v->cfg[omni::CFG_VLAD_MASK_SKIP] || !v->cfg[omni::CFG_VLAD_STEM_FUSE] || v->blocks.empty()) return;
+    const VladLayerDev& S = v->layers[0];
+    const VladFusedBlock& B0 = v->blocks[0];
+    if (!(S.cout == 16 && S.stride == 2 && !B0.expand && !B0.res && B0.cin == 16 && B0.hid == 16 && B0.cout == 8 && B0.stride == 1)) return;      // (vlad_stem_b0_kernel's shape)
+    int m0, m1;
+    omni_fisheye_mask_rows(v->H, 1, &m0, &m1);
+    int a = m0, b = m1 - 1, c = 0, d = v->W - 1;                 // constant rows [a, b] x columns [c, d] (inclusive) of the current map
+    auto conv3 = [&](int stride) {                               // through a 3x3 convolution, padding 1
+        if (stride == 2) { a = (a + 2) / 2; b = (b - 1) >> 1; c = (c + 2) / 2; d = (d - 1) >> 1; }      // rows 2r - 1 .. 2r + 1 inside [a, b]
+        else { a += 1; b -= 1; c += 1; d -= 1; }
+    };
+    auto plan = [&](int th, int tw, int oh, int ow, int oc) -> bool {
+        omni_vlad::MaskSkip k;
+        if (b < a || d < c) return false;
+        k.ty0 = (a + th - 1) / th; k.ty1 = (b + 1) / th; k.tx0 = (c + tw - 1) / tw; k.tx1 = (d + 1) / tw;
+        if (k.ty1 <= k.ty0 || k.tx1 <= k.tx0) return false;
+        k.oy0 = k.ty0 * th; k.oy1 = k.ty1 * th; k.ox0 = k.tx0 * tw; k.ox1 = k.tx1 * tw;
+        k.oh = oh; k.ow = ow; k.oc = oc;
+        k.frac = (double)(k.ty1 - k.ty0) * (k.tx1 - k.tx0) / ((double)cdiv(oh, th) * cdiv(ow, tw));
+        v->mskip.push_back(k);
+        return true;
+    };
+    conv3(2);                                                    // the stem
+    conv3(1);                                                    // block 0's depthwise convolution (its projection is 1x1)
+    if (!plan(SB_TH, SB_TW, B0.hout, B0.wout, B0.cout)) return;
+    for (size_t bi = 1; bi < v->blocks.size(); ++bi) {
+        const VladFusedBlock& B = v->blocks[bi];
+        if (!B.sblob || (B.cout * 4) % 16 != 0) break;
+        conv3(B.stride);                                         // (expand and projection are 1x1; the residual adds two constants)
+        if (!plan(B.stride == 1 ? 8 : 4, 8, B.hout, B.wout, B.cout)) break;
+    }
 }
 
 static int vlad_forward(omni_vlad* v, const uint8_t* gray_dev, int stride, int batch, int fisheye_mask) {
     hipStream_t st = v->ctx->stream;
     int cur = 0, rc;
-    if (v->fused) { if ((rc = vlad_backbone_fused(v, gray_dev, stride, batch, fisheye_mask, &cur))) return rc; }
-    else if ((rc = vlad_backbone_unfused(v, gray_dev, stride, batch, fisheye_mask, &cur))) return rc;
+    const float* feat = nullptr;             // the backbone's output map
+    if (v->fused) {
+        // the mask's constant region (omni_vlad::MaskSkip): only the split block kernels know the shortened tile walk
+        const bool skip = fisheye_mask && !v->mskip.empty() && v->sblock && v->prec != OMNI_PREC_F16;
+        if (skip && !v->mask_skip_ready && (rc = vlad_calibrate_mask_skip(v))) return rc;
+        if ((rc = vlad_backbone_fused(v, gray_dev, stride, batch, fisheye_mask, skip ? 2 : 0, &feat))) return rc;
+    } else {
+        if ((rc = vlad_backbone_unfused(v, gray_dev, stride, batch, fisheye_mask, &cur))) return rc;
+        feat = v->buf[cur];
+    }
     const int n_pos = v->hf * v->wf;
     const int64_t n_all = (int64_t)batch * n_pos;
     if (v->fused && v->K <= 32) {
         const size_t smem = ((size_t)v->Dm * v->K + 8 * v->Dm) * 4;
-        hipLaunchKernelGGL(vlad_assign2_kernel, dim3((unsigned)cdiv64(n_all, 8)), dim3(256), smem, st, v->buf[cur], n_all, v->Dm, v->K,
+        hipLaunchKernelGGL(vlad_assign2_kernel, dim3((unsigned)cdiv64(n_all, 8)), dim3(256), smem, st, feat, n_all, v->Dm, v->K,
                            v->assign_wT, v->assign_b, v->assign);
         OMNI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(vlad_aggregate8_kernel, dim3(v->K, batch), dim3(1024), 0, st, v->buf[cur], v->assign, n_pos, v->Dm, v->K,
+        hipLaunchKernelGGL(vlad_aggregate8_kernel, dim3(v->K, batch), dim3(1024), 0, st, feat, v->assign, n_pos, v->Dm, v->K,
                            v->clusters, v->vlad);
     } else {
-        hipLaunchKernelGGL(vlad_assign_kernel, dim3((unsigned)cdiv64(n_all, 4)), dim3(256), 0, st, v->buf[cur], n_all, v->Dm, v->K, v->assign_wT,
+        hipLaunchKernelGGL(vlad_assign_kernel, dim3((unsigned)cdiv64(n_all, 4)), dim3(256), 0, st, feat, n_all, v->Dm, v->K, v->assign_wT,
                            v->assign_b, v->assign);
         OMNI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(v->K, batch), dim3(128), 0, st, v->buf[cur], v->assign, n_pos, v->Dm, v->K, v->clusters,
+        hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(v->K, batch), dim3(128), 0, st, feat, v->assign, n_pos, v->Dm, v->K, v->clusters,
                            v->vlad);
     }
     OMNI_LAUNCH_CHECK();
@@ -1442,6 +1540,11 @@ omni_vlad* omni_vlad_create(omni_ctx* ctx, const omni_vlad_weights* w, int width
             }
         }
         for (int i = 0; i < 3 && ok; ++i) ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess;
+        if (ok) {
+            omni::vlad_plan_mask_skip(v);
+            for (auto& k : v->mskip)
+                ok = ok && hipMalloc((void**)&k.buf, (size_t)max_batch * k.oh * k.ow * k.oc * 4) == hipSuccess && hipMalloc(&k.vec, (size_t)k.oc * 4) == hipSuccess;
+        }
         ok = ok && hipMalloc((void**)&v->assign, (size_t)max_batch * h * wd * v->K * 4) == hipSuccess &&
              hipMalloc((void**)&v->vlad, (size_t)max_batch * n_in * 4) == hipSuccess &&
              hipMalloc((void**)&v->out, (size_t)max_batch * v->out_dim * 4) == hipSuccess &&
@@ -1460,6 +1563,8 @@ void omni_vlad_destroy(omni_vlad* v) {
     for (auto& B : v->blocks) { if (B.blob) (void)hipFree(B.blob); if (B.mblob) (void)hipFree(B.mblob); if (B.hblob) (void)hipFree(B.hblob); if (B.sblob) (void)hipFree(B.sblob); }
     void* ptrs[] = {v->mb_partial, v->fc_wp, v->fc_part, v->assign_wT, v->assign_b, v->clusters, v->fc_w, v->fc_b, v->buf[0], v->buf[1], v->buf[2], v->assign, v->vlad, v->out, v->gray_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& k : v->mskip) { if (k.buf) (void)hipFree(k.buf); if (k.vec) (void)hipFree(k.vec); }
+    if (v->zero_gray) (void)hipFree(v->zero_gray);
     v->hstage.release();
     delete v;
 }
@@ -1510,6 +1615,13 @@ int omni_vlad_fetch(omni_vlad* v, int batch, float* out) {
     OMNI_HIP_TRY(hipStreamSynchronize(v->ctx->stream));
     memcpy(out, v->hstage.p, bytes);
     return OMNI_OK;
+}
+
+int omni_vlad_mask_skip_layers(const omni_vlad* v, double* frac, int max_layers) {
+    if (!v) return 0;
+    const int n = (int)v->mskip.size();
+    for (int i = 0; i < n && i < max_layers && frac; ++i) frac[i] = v->mskip[i].frac;
+    return n;
 }
 
 int omni_vlad_dev_output(omni_vlad* v, const float** out_dev) {

@@ -31,6 +31,11 @@ struct VladSBlockArgs {
     unsigned m_img, m_tx;            // ceil(2^32 / tiles per image), ceil(2^32 / tiles per row): set by the launcher
     int dbg;                         // OMNI_VLAD_SB_DBG (timing ablations only, WRONG results): bit 0 no result stores, bit 1 no input prefetch
     unsigned long long* trace;       // OMNI_VLAD_SB_TRACE=1: s_memtime stamps of workgroup 0 (debug only), else nullptr
+    // the constant region of the fisheye mask (vlad.hip, vlad_plan_mask_skip): tile rows [sk_y0, sk_y1) x tile columns [sk_x0, sk_x0 + sk_w) hold one
+    // constant vector, written once, and are left out of the tile walk (sk_y1 <= sk_y0: every tile runs); the rest is set by the launcher
+    int sk_y0 = 0, sk_y1 = 0, sk_x0 = 0, sk_w = 0;
+    int sk_bw = 0, sk_act = 0, sk_above = 0, sk_upto = 0;      // tile columns left in a band row, tiles of an image that run, ... above the band, ... down to its last row
+    unsigned m_act = 0, m_bw = 0;
     int persist;                     // OMNI_VLAD_SB_PERSIST as the handle saw it: 0 = one tile per workgroup, N >= 1 = N x (CUs x resident workgroups) persistent workgroups (read by the launcher only)
 };
 bool vlad_sblock_supported(int cin, int hid, int cout, int stride);

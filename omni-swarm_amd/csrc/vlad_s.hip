@@ -74,7 +74,7 @@ vlad_sblock_kernel(VladSBlockArgs a) {
     float* wdl = reinterpret_cast<float*>(h + R * SB_HS);    // [chunk][10][48] depthwise taps + bias
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, kk = lane >> 5;
-    const int tiles_x = (a.Wo + 7) >> 3, tiles_y = (a.Ho + TH - 1) / TH, tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * a.batch;
+    const int tiles_x = (a.Wo + 7) >> 3, tiles_y = (a.Ho + TH - 1) / TH, tiles_img = tiles_x * tiles_y;
     const char* blob = reinterpret_cast<const char*>(a.blob);
     const char* frag = blob + (size_t)n_chunks * SB_WD * 4;  // per-chunk matrix fragments
 
@@ -116,6 +116,19 @@ vlad_sblock_kernel(VladSBlockArgs a) {
         tb = sb_div(tile, a.m_img);
         const int ttr = tile - tb * tiles_img, tty = sb_div(ttr, a.m_tx);
         toy = tty * TH; tox = (ttr - tty * tiles_x) * 8;
+    };
+    // the t-th tile that RUNS -> its number in the full grid (the band of the fisheye mask's constant region is not walked: VladSBlockArgs::sk_*)
+    const int act_total = a.sk_act * a.batch;
+    auto full_tile = [&](int t) -> int {
+        if (a.sk_y1 <= a.sk_y0) return t;
+        const int tb = sb_div(t, a.m_act), r = t - tb * a.sk_act;
+        int ttr;
+        if (r < a.sk_above) ttr = r;
+        else if (r < a.sk_upto) {
+            const int q = r - a.sk_above, ry = sb_div(q, a.m_bw), c = q - ry * a.sk_bw;
+            ttr = (a.sk_y0 + ry) * tiles_x + (c < a.sk_x0 ? c : c + a.sk_w);
+        } else ttr = r - a.sk_upto + a.sk_y1 * tiles_x;
+        return tb * tiles_img + ttr;
     };
     // input region of a tile: thread = (region pixel, half of its channels); fetched into registers one tile ahead
     const int xhf = tid & 1;
@@ -221,10 +234,11 @@ vlad_sblock_kernel(VladSBlockArgs a) {
       }
     };
 
-    fetch_x(blockIdx.x);
+    if ((int)blockIdx.x < act_total) fetch_x(full_tile(blockIdx.x));
 #define TR(k) do { if (trw) a.trace[wave * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-    for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
-        const bool trw = a.trace && blockIdx.x == 0 && (tid & 63) == 0 && tile == (int)blockIdx.x + 2 * (int)gridDim.x;
+    for (int t = blockIdx.x; t < act_total; t += gridDim.x) {
+        const int tile = full_tile(t);
+        const bool trw = a.trace && blockIdx.x == 0 && (tid & 63) == 0 && t == (int)blockIdx.x + 2 * (int)gridDim.x;
         TR(8);
 #pragma unroll
         for (int ps = 0; ps < XP; ++ps) {
@@ -251,7 +265,7 @@ vlad_sblock_kernel(VladSBlockArgs a) {
             out_ok = out_pixel(tile, out_off, off_res);
             fetch_res(out_ok, off_res);
         }
-        if (tile + (int)gridDim.x < tiles_total && !(a.dbg & 2)) fetch_x(tile + gridDim.x);
+        if (t + (int)gridDim.x < act_total && !(a.dbg & 2)) fetch_x(full_tile(t + gridDim.x));
 #pragma unroll
         for (int p = 0; p < MQ; ++p)
 #pragma unroll
@@ -431,7 +445,12 @@ static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
     static DynSmemState attr;
     OMNI_HIP_TRY(ensure_dyn_smem(attr, (const void*)kfn, smem));
     // persistent workgroups: as many as fit the CUs' LDS at once, each walking tiles blockIdx.x, + gridDim.x, ... with the next tile's input in flight
-    const int tiles = cdiv(a.Wo, 8) * cdiv(a.Ho, C::TH) * a.batch;
+    const int tiles_x = cdiv(a.Wo, 8), tiles_y = cdiv(a.Ho, C::TH);
+    const bool skip = a.sk_y1 > a.sk_y0 && a.sk_w > 0;
+    OMNI_REQUIRE(!skip || (a.sk_y0 >= 0 && a.sk_y1 <= tiles_y && a.sk_x0 >= 0 && a.sk_x0 + a.sk_w <= tiles_x), OMNI_ERR_INVALID, "vlad_sblock: skip rectangle outside the tile grid");
+    const int act_img = tiles_x * tiles_y - (skip ? (a.sk_y1 - a.sk_y0) * a.sk_w : 0);
+    OMNI_REQUIRE(act_img > 0, OMNI_ERR_INVALID, "vlad_sblock: the skip rectangle covers the whole map");
+    const int tiles = act_img * a.batch;                          // the tiles that run
     OMNI_REQUIRE((int64_t)a.batch * a.Hi * a.Wi * a.cin < (1ll << 31) && (int64_t)a.batch * a.Ho * a.Wo * a.cout < (1ll << 31) && tiles < (1 << 20),
                  OMNI_ERR_CAPACITY, "vlad_sblock: tensor beyond 32-bit element offsets");
     // how many of these workgroups a CU really holds: the runtime knows (registers AND LDS AND wave slots).  Rounds 2-4 estimated it from the LDS alone
@@ -460,6 +479,12 @@ static int launch_sb(hipStream_t st, const VladSBlockArgs& a) {
         const unsigned d_img = (unsigned)(cdiv(a.Wo, 8) * cdiv(a.Ho, C::TH)), d_tx = (unsigned)cdiv(a.Wo, 8);
         at.m_img = d_img > 1 ? (unsigned)(((1ull << 32) + d_img - 1) / d_img) : 0u;
         at.m_tx = d_tx > 1 ? (unsigned)(((1ull << 32) + d_tx - 1) / d_tx) : 0u;
+        if (!skip) { at.sk_y0 = at.sk_y1 = at.sk_x0 = at.sk_w = 0; }
+        at.sk_bw = tiles_x - at.sk_w; at.sk_act = act_img;
+        at.sk_above = skip ? at.sk_y0 * tiles_x : act_img;
+        at.sk_upto = at.sk_above + (at.sk_y1 - at.sk_y0) * at.sk_bw;
+        at.m_act = act_img > 1 ? (unsigned)(((1ull << 32) + (unsigned)act_img - 1) / (unsigned)act_img) : 0u;
+        at.m_bw = at.sk_bw > 1 ? (unsigned)(((1ull << 32) + (unsigned)at.sk_bw - 1) / (unsigned)at.sk_bw) : 0u;
     }
     if (want_trace) {
         if (!trace_dev) OMNI_HIP_TRY(hipMalloc((void**)&trace_dev, 8 * 16 * 8));

@@ -51,6 +51,35 @@ def test_fused_stem_block0_is_bit_identical(omni, ctx, monkeypatch):
         assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("h,w", [(480, 600), (480, 640), (360, 488), (240, 320), (104, 136)])
+def test_masked_passes_skip_the_constant_region_bit_identically(omni, ctx, monkeypatch, h, w):
+    """LoopCam blanks the bottom quarter of a fisheye frame before BOTH networks run (loop_cam.cpp:536-539, then :556-558 netvlad_net.inference): inside that
+    band the stem's and the first blocks' outputs are one constant vector, which a masked pass leaves out of its tile walk (csrc/vlad.hip, omni_vlad::MaskSkip;
+    OMNI_VLAD_MASK_SKIP=0 = the dense pass).  Same descriptors bit for bit: every image slot, a partial batch, an unmasked pass in between, sizes whose tiles
+    overhang the map and a size too small to hold a rectangle."""
+    vw = V.synth_weights()
+    imgs = np.stack([synth.image_u8(900 + i, h, w, n_shapes=120) for i in range(3)])
+    imgs[:, h * 3 // 4:] = 200                                       # the band's content must not matter
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OMNI_VLAD_MASK_SKIP", flag)
+        net = omni.capi.MobileNetVLAD(ctx, vw, V.layer_specs(), V.N_CLUSTERS, V.FEAT_DIM, V.OUT_DIM, w, h, 3)
+        fr = net.mask_skip_layers()
+        if flag == "0":
+            assert fr == []
+        elif h >= 240:
+            assert len(fr) >= 2 and all(0.02 < f < 0.25 for f in fr), fr
+        a = net.inference(imgs, fisheye_mask=True)
+        b = net.inference(imgs[::-1], fisheye_mask=False)             # the rotating buffers: the rectangles stay as they are
+        c = net.inference(imgs[1:], fisheye_mask=True)
+        d = net.inference(imgs, fisheye_mask=True)
+        outs[flag] = (a, b, c, d)
+        net.close()
+    for x, y in zip(outs["1"], outs["0"]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(outs["1"][0], outs["1"][3]) and np.array_equal(outs["1"][2], outs["1"][0][1:])
+
+
 @pytest.mark.parametrize("size", [(96, 128, 2, False), (104, 136, 1, True), (150, 210, 3, False), (480, 600, 2, True)])
 def test_split_fp16_blocks_are_fp32_class(omni, ctx, monkeypatch, size):
     """vlad_sblock_kernel (fp16 matrix cores, every operand carried as hi + lo, fp32 everywhere else) against the exact-f32 kernels it
