@@ -15,7 +15,7 @@ namespace omni {
 enum CfgId {
     // SuperPoint
     CFG_CONV_V1 = 0, CFG_CONV_RS, CFG_RS_TRN, CFG_DET16, CFG_SP_SPARSE_DESC, CFG_SP_SPARSE_DA, CFG_SP_FUSED_CAND, CFG_SP_SPLIT_DB, CFG_SP_MASK_SKIP, CFG_SP_MASK_SKIP_SPLIT, CFG_SPLIT_FUSE1A, CFG_SPLIT_WINO,
-    CFG_SPLIT_TRN, CFG_CONV_XCD, CFG_SP_PROFILE_MASK, CFG_PP_TRACE, CFG_PP_DBG, CFG_RS_TRACE, CFG_SPLIT_TRACE, CFG_SPLIT_DBG, CFG_WINO_TRACE, CFG_ROCTX,
+    CFG_SPLIT_TRN, CFG_CONV_XCD, CFG_SP_PROFILE_MASK, CFG_PP_U8, CFG_PP_TRACE, CFG_PP_DBG, CFG_RS_TRACE, CFG_SPLIT_TRACE, CFG_SPLIT_DBG, CFG_WINO_TRACE, CFG_ROCTX,
     // MobileNetVLAD
     CFG_VLAD_BIG, CFG_VLAD_STEM_FUSE, CFG_VLAD_UNFUSED, CFG_VLAD_MFMA, CFG_VLAD_SBLOCK, CFG_VLAD_MBLOCK_PX, CFG_VLAD_MFMA_PX, CFG_VLAD_FC_MFMA, CFG_VLAD_MBLOCK_CPW,
     CFG_VLAD_SB_LDSPAD, CFG_VLAD_SB_PERSIST, CFG_VLAD_SB_TRACE, CFG_VLAD_SB_DBG, CFG_VLAD_MASK_SKIP,

@@ -29,6 +29,7 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_CONV_XCD", 1, 0, 1, CFG_VARIANT, "persistent convolution kernels derive (cout group, tile walk) from an XCD-aware block id: the cout groups of a pixel tile and its neighbours "
                                            "share one L2 (0: plain blockIdx; process-wide, same results either way)"},
     {"OMNI_SP_PROFILE_MASK", 0, 0, 1, CFG_TUNING, "omni_sp_profile times the stages with the fisheye mask on (what the key-frame pipeline runs)"},
+    {"OMNI_PP_U8", 1, 0, 1, CFG_VARIANT, "fp16 conv1a inside conv1b's kernel: matrix-core operands straight from the image bytes (0: through the 256-entry u8 -> (hi, lo) table in LDS)"},
     {"OMNI_PP_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the ping-pong conv kernel on stderr"},
     {"OMNI_PP_DBG", 0, 0, 255, CFG_DEBUG, "ping-pong conv kernel timing ablations (WRONG results)"},
     {"OMNI_RS_TRACE", 0, 0, 1, CFG_DEBUG, "s_memtime trace of the register-stationary kernel"},

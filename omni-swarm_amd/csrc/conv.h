@@ -99,6 +99,7 @@ int conv1ab_fused(hipStream_t stream, const ConvArgs& a, const uint8_t* gray, in
                   const float* bias1a, const uint32_t* lut_hl);
 void conv1a_pack_split_weights(const float* w /*[64][9]*/, const float* bias /*[64]*/, uint16_t* frag /*[2048]*/);
 void conv1a_make_split_lut(uint32_t* lut /*[256]*/);
+void conv1a_pack_u8_weights(const float* w /*[64][9]*/, const float* bias /*[64]*/, uint16_t* frag /*[2048]*/);      // for lut_hl = nullptr: operands straight from the bytes
 
 // conv1a: 1 -> 64 channels, 3x3, + ReLU, straight from the u8 image (u8 -> f32 * 1/255 via a 256-entry table that
 // reproduces cv::Mat::convertTo(CV_32F, 1/255.0), superpoint_tensorrt.cpp:127; optional fisheye row mask,

@@ -678,7 +678,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
     uint32_t* const lut_lds = reinterpret_cast<uint32_t*>(bias_lds + 128);
     if constexpr (FUSE1A) {
         if (tid < 64) bias1a_lds[tid] = fz.bias1a[tid];
-        if (tid < 256) lut_lds[tid] = fz.lut_hl[tid];
+        if (tid < 256 && fz.lut_hl) lut_lds[tid] = fz.lut_hl[tid];
     }
     auto bias4 = [&](int m, float4 (&bs)[4]) {
 #pragma unroll
@@ -747,15 +747,24 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
             iyc = iyc > 3 ? 3 : iyc;
             const unsigned char* pb = patch + iyc * 40 + fr_ix[fi] + xsh;
             uint32_t T[5];
+            const uint32_t one2 = 0x3C003C00u & pinm;
+            uint32_t b1[4];
+            if (!fz.lut_hl) {
+                // no table (conv1a_pack_u8_weights): the byte p IS the operand -- 0x4400 | p = half(4 + p / 256) exactly, in both halves of the dword;
+                // the weights carry 256 / 255 and the bias slot takes the 4 sum(w) back.  One VALU operation per tap instead of a gather whose 64 lanes
+                // hit the table's banks at random
+#pragma unroll
+                for (int k = 0; k < 5; ++k) T[k] = ((uint32_t)pb[tap_off[k]] * 0x00010001u + 0x44004400u) & pinm;
+                b1[0] = hh ? one2 : T[4]; b1[1] = 0u; b1[2] = 0u; b1[3] = 0u;
+            } else {
 #pragma unroll
             for (int k = 0; k < 5; ++k) T[k] = lut_lds[pb[tap_off[k]]] & pinm;
             const uint32_t h01 = (T[0] & 0xFFFFu) | (T[1] << 16), h23 = (T[2] & 0xFFFFu) | (T[3] << 16);
-            const uint32_t one2 = 0x3C003C00u & pinm;
-            uint32_t b1[4];
             b1[0] = hh ? h01 : T[4];
             b1[1] = hh ? h23 : h01;
             b1[2] = hh ? one2 : h23;
             b1[3] = hh ? 0u : (T[4] & 0xFFFFu);
+            }
             B0[fi] = __builtin_bit_cast(half8_t, make_uint4(T[0], T[1], T[2], T[3]));
             B1[fi] = __builtin_bit_cast(half8_t, make_uint4(b1[0], b1[1], b1[2], b1[3]));
         }
@@ -1759,6 +1768,34 @@ void conv1a_pack_split_weights(const float* w, const float* bias, uint16_t* frag
                     else v = e < 4 ? lo(5 + e) : (e == 4 ? f2h_bits(bias[co]) : (e == 5 ? f2h_bits(bias[co] - h2f(f2h_bits(bias[co]))) : 0));
                     frag[((j * 2 + m) * 64 + l) * 8 + e] = v;
                 }
+}
+// The table-free form (Fuse1aArgs::lut_hl = nullptr): the B operand of tap t is the pair (P_t, P_t), P_t = half(4 + p_t / 256) = 0x4400 | p_t exactly, against
+// (Wh_t, Wl_t) = the split of W_t = fl32(w_t * 256 / 255); the bias slot (1, 1) carries the split of bias - 4 sum_t (Wh_t + Wl_t) (in double):
+//   sum_t W_t (4 + p_t / 256) + bias - 4 sum_t W_t = sum_t w_t p_t / 255 + bias     (W_t to 22 bits; the products are exact in fp32)
+//   hh = 0:  j = 0: Wh0 Wl0 Wh1 Wl1 Wh2 Wl2 Wh3 Wl3      j = 1: Wh4 Wl4 0 0 0 0 0 0
+//   hh = 1:  j = 0: Wh5 Wl5 Wh6 Wl6 Wh7 Wl7 Wh8 Wl8      j = 1: bias_hi bias_lo 0 0 0 0 0 0
+void conv1a_pack_u8_weights(const float* w, const float* bias, uint16_t* frag /*2*2*64*8*/) {
+    for (int m = 0; m < 2; ++m)
+        for (int l = 0; l < 64; ++l) {
+            const int co = m * 32 + (l & 31), hh = l >> 5;
+            uint16_t Wh[9], Wl[9];
+            double sum = 0.0;
+            for (int t = 0; t < 9; ++t) {
+                const float W = (float)((double)w[co * 9 + t] * 256.0 / 255.0);
+                Wh[t] = f2h_bits(W); Wl[t] = f2h_bits(W - h2f(Wh[t]));
+                sum += (double)h2f(Wh[t]) + (double)h2f(Wl[t]);
+            }
+            const float b = (float)((double)bias[co] - 4.0 * sum);
+            const uint16_t bh = f2h_bits(b), bl = f2h_bits(b - h2f(bh));
+            for (int j = 0; j < 2; ++j)
+                for (int e = 0; e < 8; ++e) {
+                    uint16_t v = 0;
+                    if (j == 0) { const int t = (hh ? 5 : 0) + e / 2; v = (e & 1) ? Wl[t] : Wh[t]; }
+                    else if (hh == 0) v = e == 0 ? Wh[4] : (e == 1 ? Wl[4] : 0);
+                    else v = e == 0 ? bh : (e == 1 ? bl : 0);
+                    frag[((j * 2 + m) * 64 + l) * 8 + e] = v;
+                }
+        }
 }
 void conv1a_make_split_lut(uint32_t* lut /*256*/) {
     for (int i = 0; i < 256; ++i) {

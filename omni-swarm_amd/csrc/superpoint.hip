@@ -241,11 +241,16 @@ static int sp_init(omni_sp* s, const omni_sp_weights* w, const float* pca_comp, 
     }
     if (s->precision == OMNI_PREC_F16) {
         std::vector<uint16_t> fr(2048);
-        conv1a_pack_split_weights(w->weight[L1A], w->bias[L1A], fr.data());
-        if ((rc = dev_upload((void**)&s->w1a_frag, fr.data(), fr.size() * 2, st))) return rc;
-        uint32_t lh[256];
-        conv1a_make_split_lut(lh);
-        if ((rc = dev_upload((void**)&s->lut_hl, lh, sizeof(lh), st))) return rc;
+        if (s->cfg[CFG_PP_U8]) {              // operands straight from the bytes: no table (lut_hl stays null)
+            conv1a_pack_u8_weights(w->weight[L1A], w->bias[L1A], fr.data());
+            if ((rc = dev_upload((void**)&s->w1a_frag, fr.data(), fr.size() * 2, st))) return rc;
+        } else {
+            conv1a_pack_split_weights(w->weight[L1A], w->bias[L1A], fr.data());
+            if ((rc = dev_upload((void**)&s->w1a_frag, fr.data(), fr.size() * 2, st))) return rc;
+            uint32_t lh[256];
+            conv1a_make_split_lut(lh);
+            if ((rc = dev_upload((void**)&s->lut_hl, lh, sizeof(lh), st))) return rc;
+        }
     }
     // packed MFMA weights
     auto pack_upload = [&](int l, const float* w_oihw, int cin, int cout, int ks) -> int {

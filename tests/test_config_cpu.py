@@ -17,7 +17,7 @@ VARIANT, TUNING, DEBUG, TEST, STRING = range(5)
 PRODUCTION = {
     "OMNI_CONV_V1": 0, "OMNI_CONV_RS": 2, "OMNI_RS_TRN": -1, "OMNI_DET16": 1, "OMNI_SP_SPARSE_DESC": 1, "OMNI_SP_SPARSE_DA": 1, "OMNI_SP_FUSED_CAND": 1, "OMNI_SP_SPLIT_DB": 1, "OMNI_SP_MASK_SKIP": 1,
     "OMNI_SP_MASK_SKIP_SPLIT": 1, "OMNI_SPLIT_FUSE1A": 1, "OMNI_SPLIT_WINO": 7, "OMNI_SPLIT_TRN": -1, "OMNI_CONV_XCD": 1, "OMNI_VLAD_STEM_FUSE": 1, "OMNI_VLAD_UNFUSED": 0, "OMNI_VLAD_MFMA": 1,
-    "OMNI_VLAD_SBLOCK": 1, "OMNI_VLAD_FC_MFMA": 1, "OMNI_VLAD_SB_PERSIST": 1, "OMNI_VLAD_MASK_SKIP": 1, "OMNI_MQ_ROT": 1, "OMNI_INDEX_MIRROR": 1, "OMNI_GEOMETRY_ASYNC": 1, "OMNI_DETECTOR_ASYNC": 1, "OMNI_PIPELINE_ONE_STREAM": 0, "OMNI_PIPELINE_FIFO": -1, "OMNI_PIPELINE_UNIT_PLAN": 1,
+    "OMNI_VLAD_SBLOCK": 1, "OMNI_VLAD_FC_MFMA": 1, "OMNI_VLAD_SB_PERSIST": 1, "OMNI_VLAD_MASK_SKIP": 1, "OMNI_PP_U8": 1, "OMNI_MQ_ROT": 1, "OMNI_INDEX_MIRROR": 1, "OMNI_GEOMETRY_ASYNC": 1, "OMNI_DETECTOR_ASYNC": 1, "OMNI_PIPELINE_ONE_STREAM": 0, "OMNI_PIPELINE_FIFO": -1, "OMNI_PIPELINE_UNIT_PLAN": 1,
 }
 
 
