@@ -638,9 +638,9 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         goff[j] = (uint32_t)((iy * W + ix) * 128 + ((phys ^ ((pix >> 1) & 7)) << 4));
     }
     // LDS-DMA of tile t into this group's buffer: 43 wave-instructions of 1 KiB, 11 per wave (10 for the last)
-    auto issue = [&](int t) {
-        int b, ty0, tx0;
-        tile_origin(t, b, ty0, tx0);
+    // (every lambda below takes the tile's origin, decoded ONCE per tile by the service phase: next to an MFMA-streaming partner wave every instruction of
+    // the service role costs ~7 cycles, and a decode is ~40 of them)
+    auto issue = [&](int b, int ty0, int tx0) {
         const int y0 = ty0 - 1, x0 = tx0 - 1;
         const _Float16* img = in + (int64_t)b * H * W * 64;
         if (y0 >= 0 && y0 + C64_ITH <= H && x0 >= 0 && x0 + C64_ITW <= W) {       // interior (wave-uniform): base + 32-bit lane offset
@@ -701,9 +701,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
     int tap_off[5];                          // patch offsets of this half-wave's taps: 0-4 (lanes 0-31) or 5-8 (+ a dummy) (lanes 32-63)
 #pragma unroll
     for (int k = 0; k < 5; ++k) { const int tp = hh ? (k < 4 ? 5 + k : 8) : k; tap_off[k] = (tp / 3) * 40 + tp % 3; }
-    auto build_issue = [&](int t, uint32_t& pv) {
-        int b, ty0, tx0;
-        tile_origin(t, b, ty0, tx0);
+    auto build_issue = [&](int b, int ty0, int tx0, uint32_t& pv) {
         const int j = lane / 10, d = lane - j * 10;
         int yy = ty0 - 2 + fr_r0 + j, xo = ((tx0 - 2) & ~3) + 4 * d;
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
@@ -712,9 +710,8 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
         pv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (b * H + yy) * fz.gstride + xo, 0, 0);
     };
     // table reads and operand packing of all three fragments first (their latencies overlap), then MFMAs + stores per fragment
-    auto build_finish = [&](int t, uint32_t pv, unsigned long long* stamp = nullptr) {
-        int b, ty0, tx0;
-        tile_origin(t, b, ty0, tx0);
+    auto build_finish = [&](int b, int ty0, int tx0, uint32_t pv, unsigned long long* stamp = nullptr) {
+        (void)b;
         const int cx0 = (tx0 - 2) & ~3, xsh = (tx0 - 2) - cx0;
         {   // park the patch in LDS with everything that must read as x = 0 already zeroed: rows outside the image or inside the
             // fisheye mask, columns outside the image (the loads were clamped to valid addresses) -- no per-tap checks later
@@ -814,14 +811,16 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
     // group g computes tiles k = g, g+2, ... in phases p = k; services (epilogue of k, DMA of k+2) in phase k+1.
     // group 0 loads its first tile here, group 1 during phase 0.
     int k_load = grp;                       // next tile index this group will DMA
+    int ob = 0, oty0 = 0, otx0 = 0;          // origin of the tile this group built last = the tile whose epilogue comes next
     __syncthreads();                         // weights / bias / table staged (FUSE1A reads them in the prologue already)
     if (grp == 0 && k_load < n_mine) {
+        tile_origin(wg + k_load * nwg, ob, oty0, otx0);
         if constexpr (FUSE1A) {
             uint32_t pv;
-            build_issue(wg + k_load * nwg, pv);
-            build_finish(wg + k_load * nwg, pv);
+            build_issue(ob, oty0, otx0, pv);
+            build_finish(ob, oty0, otx0, pv);
         } else {
-            issue(wg + k_load * nwg);
+            issue(ob, oty0, otx0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         k_load += 2;
@@ -868,15 +867,16 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
             uint32_t pv = 0;
             const bool tr = fz.trace && blockIdx.x == 0 && wl == 0 && lane == 0 && p >= 2 && p < 6;
             if (tr) fz.trace[p * 8 + 0] = __builtin_amdgcn_s_memtime();
+            int nb = 0, nty0 = 0, ntx0 = 0;   // origin of the tile built in this phase
             if (load) {
-                if constexpr (FUSE1A) build_issue(wg + k_load * nwg, pv);   // the patch load flies under the epilogue
-                else issue(wg + k_load * nwg);
+                tile_origin(wg + k_load * nwg, nb, nty0, ntx0);
+                if constexpr (FUSE1A) build_issue(nb, nty0, ntx0, pv);   // the patch load flies under the epilogue
+                else issue(nb, nty0, ntx0);
             }
             if (tr) fz.trace[p * 8 + 1] = __builtin_amdgcn_s_memtime();
             bool full = false;               // every lane of every store instruction of the epilogue is active
             if (t_pending >= 0 && !(dbg & 2)) {
-                int b, ty0, tx0;
-                tile_origin(t_pending, b, ty0, tx0);
+                const int b = ob, ty0 = oty0, tx0 = otx0;        // (= tile_origin(t_pending): no build of this group in between)
                 full = (ty0 + CONV_TH <= H) && (tx0 + CONV_TW <= W);
                 const int ox = tx0 + n;
                 if constexpr (POOL) {
@@ -914,9 +914,10 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
             }
             if (tr) fz.trace[p * 8 + 2] = __builtin_amdgcn_s_memtime();
             if (load && FUSE1A) {
-                if constexpr (FUSE1A) build_finish(wg + k_load * nwg, pv, tr ? fz.trace + p * 8 + 6 : nullptr);
+                if constexpr (FUSE1A) build_finish(nb, nty0, ntx0, pv, tr ? fz.trace + p * 8 + 6 : nullptr);
                 if (tr) fz.trace[p * 8 + 3] = __builtin_amdgcn_s_memtime();
                 k_load += 2;
+                ob = nb; oty0 = nty0; otx0 = ntx0;
             } else if (load) {
                 // vmcnt retires in issue order: the DMA loads were issued before the epilogue's stores, so waiting down to
                 // the number of store instructions leaves the stores in flight across the barrier (only when every store
@@ -929,6 +930,7 @@ conv3x3_c64_pp_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ ou
                 }
                 if (tr) fz.trace[p * 8 + 3] = __builtin_amdgcn_s_memtime();
                 k_load += 2;
+                ob = nb; oty0 = nty0; otx0 = ntx0;
             }
         }
         if (dbg & 32) __builtin_amdgcn_s_setprio(0);
