@@ -630,11 +630,20 @@ def main():
                                                           "shader clock by s_memtime against s_memrealtime; extra information -- `frac` stays against `peak`"}
         except Exception as e:                                    # noqa: BLE001
             roofline["measured_ceiling"] = {"error": str(e)}
+    try:
+        _vl = capi.MobileNetVLAD(ictx, vl_w, vl_specs, *vl_shape, W, H, 1)
+        vlad_left_out = [round(f, 4) for f in _vl.mask_skip_layers()]
+        _vl.close()
+    except Exception as e:                                        # noqa: BLE001
+        vlad_left_out = str(e)
     roofline.update({
         "mask_skip": {"note": "stage times with the fisheye mask on, as the key-frame pipeline runs the network (loop_cam.cpp:536-539): the tiles whose whole "
                               "receptive field lies in the blanked rows hold one constant vector per layer, written once, and are left out of the tile walk "
                               "(bit-identical: tests/test_gpu_mask_skip.py; OMNI_SP_MASK_SKIP=0 / OMNI_SP_MASK_SKIP_SPLIT=0 = the dense pass)",
-                      "tiles_left_out": {p["stage"]: round(p["tiles_left_out"], 4) for p in prof if p["tiles_left_out"] > 0}},
+                      "tiles_left_out": {p["stage"]: round(p["tiles_left_out"], 4) for p in prof if p["tiles_left_out"] > 0},
+                      "mobilenetvlad_tiles_left_out": vlad_left_out,
+                      "mobilenetvlad_note": "the same for MobileNetVLAD (the frame is blanked before both networks, loop_cam.cpp:536-539, 556-558): stem + block 0, blocks 1, 2, ... "
+                                            "(csrc/vlad.hip, omni_vlad::MaskSkip; OMNI_VLAD_MASK_SKIP=0 = the dense pass; tests/test_gpu_vlad_detector.py)"},
         "conv_stack_tflops": round(mfma_terms_of(args.precision) * sp_flop_executed(args.precision, MAXN, True, left_out_flop) * KF_IMAGES / (conv_ms * 1e-3) / 1e12, 1),
         "conv_stack_note": "MFMA FLOP executed by the stages named conv* (fp16 path: without convDa / convDb, which run only at the cells around the key points "
                            "inside the post-processing stage; split: x 3 terms of the direct form for every layer -- the layers OMNI_SPLIT_WINO runs as Winograd kernels execute 4/3 -- so this is a rate of useful work) / their time",
