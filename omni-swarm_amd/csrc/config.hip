@@ -68,7 +68,7 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_PIPELINE_ONE_STREAM", 0, 0, 1, CFG_VARIANT, "a unit's MobileNetVLAD launches behind its SuperPoint launches on one stream (0: next to them on a second stream)"},
     {"OMNI_PIPELINE_FIFO", -1, -1, 2, CFG_VARIANT, "units in flight run oldest first: a unit's SuperPoint stream (1) / both its streams (2) start behind the convolution stack of the unit "
                                                    "enqueued before it; 0: the units' kernels take turns; -1: by measurement -- 1 for the fp32-class precisions, whose time is all "
-                                                   "CU-filling convolutions (+2-4 %), and for an fp16 run() of fewer than 8 units (it drains: +7-11 %), 0 for fp16 otherwise, whose small-grid "
+                                                   "CU-filling convolutions (+2-4 %), and for an fp16 run() of no more units than lanes (all in flight at once: +13 % at 3 units), 0 for fp16 otherwise, whose small-grid "
                                                    "tails the next units' kernels fill (-5 % when chained)"},
     {"OMNI_PIPELINE_UNIT_PLAN", 1, 0, 2, CFG_VARIANT, "KeyframePipeline::run on host blocks, a run that is not a whole number of micro-batches: 1 = units of equal size (20 key frames = "
                                                        "7 + 7 + 6), 2 = the same behind half a unit, 0 = the blocks' own cut (8 + 8 + 4)"},

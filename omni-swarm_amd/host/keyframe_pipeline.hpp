@@ -334,11 +334,12 @@ public:
         std::deque<std::pair<Lane*, int64_t>> pending;
         int hits = 0;
         // units oldest first (omni_cam_order_after)?  OMNI_PIPELINE_FIFO >= 0 decides; the default (-1) does by what this call is given: the fp32-class
-        // modes always (CU-filling convolutions end to end: +2-4 %); fp16 when the run drains before the pipeline is in steady state (fewer than 8
-        // units: the first unit then finishes early and the host's work on it overlaps the rest, +7-11 % at 20 key frames,
-        // profiles/r04ab_short_regions.log), not in a run that keeps the pipeline full (the units' kernels taking turns fill each other's tails: +5 %)
+        // modes always (CU-filling convolutions end to end: +2-4 %); fp16 when the whole run is in flight at once (no more units than lanes: the first
+        // unit then finishes early and the host's work on it overlaps the rest, +13 % at 3 units, +1.5 % at 4), not in a run the lanes' in-flight limit
+        // staggers anyway (the units' kernels taking turns fill each other's tails: +6 % at 5 units, +4 % at 7, +5 % at 8;
+        // profiles/r06k_fifo_by_units.log -- until round 6 the rule chained every run of fewer than 8 units)
         const int n_units = (int)sizes.size();
-        const int fifo = fifo_cfg_ >= 0 ? fifo_cfg_ : ((cfg_.precision != OMNI_PREC_F16 || n_units < 8) ? 1 : 0);
+        const int fifo = fifo_cfg_ >= 0 ? fifo_cfg_ : ((cfg_.precision != OMNI_PREC_F16 || n_units <= (int)lanes_.size()) ? 1 : 0);
         last_fifo_ = fifo;
         const size_t img = (size_t)cfg_.width * cfg_.height;
         // key frame f of the call: its block (pool entry or the tail), the block's frame count, its index inside
