@@ -22,7 +22,7 @@ enum CfgId {
     // index
     CFG_SCAN_ROWS_MIN, CFG_MQ_ROT, CFG_MQ_MIN, CFG_INDEX_MIRROR, CFG_INDEX_MIRROR_MIN_ROWS, CFG_INDEX_CERT_FAIL,
     // host loop (libomni_host.so reads them through omni_config_value)
-    CFG_GEOMETRY_THREADS, CFG_GEOMETRY_ASYNC, CFG_DETECTOR_ASYNC, CFG_PIPELINE_ONE_STREAM, CFG_PIPELINE_FIFO, CFG_PIPELINE_UNIT_PLAN,
+    CFG_GEOMETRY_THREADS, CFG_MESSAGE_THREADS, CFG_GEOMETRY_ASYNC, CFG_DETECTOR_ASYNC, CFG_PIPELINE_ONE_STREAM, CFG_PIPELINE_FIFO, CFG_PIPELINE_UNIT_PLAN,
     // runtime
     CFG_HW_QUEUES,
     // strings

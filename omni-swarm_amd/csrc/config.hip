@@ -63,6 +63,8 @@ const CfgOption kCfgOptions[CFG_COUNT] = {
     {"OMNI_INDEX_CERT_FAIL", 0, 0, 1, CFG_TEST, "1: every certificate fails (exercises the exact fallback)"},
     // ---- host loop -------------------------------------------------------------------------------------------------------------------------------------
     {"OMNI_GEOMETRY_THREADS", -1, -1, 1024, CFG_TUNING, "threads of the geometric-verification pool (-1: min(16, cores / 2); 0: inline)"},
+    {"OMNI_MESSAGE_THREADS", 3, 0, 64, CFG_TUNING, "helper threads that fill a unit's key-frame messages (key points, descriptors, lifted points: ~75 KB per image, first-touch page "
+                                                  "faults included) next to the calling thread while the unit's detector step runs on the GPU (0: inline)"},
     {"OMNI_GEOMETRY_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's geometry tasks run while the next unit is waited for (0: drained at once)"},
     {"OMNI_DETECTOR_ASYNC", 1, 0, 1, CFG_VARIANT, "a micro-batch's detector step (appends, searches) is enqueued and collected one unit later (0: the host waits for it on the spot)"},
     {"OMNI_PIPELINE_ONE_STREAM", 0, 0, 1, CFG_VARIANT, "a unit's MobileNetVLAD launches behind its SuperPoint launches on one stream (0: next to them on a second stream)"},

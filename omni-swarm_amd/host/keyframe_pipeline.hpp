@@ -708,8 +708,19 @@ private:
         if (defer_heavy) {                                                      // the messages' contents, into the frames the detector holds, under its GPU work
             t_a = std::chrono::steady_clock::now();
             std::vector<FisheyeFrameDescriptor>& held = det_.held_frames();
-            for (int m = 0; m < lane.cur && m < (int)held.size(); ++m)
-                for (int d = 0; d < nd && d < (int)held[(size_t)m].images.size(); ++d) heavy(held[(size_t)m].images[(size_t)d], nd * m + d);
+            // key frames in stripes over the helper threads and this one (OMNI_MESSAGE_THREADS): each message is written by one thread, the result block is
+            // only read; what the stripes share is the allocator.  Matters where this is exposed: behind the LAST unit of a run() call
+            const int n_kf = std::min(lane.cur, (int)held.size()), parts = msg_pool_ ? std::min(n_kf, msg_pool_->size() + 1) : 1;
+            auto stripe = [&, n_kf, parts](int p) {
+                for (int m = p; m < n_kf; m += parts)
+                    for (int d = 0; d < nd && d < (int)held[(size_t)m].images.size(); ++d) heavy(held[(size_t)m].images[(size_t)d], nd * m + d);
+            };
+            std::vector<std::future<void>> helpers;
+            for (int p = 1; p < parts; ++p) helpers.push_back(msg_pool_->submit([&stripe, p] { stripe(p); }));
+            std::exception_ptr first;
+            try { stripe(0); } catch (...) { first = std::current_exception(); }
+            for (auto& h : helpers) { try { h.get(); } catch (...) { if (!first) first = std::current_exception(); } }      // (every helper is joined: they reference this frame's locals)
+            if (first) std::rethrow_exception(first);
             host_ms_[2] += since(t_a);
         }
         if (!async_detector_) hits += collect_detector();                       // OMNI_DETECTOR_ASYNC=0: wait for it here, as before (A/B)
@@ -736,6 +747,7 @@ private:
     bool async_detector_ = [] { int v = 1; check(omni_config_value("OMNI_DETECTOR_ASYNC", &v), "omni_config_value"); return v != 0; }();
     bool async_geometry_ = [] { int v = 1; check(omni_config_value("OMNI_GEOMETRY_ASYNC", &v), "omni_config_value"); return v != 0; }();
     std::unique_ptr<TaskPool> pool_;
+    std::unique_ptr<TaskPool> msg_pool_ = [] { const int n = cfg_int("OMNI_MESSAGE_THREADS"); return n > 0 ? std::make_unique<TaskPool>(n) : nullptr; }();
     std::vector<ImageDescriptor> downs_;        // the down-camera halves of the micro-batch being finished
     std::vector<std::future<void>> stereo_tasks_;
     struct Deferred { const FisheyeFrameDescriptor *a, *b; int da, db; bool im; };
