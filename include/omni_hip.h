@@ -221,6 +221,11 @@ int        omni_vlad_set_precision(omni_vlad* v, int precision);
  * We_hi, We_hi, be_hi, be_lo; x_hi pass with We_lo) and the projection A fragments (hi, lo per k-step), each fragment [64 lanes][8 halfs]. */
 int64_t    omni_vlad_pack_block(int cin, int hid, int cout, int stride, const float* we, const float* be, const float* wd, const float* bd,
                                 const float* wp, void* out, int64_t out_bytes);
+/* Host-only test hooks (no GPU): the packed constants of two SuperPoint kernels, so that their algebra can be checked on the CPU.
+ * which = 0: conv1a's matrix-core fragments for operands taken straight from the image bytes (csrc/conv.hip conv1a_pack_u8_weights): w [64][9],
+ *   bias [64] -> out [2048] halfs, *scale = 1; which = 1: a cin = 64 layer's Winograd F(2x2,3x3) fragments (csrc/conv_wino.hip conv_pack_weights_wino):
+ *   w OIHW [cout][64][3][3] -> out [64 * cout * 32] halfs, *scale = 2^-k of the packed values.  Returns the number of halfs written, -2 on bad arguments. */
+int64_t omni_sp_pack_constants(int which, const float* w, const float* bias, int cout, uint16_t* out, int64_t out_halfs, float* scale);
 /* std::vector<float> MobileNetVLADTensorRT::inference(const cv::Mat&) (mobilenetvlad_tensorrt.cpp:4-14):
  * u8 -> f32 with NO scaling feeds the net; out [batch][out_dim] */
 int omni_vlad_infer(omni_vlad* v, const uint8_t* gray_host, int stride, int batch, int fisheye_mask, float* out);

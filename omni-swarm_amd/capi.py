@@ -30,7 +30,7 @@ SYMBOLS = [
     "omni_ctx_device_info", "omni_ctx_mfma_ceiling", "omni_dev_alloc", "omni_dev_free", "omni_host_alloc", "omni_host_free", "omni_memcpy_h2d", "omni_memcpy_d2h", "omni_timer_start",
     "omni_timer_stop", "omni_sp_create", "omni_sp_destroy", "omni_sp_desc_dim", "omni_sp_image_size", "omni_sp_infer", "omni_sp_enqueue_dev",
     "omni_sp_fetch", "omni_sp_dev_outputs", "omni_sp_get_dense", "omni_sp_postprocess_dense", "omni_sp_debug_layer",
-    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_sp_stage_tiles_left_out", "omni_sp_mask_skip_plan", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block",
+    "omni_sp_profile", "omni_sp_stage_name", "omni_sp_stage_flops", "omni_sp_stage_tiles_left_out", "omni_sp_mask_skip_plan", "omni_vlad_create", "omni_vlad_destroy", "omni_vlad_set_precision", "omni_vlad_pack_block", "omni_sp_pack_constants",
     "omni_vlad_infer", "omni_vlad_enqueue_dev", "omni_vlad_fetch", "omni_vlad_dev_output", "omni_vlad_mask_skip_layers", "omni_index_create",
     "omni_index_destroy", "omni_index_add", "omni_index_add_dev", "omni_index_ntotal", "omni_index_dim", "omni_index_reset", "omni_index_truncate", "omni_index_cert_stats",
     "omni_index_search", "omni_index_search_dev", "omni_index_search_prefix_dev", "omni_index_search_batch_prefix_dev", "omni_index_set_shard", "omni_topk_merge", "omni_index_last_scan_ms",
@@ -127,6 +127,7 @@ def lib():
     sig("omni_vlad_create", _vp, [_vp, C.POINTER(_VladWeights), C.c_int, C.c_int, C.c_int])
     sig("omni_vlad_destroy", None, [_vp])
     sig("omni_vlad_set_precision", C.c_int, [_vp, C.c_int])
+    sig("omni_sp_pack_constants", C.c_int64, [C.c_int, _fp, _fp, C.c_int, _vp, C.c_int64, C.POINTER(C.c_float)])
     sig("omni_vlad_pack_block", C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _vp, C.c_int64])
     sig("omni_vlad_infer", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _fp])
     sig("omni_vlad_enqueue_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int])
@@ -467,6 +468,18 @@ class MobileNetVLAD:
         f = (C.c_double * 32)()
         n = lib().omni_vlad_mask_skip_layers(self.h, f, 32)
         return [f[i] for i in range(min(n, 32))]
+
+
+def sp_pack_constants(which, w, bias=None, cout=64):
+    """Host-only test hook: (halfs as uint16, scale) of conv1a's byte-operand fragments (which = 0) or a cin = 64 layer's Winograd fragments (which = 1)."""
+    w = _f32(w)
+    b = _f32(bias) if bias is not None else None
+    out = np.zeros(2048 if which == 0 else 64 * cout * 32, np.uint16)
+    sc = C.c_float(0)
+    n = lib().omni_sp_pack_constants(which, _pf(w), _pf(b) if b is not None else None, cout, out.ctypes.data_as(_vp), out.size, C.byref(sc))
+    if n != out.size:
+        raise OmniError(f"omni_sp_pack_constants failed: {lib().omni_last_error().decode()}")
+    return out, float(sc.value)
 
 
 def vlad_pack_block(cin, hid, cout, stride, we, be, wd, bd, wp):

@@ -846,6 +846,24 @@ double omni_sp_stage_tiles_left_out(const omni_sp* s, int stage) {
 
 // enable_perf of the reference's runners (superpoint_tensorrt.cpp:130-162 prints the engine time and the post-processing time of every call): with perf on, every
 // pass records an event in front of each stage (a dozen hipEventRecord: microseconds of host time) and omni_sp_last_stage_ms returns the LAST pass's stage times
+int64_t omni_sp_pack_constants(int which, const float* w, const float* bias, int cout, uint16_t* out, int64_t out_halfs, float* scale) {
+    if (!w || !out || !scale) { omni::set_error("omni_sp_pack_constants: null argument"); return -2; }
+    if (which == 0) {
+        if (!bias || out_halfs < 2048) { omni::set_error("omni_sp_pack_constants: conv1a needs a bias and 2048 halfs"); return -2; }
+        omni::conv1a_pack_u8_weights(w, bias, out);
+        *scale = 1.f;
+        return 2048;
+    }
+    if (which == 1) {
+        const int64_t need = (int64_t)64 * cout * 32;
+        if (cout < 64 || cout % 64 || out_halfs < need) { omni::set_error("omni_sp_pack_constants: cout %d, %lld halfs", cout, (long long)out_halfs); return -2; }
+        *scale = omni::conv_pack_weights_wino(w, 64, cout, out);
+        return need;
+    }
+    omni::set_error("omni_sp_pack_constants: which = %d", which);
+    return -2;
+}
+
 int omni_sp_set_perf(omni_sp* s, int on) {
     OMNI_REQUIRE(s, OMNI_ERR_INVALID, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
