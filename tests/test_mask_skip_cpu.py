@@ -55,6 +55,47 @@ def test_tile_walk_enumerates_the_tiles_outside_the_rectangle_once():
             assert sorted(seen) == want and len(set(seen)) == len(seen), (tx, ty, sy0, sy1, sx0, sx1)
 
 
+def _walk_vlad(tiles_x, tiles_y, sy0, sy1, sx0, sw, batch):
+    """vlad_s.hip: launch_sb (the parameters) + full_tile (the t-th tile that runs -> its number in the full grid), in Python integers"""
+    skip = sy1 > sy0 and sw > 0
+    y0, y1, x0, w = (sy0, sy1, sx0, sw) if skip else (0, 0, 0, 0)
+    tiles_img = tiles_x * tiles_y
+    act = tiles_img - (y1 - y0) * w
+    bw = tiles_x - w
+    above = y0 * tiles_x if skip else act
+    upto = above + (y1 - y0) * bw
+    m_act, m_bw = _magic(act), _magic(bw)
+    out = []
+    for t in range(batch * act):
+        if y1 <= y0:
+            out.append(t)
+            continue
+        tb = _umulhi(t, m_act) if m_act else t
+        r = t - tb * act
+        if r < above:
+            ttr = r
+        elif r < upto:
+            q = r - above
+            ry = _umulhi(q, m_bw) if m_bw else q
+            c = q - ry * bw
+            ttr = (y0 + ry) * tiles_x + (c if c < x0 else c + w)
+        else:
+            ttr = r - upto + y1 * tiles_x
+        out.append(tb * tiles_img + ttr)
+    return out, (y0, y1, x0, x0 + w, skip)
+
+
+def test_mobilenetvlad_tile_walk_enumerates_the_tiles_outside_the_rectangle_once():
+    """the persistent block kernel of MobileNetVLAD under the fisheye mask (round 6): rectangles up to the full width of the grid (no tile left in a band row)"""
+    for tx, ty in [(19, 30), (10, 15), (5, 8), (1, 2), (3, 4)]:
+        rects = [(0, 0, 0, 0)] + [(a, b, c, d - c) for a in range(ty) for b in range(a + 1, ty + 1) for c in range(tx) for d in range(c + 1, tx + 1)
+                                  if (b - a) * (d - c) < tx * ty and (ty <= 8 or (a % 5 == 3 and b % 4 == 1))]
+        for sy0, sy1, sx0, sw in rects:
+            seen, (y0, y1, x0, x1, skip) = _walk_vlad(tx, ty, sy0, sy1, sx0, sw, 3)
+            want = [b * tx * ty + y * tx + x for b in range(3) for y in range(ty) for x in range(tx) if not (skip and y0 <= y < y1 and x0 <= x < x1)]
+            assert seen == want, (tx, ty, sy0, sy1, sx0, sw)              # (in order: the walk is monotonic)
+
+
 def test_plan_for_600x480_is_the_one_worked_out_by_hand():
     """omni_sp_mask_skip_plan (the library's own plan, pure arithmetic: callable without a device) -- bench.py takes its executed-FLOP accounting from the
     same function through omni_sp_stage_tiles_left_out"""
