@@ -279,6 +279,30 @@ def test_f16_persistent_kernels_are_bit_identical_to_generic_kernel(omni, ctx, m
         assert np.percentile(rel, 99) < 2e-3, np.percentile(rel, 99)
 
 
+def test_f16_conv1a_operands_from_the_bytes_match_the_table_form(omni, ctx, monkeypatch):
+    """The fp16 conv1b kernel builds conv1a's matrix-core operands straight from the image bytes (OMNI_PP_U8=1, round 6: 0x4400 | p = half(4 + p / 256), weights
+    x 256 / 255, the offset folded into the bias slot; tests/test_pack_cpu.py replays the algebra) instead of through the 256-entry u8 -> (hi, lo) table
+    (OMNI_PP_U8=0, kept for the A/B).  Both are fp32-class before the fp16 rounding of the activations: the pooled conv1b maps differ in the last place on a
+    few elements, the masked rows and the image borders included, and the outputs stay inside the fp16 path's own gates."""
+    weights = S.synth_weights(0)
+    for (h, w, nb, mask) in ((480, 600, 2, True), (72, 104, 1, False)):
+        imgs = np.stack([synth.image_u8(60 + i, h, w) for i in range(nb)])
+        imgs[0, :3] = 255
+        imgs[0, :, -2:] = 0
+        outs = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("OMNI_PP_U8", flag)
+            sp = omni.capi.SuperPoint(ctx, weights, None, None, w, h, 0.015, 200, omni.capi.PREC_F16, nb)
+            sp.inference(imgs, fisheye_mask=mask)
+            outs[flag] = [sp.debug_layer("conv1b", nb)] + list(sp.get_dense(nb))
+            sp.close()
+        d = np.abs(outs["1"][0] - outs["0"][0])
+        assert d.max() < 2e-2 * max(1.0, np.abs(outs["0"][0]).max()) and d.mean() < 1e-5, (d.max(), d.mean())
+        assert np.abs(outs["1"][1] - outs["0"][1]).max() < 5e-3
+        rel = np.linalg.norm(outs["1"][2] - outs["0"][2], axis=1) / np.linalg.norm(outs["0"][2], axis=1)
+        assert np.percentile(rel, 99) < 2e-3, np.percentile(rel, 99)
+
+
 def test_bad_arguments_return_errors_not_aborts(omni, ctx):
     c = omni.capi
     weights = S.synth_weights(0)
